@@ -1,0 +1,89 @@
+"""hipcc build driver for the native libraries (replaces the reference's
+pegainfer-kernels/build.rs:1032-1353: nvcc + ar + cuBLAS/Triton-AOT with a plain
+hipcc -> shared-object build; single target arch gfx950, no CUDA/HIP dual build).
+
+  libpegainfer_kernels_hip.so  the drop-in C ABI of include/pegainfer_kernels.h   (csrc/*.hip)
+  libpegainfer_qwen3.so        C++ host runtime: KV pool, decode buffers, hipGraph capture,
+                               Qwen3 prefill/decode DAG                             (csrc/host/*.cpp)
+
+Objects are cached by source mtime; `python -m pegainfer_amd.build` rebuilds what changed.
+Also builds the oracle's C helper when oracle/Makefile exists (checker only).
+"""
+import concurrent.futures as cf
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+HOST = os.path.join(CSRC, "host")
+LIBDIR = os.path.join(PKG, "lib")
+OBJDIR = os.path.join(PKG, "build")
+ARCH = "gfx950"
+
+KERNEL_LIB = os.path.join(LIBDIR, "libpegainfer_kernels_hip.so")
+HOST_LIB = os.path.join(LIBDIR, "libpegainfer_qwen3.so")
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found (need ROCm >= 7.0 with gfx950 support)")
+
+
+def _newer(src_list, target):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in src_list)
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("build failed: %s\n%s" % (" ".join(cmd), r.stdout))
+    return r.stdout
+
+
+def _compile(src, extra, headers):
+    obj = os.path.join(OBJDIR, os.path.basename(src) + ".o")
+    if _newer([src] + headers, obj):
+        _run([_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall",
+              "-Wno-unused-function", "-I", os.path.join(ROOT, "include"), "-I", CSRC] + extra +
+             ["-c", src, "-o", obj])
+    return obj
+
+
+def build(verbose=False, force=False):
+    os.makedirs(LIBDIR, exist_ok=True)
+    os.makedirs(OBJDIR, exist_ok=True)
+    if force:
+        for f in os.listdir(OBJDIR):
+            os.remove(os.path.join(OBJDIR, f))
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers += [os.path.join(ROOT, "include", f) for f in os.listdir(os.path.join(ROOT, "include"))]
+    ksrcs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+    hsrcs, hheaders = [], []
+    if os.path.isdir(HOST):
+        hsrcs = sorted(os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".cpp"))
+        hheaders = [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".h")]
+    with cf.ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 4)) as ex:
+        kfut = [ex.submit(_compile, s, [], headers) for s in ksrcs]
+        hfut = [ex.submit(_compile, s, ["-x", "hip", "-I", HOST], headers + hheaders) for s in hsrcs]
+        kobjs = [f.result() for f in kfut]
+        hobjs = [f.result() for f in hfut]
+    if _newer(kobjs, KERNEL_LIB):
+        _run([_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", KERNEL_LIB] + kobjs)
+    if hobjs and _newer(hobjs + [KERNEL_LIB], HOST_LIB):
+        _run([_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", HOST_LIB] + hobjs +
+             ["-L", LIBDIR, "-lpegainfer_kernels_hip", "-Wl,-rpath,$ORIGIN"])
+    if verbose:
+        print("built", KERNEL_LIB, HOST_LIB if hobjs else "")
+    return KERNEL_LIB, (HOST_LIB if hobjs else None)
+
+
+if __name__ == "__main__":
+    build(verbose=True, force="--force" in sys.argv)

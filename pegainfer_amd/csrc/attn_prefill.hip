@@ -1,0 +1,373 @@
+// Causal GQA prefill attention over the paged KV cache for gfx950 (replaces FlashInfer
+// BatchPrefillWithPagedKVCacheDispatched / SinglePrefillWithKVCacheDispatched behind
+// batch_prefill_paged_cuda* and single_prefill_cuda, reference csrc/paged_attention.cu:399-608),
+// plus the host-side plan helpers (FA2DetermineCtaTileQ restated, :326-397).
+//
+// MFMA-bound (dense QK^T / PV contractions).  Flash-attention structure for wave64 + MFMA:
+//   * one workgroup (4 waves) per plan tile x kv head; a plan tile = cta_tile_q packed rows where
+//     packed row r -> (token r / GROUP, head kvh*GROUP + r % GROUP), so the GROUP query heads that
+//     share a KV head share every K/V tile staged in LDS.
+//   * swapped product S^T = K . Q^T with v_mfma_f32_16x16x32_bf16: the C fragment then holds, per
+//     lane, 4 consecutive KV tokens of ONE query row -> the row max / row sum are lane-local plus
+//     two cross-row shuffles, and bf16(P^T) is already the B operand of O^T = V^T . P^T with no
+//     cross-lane movement (k-slot permutation applied identically to the V^T fragment).
+//   * K tile [64 tok][128] in LDS with slot ^= row&15 (conflict-free ds_read_b128 A fragments);
+//     V tile transposed on the way into LDS (4 rows -> 8 x ds_write_b64 after an in-register 4x8
+//     transpose; row pitch 136 B) so V^T fragments are two ds_read_b64 each.
+//   * global->register prefetch of the next KV tile overlaps the MFMAs of the current one.
+//   * online softmax in the exp2 domain (sm_scale*log2e folded), fp32 accumulation, bf16 output.
+// kv_len comes from the page table; the causal rule is kv_idx <= q_idx + (kv_len - qo_len).
+#include "common.h"
+
+namespace pk {
+
+constexpr int TKV = 64;           // KV tokens per LDS tile
+constexpr int VT_PITCH = 68;      // bf16 elements per V^T row (64 tokens + 4 pad) = 136 B
+
+struct PagedAddr {
+  const int* page_indices; int pbase; int page_size; long stride_page; long row_stride; long head_off;
+  long k_off, v_off;
+  __device__ __forceinline__ long row(int t) const {
+    const int page = page_indices[pbase + t / page_size];
+    return (long)page * stride_page + (long)(t % page_size) * row_stride + head_off;
+  }
+};
+struct ContigAddr {  // HND: cache[head][pos][dim]
+  long head_base; int D; long k_off, v_off;
+  __device__ __forceinline__ long row(int t) const { return head_base + (long)t * D; }
+};
+
+template <int QBLK, typename Addr>
+__device__ __forceinline__ void prefill_tile(const Half* __restrict__ q_base, Half* __restrict__ o_base,
+                                             const Half* __restrict__ kbuf, const Half* __restrict__ vbuf,
+                                             const Addr& addr, int qo_len, int kv_len, int tile_row0,
+                                             int tile_rows, int group, long q_stride_n, float scale_log2,
+                                             u32x4* ks /*[TKV*16]*/, Half* vt /*[128*VT_PITCH]*/) {
+  constexpr int D = 128;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int packed_len = qo_len * group;
+  const int tile_end = (tile_row0 + tile_rows) < packed_len ? (tile_row0 + tile_rows) : packed_len;
+  const int causal_off = kv_len - qo_len;
+
+  // per-lane query rows (one per 16-row block)
+  int qtok[QBLK];
+  bool qok[QBLK];
+  bf16x8_t qf[QBLK][4];
+  long o_off[QBLK];
+#pragma unroll
+  for (int qb = 0; qb < QBLK; ++qb) {
+    const int r = tile_row0 + (wave * QBLK + qb) * 16 + l15;
+    qok[qb] = r < tile_end;
+    const int rc = qok[qb] ? r : tile_row0;
+    qtok[qb] = rc / group;
+    const long off = (long)qtok[qb] * q_stride_n + (long)(rc % group) * D;
+    o_off[qb] = off;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      qf[qb][s] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(q_base + off + s * 32 + g * 8));
+  }
+  // wave-uniform bound on the KV positions this wave can attend to
+  int wave_last_row = tile_row0 + (wave * QBLK + QBLK) * 16 - 1;
+  if (wave_last_row >= tile_end) wave_last_row = tile_end - 1;
+  const bool wave_active = tile_row0 + wave * QBLK * 16 < tile_end;
+  const int wave_kv_end = wave_active ? wave_last_row / group + causal_off + 1 : 0;
+  const int cta_kv_end_raw = (tile_end - 1) / group + causal_off + 1;
+  const int cta_kv_end = cta_kv_end_raw < kv_len ? cta_kv_end_raw : kv_len;
+
+  f32x4 acc_o[QBLK][8];
+  float m_run[QBLK], l_run[QBLK];
+#pragma unroll
+  for (int qb = 0; qb < QBLK; ++qb) {
+    m_run[qb] = -INFINITY;
+    l_run[qb] = 0.f;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) acc_o[qb][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  // staging roles
+  const int k_row[4] = {(int)(threadIdx.x >> 4), (int)(threadIdx.x >> 4) + 16, (int)(threadIdx.x >> 4) + 32,
+                        (int)(threadIdx.x >> 4) + 48};
+  const int k_slot = threadIdx.x & 15;
+  const int v_tq = threadIdx.x >> 4, v_dc = threadIdx.x & 15;
+  u32x4 kreg[4], vreg[4];
+  auto load_tile = [&](int kv0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int t = kv0 + k_row[j];
+      t = t < kv_len ? t : kv_len - 1;
+      kreg[j] = *reinterpret_cast<const u32x4*>(kbuf + addr.row(t) + addr.k_off + k_slot * 8);
+      int tv = kv0 + v_tq * 4 + j;
+      tv = tv < kv_len ? tv : kv_len - 1;
+      vreg[j] = *reinterpret_cast<const u32x4*>(vbuf + addr.row(tv) + addr.v_off + v_dc * 8);
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ks[k_row[j] * 16 + (k_slot ^ (k_row[j] & 15))] = kreg[j];
+    // 4 tokens x 8 dims -> 8 rows of V^T, 4 tokens each
+    const uint32_t w[4][4] = {{vreg[0].x, vreg[0].y, vreg[0].z, vreg[0].w},
+                              {vreg[1].x, vreg[1].y, vreg[1].z, vreg[1].w},
+                              {vreg[2].x, vreg[2].y, vreg[2].z, vreg[2].w},
+                              {vreg[3].x, vreg[3].y, vreg[3].z, vreg[3].w}};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {  // dims 2c, 2c+1
+      u32x2 lo, hi;
+      lo.x = (w[0][c] & 0xFFFFu) | (w[1][c] << 16);
+      lo.y = (w[2][c] & 0xFFFFu) | (w[3][c] << 16);
+      hi.x = (w[0][c] >> 16) | (w[1][c] & 0xFFFF0000u);
+      hi.y = (w[2][c] >> 16) | (w[3][c] & 0xFFFF0000u);
+      *reinterpret_cast<u32x2*>(vt + (v_dc * 8 + 2 * c) * VT_PITCH + v_tq * 4) = lo;
+      *reinterpret_cast<u32x2*>(vt + (v_dc * 8 + 2 * c + 1) * VT_PITCH + v_tq * 4) = hi;
+    }
+  };
+
+  if (cta_kv_end > 0) load_tile(0);
+  for (int kv0 = 0; kv0 < cta_kv_end; kv0 += TKV) {
+    __syncthreads();  // previous tile fully consumed
+    store_tile();
+    __syncthreads();
+    if (kv0 + TKV < cta_kv_end) load_tile(kv0 + TKV);  // prefetch under the MFMAs
+    if (!wave_active || kv0 >= wave_kv_end) continue;
+
+    // ---- S^T = K . Q^T ----
+    f32x4 sacc[QBLK][4];
+#pragma unroll
+    for (int qb = 0; qb < QBLK; ++qb)
+#pragma unroll
+      for (int tb = 0; tb < 4; ++tb) sacc[qb][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tb = 0; tb < 4; ++tb) {
+      const int row = tb * 16 + l15;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const bf16x8_t kf = __builtin_bit_cast(bf16x8_t, ks[row * 16 + ((s * 4 + g) ^ (row & 15))]);
+#pragma unroll
+        for (int qb = 0; qb < QBLK; ++qb)
+          sacc[qb][tb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qb][s], sacc[qb][tb], 0, 0, 0);
+      }
+    }
+    // ---- online softmax per query row (= per lane column) ----
+    bf16x8_t pf[QBLK][2];
+#pragma unroll
+    for (int qb = 0; qb < QBLK; ++qb) {
+      const int limit = qok[qb] ? qtok[qb] + causal_off : -1;  // last visible kv index
+      float mx = -INFINITY;
+#pragma unroll
+      for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int kvt = kv0 + tb * 16 + g * 4 + i;
+          float v = sacc[qb][tb][i] * scale_log2;
+          v = (kvt <= limit && kvt < kv_len) ? v : -INFINITY;
+          sacc[qb][tb][i] = v;
+          mx = fmaxf(mx, v);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, kWave));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, kWave));
+      const float mn = fmaxf(m_run[qb], mx);
+      const float msafe = mn == -INFINITY ? 0.f : mn;
+      const float alpha = exp2f(m_run[qb] - msafe);
+      m_run[qb] = mn;
+      float ps = 0.f;
+      float p[4][4];
+#pragma unroll
+      for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          p[tb][i] = exp2f(sacc[qb][tb][i] - msafe);
+          ps += p[tb][i];
+        }
+      l_run[qb] = l_run[qb] * alpha + ps;  // lane-partial; summed over g at the end
+#pragma unroll
+      for (int d = 0; d < 8; ++d) acc_o[qb][d] *= alpha;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        u32x4 pk4;
+        pk4.x = pack_bf2(p[2 * kb][0], p[2 * kb][1]);
+        pk4.y = pack_bf2(p[2 * kb][2], p[2 * kb][3]);
+        pk4.z = pack_bf2(p[2 * kb + 1][0], p[2 * kb + 1][1]);
+        pk4.w = pack_bf2(p[2 * kb + 1][2], p[2 * kb + 1][3]);
+        pf[qb][kb] = __builtin_bit_cast(bf16x8_t, pk4);
+      }
+    }
+    // ---- O^T += V^T . P^T ----
+#pragma unroll
+    for (int db = 0; db < 8; ++db) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        const Half* vrow = vt + (db * 16 + l15) * VT_PITCH + kb * 32 + g * 4;
+        u32x2 a0 = *reinterpret_cast<const u32x2*>(vrow);
+        u32x2 a1 = *reinterpret_cast<const u32x2*>(vrow + 16);
+        const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, u32x4{a0.x, a0.y, a1.x, a1.y});
+#pragma unroll
+        for (int qb = 0; qb < QBLK; ++qb)
+          acc_o[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qb][kb], acc_o[qb][db], 0, 0, 0);
+      }
+    }
+  }
+  // ---- epilogue: O = acc / l ; lane (row l15, g) holds dims db*16 + g*4 .. +3 ----
+#pragma unroll
+  for (int qb = 0; qb < QBLK; ++qb) {
+    float l = l_run[qb];
+    l += __shfl_xor(l, 16, kWave);
+    l += __shfl_xor(l, 32, kWave);
+    if (!qok[qb]) continue;
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+#pragma unroll
+    for (int db = 0; db < 8; ++db) {
+      u32x2 o;
+      o.x = pack_bf2(acc_o[qb][db][0] * inv, acc_o[qb][db][1] * inv);
+      o.y = pack_bf2(acc_o[qb][db][2] * inv, acc_o[qb][db][3] * inv);
+      *reinterpret_cast<u32x2*>(o_base + o_off[qb] + db * 16 + g * 4) = o;
+    }
+  }
+}
+
+template <int QBLK>
+__global__ __launch_bounds__(256) void batch_prefill_paged_kernel(
+    const Half* __restrict__ q, Half* __restrict__ out, const Half* __restrict__ kv, long k_off, long v_off,
+    const int* __restrict__ page_indices, const int* __restrict__ page_indptr,
+    const int* __restrict__ last_page_len, const int* __restrict__ q_indptr,
+    const int* __restrict__ request_indices, const int* __restrict__ qo_tile_indices, int num_qo_heads,
+    int num_kv_heads, int page_size, long stride_page, float scale_log2, int cta_tile_q) {
+  __shared__ __attribute__((aligned(16))) u32x4 ks[TKV * 16];
+  __shared__ __attribute__((aligned(16))) Half vt[128 * VT_PITCH];
+  const int tile = blockIdx.x, kvh = blockIdx.y;
+  const int req = request_indices[tile];
+  const int group = num_qo_heads / num_kv_heads;
+  const int q0 = q_indptr[req];
+  const int qo_len = q_indptr[req + 1] - q0;
+  const int pbase = page_indptr[req];
+  const int npages = page_indptr[req + 1] - pbase;
+  const int kv_len = npages > 0 ? (npages - 1) * page_size + last_page_len[req] : 0;
+  const int row0 = qo_tile_indices[tile] * cta_tile_q;
+  if (row0 >= qo_len * group || kv_len <= 0) return;
+  PagedAddr addr{page_indices, pbase, page_size, stride_page, (long)num_kv_heads * 128, (long)kvh * 128, k_off, v_off};
+  const long q_stride_n = (long)num_qo_heads * 128;
+  const long qo_base = (long)q0 * q_stride_n + (long)kvh * group * 128;
+  prefill_tile<QBLK>(q + qo_base, out + qo_base, kv, kv, addr, qo_len, kv_len, row0, cta_tile_q, group,
+                     q_stride_n, scale_log2, ks, vt);
+}
+
+template <int QBLK>
+__global__ __launch_bounds__(256) void single_prefill_kernel(const Half* __restrict__ q, Half* __restrict__ out,
+                                                             const Half* __restrict__ k_cache,
+                                                             const Half* __restrict__ v_cache, int num_qo_heads,
+                                                             int num_kv_heads, int seq_len, int kv_len,
+                                                             int max_seq_len, float scale_log2, int cta_tile_q) {
+  __shared__ __attribute__((aligned(16))) u32x4 ks[TKV * 16];
+  __shared__ __attribute__((aligned(16))) Half vt[128 * VT_PITCH];
+  const int kvh = blockIdx.y;
+  const int group = num_qo_heads / num_kv_heads;
+  const int row0 = blockIdx.x * cta_tile_q;
+  if (row0 >= seq_len * group || kv_len <= 0) return;
+  ContigAddr addr{(long)kvh * max_seq_len * 128, 128, 0, 0};
+  const long q_stride_n = (long)num_qo_heads * 128;
+  const long qo_base = (long)kvh * group * 128;
+  prefill_tile<QBLK>(q + qo_base, out + qo_base, k_cache, v_cache, addr, seq_len, kv_len, row0, cta_tile_q,
+                     group, q_stride_n, scale_log2, ks, vt);
+}
+
+// ---- host plan helpers: FlashInfer FA2DetermineCtaTileQ restated (utils.cuh, un-vendored) ----
+static inline uint32_t fa2_cta_tile_q(int64_t avg_packed_qo_len, int head_dim) {
+  if (avg_packed_qo_len > 64 && head_dim < 256) return 128;
+  return avg_packed_qo_len > 16 ? 64 : 16;
+}
+static inline uint32_t resolve_cta_tile_q(int64_t packed, int head_dim, int override_q) {
+  if (override_q == 0) return fa2_cta_tile_q(packed, head_dim);
+  if (override_q == 16 || override_q == 64 || override_q == 128) return (uint32_t)override_q;
+  return 0;
+}
+
+}  // namespace pk
+
+using namespace pk;
+
+extern "C" {
+
+int32_t batch_prefill_paged_num_tiles(int32_t seq_len, int32_t num_qo_heads, int32_t num_kv_heads, int32_t head_dim) {
+  const int64_t packed = (int64_t)seq_len * (num_qo_heads / num_kv_heads);
+  const uint32_t t = fa2_cta_tile_q(packed, head_dim);
+  return (int32_t)((packed + t - 1) / t);
+}
+int32_t batch_prefill_paged_num_tiles_with_cta_tile_q(int32_t seq_len, int32_t num_qo_heads, int32_t num_kv_heads,
+                                                      int32_t head_dim, int32_t cta_tile_q_override) {
+  const int64_t packed = (int64_t)seq_len * (num_qo_heads / num_kv_heads);
+  const uint32_t t = resolve_cta_tile_q(packed, head_dim, cta_tile_q_override);
+  if (t == 0) return -1;
+  return (int32_t)((packed + t - 1) / t);
+}
+int32_t batch_prefill_cta_tile_q(int32_t total_seq_len, int32_t num_qo_heads, int32_t num_kv_heads, int32_t head_dim) {
+  return (int32_t)fa2_cta_tile_q((int64_t)total_seq_len * (num_qo_heads / num_kv_heads), head_dim);
+}
+int32_t batch_prefill_cta_tile_q_with_override(int32_t total_seq_len, int32_t num_qo_heads, int32_t num_kv_heads,
+                                               int32_t head_dim, int32_t cta_tile_q_override) {
+  return (int32_t)resolve_cta_tile_q((int64_t)total_seq_len * (num_qo_heads / num_kv_heads), head_dim,
+                                     cta_tile_q_override);
+}
+
+int32_t batch_prefill_paged_cuda_with_cta_tile_q(
+    const Half* q, Half* output, const Half* kv_data, int64_t k_offset_elems, int64_t v_offset_elems,
+    const int32_t* page_indices, const int32_t* page_indptr, const int32_t* last_page_len_d,
+    const int32_t* q_indptr, const int32_t* request_indices, const int32_t* qo_tile_indices,
+    const int32_t* kv_tile_indices, const int32_t* kv_chunk_size_ptr, const uint32_t* total_num_rows,
+    int32_t num_qo_heads, int32_t num_kv_heads, int32_t head_dim, int32_t page_size, int32_t seq_len,
+    int32_t batch_size, int32_t padded_batch_size, int64_t stride_page, float sm_scale,
+    int32_t cta_tile_q_override, pegainfer_stream_t stream) {
+  (void)kv_tile_indices; (void)kv_chunk_size_ptr; (void)total_num_rows; (void)batch_size;
+  if (head_dim != 128 || num_kv_heads <= 0 || num_qo_heads % num_kv_heads != 0)
+    return (int32_t)hipErrorInvalidValue;
+  const int group = num_qo_heads / num_kv_heads;
+  const uint32_t cta = resolve_cta_tile_q((int64_t)seq_len * group, head_dim, cta_tile_q_override);
+  if (cta == 0) return -1;
+  if (padded_batch_size <= 0) return 0;
+  const float scale_log2 = sm_scale * 1.4426950408889634f;
+  dim3 grid(padded_batch_size, num_kv_heads);
+  hipStream_t s = as_stream(stream);
+  if (cta == 128)
+    batch_prefill_paged_kernel<2><<<grid, 256, 0, s>>>(q, output, kv_data, k_offset_elems, v_offset_elems,
+                                                       page_indices, page_indptr, last_page_len_d, q_indptr,
+                                                       request_indices, qo_tile_indices, num_qo_heads,
+                                                       num_kv_heads, page_size, stride_page, scale_log2, 128);
+  else
+    batch_prefill_paged_kernel<1><<<grid, 256, 0, s>>>(q, output, kv_data, k_offset_elems, v_offset_elems,
+                                                       page_indices, page_indptr, last_page_len_d, q_indptr,
+                                                       request_indices, qo_tile_indices, num_qo_heads,
+                                                       num_kv_heads, page_size, stride_page, scale_log2, (int)cta);
+  return (int32_t)hipGetLastError();
+}
+
+int32_t batch_prefill_paged_cuda(
+    const Half* q, Half* output, const Half* kv_data, int64_t k_offset_elems, int64_t v_offset_elems,
+    const int32_t* page_indices, const int32_t* page_indptr, const int32_t* last_page_len_d,
+    const int32_t* q_indptr, const int32_t* request_indices, const int32_t* qo_tile_indices,
+    const int32_t* kv_tile_indices, const int32_t* kv_chunk_size_ptr, const uint32_t* total_num_rows,
+    int32_t num_qo_heads, int32_t num_kv_heads, int32_t head_dim, int32_t page_size, int32_t seq_len,
+    int32_t batch_size, int32_t padded_batch_size, int64_t stride_page, float sm_scale,
+    pegainfer_stream_t stream) {
+  return batch_prefill_paged_cuda_with_cta_tile_q(q, output, kv_data, k_offset_elems, v_offset_elems,
+                                                  page_indices, page_indptr, last_page_len_d, q_indptr,
+                                                  request_indices, qo_tile_indices, kv_tile_indices,
+                                                  kv_chunk_size_ptr, total_num_rows, num_qo_heads, num_kv_heads,
+                                                  head_dim, page_size, seq_len, batch_size, padded_batch_size,
+                                                  stride_page, sm_scale, 0, stream);
+}
+
+int32_t single_prefill_cuda(const Half* q, Half* output, const Half* k_cache, const Half* v_cache,
+                            int32_t num_qo_heads, int32_t num_kv_heads, int32_t head_dim, int32_t seq_len,
+                            int32_t kv_len, int32_t max_seq_len, float sm_scale, pegainfer_stream_t stream) {
+  if (head_dim != 128 || num_kv_heads <= 0 || num_qo_heads % num_kv_heads != 0)
+    return (int32_t)hipErrorInvalidValue;
+  if (seq_len <= 0) return 0;
+  const int group = num_qo_heads / num_kv_heads;
+  const int packed = seq_len * group;
+  const float scale_log2 = sm_scale * 1.4426950408889634f;
+  dim3 grid(ceil_div(packed, 128), num_kv_heads);
+  single_prefill_kernel<2><<<grid, 256, 0, as_stream(stream)>>>(q, output, k_cache, v_cache, num_qo_heads,
+                                                                num_kv_heads, seq_len, kv_len, max_seq_len,
+                                                                scale_log2, 128);
+  return (int32_t)hipGetLastError();
+}
+
+}  // extern "C"

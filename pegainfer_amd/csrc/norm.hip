@@ -1,0 +1,201 @@
+// RMSNorm family for gfx950.  One 256-thread workgroup (4 waves) per row, 16-byte loads,
+// fp32 sum of squares reduced with DPP/bpermute butterflies, the row re-read from L1/L2 for
+// the scale pass (rows are <= 16 KB).  Rounding points follow the reference exactly:
+//   rms_norm            out = bf16(f32(x) * inv_rms * f32(w))                (single rounding)
+//   rms_norm_offset     same with (1 + w)                                     (Gemma / Qwen3.5)
+//   fused_add_rms_norm  hidden = bf16(h + r);  out = bf16((h + r)_fp32 * inv_rms * w)
+//                       - ONE kernel, no memcpy node, `out` is never used as scratch
+//   rms_norm_gated      per head: bf16(x * inv_rms * w_f32 * silu(gate))     (csrc/norm.cu:17-61)
+// Reference: csrc/flashinfer_norm.cu:49-133 (FlashInfer RMSNorm / FusedAddRMSNorm / GemmaRMSNorm).
+#include "common.h"
+
+namespace pk {
+
+constexpr int kNormBlock = 256;
+constexpr int kNormWaves = kNormBlock / 64;
+
+template <bool OFFSET, bool VEC>
+__global__ __launch_bounds__(kNormBlock) void rms_norm_kernel(const Half* __restrict__ x,
+                                                              const Half* __restrict__ w,
+                                                              Half* __restrict__ out, int d, float eps) {
+  __shared__ float red[kNormWaves];
+  const Half* xr = x + (size_t)blockIdx.x * d;
+  Half* orow = out + (size_t)blockIdx.x * d;
+  float ss = 0.f;
+  if (VEC) {
+    const int nvec = d >> 3;
+    for (int i = threadIdx.x; i < nvec; i += kNormBlock) {
+      u32x4 v = reinterpret_cast<const u32x4*>(xr)[i];
+      float a;
+      a = bf_lo(v.x); ss += a * a; a = bf_hi(v.x); ss += a * a;
+      a = bf_lo(v.y); ss += a * a; a = bf_hi(v.y); ss += a * a;
+      a = bf_lo(v.z); ss += a * a; a = bf_hi(v.z); ss += a * a;
+      a = bf_lo(v.w); ss += a * a; a = bf_hi(v.w); ss += a * a;
+    }
+  } else {
+    for (int i = threadIdx.x; i < d; i += kNormBlock) {
+      float a = bf2f(xr[i]);
+      ss += a * a;
+    }
+  }
+  ss = block_sum<kNormWaves>(ss, red);
+  const float inv = rsqrtf(ss / (float)d + eps);
+  const float bias = OFFSET ? 1.0f : 0.0f;
+  if (VEC) {
+    const int nvec = d >> 3;
+    for (int i = threadIdx.x; i < nvec; i += kNormBlock) {
+      u32x4 v = reinterpret_cast<const u32x4*>(xr)[i];
+      u32x4 g = reinterpret_cast<const u32x4*>(w)[i];
+      u32x4 o;
+      o.x = pack_bf2(bf_lo(v.x) * inv * (bias + bf_lo(g.x)), bf_hi(v.x) * inv * (bias + bf_hi(g.x)));
+      o.y = pack_bf2(bf_lo(v.y) * inv * (bias + bf_lo(g.y)), bf_hi(v.y) * inv * (bias + bf_hi(g.y)));
+      o.z = pack_bf2(bf_lo(v.z) * inv * (bias + bf_lo(g.z)), bf_hi(v.z) * inv * (bias + bf_hi(g.z)));
+      o.w = pack_bf2(bf_lo(v.w) * inv * (bias + bf_lo(g.w)), bf_hi(v.w) * inv * (bias + bf_hi(g.w)));
+      reinterpret_cast<u32x4*>(orow)[i] = o;
+    }
+  } else {
+    for (int i = threadIdx.x; i < d; i += kNormBlock)
+      orow[i] = f2bf(bf2f(xr[i]) * inv * (bias + bf2f(w[i])));
+  }
+}
+
+template <bool OFFSET, bool VEC>
+__global__ __launch_bounds__(kNormBlock) void fused_add_rms_norm_kernel(Half* __restrict__ hidden,
+                                                                        const Half* __restrict__ residual,
+                                                                        const Half* __restrict__ w,
+                                                                        Half* __restrict__ out, int d,
+                                                                        float eps) {
+  __shared__ float red[kNormWaves];
+  Half* hr = hidden + (size_t)blockIdx.x * d;
+  const Half* rr = residual + (size_t)blockIdx.x * d;
+  Half* orow = out + (size_t)blockIdx.x * d;
+  float ss = 0.f;
+  // pass 1: sum of squares of the UNROUNDED fp32 sum (hidden is not modified yet)
+  if (VEC) {
+    const int nvec = d >> 3;
+    for (int i = threadIdx.x; i < nvec; i += kNormBlock) {
+      u32x4 h = reinterpret_cast<const u32x4*>(hr)[i];
+      u32x4 r = reinterpret_cast<const u32x4*>(rr)[i];
+      float a;
+      a = bf_lo(h.x) + bf_lo(r.x); ss += a * a; a = bf_hi(h.x) + bf_hi(r.x); ss += a * a;
+      a = bf_lo(h.y) + bf_lo(r.y); ss += a * a; a = bf_hi(h.y) + bf_hi(r.y); ss += a * a;
+      a = bf_lo(h.z) + bf_lo(r.z); ss += a * a; a = bf_hi(h.z) + bf_hi(r.z); ss += a * a;
+      a = bf_lo(h.w) + bf_lo(r.w); ss += a * a; a = bf_hi(h.w) + bf_hi(r.w); ss += a * a;
+    }
+  } else {
+    for (int i = threadIdx.x; i < d; i += kNormBlock) {
+      float a = bf2f(hr[i]) + bf2f(rr[i]);
+      ss += a * a;
+    }
+  }
+  ss = block_sum<kNormWaves>(ss, red);
+  const float inv = rsqrtf(ss / (float)d + eps);
+  const float bias = OFFSET ? 1.0f : 0.0f;
+  // pass 2: each thread re-reads exactly the elements it will overwrite
+  if (VEC) {
+    const int nvec = d >> 3;
+    for (int i = threadIdx.x; i < nvec; i += kNormBlock) {
+      u32x4 h = reinterpret_cast<const u32x4*>(hr)[i];
+      u32x4 r = reinterpret_cast<const u32x4*>(rr)[i];
+      u32x4 g = reinterpret_cast<const u32x4*>(w)[i];
+      u32x4 nh, o;
+      float s0, s1;
+      s0 = bf_lo(h.x) + bf_lo(r.x); s1 = bf_hi(h.x) + bf_hi(r.x);
+      nh.x = pack_bf2(s0, s1); o.x = pack_bf2(s0 * inv * (bias + bf_lo(g.x)), s1 * inv * (bias + bf_hi(g.x)));
+      s0 = bf_lo(h.y) + bf_lo(r.y); s1 = bf_hi(h.y) + bf_hi(r.y);
+      nh.y = pack_bf2(s0, s1); o.y = pack_bf2(s0 * inv * (bias + bf_lo(g.y)), s1 * inv * (bias + bf_hi(g.y)));
+      s0 = bf_lo(h.z) + bf_lo(r.z); s1 = bf_hi(h.z) + bf_hi(r.z);
+      nh.z = pack_bf2(s0, s1); o.z = pack_bf2(s0 * inv * (bias + bf_lo(g.z)), s1 * inv * (bias + bf_hi(g.z)));
+      s0 = bf_lo(h.w) + bf_lo(r.w); s1 = bf_hi(h.w) + bf_hi(r.w);
+      nh.w = pack_bf2(s0, s1); o.w = pack_bf2(s0 * inv * (bias + bf_lo(g.w)), s1 * inv * (bias + bf_hi(g.w)));
+      reinterpret_cast<u32x4*>(hr)[i] = nh;
+      reinterpret_cast<u32x4*>(orow)[i] = o;
+    }
+  } else {
+    for (int i = threadIdx.x; i < d; i += kNormBlock) {
+      float s = bf2f(hr[i]) + bf2f(rr[i]);
+      hr[i] = f2bf(s);
+      orow[i] = f2bf(s * inv * (bias + bf2f(w[i])));
+    }
+  }
+}
+
+// one wave per head; block = 4 heads
+__global__ __launch_bounds__(256) void rms_norm_gated_kernel(const Half* __restrict__ x,
+                                                             const float* __restrict__ w,
+                                                             const Half* __restrict__ gate,
+                                                             Half* __restrict__ out, int num_heads,
+                                                             int head_dim, float eps) {
+  const int head = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (head >= num_heads) return;
+  const int lane = threadIdx.x & 63;
+  const size_t base = (size_t)head * head_dim;
+  float ss = 0.f;
+  for (int i = lane; i < head_dim; i += 64) {
+    float a = bf2f(x[base + i]);
+    ss += a * a;
+  }
+  ss = wave_sum(ss);
+  const float inv = rsqrtf(ss / (float)head_dim + eps);
+  for (int i = lane; i < head_dim; i += 64) {
+    float normed = bf2f(x[base + i]) * inv * w[i];
+    float g = bf2f(gate[base + i]);
+    out[base + i] = f2bf(normed * (g / (1.0f + expf(-g))));
+  }
+}
+
+template <bool OFFSET>
+static void launch_rms(const Half* x, const Half* w, Half* out, int d, int rows, float eps, hipStream_t s) {
+  if (d <= 0 || rows <= 0) return;
+  const bool vec = (d & 7) == 0 && host_aligned16(x) && host_aligned16(w) && host_aligned16(out);
+  if (vec) rms_norm_kernel<OFFSET, true><<<rows, kNormBlock, 0, s>>>(x, w, out, d, eps);
+  else rms_norm_kernel<OFFSET, false><<<rows, kNormBlock, 0, s>>>(x, w, out, d, eps);
+}
+
+static void launch_fused(Half* hidden, const Half* residual, const Half* w, Half* out, int d, int rows,
+                         float eps, hipStream_t s) {
+  if (d <= 0 || rows <= 0) return;
+  const bool vec = (d & 7) == 0 && host_aligned16(hidden) && host_aligned16(residual) &&
+                   host_aligned16(w) && host_aligned16(out);
+  if (vec) fused_add_rms_norm_kernel<false, true><<<rows, kNormBlock, 0, s>>>(hidden, residual, w, out, d, eps);
+  else fused_add_rms_norm_kernel<false, false><<<rows, kNormBlock, 0, s>>>(hidden, residual, w, out, d, eps);
+}
+
+}  // namespace pk
+
+using namespace pk;
+
+extern "C" {
+
+void rms_norm_cuda(const Half* x, const Half* weight, Half* out, int32_t n, float eps, pegainfer_stream_t stream) {
+  launch_rms<false>(x, weight, out, n, 1, eps, as_stream(stream));
+}
+void rms_norm_batched_cuda(const Half* x, const Half* weight, Half* out, int32_t hidden_dim, int32_t seq_len,
+                           float eps, pegainfer_stream_t stream) {
+  launch_rms<false>(x, weight, out, hidden_dim, seq_len, eps, as_stream(stream));
+}
+void rms_norm_offset_cuda(const Half* x, const Half* weight, Half* out, int32_t n, float eps,
+                          pegainfer_stream_t stream) {
+  launch_rms<true>(x, weight, out, n, 1, eps, as_stream(stream));
+}
+void rms_norm_batched_offset_cuda(const Half* x, const Half* weight, Half* out, int32_t hidden_dim,
+                                  int32_t seq_len, float eps, pegainfer_stream_t stream) {
+  launch_rms<true>(x, weight, out, hidden_dim, seq_len, eps, as_stream(stream));
+}
+void fused_add_rms_norm_cuda(Half* hidden, const Half* residual, const Half* weight, Half* out, int32_t n,
+                             float eps, pegainfer_stream_t stream) {
+  launch_fused(hidden, residual, weight, out, n, 1, eps, as_stream(stream));
+}
+void fused_add_rms_norm_batched_cuda(Half* hidden, const Half* residual, const Half* weight, Half* out,
+                                     int32_t hidden_dim, int32_t batch_size, float eps,
+                                     pegainfer_stream_t stream) {
+  launch_fused(hidden, residual, weight, out, hidden_dim, batch_size, eps, as_stream(stream));
+}
+void rms_norm_gated_cuda(const Half* x, const float* weight, const Half* gate, Half* out, int32_t num_heads,
+                         int32_t head_dim, float eps, pegainfer_stream_t stream) {
+  if (num_heads <= 0 || head_dim <= 0) return;
+  rms_norm_gated_kernel<<<ceil_div(num_heads, 4), 256, 0, as_stream(stream)>>>(x, weight, gate, out,
+                                                                              num_heads, head_dim, eps);
+}
+
+}  // extern "C"

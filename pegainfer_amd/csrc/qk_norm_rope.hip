@@ -1,0 +1,95 @@
+// Per-head QK RMSNorm + NeoX (half-split) RoPE, in place, for gfx950.
+// One wave per (head, token): lane l owns the RoPE pair (d, d+half) for d = l, l+64, ...,
+// the sum of squares is a single wave64 butterfly (no LDS, no barrier - the reference needs
+// 3 __syncthreads and a 128-thread block because its warp is 32 wide).
+// Rounding sequence is the reference's (csrc/prefill_attention.cu:55-84):
+//   n = bf16(x*inv_rms);  m = bf16(f32(n)*f32(w));
+//   out[d]      = bf16(m[d]*c - m[d+half]*s)
+//   out[d+half] = bf16(m[d]*s + m[d+half]*c)          c,s = bf16 table[pos*head_dim + d]
+#include "common.h"
+
+namespace pk {
+
+constexpr int kMaxPairsPerLane = 4;  // head_dim <= 512
+
+__global__ __launch_bounds__(256) void qk_norm_rope_kernel(
+    Half* __restrict__ q, Half* __restrict__ k, const Half* __restrict__ q_w, const Half* __restrict__ k_w,
+    const Half* __restrict__ cos_cache, const Half* __restrict__ sin_cache, int num_q_heads, int num_kv_heads,
+    int head_dim, int tokens, int start_pos, const int* __restrict__ positions, float eps) {
+  const int heads = num_q_heads + num_kv_heads;
+  const long unit = (long)blockIdx.x * 4 + (threadIdx.x >> 6);  // (token, head) pair index
+  if (unit >= (long)tokens * heads) return;
+  const int token = (int)(unit / heads);
+  const int hg = (int)(unit - (long)token * heads);
+  const int lane = threadIdx.x & 63;
+  const bool is_q = hg < num_q_heads;
+  const int head = is_q ? hg : hg - num_q_heads;
+  Half* data = (is_q ? q : k) + (size_t)token * (is_q ? num_q_heads : num_kv_heads) * head_dim +
+               (size_t)head * head_dim;
+  const Half* w = is_q ? q_w : k_w;
+  const int half = head_dim >> 1;
+  const int pos = positions ? positions[token] : start_pos + token;
+  const Half* crow = cos_cache + (size_t)pos * head_dim;
+  const Half* srow = sin_cache + (size_t)pos * head_dim;
+
+  float lo[kMaxPairsPerLane], hi[kMaxPairsPerLane];
+  float ss = 0.f;
+#pragma unroll
+  for (int j = 0; j < kMaxPairsPerLane; ++j) {
+    const int d = lane + j * 64;
+    lo[j] = hi[j] = 0.f;
+    if (d < half) {
+      lo[j] = bf2f(data[d]);
+      hi[j] = bf2f(data[d + half]);
+      ss += lo[j] * lo[j];
+      ss += hi[j] * hi[j];
+    }
+  }
+  ss = wave_sum(ss);
+  const float inv = rsqrtf(ss / (float)head_dim + eps);
+#pragma unroll
+  for (int j = 0; j < kMaxPairsPerLane; ++j) {
+    const int d = lane + j * 64;
+    if (d < half) {
+      const float ml = bf16_round_f(bf16_round_f(lo[j] * inv) * bf2f(w[d]));
+      const float mh = bf16_round_f(bf16_round_f(hi[j] * inv) * bf2f(w[d + half]));
+      const float c = bf2f(crow[d]), s = bf2f(srow[d]);
+      data[d] = f2bf(ml * c - mh * s);
+      data[d + half] = f2bf(ml * s + mh * c);
+    }
+  }
+}
+
+static void launch(Half* q, Half* k, const Half* qw, const Half* kw, const Half* c, const Half* s, int hq,
+                   int hkv, int hd, int tokens, int start_pos, const int* positions, float eps,
+                   hipStream_t stream) {
+  if (tokens <= 0 || hq + hkv <= 0) return;
+  const long units = (long)tokens * (hq + hkv);
+  qk_norm_rope_kernel<<<ceil_div(units, 4), 256, 0, stream>>>(q, k, qw, kw, c, s, hq, hkv, hd, tokens,
+                                                              start_pos, positions, eps);
+}
+
+}  // namespace pk
+
+extern "C" {
+
+// ffi.rs:164 - prefill: positions are start_pos + token
+void prefill_qk_norm_rope_only_cuda(Half* q_batch, Half* k_batch, const Half* q_norm_weight,
+                                    const Half* k_norm_weight, const Half* cos_cache, const Half* sin_cache,
+                                    int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim,
+                                    int32_t seq_len, int32_t start_pos, float rms_eps,
+                                    pegainfer_stream_t stream) {
+  pk::launch(q_batch, k_batch, q_norm_weight, k_norm_weight, cos_cache, sin_cache, num_q_heads, num_kv_heads,
+             head_dim, seq_len, start_pos, nullptr, rms_eps, pk::as_stream(stream));
+}
+
+// ffi.rs:1143 - decode / multi-request prefill: per-token positions from a device array
+void qk_norm_rope_batched_decode_cuda(Half* q, Half* k, const Half* q_norm_weight, const Half* k_norm_weight,
+                                      const Half* cos_cache, const Half* sin_cache, const int32_t* positions,
+                                      int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim,
+                                      int32_t batch_size, float rms_eps, pegainfer_stream_t stream) {
+  pk::launch(q, k, q_norm_weight, k_norm_weight, cos_cache, sin_cache, num_q_heads, num_kv_heads, head_dim,
+             batch_size, 0, positions, rms_eps, pk::as_stream(stream));
+}
+
+}  // extern "C"

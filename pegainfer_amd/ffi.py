@@ -1,0 +1,92 @@
+"""ctypes binding of the C ABI - the Python twin of the reference's
+``pegainfer-kernels/src/ffi.rs`` (one ``extern "C"`` block, raw device pointers, stream last).
+
+Prototypes are parsed from ``include/*.h`` so the header stays the single source of truth;
+``declared_symbols()`` is what the CPU test suite checks the shared objects against.
+There is NO fallback: if the library cannot be loaded the import of ``lib()`` raises.
+"""
+import ctypes
+import os
+import re
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+INCLUDE = os.path.join(ROOT, "include")
+LIBDIR = os.path.join(PKG, "lib")
+
+_SCALARS = {
+    "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "uint32_t": ctypes.c_uint32,
+    "uint64_t": ctypes.c_uint64, "float": ctypes.c_float, "int": ctypes.c_int,
+    "pegainfer_stream_t": ctypes.c_void_p, "pegainfer_status_t": ctypes.c_int32,
+    "pegainfer_qwen3_t": ctypes.c_void_p, "size_t": ctypes.c_size_t, "double": ctypes.c_double,
+}
+
+_PROTO = re.compile(r"^\s*([A-Za-z_][\w\s\*]*?)\s*\b([a-z_][a-z0-9_]*)\s*\(([^;{}]*)\)\s*;", re.M)
+
+
+def _ctype(decl):
+    decl = decl.strip()
+    if decl == "void":
+        return None
+    if "*" in decl:
+        return ctypes.c_void_p
+    base = decl.replace("const", "").split()
+    # "int32_t name" or "int32_t"
+    for tok in base:
+        if tok in _SCALARS:
+            return _SCALARS[tok]
+    raise ValueError(f"unknown C type in header: {decl!r}")
+
+
+def parse_header(path):
+    """-> {symbol: (restype, [argtypes])} for every prototype in the header."""
+    text = open(path).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    out = {}
+    for m in _PROTO.finditer(text):
+        ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()
+        if ret.startswith("typedef") or name in ("defined",):
+            continue
+        argtypes = [] if args in ("", "void") else [_ctype(a) for a in args.split(",")]
+        out[name] = (_ctype(ret), argtypes)
+    return out
+
+
+def declared_symbols(header):
+    return sorted(parse_header(os.path.join(INCLUDE, header)))
+
+
+class _Lib:
+    def __init__(self, so_name, header):
+        path = os.path.join(LIBDIR, so_name)
+        if not os.path.exists(path):
+            raise ImportError(
+                f"{path} is missing - build it with `python -m pegainfer_amd.build` "
+                "(hipcc, gfx950). There is no CPU fallback for the product path.")
+        self.path = path
+        self.cdll = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+        self.protos = parse_header(os.path.join(INCLUDE, header))
+        for name, (res, args) in self.protos.items():
+            fn = getattr(self.cdll, name)  # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+            setattr(self, name, fn)
+
+
+_cache = {}
+
+
+def lib():
+    """libpegainfer_kernels_hip.so (include/pegainfer_kernels.h)."""
+    if "k" not in _cache:
+        _cache["k"] = _Lib("libpegainfer_kernels_hip.so", "pegainfer_kernels.h")
+    return _cache["k"]
+
+
+def host_lib():
+    """libpegainfer_qwen3.so (include/pegainfer_qwen3.h)."""
+    if "h" not in _cache:
+        lib()
+        _cache["h"] = _Lib("libpegainfer_qwen3.so", "pegainfer_qwen3.h")
+    return _cache["h"]
