@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""bench.py - decode tokens/s (+ TTFT) of the Qwen3-4B bf16 greedy forward-pass hot path on MI355X.
+
+Workload (BASELINE.json configs[1], reference method bench_serving.rs:37-43,761-763,856-890):
+  Qwen3-4B shape (36 layers, hidden 2560, 32/8 heads x 128, MLP 9728, vocab 151936, tied lm_head),
+  bf16, greedy, hipGraph on, ONE request: synthetic prompt token_id = 100 + (i % 1000) of --ctx tokens
+  (default 1024 = the reference's decode_heavy profile), then decode steps.  A "step" = one decode step
+  (one new token through all 36 layers + lm_head + on-device greedy sampling + 4-byte D2H).
+  Weights are a seeded synthetic checkpoint generated on the device (no weights on disk / no network;
+  decode throughput is data-independent) unless PEGAINFER_TEST_MODEL_PATH points at a safetensors dir.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line from rank 0.
+  value = whole-job decode tokens/s over the K timed steps (max over ranks of the wall time).
+  N > 1 (torchrun, one rank per GPU): independent requests shard across ranks with no data-path
+  collective ("replicas": weak scaling, every rank decodes its own request); see DESIGN.md §multi-GPU.
+Extra objects: roofline (dominant kernel, HBM bound), cpu_baseline (oracle port on host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+
+
+def synthetic_prompt(n):
+    return [100 + (i % 1000) for i in range(n)]  # bench_serving.rs synthetic_prompt_tokens
+
+
+def algorithmic_bytes_per_token(cfg, ctx, batch=1):
+    """weights once + KV read per request + KV write + logits."""
+    H, L, I, V = cfg["hidden_size"], cfg["num_hidden_layers"], cfg["intermediate_size"], cfg["vocab_size"]
+    q_dim = cfg["num_attention_heads"] * cfg["head_dim"]
+    kv_dim = cfg["num_key_value_heads"] * cfg["head_dim"]
+    per_layer = (q_dim + 2 * kv_dim) * H + H * q_dim + 2 * I * H + H * I
+    norms = L * (2 * H + 2 * cfg["head_dim"]) + H
+    lm = V * H * (1 if cfg["tie_word_embeddings"] else 2)
+    params = L * per_layer + lm + norms - (0 if cfg["tie_word_embeddings"] else V * H)  # embed row read, not table
+    weights = 2 * params
+    kv_tok = L * 2 * kv_dim * 2
+    return weights + batch * (kv_tok * ctx + kv_tok + 2 * H + 2 * V)
+
+
+def cpu_baseline(cfg, steps, threads):
+    """Oracle ("port") decode on the host cores: the numpy restatement of the same DAG on a synthetic
+    checkpoint of the SAME shape, bounded to `steps` decode steps at ctx 16 (weight streaming dominates
+    the CPU cost just as on the GPU).  Reported baseline only."""
+    from oracle import ops as oracle_ops
+    from oracle.bf16 import bf16_round
+    from oracle.qwen3_ref import KvState, Qwen3Config, Qwen3Oracle
+    oracle_ops.GEMM_ACCUM = np.float32   # timing leg: fp32 sgemm like a CPU engine would use
+    keys = ["hidden_size", "num_hidden_layers", "num_attention_heads", "num_key_value_heads", "head_dim",
+            "intermediate_size", "vocab_size", "rms_norm_eps", "rope_theta", "tie_word_embeddings"]
+    c = Qwen3Config(**{k: cfg[k] for k in keys})
+    rng = np.random.default_rng(42)
+    t_gen = time.perf_counter()
+
+    class Lazy(dict):
+        """weights materialised layer by layer from a small seeded pool (shape-faithful, values irrelevant
+        for timing; avoids 16 GB of RNG work before the timed region)."""
+    pool = bf16_round((rng.standard_normal(1 << 22) * 0.02).astype(np.float32))
+
+    def t(*shape, mean=0.0):
+        n = int(np.prod(shape))
+        reps = -(-n // pool.size)
+        a = np.tile(pool, reps)[:n].reshape(shape)
+        return a + np.float32(mean) if mean else a
+    w = {"model.embed_tokens.weight": t(c.vocab_size, c.hidden_size), "model.norm.weight": t(c.hidden_size, mean=1.0)}
+    if not c.tie_word_embeddings:
+        w["lm_head.weight"] = t(c.vocab_size, c.hidden_size)
+    for i in range(c.num_hidden_layers):
+        p = f"model.layers.{i}."
+        w[p + "self_attn.q_proj.weight"] = t(c.q_dim, c.hidden_size)
+        w[p + "self_attn.k_proj.weight"] = t(c.kv_dim, c.hidden_size)
+        w[p + "self_attn.v_proj.weight"] = t(c.kv_dim, c.hidden_size)
+        w[p + "self_attn.o_proj.weight"] = t(c.hidden_size, c.q_dim)
+        w[p + "self_attn.q_norm.weight"] = t(c.head_dim, mean=1.0)
+        w[p + "self_attn.k_norm.weight"] = t(c.head_dim, mean=1.0)
+        w[p + "mlp.gate_proj.weight"] = t(c.intermediate_size, c.hidden_size)
+        w[p + "mlp.up_proj.weight"] = t(c.intermediate_size, c.hidden_size)
+        w[p + "mlp.down_proj.weight"] = t(c.hidden_size, c.intermediate_size)
+        w[p + "input_layernorm.weight"] = t(c.hidden_size, mean=1.0)
+        w[p + "post_attention_layernorm.weight"] = t(c.hidden_size, mean=1.0)
+    m = Qwen3Oracle(c, w, num_pages=8, rope_positions=64)
+    st = KvState()
+    m.batch_prefill([synthetic_prompt(16)], [st])
+    setup_s = time.perf_counter() - t_gen
+    t0 = time.perf_counter()
+    tok = 100
+    for _ in range(steps):
+        tok = int(m.batch_decode([tok], [st])[0].argmax())
+    dt = time.perf_counter() - t0
+    return {"value": steps / dt, "unit": "tokens/s", "cores": threads, "kind": "port",
+            "sample": f"{steps} greedy decode steps, bs=1, ctx 16->{16 + steps}, oracle/qwen3_ref.py (numpy fp32 "
+                      f"matmul over bf16-valued weights) on a synthetic checkpoint of the same shape; "
+                      f"{dt:.1f} s timed, {setup_s:.0f} s untimed setup"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=256)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--ctx", type=int, default=1024, help="prompt length before the timed decode steps")
+    ap.add_argument("--batch", type=int, default=1, help="requests decoded together per rank")
+    ap.add_argument("--model", default="qwen3-4b", choices=["qwen3-4b", "qwen3-8b"])
+    ap.add_argument("--decode-mode", type=int, default=int(os.environ.get("PEGAINFER_DECODE_MODE", "0")))
+    ap.add_argument("--split-policy", type=int, default=1)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=12, help="decode steps for the CPU baseline (0 = skip)")
+    ap.add_argument("--ttft-iters", type=int, default=5)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from pegainfer_amd.qwen3 import QWEN3_4B, QWEN3_8B, Qwen3Engine
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+
+    cfg = dict(QWEN3_4B if args.model == "qwen3-4b" else QWEN3_8B)
+    total_ctx = args.ctx + args.warmup + args.steps + 8
+    pages = args.batch * (-(-total_ctx // 16) + 1) + 8
+    eng = Qwen3Engine(cfg, num_kv_pages=pages, max_batch_size=max(args.batch, 1), enable_graph=not args.no_graph,
+                      decode_mode=args.decode_mode, split_policy=args.split_policy, device=local,
+                      max_positions=max(4096, total_ctx + 16))
+    path = os.environ.get("PEGAINFER_TEST_MODEL_PATH")
+    if path and os.path.isdir(path):
+        eng.load_safetensors(path)
+        data = "synthetic prompt, real weights"
+    else:
+        eng.fill_synthetic(seed=42 + rank, std=0.02)
+        data = "synthetic"
+
+    prompt = synthetic_prompt(args.ctx)
+    # ---- TTFT (submit -> first token): prefill of the ctx-token prompt, fresh request each time ----
+    ttfts = []
+    for _ in range(1 + args.ttft_iters):
+        r = eng.new_request()
+        t0 = time.perf_counter()
+        eng.prefill([r], [prompt])
+        ttfts.append((time.perf_counter() - t0) * 1e3)
+        eng.drop_request(r)
+    ttfts = sorted(ttfts[1:]) if len(ttfts) > 1 else ttfts
+
+    rids = [eng.new_request() for _ in range(args.batch)]
+    toks = eng.prefill(rids, [prompt] * args.batch)
+    for _ in range(args.warmup):
+        toks = eng.decode(rids, toks)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    step_ms, dev_ms = [], []
+    barrier()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        t0 = time.perf_counter()
+        toks = eng.decode(rids, toks)
+        step_ms.append((time.perf_counter() - t0) * 1e3)
+        dev_ms.append(eng.last_step_ms())
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        tmax = torch.tensor([elapsed], device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    tokens = args.steps * args.batch * world
+    value = tokens / elapsed
+    ctx_mid = args.ctx + args.warmup + args.steps / 2
+    step_bytes = algorithmic_bytes_per_token(cfg, ctx_mid, args.batch)
+
+    out = {
+        "metric": "decode tokens/sec + TTFT, Qwen3-4B bf16 greedy, 1xMI355X" if args.model == "qwen3-4b"
+                  else "decode tokens/sec + TTFT, Qwen3-8B bf16 greedy, 1xMI355X",
+        "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16", "data": data,
+        "config": {"workload": f"{args.model} greedy decode, hipGraph {'off' if args.no_graph else 'on'}, "
+                               f"bs={args.batch}/GPU, ctx {args.ctx}->{args.ctx + args.warmup + args.steps} "
+                               f"(reference decode_heavy: synthetic prompt 100+(i%1000))",
+                   "batch_per_gpu": args.batch, "ctx": args.ctx, "decode_mode": args.decode_mode,
+                   "split_policy": args.split_policy, "parallelism": "replicas" if world > 1 else "single"},
+        "ttft_ms": {"prompt_tokens": args.ctx, "p50": round(float(np.median(ttfts)), 3),
+                    "min": round(float(min(ttfts)), 3), "iters": len(ttfts)},
+        "tpot_ms": {"p50": round(float(np.median(step_ms)), 4), "p95": round(float(np.percentile(step_ms, 95)), 4),
+                    "device_p50": round(float(np.median(dev_ms)), 4)},
+        "step_roofline": {"algorithmic_bytes_per_step": int(step_bytes),
+                          "achieved_GBps": round(step_bytes / (np.median(dev_ms) * 1e-3) / 1e9, 1),
+                          "frac_of_8TBps": round(step_bytes / (np.median(dev_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+    }
+    if rank == 0:
+        # ---- roofline of the dominant kernel: the gate_up weight-streaming GEMV (45 % of the step's bytes) ----
+        H, I = cfg["hidden_size"], cfg["intermediate_size"]
+        gate_up_bytes = 2 * I * H * 2 + args.batch * (H * 2 + 2 * I * 2)   # weights once + x in + y out
+        ms = eng.bench_gemv(2, 360, args.batch)
+        achieved = gate_up_bytes / (ms * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": "gemv_kernel (gate_up call site, M=%d K=%d N=%d)" % (2 * I, H, args.batch),
+                           "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                           "bytes_per_launch": gate_up_bytes, "avg_launch_us": round(ms * 1e3, 2)}
+        per_site = {}
+        for which, name, M, K in [(0, "qkv", (cfg["num_attention_heads"] + 2 * cfg["num_key_value_heads"]) * cfg["head_dim"], H),
+                                  (1, "o", H, cfg["num_attention_heads"] * cfg["head_dim"]), (2, "gate_up", 2 * I, H),
+                                  (3, "down", H, I), (4, "lm_head", cfg["vocab_size"], H)]:
+            t = eng.bench_gemv(which, 72 if which != 4 else 20, args.batch)
+            per_site[name] = {"us": round(t * 1e3, 2), "GBps": round(M * K * 2 / (t * 1e-3) / 1e9, 1)}
+        out["gemv_sites"] = per_site
+    eng.close()
+    if rank == 0:
+        if args.cpu_steps > 0 and world == 1:
+            threads = os.cpu_count() or 1
+            try:
+                out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_steps, threads)
+            except MemoryError:
+                out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": threads, "kind": "port",
+                                       "sample": "skipped: host RAM too small for the fp32 oracle weights"}
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,99 @@
+/*
+ * pegainfer_qwen3.h - C ABI of libpegainfer_qwen3.so: the C++ host runtime that sits directly
+ * above the kernel ABI and mirrors, for the forward-pass hot path only, what the reference
+ * keeps in Rust:
+ *
+ *   pegainfer-core/src/page_pool.rs, kv_pool.rs      -> PagePool / KvPool / KvState
+ *   pegainfer-core/src/cuda_graph.rs:25-57           -> run_or_capture (hipGraph per bucket x path)
+ *   pegainfer-core/src/weight_loader.rs:210-244      -> RoPE tables
+ *   pegainfer-qwen3-4b/src/weights.rs:83-334         -> weight upload, q/k/v + gate/up vstack
+ *   pegainfer-qwen3-4b/src/batch_decode_buffers.rs   -> fixed decode buffers + split-KV plan
+ *   pegainfer-qwen3-4b/src/batch_decode.rs:17-295    -> batch_decode DAG
+ *   pegainfer-qwen3-4b/src/prefill.rs:73-285         -> batch_prefill DAG
+ *   pegainfer-qwen3-4b/src/executor.rs:541-640       -> execute_prefill / execute_decode / drop_request
+ *
+ * The reference's Rust crates cannot be built here (no cargo); this library is the stand-in
+ * host that drives the kernels the same way, so tests/bench exercise the real call sequence.
+ * Scheduler, HTTP frontend and tokenizer are out of scope.
+ * All functions return 0 on success or a negative error (see pegainfer_qwen3_last_error).
+ */
+#ifndef PEGAINFER_QWEN3_H
+#define PEGAINFER_QWEN3_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* pegainfer_qwen3_t;
+
+/* decode_mode: 0 = replay the reference's op sequence 1:1 through the reference-named symbols
+ *              1 = MI355X fused decode kernels (bit-identical results, fewer launches)
+ * split_policy: 0 = reference gate (bs<=2 && L>=1024, chunk max(256, ceil(L/64)))
+ *               1 = MI355X policy (fill >=256 workgroups) */
+pegainfer_qwen3_t pegainfer_qwen3_create(int32_t device_ordinal, int32_t hidden_size, int32_t num_layers,
+                                         int32_t num_attention_heads, int32_t num_kv_heads, int32_t head_dim,
+                                         int32_t intermediate_size, int32_t vocab_size, float rms_norm_eps,
+                                         float rope_theta, int32_t tie_word_embeddings,
+                                         int32_t max_position_embeddings, int32_t num_kv_pages,
+                                         int32_t max_batch_size, int32_t enable_graph, int32_t decode_mode,
+                                         int32_t split_policy);
+void pegainfer_qwen3_destroy(pegainfer_qwen3_t m);
+const char* pegainfer_qwen3_last_error(pegainfer_qwen3_t m);
+
+/* weights: HF tensor names (weights.rs:102-296), host bf16 bits, uploaded verbatim */
+int32_t pegainfer_qwen3_load_tensor(pegainfer_qwen3_t m, const char* name, const void* host_bf16, int64_t numel);
+/* seeded N(mean, std) bf16 checkpoint generated on the device (BASELINE.md §3 synthetic weights) */
+int32_t pegainfer_qwen3_fill_synthetic(pegainfer_qwen3_t m, uint64_t seed, float std);
+int32_t pegainfer_qwen3_finalize(pegainfer_qwen3_t m);
+
+/* requests = KvState handles (kv_pool.rs:147-260) */
+int32_t pegainfer_qwen3_new_request(pegainfer_qwen3_t m);
+int32_t pegainfer_qwen3_drop_request(pegainfer_qwen3_t m, int32_t request_id);
+int32_t pegainfer_qwen3_request_seq_len(pegainfer_qwen3_t m, int32_t request_id);
+int32_t pegainfer_qwen3_available_pages(pegainfer_qwen3_t m);
+
+/* batch_prefill (prefill.rs:220-285): greedy first token per request; optional last-position
+ * logits copied to host as bf16 bits [n_requests, vocab]. */
+int32_t pegainfer_qwen3_prefill(pegainfer_qwen3_t m, int32_t n_requests, const int32_t* request_ids,
+                                const int32_t* prompt_lens, const uint32_t* tokens_concat, int32_t* out_tokens,
+                                void* out_logits_host);
+/* batch_decode (batch_decode.rs:17-80) + greedy token per request; optional logits [n, vocab]. */
+int32_t pegainfer_qwen3_decode(pegainfer_qwen3_t m, int32_t n_requests, const int32_t* request_ids,
+                               const uint32_t* token_ids, int32_t* out_tokens, void* out_logits_host);
+/* Sample request `column` of the LAST prefill/decode step's logits with the reference's
+ * gpu_sample rule (ops/sampling.rs:109-170). */
+int32_t pegainfer_qwen3_sample(pegainfer_qwen3_t m, int32_t column, float temperature, int32_t top_k, float top_p,
+                               float random_val, int32_t* out_token);
+
+/* device-side timing of the last decode step's graph (hipEvent pair on the model stream), ms */
+float pegainfer_qwen3_last_step_ms(pegainfer_qwen3_t m);
+int32_t pegainfer_qwen3_last_attention_path(pegainfer_qwen3_t m); /* 0 non-partition, 1 split-KV */
+/* average ms per launch of one GEMM call site over the layers' real weights, hipEvents on the model
+ * stream (bench.py roofline).  which: 0 fused qkv, 1 o, 2 gate_up, 3 down, 4 lm_head; bs = token columns */
+float pegainfer_qwen3_bench_gemv(pegainfer_qwen3_t m, int32_t which, int32_t iters, int32_t bs);
+int64_t pegainfer_qwen3_weight_bytes(pegainfer_qwen3_t m);
+void* pegainfer_qwen3_stream(pegainfer_qwen3_t m);
+
+/* ---- pure-host pieces, exported for CPU unit tests (no device needed) ---- */
+void* pegainfer_pagepool_create(int32_t capacity_pages);
+void pegainfer_pagepool_destroy(void* pool);
+int32_t pegainfer_pagepool_available(void* pool);
+/* pops n pages into out (page ids) or returns -1 leaving the pool unchanged (page_pool.rs:46-70) */
+int32_t pegainfer_pagepool_acquire(void* pool, int32_t n, int32_t* out_pages);
+/* returns pages in reverse so the next acquire hands them out in the original order (:118-127) */
+void pegainfer_pagepool_release(void* pool, const int32_t* pages, int32_t n);
+/* BatchDecodeBuffers::sync_split_kv_meta / attention_path (batch_decode_buffers.rs:229-287) for
+ * the given policy.  Outputs sized padded_bs*64 (+1 for o_indptr: padded_bs+1).
+ * Returns the number of split slots; *use_split = 1 when the split path is chosen. */
+int32_t pegainfer_split_kv_plan(int32_t policy, int32_t n_requests, const int32_t* seq_lens, int32_t padded_bs,
+                                int32_t num_kv_heads, int32_t* request_indices, int32_t* kv_tile_indices,
+                                int32_t* o_indptr, uint8_t* block_valid_mask, int32_t* kv_chunk_size,
+                                int32_t* use_split);
+int32_t pegainfer_bucket_for(int32_t bs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PEGAINFER_QWEN3_H */

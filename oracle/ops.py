@@ -162,10 +162,15 @@ def qk_norm_rope(q, k, q_w, k_w, cos, sin, positions, num_q_heads, num_kv_heads,
 # --------------------------------------------------------------------------
 # GEMM
 # --------------------------------------------------------------------------
+GEMM_ACCUM = np.float64  # bench.py's cpu_baseline switches to float32 (plain sgemm) for timing only
+
+
 def gemm(W, X):
     """Y[T,M] = X[T,K] @ W[M,K]^T, bf16 in, fp32 accumulate, bf16 store
     (csrc/linear.cu:45-75; cublasGemmEx COMPUTE_32F — reduction order is cuBLAS
     internal, so this oracle accumulates in float64 and parity is by tolerance)."""
+    if GEMM_ACCUM is np.float32:
+        return bf16_round(X.astype(F32) @ W.T)
     y = X.astype(np.float64) @ W.astype(np.float64).T
     return bf16_round(y.astype(F32))
 

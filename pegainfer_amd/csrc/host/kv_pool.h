@@ -1,0 +1,138 @@
+// Pure-host paged-KV bookkeeping, mirroring the reference's allocator behaviour exactly:
+//   PagePool  - pegainfer-core/src/page_pool.rs:34-127 (LIFO free list seeded so pops yield 0,1,2,...;
+//               release pushes the pages back reversed so they are handed out again in order)
+//   KvLayout  - pegainfer-core/src/kv_pool.rs:14-54
+//   KvState   - kv_pool.rs:147-237 (ensure_capacity / advance / last_page_len / reset)
+//   decode buckets + split-KV plan - pegainfer-qwen3-4b/src/batch_decode_buffers.rs:12-46,229-287
+// No device code here: unit-tested on CPU through the C hooks in pegainfer_qwen3.h.
+#pragma once
+
+#include <algorithm>
+#include <cstdint>
+#include <vector>
+
+namespace pq {
+
+class PagePool {
+ public:
+  explicit PagePool(int capacity) : capacity_(capacity) {
+    free_.reserve(capacity);
+    for (int p = capacity - 1; p >= 0; --p) free_.push_back(p);
+  }
+  int capacity() const { return capacity_; }
+  int available() const { return static_cast<int>(free_.size()); }
+  // all-or-nothing (page_pool.rs:46-70)
+  bool acquire(int n, std::vector<int32_t>* out) {
+    if (n < 0 || static_cast<int>(free_.size()) < n) return false;
+    for (int i = 0; i < n; ++i) {
+      out->push_back(free_.back());
+      free_.pop_back();
+    }
+    return true;
+  }
+  void release(const int32_t* pages, int n) {  // page_pool.rs:118-127: extend(pages.rev())
+    for (int i = n - 1; i >= 0; --i) free_.push_back(pages[i]);
+  }
+
+ private:
+  int capacity_;
+  std::vector<int32_t> free_;
+};
+
+struct KvLayout {
+  int page_size, num_layers, num_kv_heads, head_dim;
+  int64_t kv_block_len, layer_stride, page_stride;
+  KvLayout(int layers, int kv_heads, int hd, int ps)
+      : page_size(ps), num_layers(layers), num_kv_heads(kv_heads), head_dim(hd) {
+    kv_block_len = static_cast<int64_t>(ps) * kv_heads * hd;
+    layer_stride = 2 * kv_block_len;
+    page_stride = layers * layer_stride;
+  }
+  int64_t k_offset(int layer) const { return layer * layer_stride; }
+  int64_t v_offset(int layer) const { return layer * layer_stride + kv_block_len; }
+};
+
+struct KvState {
+  std::vector<int32_t> pages;
+  int seq_len = 0;
+  bool live = false;
+  int last_page_len(int page_size) const {
+    if (seq_len == 0) return 0;
+    const int rem = seq_len % page_size;
+    return rem == 0 ? page_size : rem;
+  }
+  bool ensure_capacity(PagePool* pool, int tokens, int page_size) {
+    const int needed = (tokens + page_size - 1) / page_size;
+    const int held = static_cast<int>(pages.size());
+    if (needed <= held) return true;
+    return pool->acquire(needed - held, &pages);
+  }
+  void reset(PagePool* pool) {
+    if (!pages.empty()) pool->release(pages.data(), static_cast<int>(pages.size()));
+    pages.clear();
+    seq_len = 0;
+  }
+};
+
+constexpr int kBatchBuckets[] = {1, 2, 4, 8, 16, 32, 64};
+constexpr int kNumBuckets = 7;
+constexpr int kSplitMaxChunksPerRequest = 64;
+
+inline int bucket_for(int bs) {
+  for (int b : kBatchBuckets)
+    if (b >= bs) return b;
+  return -1;
+}
+inline int bucket_index(int padded) {
+  for (int i = 0; i < kNumBuckets; ++i)
+    if (kBatchBuckets[i] == padded) return i;
+  return -1;
+}
+
+struct SplitPlan {
+  std::vector<int32_t> request_indices, kv_tile_indices, o_indptr;
+  std::vector<uint8_t> valid;
+  int chunk = 0, slots = 0;
+  bool use_split = false;
+};
+
+// policy 0: the reference's rule. policy 1: MI355X - split whenever it raises the number of
+// workgroups towards >= 256 (256 CUs): chunks/request = clamp(ceil(256/(bs*kv_heads)), 1, 64),
+// chunk = max(128, round_up16(ceil(L/chunks))).
+inline SplitPlan make_split_plan(int policy, const std::vector<int>& seq_lens, int padded_bs, int num_kv_heads) {
+  SplitPlan p;
+  int max_seq = 0;
+  for (int n : seq_lens) max_seq = std::max(max_seq, n);
+  if (policy == 0) {
+    p.chunk = std::max(256, (max_seq + kSplitMaxChunksPerRequest - 1) / kSplitMaxChunksPerRequest);
+    p.use_split = padded_bs <= 2 && max_seq >= 1024;
+  } else {
+    int want = (256 + padded_bs * num_kv_heads - 1) / (padded_bs * num_kv_heads);
+    want = std::min(std::max(want, 1), kSplitMaxChunksPerRequest);
+    int chunk = (max_seq + want - 1) / want;
+    chunk = std::max(128, (chunk + 15) / 16 * 16);
+    p.chunk = chunk;
+    p.use_split = want > 1 && max_seq > chunk;
+  }
+  p.slots = padded_bs * kSplitMaxChunksPerRequest;
+  p.o_indptr.push_back(0);
+  for (size_t r = 0; r < seq_lens.size(); ++r) {
+    const int chunks = std::max(1, (seq_lens[r] + p.chunk - 1) / p.chunk);
+    for (int c = 0; c < chunks; ++c) {
+      p.request_indices.push_back(static_cast<int32_t>(r));
+      p.kv_tile_indices.push_back(c);
+      p.valid.push_back(1);
+    }
+    p.o_indptr.push_back(static_cast<int32_t>(p.request_indices.size()));
+  }
+  for (int r = static_cast<int>(seq_lens.size()); r < padded_bs; ++r)
+    p.o_indptr.push_back(static_cast<int32_t>(p.request_indices.size()));
+  while (static_cast<int>(p.request_indices.size()) < p.slots) {
+    p.request_indices.push_back(0);
+    p.kv_tile_indices.push_back(0);
+    p.valid.push_back(0);
+  }
+  return p;
+}
+
+}  // namespace pq

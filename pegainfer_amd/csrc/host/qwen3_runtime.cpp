@@ -1,0 +1,748 @@
+// C++ host runtime for the Qwen3 forward-pass hot path on MI355X (see include/pegainfer_qwen3.h for
+// the reference files each piece mirrors).  One model instance = one device + one in-order HIP stream
+// (reference: DeviceContext, pegainfer-kernels/src/tensor.rs:12-67); every op is enqueued on it through
+// the C ABI of libpegainfer_kernels_hip.so; the decode step is captured once per (batch bucket,
+// attention path) into a hipGraph and replayed (core/src/cuda_graph.rs:25-57), with all per-step
+// metadata packed into ONE pinned block and uploaded by ONE hipMemcpyAsync before the launch
+// (the reference issues 13 small H2D copies, batch_decode.rs:51-59).
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "kv_pool.h"
+#include "pegainfer_kernels.h"
+#include "pegainfer_kernels_ext.h"
+#include "pegainfer_qwen3.h"
+
+namespace pq {
+
+#define PQ_HIP(expr)                                                                         \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess) {                                                                  \
+      set_error(std::string(#expr) + ": " + hipGetErrorString(e_));                          \
+      return -1;                                                                             \
+    }                                                                                        \
+  } while (0)
+
+static inline uint16_t host_f2bf(float f) {  // RNE, like half::bf16::from_f32
+  uint32_t u;
+  std::memcpy(&u, &f, 4);
+  if ((u & 0x7FFFFFFFu) > 0x7F800000u) return 0x7FC0;
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return static_cast<uint16_t>(u >> 16);
+}
+
+// seeded N(mean, std) bf16 fill: hash(index, seed) -> two uniforms -> Box-Muller
+__global__ void fill_normal_kernel(Half* out, long n, uint64_t seed, float std, float mean) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    uint64_t z = (uint64_t)i * 0x9E3779B97F4A7C15ull + seed;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    const float u1 = ((float)(z >> 40) + 1.0f) * (1.0f / 16777217.0f);
+    const float u2 = (float)((z >> 16) & 0xFFFFFF) * (1.0f / 16777216.0f);
+    const float g = sqrtf(-2.0f * logf(u1)) * cosf(6.2831853f * u2);
+    out[i] = __builtin_bit_cast(uint16_t, static_cast<__bf16>(mean + std * g));
+  }
+}
+
+struct Layer {
+  Half *qkv = nullptr, *o = nullptr, *q_norm = nullptr, *k_norm = nullptr, *gate_up = nullptr, *down = nullptr,
+       *ln1 = nullptr, *ln2 = nullptr;
+};
+
+// byte offsets of the per-step metadata inside the packed block (all int32 unless noted)
+struct MetaLayout {
+  size_t token_ids, positions, page_indptr, last_page_len, request_indices, kv_tile_indices, kv_chunk_size,
+      split_request_indices, split_kv_tile_indices, split_kv_chunk_size, split_o_indptr, split_valid /*u8*/,
+      page_indices, total;
+};
+
+struct Model {
+  // config
+  int device, H, L, Hq, Hkv, D, I, V, tie, max_pos, num_pages, max_bs, enable_graph, decode_mode, split_policy;
+  float eps, theta;
+  int q_dim, kv_dim;
+  std::string err;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // weights
+  Half *embed = nullptr, *lm_head = nullptr, *final_norm = nullptr, *cos = nullptr, *sin = nullptr;
+  std::vector<Layer> layers;
+  std::vector<void*> owned;
+  int64_t weight_bytes = 0;
+  bool finalized = false;
+  // kv
+  KvLayout layout;
+  PagePool pool;
+  Half* kv_buffer = nullptr;
+  int padding_page = 0;
+  std::vector<KvState> requests;
+  // decode buffers
+  Half *normed = nullptr, *q = nullptr, *k = nullptr, *v = nullptr, *attn_out = nullptr, *attn_proj = nullptr,
+       *gate_up_out = nullptr, *mlp_act = nullptr, *mlp_out = nullptr, *hidden = nullptr, *logits = nullptr;
+  Half* split_tmp_v = nullptr;
+  float* split_tmp_s = nullptr;
+  int32_t* tokens_out_d = nullptr;
+  uint8_t* top1_state = nullptr;
+  // sampling scratch (ops/sampling.rs)
+  float* probs_scratch = nullptr;
+  Half* top1_value = nullptr;
+  uint8_t* row_states = nullptr;
+  uint8_t* valid_scratch = nullptr;
+  int32_t* sample_out_d = nullptr;
+  // metadata
+  MetaLayout ml;
+  uint8_t* meta_host = nullptr;  // pinned
+  uint8_t* meta_dev = nullptr;
+  int32_t* tokens_out_host = nullptr;  // pinned
+  hipGraphExec_t graphs[kNumBuckets][2];
+  // prefill workspace (grow-only)
+  size_t pf_cap_tokens = 0;
+  Half *pf_hidden = nullptr, *pf_hidden_out = nullptr, *pf_normed = nullptr, *pf_q = nullptr, *pf_k = nullptr,
+       *pf_v = nullptr, *pf_o = nullptr, *pf_gate_up = nullptr, *pf_act = nullptr, *pf_attn = nullptr;
+  uint8_t* pf_meta_dev = nullptr;
+  uint8_t* pf_meta_host = nullptr;
+  size_t pf_meta_cap = 0;
+  Half* pf_last_hidden = nullptr;
+  Half* pf_last_normed = nullptr;
+  Half* pf_logits = nullptr;
+  int pf_logits_rows = 0;
+  // last step
+  const Half* last_logits = nullptr;
+  int last_rows = 0;
+  float last_step_ms = 0.f;
+  int last_path = 0;
+
+  Model(int dev, int h, int l, int hq, int hkv, int d, int inter, int vocab, float e, float th, int tie_, int mp,
+        int pages, int mbs, int graph, int mode, int pol)
+      : device(dev), H(h), L(l), Hq(hq), Hkv(hkv), D(d), I(inter), V(vocab), tie(tie_), max_pos(mp),
+        num_pages(pages), max_bs(mbs), enable_graph(graph), decode_mode(mode), split_policy(pol), eps(e),
+        theta(th), q_dim(hq * d), kv_dim(hkv * d), layout(l, hkv, d, 16), pool(pages) {
+    for (auto& b : graphs) b[0] = b[1] = nullptr;
+  }
+
+  void set_error(const std::string& s) { err = s; }
+  void* S() const { return reinterpret_cast<void*>(stream); }
+
+  template <typename T>
+  int dalloc(T** p, size_t count, bool zero = true) {
+    void* raw = nullptr;
+    PQ_HIP(hipMalloc(&raw, count * sizeof(T)));
+    if (zero) PQ_HIP(hipMemsetAsync(raw, 0, count * sizeof(T), stream));
+    owned.push_back(raw);
+    *p = static_cast<T*>(raw);
+    return 0;
+  }
+
+  int init() {
+    PQ_HIP(hipSetDevice(device));
+    cublas_init();
+    PQ_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    PQ_HIP(hipEventCreate(&ev0));
+    PQ_HIP(hipEventCreate(&ev1));
+    layers.resize(L);
+    auto W = [&](Half** p, size_t n) {
+      weight_bytes += (int64_t)n * 2;
+      return dalloc(p, n, false);
+    };
+    if (W(&embed, (size_t)V * H)) return -1;
+    if (tie) lm_head = embed;
+    else if (W(&lm_head, (size_t)V * H)) return -1;
+    if (W(&final_norm, H)) return -1;
+    for (auto& ly : layers) {
+      if (W(&ly.qkv, (size_t)(q_dim + 2 * kv_dim) * H) || W(&ly.o, (size_t)H * q_dim) || W(&ly.q_norm, D) ||
+          W(&ly.k_norm, D) || W(&ly.gate_up, (size_t)2 * I * H) || W(&ly.down, (size_t)H * I) || W(&ly.ln1, H) ||
+          W(&ly.ln2, H))
+        return -1;
+    }
+    if (dalloc(&cos, (size_t)max_pos * D, false) || dalloc(&sin, (size_t)max_pos * D, false)) return -1;
+    // KV pool (kv_pool.rs:86-118): zeroed buffer, first page reserved as the graph padding page
+    if (dalloc(&kv_buffer, (size_t)num_pages * layout.page_stride)) return -1;
+    std::vector<int32_t> pad;
+    if (!pool.acquire(1, &pad)) { set_error("pool must have at least 1 page for padding"); return -1; }
+    padding_page = pad[0];
+    // decode buffers (batch_decode_buffers.rs:103-153)
+    const size_t bs = max_bs, slots = bs * kSplitMaxChunksPerRequest;
+    if (dalloc(&normed, bs * H) || dalloc(&q, bs * q_dim) || dalloc(&k, bs * kv_dim) || dalloc(&v, bs * kv_dim) ||
+        dalloc(&attn_out, bs * q_dim) || dalloc(&attn_proj, bs * H) || dalloc(&gate_up_out, bs * 2 * I) ||
+        dalloc(&mlp_act, bs * I) || dalloc(&mlp_out, bs * H) || dalloc(&hidden, bs * H) ||
+        dalloc(&logits, bs * (size_t)V) || dalloc(&split_tmp_v, slots * q_dim) || dalloc(&split_tmp_s, slots * Hq) ||
+        dalloc(&tokens_out_d, bs) || dalloc(&top1_state, bs * 16) || dalloc(&probs_scratch, (size_t)V) ||
+        dalloc(&top1_value, 1) || dalloc(&row_states, 1024 * 1024) || dalloc(&valid_scratch, 1) ||
+        dalloc(&sample_out_d, 1))
+      return -1;
+    // packed metadata block
+    auto al = [](size_t x) { return (x + 63) & ~size_t(63); };
+    size_t off = 0;
+    ml.token_ids = off; off = al(off + bs * 4);
+    ml.positions = off; off = al(off + bs * 4);
+    ml.page_indptr = off; off = al(off + (bs + 1) * 4);
+    ml.last_page_len = off; off = al(off + bs * 4);
+    ml.request_indices = off; off = al(off + bs * 4);
+    ml.kv_tile_indices = off; off = al(off + bs * 4);
+    ml.kv_chunk_size = off; off = al(off + bs * 4);
+    ml.split_request_indices = off; off = al(off + slots * 4);
+    ml.split_kv_tile_indices = off; off = al(off + slots * 4);
+    ml.split_kv_chunk_size = off; off = al(off + 4);
+    ml.split_o_indptr = off; off = al(off + (bs + 1) * 4);
+    ml.split_valid = off; off = al(off + slots);
+    ml.page_indices = off; off = al(off + ((size_t)num_pages + bs) * 4);
+    ml.total = off;
+    PQ_HIP(hipHostMalloc(reinterpret_cast<void**>(&meta_host), ml.total, hipHostMallocDefault));
+    std::memset(meta_host, 0, ml.total);
+    if (dalloc(&meta_dev, ml.total)) return -1;
+    PQ_HIP(hipHostMalloc(reinterpret_cast<void**>(&tokens_out_host), bs * 4, hipHostMallocDefault));
+    PQ_HIP(hipStreamSynchronize(stream));
+    return 0;
+  }
+
+  // ------------------------------------------------------------------ weights
+  int load_tensor(const char* name_c, const void* host, int64_t numel) {
+    const std::string name(name_c);
+    Half* dst = nullptr;
+    int64_t expect = 0;
+    auto set = [&](Half* p, int64_t n) { dst = p; expect = n; };
+    if (name == "model.embed_tokens.weight") set(embed, (int64_t)V * H);
+    else if (name == "lm_head.weight") { if (tie) return 0; set(lm_head, (int64_t)V * H); }
+    else if (name == "model.norm.weight") set(final_norm, H);
+    else if (name.rfind("model.layers.", 0) == 0) {
+      const size_t p0 = 13, p1 = name.find('.', p0);
+      const int li = std::stoi(name.substr(p0, p1 - p0));
+      if (li < 0 || li >= L) { set_error("layer index out of range: " + name); return -1; }
+      const std::string rest = name.substr(p1 + 1);
+      Layer& ly = layers[li];
+      if (rest == "self_attn.q_proj.weight") set(ly.qkv, (int64_t)q_dim * H);
+      else if (rest == "self_attn.k_proj.weight") set(ly.qkv + (size_t)q_dim * H, (int64_t)kv_dim * H);
+      else if (rest == "self_attn.v_proj.weight") set(ly.qkv + (size_t)(q_dim + kv_dim) * H, (int64_t)kv_dim * H);
+      else if (rest == "self_attn.o_proj.weight") set(ly.o, (int64_t)H * q_dim);
+      else if (rest == "self_attn.q_norm.weight") set(ly.q_norm, D);
+      else if (rest == "self_attn.k_norm.weight") set(ly.k_norm, D);
+      else if (rest == "mlp.gate_proj.weight") set(ly.gate_up, (int64_t)I * H);
+      else if (rest == "mlp.up_proj.weight") set(ly.gate_up + (size_t)I * H, (int64_t)I * H);
+      else if (rest == "mlp.down_proj.weight") set(ly.down, (int64_t)H * I);
+      else if (rest == "input_layernorm.weight") set(ly.ln1, H);
+      else if (rest == "post_attention_layernorm.weight") set(ly.ln2, H);
+    }
+    if (!dst) { set_error("unknown tensor name: " + name); return -1; }
+    if (numel != expect) { set_error("shape mismatch for " + name); return -1; }
+    PQ_HIP(hipMemcpy(dst, host, (size_t)numel * 2, hipMemcpyHostToDevice));
+    return 0;
+  }
+
+  int fill(Half* p, size_t n, uint64_t seed, float std, float mean) {
+    fill_normal_kernel<<<2048, 256, 0, stream>>>(p, (long)n, seed, std, mean);
+    return 0;
+  }
+  int fill_synthetic(uint64_t seed, float std) {
+    uint64_t s = seed * 1000003ull;
+    fill(embed, (size_t)V * H, ++s, std, 0.f);
+    if (!tie) fill(lm_head, (size_t)V * H, ++s, std, 0.f);
+    fill(final_norm, H, ++s, 0.1f, 1.f);
+    for (auto& ly : layers) {
+      fill(ly.qkv, (size_t)(q_dim + 2 * kv_dim) * H, ++s, std, 0.f);
+      fill(ly.o, (size_t)H * q_dim, ++s, std, 0.f);
+      fill(ly.q_norm, D, ++s, 0.1f, 1.f);
+      fill(ly.k_norm, D, ++s, 0.1f, 1.f);
+      fill(ly.gate_up, (size_t)2 * I * H, ++s, std, 0.f);
+      fill(ly.down, (size_t)H * I, ++s, std, 0.f);
+      fill(ly.ln1, H, ++s, 0.1f, 1.f);
+      fill(ly.ln2, H, ++s, 0.1f, 1.f);
+    }
+    PQ_HIP(hipStreamSynchronize(stream));
+    return 0;
+  }
+
+  // RoPE tables: fp32 pos * theta^(-2i/D) -> cos/sin -> bf16, duplicated halves (weight_loader.rs:210-244),
+  // sized to max_position_embeddings (the reference's 4096-row table is a latent OOB).
+  int finalize() {
+    const int half = D / 2;
+    std::vector<float> inv(half);
+    for (int i = 0; i < half; ++i) inv[i] = 1.0f / std::pow(theta, (float)i * 2.0f / (float)D);
+    std::vector<uint16_t> c((size_t)max_pos * D), s((size_t)max_pos * D);
+    for (int pos = 0; pos < max_pos; ++pos)
+      for (int i = 0; i < half; ++i) {
+        const float f = (float)pos * inv[i];
+        const uint16_t cv = host_f2bf(std::cos(f)), sv = host_f2bf(std::sin(f));
+        c[(size_t)pos * D + i] = c[(size_t)pos * D + i + half] = cv;
+        s[(size_t)pos * D + i] = s[(size_t)pos * D + i + half] = sv;
+      }
+    PQ_HIP(hipMemcpy(cos, c.data(), c.size() * 2, hipMemcpyHostToDevice));
+    PQ_HIP(hipMemcpy(sin, s.data(), s.size() * 2, hipMemcpyHostToDevice));
+    finalized = true;
+    return 0;
+  }
+
+  // ------------------------------------------------------------------ requests
+  int new_request() {
+    for (size_t i = 0; i < requests.size(); ++i)
+      if (!requests[i].live) { requests[i] = KvState(); requests[i].live = true; return (int)i; }
+    requests.emplace_back();
+    requests.back().live = true;
+    return (int)requests.size() - 1;
+  }
+  KvState* req(int id) {
+    if (id < 0 || id >= (int)requests.size() || !requests[id].live) { set_error("bad request id"); return nullptr; }
+    return &requests[id];
+  }
+  int drop_request(int id) {
+    KvState* r = req(id);
+    if (!r) return -1;
+    r->reset(&pool);
+    r->live = false;
+    return 0;
+  }
+
+  // ------------------------------------------------------------------ decode (batch_decode.rs)
+  template <typename T>
+  T* mh(size_t off) { return reinterpret_cast<T*>(meta_host + off); }
+  template <typename T>
+  T* md(size_t off) { return reinterpret_cast<T*>(meta_dev + off); }
+
+  int decode_layer_reference(int li, int bs, bool split, int split_slots) {
+    const Layer& ly = layers[li];
+    // Q/K/V as three row-sliced GEMMs on purpose (batch_decode.rs:160-186)
+    gemm_graphsafe_cuda(ly.qkv, normed, q, q_dim, bs, H, S());
+    gemm_graphsafe_cuda(ly.qkv + (size_t)q_dim * H, normed, k, kv_dim, bs, H, S());
+    gemm_graphsafe_cuda(ly.qkv + (size_t)(q_dim + kv_dim) * H, normed, v, kv_dim, bs, H, S());
+    qk_norm_rope_batched_decode_cuda(q, k, ly.q_norm, ly.k_norm, cos, sin, md<int32_t>(ml.positions), Hq, Hkv, D, bs,
+                                     eps, S());
+    int rc = paged_kv_scatter_cuda(kv_buffer, layout.k_offset(li), layout.v_offset(li), md<int32_t>(ml.page_indices),
+                                   md<int32_t>(ml.page_indptr), md<int32_t>(ml.last_page_len), k, v,
+                                   md<int32_t>(ml.request_indices), md<int32_t>(ml.positions), bs, Hkv, D,
+                                   layout.page_size, layout.page_stride, kv_dim, D, S());
+    if (rc) { set_error("paged_kv_scatter_cuda failed"); return -1; }
+    const float sm = 1.0f / std::sqrt((float)D);
+    if (!split) {
+      rc = paged_attention_decode_cuda(q, attn_out, kv_buffer, layout.k_offset(li), layout.v_offset(li),
+                                       md<int32_t>(ml.page_indices), md<int32_t>(ml.page_indptr),
+                                       md<int32_t>(ml.last_page_len), md<int32_t>(ml.request_indices),
+                                       md<int32_t>(ml.kv_tile_indices), md<int32_t>(ml.kv_chunk_size), Hq, Hkv, D,
+                                       layout.page_size, bs, layout.page_stride, sm, S());
+    } else {
+      rc = paged_attention_decode_split_kv_cuda(
+          q, attn_out, kv_buffer, layout.k_offset(li), layout.v_offset(li), md<int32_t>(ml.page_indices),
+          md<int32_t>(ml.page_indptr), md<int32_t>(ml.last_page_len), md<int32_t>(ml.split_request_indices),
+          md<int32_t>(ml.split_kv_tile_indices), md<int32_t>(ml.split_kv_chunk_size), md<int32_t>(ml.split_o_indptr),
+          md<uint8_t>(ml.split_valid), split_tmp_v, split_tmp_s, Hq, Hkv, D, layout.page_size, bs, split_slots,
+          layout.page_stride, sm, S());
+    }
+    if (rc) { set_error("paged attention decode failed"); return -1; }
+    gemm_graphsafe_cuda(ly.o, attn_out, attn_proj, H, bs, q_dim, S());
+    fused_add_rms_norm_batched_cuda(hidden, attn_proj, ly.ln2, normed, H, bs, eps, S());
+    gemm_graphsafe_cuda(ly.gate_up, normed, gate_up_out, 2 * I, bs, H, S());
+    silu_mul_fused_cuda(gate_up_out, mlp_act, I, bs, S());
+    gemm_graphsafe_cuda(ly.down, mlp_act, mlp_out, H, bs, I, S());
+    return 0;
+  }
+
+  int decode_kernels(int bs, bool split, int split_slots) {
+    if (embedding_batched_cuda(embed, md<uint32_t>(ml.token_ids), hidden, H, bs, S())) {
+      set_error("embedding_batched_cuda failed");
+      return -1;
+    }
+    rms_norm_batched_cuda(hidden, layers[0].ln1, normed, H, bs, eps, S());
+    for (int li = 0; li < L; ++li) {
+      if (decode_layer_reference(li, bs, split, split_slots)) return -1;
+      const Half* next_w = li + 1 < L ? layers[li + 1].ln1 : final_norm;
+      fused_add_rms_norm_batched_cuda(hidden, mlp_out, next_w, normed, H, bs, eps, S());
+    }
+    gemm_graphsafe_cuda(lm_head, normed, logits, V, bs, H, S());
+    // greedy token for every column inside the captured step
+    if (pegainfer_batched_top1(logits, V, bs, V, top1_state, tokens_out_d, S())) {
+      set_error("pegainfer_batched_top1 failed");
+      return -1;
+    }
+    return 0;
+  }
+
+  int decode(int n, const int32_t* ids, const uint32_t* token_ids, int32_t* out_tokens, void* out_logits_host) {
+    if (!finalized) { set_error("model not finalized"); return -1; }
+    if (n <= 0 || n > max_bs) { set_error("bad batch size"); return -1; }
+    std::vector<KvState*> st(n);
+    std::vector<int> positions(n), seq_lens(n);
+    for (int i = 0; i < n; ++i) {
+      st[i] = req(ids[i]);
+      if (!st[i]) return -1;
+      positions[i] = st[i]->seq_len;
+      if (positions[i] + 1 > max_pos) { set_error("position exceeds RoPE table"); return -1; }
+      if (!st[i]->ensure_capacity(&pool, positions[i] + 1, layout.page_size)) {
+        set_error("KvState: out of pages");
+        return -2;
+      }
+      st[i]->seq_len += 1;
+      seq_lens[i] = st[i]->seq_len;
+    }
+    const int padded = enable_graph ? bucket_for(n) : n;
+    if (padded < 0 || padded > max_bs) { set_error("batch exceeds largest bucket"); return -1; }
+    // ---- pack metadata (batch_decode.rs:45-59, batch_decode_buffers.rs:178-279) ----
+    auto* tok = mh<uint32_t>(ml.token_ids);
+    auto* pos = mh<int32_t>(ml.positions);
+    auto* indptr = mh<int32_t>(ml.page_indptr);
+    auto* lpl = mh<int32_t>(ml.last_page_len);
+    auto* ri = mh<int32_t>(ml.request_indices);
+    auto* kti = mh<int32_t>(ml.kv_tile_indices);
+    auto* kcs = mh<int32_t>(ml.kv_chunk_size);
+    auto* pgs = mh<int32_t>(ml.page_indices);
+    int np = 0;
+    indptr[0] = 0;
+    for (int i = 0; i < padded; ++i) {
+      if (i < n) {
+        tok[i] = token_ids[i];
+        pos[i] = positions[i];
+        for (int32_t p : st[i]->pages) pgs[np++] = p;
+        lpl[i] = st[i]->last_page_len(layout.page_size);
+        kcs[i] = st[i]->seq_len;
+      } else {  // padding slot -> padding page, seq_len 1
+        tok[i] = 0;
+        pos[i] = 0;
+        pgs[np++] = padding_page;
+        lpl[i] = 1;
+        kcs[i] = 1;
+      }
+      indptr[i + 1] = np;
+      ri[i] = i;
+      kti[i] = 0;
+    }
+    const SplitPlan plan = make_split_plan(split_policy, seq_lens, padded, Hkv);
+    std::memcpy(mh<int32_t>(ml.split_request_indices), plan.request_indices.data(), plan.slots * 4);
+    std::memcpy(mh<int32_t>(ml.split_kv_tile_indices), plan.kv_tile_indices.data(), plan.slots * 4);
+    mh<int32_t>(ml.split_kv_chunk_size)[0] = plan.chunk;
+    std::memcpy(mh<int32_t>(ml.split_o_indptr), plan.o_indptr.data(), (padded + 1) * 4);
+    std::memcpy(mh<uint8_t>(ml.split_valid), plan.valid.data(), plan.slots);
+    const size_t upload = ml.page_indices + (size_t)np * 4;
+    PQ_HIP(hipMemcpyAsync(meta_dev, meta_host, upload, hipMemcpyHostToDevice, stream));
+    const bool split = plan.use_split;
+    last_path = split ? 1 : 0;
+
+    PQ_HIP(hipEventRecord(ev0, stream));
+    if (enable_graph) {
+      const int bi = bucket_index(padded);
+      hipGraphExec_t& exec = graphs[bi][split ? 1 : 0];
+      if (!exec) {  // capture once (cuda_graph.rs:36-55), thread-local mode
+        hipGraph_t graph = nullptr;
+        PQ_HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+        const int rc = decode_kernels(padded, split, plan.slots);
+        hipError_t e = hipStreamEndCapture(stream, &graph);
+        if (rc || e != hipSuccess) { set_error("graph capture failed: " + err); return -1; }
+        PQ_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        PQ_HIP(hipGraphDestroy(graph));
+      }
+      PQ_HIP(hipGraphLaunch(exec, stream));
+    } else {
+      if (decode_kernels(padded, split, plan.slots)) return -1;
+    }
+    PQ_HIP(hipEventRecord(ev1, stream));
+    PQ_HIP(hipMemcpyAsync(tokens_out_host, tokens_out_d, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
+    PQ_HIP(hipStreamSynchronize(stream));
+    hipEventElapsedTime(&last_step_ms, ev0, ev1);
+    for (int i = 0; i < n; ++i) out_tokens[i] = tokens_out_host[i];
+    last_logits = logits;
+    last_rows = n;
+    if (out_logits_host) PQ_HIP(hipMemcpy(out_logits_host, logits, (size_t)n * V * 2, hipMemcpyDeviceToHost));
+    return 0;
+  }
+
+  // ------------------------------------------------------------------ prefill (prefill.rs)
+  int ensure_prefill_ws(size_t T, int nreq) {
+    if (T > pf_cap_tokens) {
+      const size_t cap = std::max<size_t>(T, pf_cap_tokens * 2);
+      Half** bufs[] = {&pf_hidden, &pf_hidden_out, &pf_normed, &pf_q, &pf_k, &pf_v, &pf_o, &pf_gate_up, &pf_act, &pf_attn};
+      const size_t dims[] = {(size_t)H, (size_t)H, (size_t)H, (size_t)q_dim, (size_t)kv_dim, (size_t)kv_dim,
+                             (size_t)H, (size_t)2 * I, (size_t)I, (size_t)q_dim};
+      PQ_HIP(hipStreamSynchronize(stream));
+      for (int i = 0; i < 10; ++i) {
+        if (*bufs[i]) PQ_HIP(hipFree(*bufs[i]));
+        PQ_HIP(hipMalloc(reinterpret_cast<void**>(bufs[i]), cap * dims[i] * 2));
+      }
+      pf_cap_tokens = cap;
+    }
+    if (nreq > pf_logits_rows) {
+      PQ_HIP(hipStreamSynchronize(stream));
+      if (pf_logits) { PQ_HIP(hipFree(pf_logits)); PQ_HIP(hipFree(pf_last_hidden)); PQ_HIP(hipFree(pf_last_normed)); }
+      const int rows = std::max(nreq, 4);
+      PQ_HIP(hipMalloc(reinterpret_cast<void**>(&pf_logits), (size_t)rows * V * 2));
+      PQ_HIP(hipMalloc(reinterpret_cast<void**>(&pf_last_hidden), (size_t)rows * H * 2));
+      PQ_HIP(hipMalloc(reinterpret_cast<void**>(&pf_last_normed), (size_t)rows * H * 2));
+      pf_logits_rows = rows;
+    }
+    return 0;
+  }
+
+  int prefill(int n, const int32_t* ids, const int32_t* lens, const uint32_t* tokens, int32_t* out_tokens,
+              void* out_logits_host) {
+    if (!finalized) { set_error("model not finalized"); return -1; }
+    if (n <= 0) { set_error("empty prefill"); return -1; }
+    std::vector<KvState*> st(n);
+    std::vector<int> starts(n);
+    size_t T = 0;
+    for (int i = 0; i < n; ++i) {
+      st[i] = req(ids[i]);
+      if (!st[i]) return -1;
+      if (lens[i] <= 0) { set_error("empty prompt"); return -1; }
+      starts[i] = st[i]->seq_len;
+      if (starts[i] + lens[i] > max_pos) { set_error("position exceeds RoPE table"); return -1; }
+      T += lens[i];
+    }
+    for (int i = 0; i < n; ++i) {  // ensure_capacity + advance (prefill.rs:236-240)
+      if (!st[i]->ensure_capacity(&pool, starts[i] + lens[i], layout.page_size)) { set_error("KvState: out of pages"); return -2; }
+      st[i]->seq_len += lens[i];
+    }
+    if (ensure_prefill_ws(T, n)) return -1;
+    // ---- plan (PrefillPagedPlan::new_batch_with_cta_tile_q, ops/attention.rs:208-302; tile 64 = config.rs:5) ----
+    const int group = Hq / Hkv;
+    const int cta = batch_prefill_cta_tile_q_with_override((int)T, Hq, Hkv, D, 64);
+    std::vector<int32_t> pages, indptr{0}, lpl, kvc, bidx, pos, qind{0}, rq, qt, kt;
+    for (int i = 0; i < n; ++i) {
+      pages.insert(pages.end(), st[i]->pages.begin(), st[i]->pages.end());
+      indptr.push_back((int32_t)pages.size());
+      lpl.push_back(st[i]->last_page_len(layout.page_size));
+      kvc.push_back(starts[i] + lens[i]);
+      for (int t = 0; t < lens[i]; ++t) { bidx.push_back(i); pos.push_back(starts[i] + t); }
+      qind.push_back(qind.back() + lens[i]);
+      const int tiles = (lens[i] * group + cta - 1) / cta;
+      for (int t = 0; t < tiles; ++t) { rq.push_back(i); qt.push_back(t); kt.push_back(0); }
+    }
+    const int num_tiles = (int)rq.size();
+    std::vector<std::pair<const void*, size_t>> parts = {
+        {tokens, T * 4}, {pages.data(), pages.size() * 4}, {indptr.data(), indptr.size() * 4},
+        {lpl.data(), lpl.size() * 4}, {bidx.data(), bidx.size() * 4}, {pos.data(), pos.size() * 4},
+        {qind.data(), qind.size() * 4}, {rq.data(), rq.size() * 4}, {qt.data(), qt.size() * 4},
+        {kt.data(), kt.size() * 4}, {kvc.data(), kvc.size() * 4}};
+    uint32_t total_rows = (uint32_t)T;
+    parts.push_back({&total_rows, 4});
+    std::vector<size_t> offs;
+    size_t off = 0;
+    for (auto& p : parts) { offs.push_back(off); off = (off + p.second + 63) & ~size_t(63); }
+    if (off > pf_meta_cap) {
+      PQ_HIP(hipStreamSynchronize(stream));
+      if (pf_meta_dev) { PQ_HIP(hipFree(pf_meta_dev)); PQ_HIP(hipHostFree(pf_meta_host)); }
+      pf_meta_cap = off * 2;
+      PQ_HIP(hipMalloc(reinterpret_cast<void**>(&pf_meta_dev), pf_meta_cap));
+      PQ_HIP(hipHostMalloc(reinterpret_cast<void**>(&pf_meta_host), pf_meta_cap, hipHostMallocDefault));
+    }
+    for (size_t i = 0; i < parts.size(); ++i) std::memcpy(pf_meta_host + offs[i], parts[i].first, parts[i].second);
+    PQ_HIP(hipMemcpyAsync(pf_meta_dev, pf_meta_host, off, hipMemcpyHostToDevice, stream));
+    auto D32 = [&](int i) { return reinterpret_cast<int32_t*>(pf_meta_dev + offs[i]); };
+    const uint32_t* tok_d = reinterpret_cast<uint32_t*>(pf_meta_dev + offs[0]);
+
+    const int Ti = (int)T;
+    if (embedding_batched_cuda(embed, tok_d, pf_hidden, H, Ti, S())) { set_error("embedding failed"); return -1; }
+    Half *hid = pf_hidden, *hid_out = pf_hidden_out;
+    const float sm = 1.0f / std::sqrt((float)D);
+    for (int li = 0; li < L; ++li) {
+      const Layer& ly = layers[li];
+      rms_norm_batched_cuda(hid, ly.ln1, pf_normed, H, Ti, eps, S());
+      auto G = [&](const Half* w, const Half* x, Half* y, int M, int K) {
+        if (Ti == 1) gemm_graphsafe_cuda(w, x, y, M, 1, K, S());
+        else gemm_cuda(w, x, y, M, Ti, K, S());
+      };
+      G(ly.qkv, pf_normed, pf_q, q_dim, H);
+      G(ly.qkv + (size_t)q_dim * H, pf_normed, pf_k, kv_dim, H);
+      G(ly.qkv + (size_t)(q_dim + kv_dim) * H, pf_normed, pf_v, kv_dim, H);
+      if (n == 1)
+        prefill_qk_norm_rope_only_cuda(pf_q, pf_k, ly.q_norm, ly.k_norm, cos, sin, Hq, Hkv, D, Ti, starts[0], eps, S());
+      else
+        qk_norm_rope_batched_decode_cuda(pf_q, pf_k, ly.q_norm, ly.k_norm, cos, sin, D32(5), Hq, Hkv, D, Ti, eps, S());
+      int rc = paged_kv_scatter_cuda(kv_buffer, layout.k_offset(li), layout.v_offset(li), D32(1), D32(2), D32(3), pf_k,
+                                     pf_v, D32(4), D32(5), Ti, Hkv, D, layout.page_size, layout.page_stride, kv_dim, D, S());
+      if (rc) { set_error("paged_kv_scatter_cuda failed"); return -1; }
+      rc = batch_prefill_paged_cuda_with_cta_tile_q(
+          pf_q, pf_attn, kv_buffer, layout.k_offset(li), layout.v_offset(li), D32(1), D32(2), D32(3), D32(6), D32(7),
+          D32(8), D32(9), D32(10), reinterpret_cast<uint32_t*>(pf_meta_dev + offs[11]), Hq, Hkv, D, layout.page_size,
+          Ti, n, num_tiles, layout.page_stride, sm, cta, S());
+      if (rc) { set_error("batch_prefill_paged_cuda failed"); return -1; }
+      G(ly.o, pf_attn, pf_o, H, q_dim);
+      fused_add_rms_norm_batched_cuda(hid, pf_o, ly.ln2, pf_normed, H, Ti, eps, S());
+      G(ly.gate_up, pf_normed, pf_gate_up, 2 * I, H);
+      silu_mul_fused_cuda(pf_gate_up, pf_act, I, Ti, S());
+      G(ly.down, pf_act, pf_o, H, I);
+      if (add_cuda(hid, pf_o, hid_out, Ti * H, S())) { set_error("add_cuda failed"); return -1; }
+      std::swap(hid, hid_out);  // prefill.rs:183-185
+    }
+    // per request: last token -> final norm -> lm_head GEMV (prefill.rs:267-282); batched in groups that stay
+    // on the decode-GEMV path so each column is bit-identical to the reference's per-request call.
+    for (int i = 0; i < n; ++i)
+      PQ_HIP(hipMemcpyAsync(pf_last_hidden + (size_t)i * H, hid + (size_t)(qind[i + 1] - 1) * H, (size_t)H * 2,
+                            hipMemcpyDeviceToDevice, stream));
+    rms_norm_batched_cuda(pf_last_hidden, final_norm, pf_last_normed, H, n, eps, S());
+    for (int i0 = 0; i0 < n; i0 += 16) {
+      const int nb = std::min(16, n - i0);
+      gemm_graphsafe_cuda(lm_head, pf_last_normed + (size_t)i0 * H, pf_logits + (size_t)i0 * V, V, nb, H, S());
+    }
+    if (n > max_bs) { set_error("prefill batch larger than max_batch_size"); return -1; }
+    if (pegainfer_batched_top1(pf_logits, V, n, V, top1_state, tokens_out_d, S())) { set_error("top1 failed"); return -1; }
+    PQ_HIP(hipMemcpyAsync(tokens_out_host, tokens_out_d, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
+    PQ_HIP(hipStreamSynchronize(stream));
+    for (int i = 0; i < n; ++i) out_tokens[i] = tokens_out_host[i];
+    last_logits = pf_logits;
+    last_rows = n;
+    if (out_logits_host) PQ_HIP(hipMemcpy(out_logits_host, pf_logits, (size_t)n * V * 2, hipMemcpyDeviceToHost));
+    return 0;
+  }
+
+  // Per-kernel timing for bench.py's roofline: launch one GEMM call site `iters` times, cycling through
+  // the layers' real weights (each launch streams a different matrix, as in a decode step), bracketed
+  // by hipEvents on the model stream.  which: 0 q+k+v rows (fused qkv matrix), 1 o, 2 gate_up, 3 down, 4 lm_head.
+  float bench_gemv(int which, int iters, int bs) {
+    if (!finalized || iters <= 0 || bs < 1 || bs > max_bs) return -1.f;
+    auto launch = [&](int it) {
+      const Layer& ly = layers[it % L];
+      switch (which) {
+        case 0: gemm_graphsafe_cuda(ly.qkv, normed, gate_up_out, q_dim + 2 * kv_dim, bs, H, S()); break;
+        case 1: gemm_graphsafe_cuda(ly.o, attn_out, attn_proj, H, bs, q_dim, S()); break;
+        case 2: gemm_graphsafe_cuda(ly.gate_up, normed, gate_up_out, 2 * I, bs, H, S()); break;
+        case 3: gemm_graphsafe_cuda(ly.down, mlp_act, mlp_out, H, bs, I, S()); break;
+        default: gemm_graphsafe_cuda(lm_head, normed, logits, V, bs, H, S()); break;
+      }
+    };
+    for (int i = 0; i < 3; ++i) launch(i);
+    hipEventRecord(ev0, stream);
+    for (int i = 0; i < iters; ++i) launch(i + 3);
+    hipEventRecord(ev1, stream);
+    hipStreamSynchronize(stream);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, ev0, ev1);
+    return ms / iters;
+  }
+
+  // gpu_sample rule (ops/sampling.rs:109-170) on one column of the last step's logits
+  int sample(int column, float temperature, int top_k, float top_p, float random_val, int32_t* out) {
+    if (!last_logits || column < 0 || column >= last_rows) { set_error("no logits for that column"); return -1; }
+    const Half* lg = last_logits + (size_t)column * V;
+    if ((temperature <= 0.0f || top_k == 1) && top_p >= 1.0f) {
+      flashinfer_top1_cuda(lg, top1_value, row_states, sample_out_d, V, S());
+    } else {
+      uint32_t bits;
+      std::memcpy(&bits, &random_val, 4);
+      gpu_sample_flashinfer_cuda(lg, probs_scratch, valid_scratch, sample_out_d, V, 1.0f / temperature, top_k, top_p,
+                                 (uint64_t)bits, S());
+    }
+    PQ_HIP(hipStreamSynchronize(stream));
+    PQ_HIP(hipMemcpy(out, sample_out_d, 4, hipMemcpyDeviceToHost));
+    return 0;
+  }
+
+  ~Model() {
+    if (stream) hipStreamSynchronize(stream);
+    for (auto& b : graphs)
+      for (auto& g : b)
+        if (g) hipGraphExecDestroy(g);
+    for (void* p : owned) hipFree(p);
+    Half* pf[] = {pf_hidden, pf_hidden_out, pf_normed, pf_q, pf_k, pf_v, pf_o, pf_gate_up, pf_act, pf_attn,
+                  pf_last_hidden, pf_last_normed, pf_logits};
+    for (Half* p : pf)
+      if (p) hipFree(p);
+    if (pf_meta_dev) hipFree(pf_meta_dev);
+    if (pf_meta_host) hipHostFree(pf_meta_host);
+    if (meta_host) hipHostFree(meta_host);
+    if (tokens_out_host) hipHostFree(tokens_out_host);
+    if (ev0) hipEventDestroy(ev0);
+    if (ev1) hipEventDestroy(ev1);
+    if (stream) hipStreamDestroy(stream);
+    cublas_destroy();
+  }
+};
+
+}  // namespace pq
+
+using pq::Model;
+static Model* M(pegainfer_qwen3_t m) { return static_cast<Model*>(m); }
+static thread_local std::string g_create_error;
+
+extern "C" {
+
+pegainfer_qwen3_t pegainfer_qwen3_create(int32_t device_ordinal, int32_t hidden_size, int32_t num_layers,
+                                         int32_t num_attention_heads, int32_t num_kv_heads, int32_t head_dim,
+                                         int32_t intermediate_size, int32_t vocab_size, float rms_norm_eps,
+                                         float rope_theta, int32_t tie_word_embeddings,
+                                         int32_t max_position_embeddings, int32_t num_kv_pages,
+                                         int32_t max_batch_size, int32_t enable_graph, int32_t decode_mode,
+                                         int32_t split_policy) {
+  if (head_dim != 128 || num_kv_heads <= 0 || num_attention_heads % num_kv_heads != 0 || num_kv_pages < 2 ||
+      max_batch_size < 1 || max_batch_size > 64) {
+    g_create_error = "unsupported configuration";
+    return nullptr;
+  }
+  auto* m = new Model(device_ordinal, hidden_size, num_layers, num_attention_heads, num_kv_heads, head_dim,
+                      intermediate_size, vocab_size, rms_norm_eps, rope_theta, tie_word_embeddings,
+                      max_position_embeddings, num_kv_pages, max_batch_size, enable_graph, decode_mode, split_policy);
+  if (m->init() != 0) {
+    g_create_error = m->err;
+    fprintf(stderr, "pegainfer_qwen3_create: %s\n", m->err.c_str());
+    delete m;
+    return nullptr;
+  }
+  return m;
+}
+void pegainfer_qwen3_destroy(pegainfer_qwen3_t m) { delete M(m); }
+const char* pegainfer_qwen3_last_error(pegainfer_qwen3_t m) { return m ? M(m)->err.c_str() : g_create_error.c_str(); }
+int32_t pegainfer_qwen3_load_tensor(pegainfer_qwen3_t m, const char* name, const void* host_bf16, int64_t numel) {
+  return M(m)->load_tensor(name, host_bf16, numel);
+}
+int32_t pegainfer_qwen3_fill_synthetic(pegainfer_qwen3_t m, uint64_t seed, float std) { return M(m)->fill_synthetic(seed, std); }
+int32_t pegainfer_qwen3_finalize(pegainfer_qwen3_t m) { return M(m)->finalize(); }
+int32_t pegainfer_qwen3_new_request(pegainfer_qwen3_t m) { return M(m)->new_request(); }
+int32_t pegainfer_qwen3_drop_request(pegainfer_qwen3_t m, int32_t id) { return M(m)->drop_request(id); }
+int32_t pegainfer_qwen3_request_seq_len(pegainfer_qwen3_t m, int32_t id) {
+  auto* r = M(m)->req(id);
+  return r ? r->seq_len : -1;
+}
+int32_t pegainfer_qwen3_available_pages(pegainfer_qwen3_t m) { return M(m)->pool.available(); }
+int32_t pegainfer_qwen3_prefill(pegainfer_qwen3_t m, int32_t n, const int32_t* ids, const int32_t* lens,
+                                const uint32_t* tokens, int32_t* out_tokens, void* out_logits_host) {
+  return M(m)->prefill(n, ids, lens, tokens, out_tokens, out_logits_host);
+}
+int32_t pegainfer_qwen3_decode(pegainfer_qwen3_t m, int32_t n, const int32_t* ids, const uint32_t* token_ids,
+                               int32_t* out_tokens, void* out_logits_host) {
+  return M(m)->decode(n, ids, token_ids, out_tokens, out_logits_host);
+}
+int32_t pegainfer_qwen3_sample(pegainfer_qwen3_t m, int32_t column, float temperature, int32_t top_k, float top_p,
+                               float random_val, int32_t* out_token) {
+  return M(m)->sample(column, temperature, top_k, top_p, random_val, out_token);
+}
+float pegainfer_qwen3_last_step_ms(pegainfer_qwen3_t m) { return M(m)->last_step_ms; }
+float pegainfer_qwen3_bench_gemv(pegainfer_qwen3_t m, int32_t which, int32_t iters, int32_t bs) {
+  return M(m)->bench_gemv(which, iters, bs);
+}
+int32_t pegainfer_qwen3_last_attention_path(pegainfer_qwen3_t m) { return M(m)->last_path; }
+int64_t pegainfer_qwen3_weight_bytes(pegainfer_qwen3_t m) { return M(m)->weight_bytes; }
+void* pegainfer_qwen3_stream(pegainfer_qwen3_t m) { return M(m)->S(); }
+
+// ---- pure-host hooks ----
+void* pegainfer_pagepool_create(int32_t capacity_pages) { return new pq::PagePool(capacity_pages); }
+void pegainfer_pagepool_destroy(void* pool) { delete static_cast<pq::PagePool*>(pool); }
+int32_t pegainfer_pagepool_available(void* pool) { return static_cast<pq::PagePool*>(pool)->available(); }
+int32_t pegainfer_pagepool_acquire(void* pool, int32_t n, int32_t* out_pages) {
+  std::vector<int32_t> v;
+  if (!static_cast<pq::PagePool*>(pool)->acquire(n, &v)) return -1;
+  for (int i = 0; i < n; ++i) out_pages[i] = v[i];
+  return n;
+}
+void pegainfer_pagepool_release(void* pool, const int32_t* pages, int32_t n) {
+  static_cast<pq::PagePool*>(pool)->release(pages, n);
+}
+int32_t pegainfer_split_kv_plan(int32_t policy, int32_t n_requests, const int32_t* seq_lens, int32_t padded_bs,
+                                int32_t num_kv_heads, int32_t* request_indices, int32_t* kv_tile_indices,
+                                int32_t* o_indptr, uint8_t* block_valid_mask, int32_t* kv_chunk_size,
+                                int32_t* use_split) {
+  std::vector<int> lens(seq_lens, seq_lens + n_requests);
+  const pq::SplitPlan p = pq::make_split_plan(policy, lens, padded_bs, num_kv_heads);
+  std::memcpy(request_indices, p.request_indices.data(), p.slots * 4);
+  std::memcpy(kv_tile_indices, p.kv_tile_indices.data(), p.slots * 4);
+  std::memcpy(o_indptr, p.o_indptr.data(), (padded_bs + 1) * 4);
+  std::memcpy(block_valid_mask, p.valid.data(), p.slots);
+  *kv_chunk_size = p.chunk;
+  *use_split = p.use_split ? 1 : 0;
+  return p.slots;
+}
+int32_t pegainfer_bucket_for(int32_t bs) { return pq::bucket_for(bs); }
+
+}  // extern "C"

@@ -16,6 +16,7 @@
 //                          inverse-CDF draw in index order.  RNG = splitmix64(seed); the reference's
 //                          Philox stream lives in un-vendored FlashInfer -> distribution parity only.
 #include "common.h"
+#include "pegainfer_kernels_ext.h"
 
 namespace pk {
 
@@ -95,6 +96,27 @@ __global__ __launch_bounds__(256) void top1_kernel(const Half* __restrict__ logi
       const int idx = (int)(0xFFFFFFFFu - (uint32_t)(win & 0xFFFFFFFFu));
       out[0] = idx;
       if (top_value) top_value[0] = logits[idx];
+    }
+  }
+}
+
+// Batched greedy: grid (kTop1Blocks, rows); row r uses state words [2r, 2r+1] (self-resetting).
+__global__ __launch_bounds__(256) void batched_top1_kernel(const Half* __restrict__ logits, long row_stride,
+                                                           unsigned long long* __restrict__ state,
+                                                           int* __restrict__ out, int n) {
+  __shared__ unsigned long long red[4];
+  const int row = blockIdx.y;
+  const Half* x = logits + (size_t)row * row_stride;
+  unsigned long long* st = state + 2 * (size_t)row;
+  unsigned long long best = scan_best(x, n, blockIdx.x * 256 + threadIdx.x, kTop1Blocks * 256);
+  best = block_max_u64<4>(best, red);
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_max(&st[0], best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long ticket = __hip_atomic_fetch_add(&st[1], 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (ticket == kTop1Blocks - 1) {
+      const unsigned long long win = __hip_atomic_exchange(&st[0], 0ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&st[1], 0ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      out[row] = (int)(0xFFFFFFFFu - (uint32_t)(win & 0xFFFFFFFFu));
     }
   }
 }
@@ -202,7 +224,7 @@ __global__ __launch_bounds__(kSampleBlock) void sample_kernel(const Half* __rest
   const float target = uniform01(seed) * kept;
 
   // inverse CDF in index order: chunks of 1024 consecutive tokens, wave scan + wave offsets
-  if (tid == 0) { sh_run = 0.f; sh_pick = -1; }
+  if (tid == 0) { sh_run = 0.f; sh_pick = 0x7FFFFFFF; }
   __syncthreads();
   int last_kept = -1;
   for (int base = 0; base < n; base += kSampleBlock) {
@@ -222,7 +244,7 @@ __global__ __launch_bounds__(kSampleBlock) void sample_kernel(const Half* __rest
     const float cum = woff + incl;
     if (p > 0.f && cum > target && cum - p <= target) atomicMin(&sh_pick, i);
     __syncthreads();
-    if (sh_pick >= 0) break;
+    if (sh_pick != 0x7FFFFFFF) break;
     if (tid == 0) {
       float t = sh_run;
       for (int w = 0; w < kSampleBlock / 64; ++w) t += red[w];
@@ -230,7 +252,7 @@ __global__ __launch_bounds__(kSampleBlock) void sample_kernel(const Half* __rest
     }
     __syncthreads();
   }
-  if (sh_pick < 0) {  // rounding left the target above the running sum: take the last kept token
+  if (sh_pick == 0x7FFFFFFF) {  // rounding left the target above the running sum: take the last kept token
     __shared__ int sh_last;
     if (tid == 0) sh_last = -1;
     __syncthreads();
@@ -259,6 +281,14 @@ void flashinfer_top1_cuda(const Half* logits, Half* top1_value_scratch, uint8_t*
                           int32_t* output, int32_t vocab_size, pegainfer_stream_t stream) {
   top1_kernel<<<kTop1Blocks, 256, 0, as_stream(stream)>>>(
       logits, top1_value_scratch, reinterpret_cast<unsigned long long*>(row_states_scratch), output, vocab_size);
+}
+
+pegainfer_status_t pegainfer_batched_top1(const Half* logits, int32_t vocab_size, int32_t rows, int64_t row_stride,
+                                          uint8_t* state_scratch, int32_t* out_tokens, pegainfer_stream_t stream) {
+  if (rows <= 0) return 0;
+  batched_top1_kernel<<<dim3(kTop1Blocks, rows), 256, 0, as_stream(stream)>>>(
+      logits, row_stride, reinterpret_cast<unsigned long long*>(state_scratch), out_tokens, vocab_size);
+  return static_cast<pegainfer_status_t>(hipGetLastError());
 }
 
 void gpu_sample_flashinfer_cuda(const Half* logits, float* probs_scratch, uint8_t* valid_scratch,

@@ -28,6 +28,8 @@ def _ctype(decl):
     decl = decl.strip()
     if decl == "void":
         return None
+    if "char" in decl and "*" in decl and len(decl.replace("const", "").split()) == 1:
+        return ctypes.c_char_p  # `const char*` return value (argument strings stay c_void_p-compatible)
     if "*" in decl:
         return ctypes.c_void_p
     base = decl.replace("const", "").split()

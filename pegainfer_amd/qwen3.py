@@ -1,0 +1,160 @@
+"""Python driver of libpegainfer_qwen3.so - the thin test/bench harness above the C++ host
+runtime (which is where the hot loop lives: metadata packing, hipGraph replay, sampling).
+
+Mirrors the surface a user of the reference's ``pegainfer_qwen3_4b::runtime`` sees
+(executor.rs:541-640): ``from_config`` / ``load`` -> ``prefill`` -> ``decode`` -> ``drop_request``.
+Weights: a safetensors checkpoint (HF names, bf16) or a seeded synthetic checkpoint generated on
+the device.  No CPU fallback: missing library -> ImportError, device errors -> RuntimeError.
+"""
+import ctypes
+import json
+import os
+import struct
+
+import numpy as np
+
+from . import ffi
+
+QWEN3_4B = dict(hidden_size=2560, num_hidden_layers=36, num_attention_heads=32, num_key_value_heads=8,
+                head_dim=128, intermediate_size=9728, vocab_size=151936, rms_norm_eps=1e-6, rope_theta=1e6,
+                tie_word_embeddings=True, max_position_embeddings=40960)
+QWEN3_8B = dict(hidden_size=4096, num_hidden_layers=36, num_attention_heads=32, num_key_value_heads=8,
+                head_dim=128, intermediate_size=12288, vocab_size=151936, rms_norm_eps=1e-6, rope_theta=1e6,
+                tie_word_embeddings=False, max_position_embeddings=40960)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+class Qwen3Engine:
+    def __init__(self, config, num_kv_pages=1024, max_batch_size=8, enable_graph=True, decode_mode=0,
+                 split_policy=1, device=0, max_positions=None):
+        self.lib = ffi.host_lib()
+        self.cfg = dict(config)
+        c = self.cfg
+        max_pos = int(max_positions or c.get("max_position_embeddings", 4096))
+        self.h = self.lib.pegainfer_qwen3_create(
+            device, c["hidden_size"], c["num_hidden_layers"], c["num_attention_heads"], c["num_key_value_heads"],
+            c["head_dim"], c["intermediate_size"], c["vocab_size"], float(c.get("rms_norm_eps", 1e-6)),
+            float(c.get("rope_theta", 1e6)), int(bool(c.get("tie_word_embeddings", True))), max_pos,
+            int(num_kv_pages), int(max_batch_size), int(bool(enable_graph)), int(decode_mode), int(split_policy))
+        if not self.h:
+            raise RuntimeError("pegainfer_qwen3_create failed: %s" % self.lib.pegainfer_qwen3_last_error(None))
+        self.vocab = c["vocab_size"]
+
+    # ---- error plumbing ----
+    def _chk(self, rc, what):
+        if rc != 0:
+            msg = self.lib.pegainfer_qwen3_last_error(self.h)
+            raise RuntimeError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+    # ---- weights ----
+    def load_state(self, tensors_u16):
+        """tensors_u16: {HF name: np.uint16 array of bf16 bits}."""
+        for name, arr in tensors_u16.items():
+            a = np.ascontiguousarray(arr, dtype=np.uint16)
+            self._chk(self.lib.pegainfer_qwen3_load_tensor(self.h, name.encode(), a.ctypes.data, a.size), name)
+        self._chk(self.lib.pegainfer_qwen3_finalize(self.h), "finalize")
+        return self
+
+    def load_safetensors(self, path):
+        files = [path] if path.endswith(".safetensors") else sorted(
+            os.path.join(path, f) for f in os.listdir(path) if f.endswith(".safetensors"))
+        for fp in files:
+            with open(fp, "rb") as f:
+                n = struct.unpack("<Q", f.read(8))[0]
+                header = json.loads(f.read(n))
+                base = 8 + n
+                mm = np.memmap(fp, dtype=np.uint8, mode="r")
+                for name, meta in header.items():
+                    if name == "__metadata__":
+                        continue
+                    if meta["dtype"] != "BF16":
+                        raise ValueError(f"{name}: expected BF16, got {meta['dtype']}")
+                    lo, hi = meta["data_offsets"]
+                    a = np.ascontiguousarray(mm[base + lo: base + hi])
+                    self._chk(self.lib.pegainfer_qwen3_load_tensor(self.h, name.encode(), a.ctypes.data, a.size // 2), name)
+        self._chk(self.lib.pegainfer_qwen3_finalize(self.h), "finalize")
+        return self
+
+    def fill_synthetic(self, seed=42, std=0.02):
+        self._chk(self.lib.pegainfer_qwen3_fill_synthetic(self.h, seed, std), "fill_synthetic")
+        self._chk(self.lib.pegainfer_qwen3_finalize(self.h), "finalize")
+        return self
+
+    # ---- requests ----
+    def new_request(self):
+        r = self.lib.pegainfer_qwen3_new_request(self.h)
+        if r < 0:
+            self._chk(r, "new_request")
+        return r
+
+    def drop_request(self, rid):
+        self._chk(self.lib.pegainfer_qwen3_drop_request(self.h, rid), "drop_request")
+
+    def seq_len(self, rid):
+        return self.lib.pegainfer_qwen3_request_seq_len(self.h, rid)
+
+    def available_pages(self):
+        return self.lib.pegainfer_qwen3_available_pages(self.h)
+
+    # ---- forward ----
+    def prefill(self, request_ids, prompts, return_logits=False):
+        ids = _i32(request_ids)
+        lens = _i32([len(p) for p in prompts])
+        toks = np.ascontiguousarray(np.concatenate([np.asarray(p, dtype=np.uint32) for p in prompts]))
+        out = np.zeros(len(ids), dtype=np.int32)
+        lg = np.zeros((len(ids), self.vocab), dtype=np.uint16) if return_logits else None
+        self._chk(self.lib.pegainfer_qwen3_prefill(self.h, len(ids), ids.ctypes.data, lens.ctypes.data, toks.ctypes.data,
+                                                   out.ctypes.data, lg.ctypes.data if return_logits else None), "prefill")
+        return (out, lg) if return_logits else out
+
+    def decode(self, request_ids, token_ids, return_logits=False):
+        ids = _i32(request_ids)
+        toks = np.ascontiguousarray(token_ids, dtype=np.uint32)
+        out = np.zeros(len(ids), dtype=np.int32)
+        lg = np.zeros((len(ids), self.vocab), dtype=np.uint16) if return_logits else None
+        self._chk(self.lib.pegainfer_qwen3_decode(self.h, len(ids), ids.ctypes.data, toks.ctypes.data, out.ctypes.data,
+                                                  lg.ctypes.data if return_logits else None), "decode")
+        return (out, lg) if return_logits else out
+
+    def sample(self, column, temperature, top_k, top_p, random_val):
+        out = ctypes.c_int32(0)
+        self._chk(self.lib.pegainfer_qwen3_sample(self.h, column, temperature, top_k, top_p, random_val,
+                                                  ctypes.addressof(out)), "sample")
+        return out.value
+
+    def last_step_ms(self):
+        return self.lib.pegainfer_qwen3_last_step_ms(self.h)
+
+    def bench_gemv(self, which, iters=200, bs=1):
+        return self.lib.pegainfer_qwen3_bench_gemv(self.h, which, iters, bs)
+
+    def last_attention_path(self):
+        return self.lib.pegainfer_qwen3_last_attention_path(self.h)
+
+    def weight_bytes(self):
+        return self.lib.pegainfer_qwen3_weight_bytes(self.h)
+
+    def generate_greedy(self, prompt, max_new_tokens):
+        """The reference's e2e loop (tests/e2e.rs:108-221): prefill then decode, greedy."""
+        rid = self.new_request()
+        try:
+            out = [int(self.prefill([rid], [prompt])[0])]
+            for _ in range(max_new_tokens - 1):
+                out.append(int(self.decode([rid], [out[-1]])[0]))
+        finally:
+            self.drop_request(rid)
+        return out
+
+    def close(self):
+        if self.h:
+            self.lib.pegainfer_qwen3_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
