@@ -20,6 +20,25 @@ extern "C" {
  * state_scratch: rows*16 bytes, zeroed once by the caller, left zeroed.  Ties -> lowest index. */
 pegainfer_status_t pegainfer_batched_top1(const Half* logits, int32_t vocab_size, int32_t rows, int64_t row_stride, uint8_t* state_scratch, int32_t* out_tokens, pegainfer_stream_t stream);
 
+/* Decode GEMV (T <= 16) with optional prologue / epilogue fused in; same accumulation core as
+ * gemm_graphsafe_cuda, so every form below is bit-identical to the unfused reference-ABI sequence:
+ *   norm_weight == NULL                : Y = W.X                                  (== gemm_graphsafe_cuda)
+ *   norm_weight, residual == NULL      : Y = W.rms_norm(X)                        (rms_norm_batched_cuda + gemm)
+ *   norm_weight, residual, hidden_out  : hidden_out = bf16(X + residual); Y = W.rms_norm(X + residual)
+ *                                        (fused_add_rms_norm_batched_cuda + gemm; hidden_out != X)
+ *   silu_intermediate = I > 0          : W = [gate; up] (M == 2I), Y[T, I] = silu_mul_fused(W.x)
+ *                                        (gemm + silu_mul_fused_cuda)
+ * Returns hipErrorInvalidValue for shapes it does not take (T > 16, K % 8, misaligned) so the caller can
+ * fall back to the unfused sequence. */
+pegainfer_status_t pegainfer_gemv_fused(const Half* W, const Half* X, Half* Y, int32_t M, int32_t T, int32_t K, const Half* residual, const Half* norm_weight, Half* hidden_out, float eps, int32_t silu_intermediate, pegainfer_stream_t stream);
+
+/* Decode attention with the per-head q/k RMSNorm + RoPE and the KV append folded in (head_dim 128):
+ * reads the raw fused-QKV GEMV output qkv[bs, (Hq + 2 Hkv) * 128], writes the new K (normalised, rotated)
+ * and V rows into the paged cache and the attention output [bs, Hq*128].  Bit-identical to
+ * qk_norm_rope_batched_decode_cuda + paged_kv_scatter_cuda + paged_attention_decode[_split_kv]_cuda
+ * (ops/attention.rs:469-511, 572-796).  use_split selects the partition-KV plan arrays. */
+int32_t pegainfer_fused_decode_attention(const Half* qkv, Half* output, const Half* kv_data, int64_t k_offset_elems, int64_t v_offset_elems, const int32_t* page_indices, const int32_t* page_indptr, const int32_t* last_page_len_d, const int32_t* positions, const Half* q_norm_weight, const Half* k_norm_weight, const Half* cos_cache, const Half* sin_cache, float rms_eps, int32_t use_split, const int32_t* split_request_indices, const int32_t* split_kv_tile_indices, const int32_t* split_kv_chunk_size_ptr, const int32_t* split_o_indptr, const uint8_t* split_block_valid_mask, Half* tmp_v, float* tmp_s, int32_t num_qo_heads, int32_t num_kv_heads, int32_t head_dim, int32_t page_size, int32_t batch_size, int32_t split_slots, int64_t stride_page, float sm_scale, pegainfer_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

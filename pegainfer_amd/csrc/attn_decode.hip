@@ -18,6 +18,8 @@
 // o_indptr[b]..o_indptr[b+1].  kv_len always comes from the page table
 // ((pages-1)*page_size + last_page_len), kv_chunk_size_ptr[0] is read only when partitioning.
 #include "common.h"
+#include "pegainfer_kernels_ext.h"
+#include "rope_core.h"
 
 namespace pk {
 
@@ -28,14 +30,40 @@ __device__ __forceinline__ float token_sum(float v) {
   return v;
 }
 
+struct DecodeAttnArgs {
+  const Half* q; Half* o_out; const Half* kv; long k_off, v_off;
+  const int* page_indices; const int* page_indptr; const int* last_page_len; const int* request_indices;
+  const int* kv_tile_indices; const int* kv_chunk_size_ptr; const uint8_t* block_valid_mask;
+  Half* tmp_v; float* tmp_s; int num_qo_heads, num_kv_heads, page_size; long stride_page; float scale_log2;
+  // fused form only: raw qkv rows [bs, (Hq + 2 Hkv) * 128], per-head norm weights, RoPE tables, positions
+  const Half* qkv; const Half* q_norm_w; const Half* k_norm_w; const Half* cos_cache; const Half* sin_cache;
+  const int* positions; float eps;
+};
+
+struct ChunkInfo { int b, pbase, kv_len, lo, hi; };
+
+template <bool PARTITION>
+__device__ __forceinline__ ChunkInfo decode_chunk(const DecodeAttnArgs& a, int slot) {
+  ChunkInfo c;
+  c.b = a.request_indices ? a.request_indices[slot] : slot;
+  c.pbase = a.page_indptr[c.b];
+  const int npages = a.page_indptr[c.b + 1] - c.pbase;
+  c.kv_len = npages > 0 ? (npages - 1) * a.page_size + a.last_page_len[c.b] : 0;
+  c.lo = 0;
+  c.hi = c.kv_len;
+  if (PARTITION) {
+    const int chunk = a.kv_chunk_size_ptr[0];
+    c.lo = a.kv_tile_indices[slot] * chunk;
+    c.hi = c.lo + chunk < c.kv_len ? c.lo + chunk : c.kv_len;
+    if (c.lo > c.hi) c.lo = c.hi;
+  }
+  return c;
+}
+
+// The KV scan + in-workgroup merge, given the (already normalised / rotated) bf16 q fragments.
 template <int D, int GROUP, bool PARTITION>
-__global__ __launch_bounds__(256) void decode_attn_kernel(
-    const Half* __restrict__ q, Half* __restrict__ o_out, const Half* __restrict__ kv, long k_off, long v_off,
-    const int* __restrict__ page_indices, const int* __restrict__ page_indptr,
-    const int* __restrict__ last_page_len, const int* __restrict__ request_indices,
-    const int* __restrict__ kv_tile_indices, const int* __restrict__ kv_chunk_size_ptr,
-    const uint8_t* __restrict__ block_valid_mask, Half* __restrict__ tmp_v, float* __restrict__ tmp_s,
-    int num_qo_heads, int num_kv_heads, int page_size, long stride_page, float scale_log2) {
+__device__ __forceinline__ void decode_attn_body(const DecodeAttnArgs& a, const ChunkInfo& ci, const u32x4 (&qv)[GROUP],
+                                                 int slot, int kvh) {
   constexpr int LPT = D / 8;     // lanes per token row
   constexpr int TPI = 64 / LPT;  // token rows per load instruction
   constexpr int U = 4;           // load instructions in flight per operand
@@ -44,27 +72,14 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(
   __shared__ float sm_m[NPART][GROUP];
   __shared__ float sm_l[NPART][GROUP];
   __shared__ __attribute__((aligned(16))) float sm_o[NPART][GROUP][D];
-
-  const int slot = blockIdx.x, kvh = blockIdx.y;
-  if (PARTITION && block_valid_mask && !block_valid_mask[slot]) return;
-  const int b = request_indices ? request_indices[slot] : slot;
-  const int pbase = page_indptr[b];
-  const int npages = page_indptr[b + 1] - pbase;
-  const int kv_len = npages > 0 ? (npages - 1) * page_size + last_page_len[b] : 0;
-  int lo = 0, hi = kv_len;
-  if (PARTITION) {
-    const int chunk = kv_chunk_size_ptr[0];
-    lo = kv_tile_indices[slot] * chunk;
-    hi = lo + chunk < kv_len ? lo + chunk : kv_len;
-    if (lo > hi) lo = hi;
-  }
+  const Half* __restrict__ kv = a.kv;
+  const int* __restrict__ page_indices = a.page_indices;
+  const long k_off = a.k_off, v_off = a.v_off, stride_page = a.stride_page;
+  const int page_size = a.page_size, num_qo_heads = a.num_qo_heads, num_kv_heads = a.num_kv_heads;
+  const float scale_log2 = a.scale_log2;
+  const int b = ci.b, pbase = ci.pbase, lo = ci.lo, hi = ci.hi;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int sub = lane % LPT, grp = lane / LPT;
-
-  u32x4 qv[GROUP];
-#pragma unroll
-  for (int h = 0; h < GROUP; ++h)
-    qv[h] = *reinterpret_cast<const u32x4*>(q + ((size_t)b * num_qo_heads + kvh * GROUP + h) * D + sub * 8);
 
   float m[GROUP], l[GROUP], o[GROUP][8];
 #pragma unroll
@@ -154,15 +169,73 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(
     const float val = L > 0.f ? O / L : 0.f;
     const int head = kvh * GROUP + h;
     if (PARTITION) {
-      tmp_v[((size_t)slot * num_qo_heads + head) * D + d] = f2bf(val);
-      if (d == 0) tmp_s[(size_t)slot * num_qo_heads + head] = L > 0.f ? M + log2f(L) : -INFINITY;
+      a.tmp_v[((size_t)slot * num_qo_heads + head) * D + d] = f2bf(val);
+      if (d == 0) a.tmp_s[(size_t)slot * num_qo_heads + head] = L > 0.f ? M + log2f(L) : -INFINITY;
     } else {
-      o_out[((size_t)b * num_qo_heads + head) * D + d] = f2bf(val);
+      a.o_out[((size_t)b * num_qo_heads + head) * D + d] = f2bf(val);
     }
   }
 }
 
-// one wave per (request, q head): out = sum_s 2^(lse_s - M) * v_s / sum_s 2^(lse_s - M)
+// ---- kernels: reference-ABI form (q already normalised + rotated, K/V already in the cache) ----
+template <int D, int GROUP, bool PARTITION>
+__global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs a) {
+  const int slot = blockIdx.x, kvh = blockIdx.y;
+  if (PARTITION && a.block_valid_mask && !a.block_valid_mask[slot]) return;
+  const ChunkInfo ci = decode_chunk<PARTITION>(a, slot);
+  const int sub = (threadIdx.x & 63) % (D / 8);
+  u32x4 qv[GROUP];
+#pragma unroll
+  for (int h = 0; h < GROUP; ++h)
+    qv[h] = *reinterpret_cast<const u32x4*>(a.q + ((size_t)ci.b * a.num_qo_heads + kvh * GROUP + h) * D + sub * 8);
+  decode_attn_body<D, GROUP, PARTITION>(a, ci, qv, slot, kvh);
+}
+
+// ---- fused form (head_dim 128): per-head q/k RMSNorm + RoPE and the KV append folded into the prologue.
+// Every workgroup normalises + rotates its GROUP query heads from the raw qkv row (cheap, redundant across
+// the request's chunks); the one workgroup per (request, kv head) whose chunk contains the new position also
+// normalises + rotates the new K row, writes K and V into the page (same bytes paged_kv_scatter_cuda would
+// write) and only then scans.  Replaces qk_norm_rope + paged_kv_scatter + decode attention: 3 launches -> 1.
+template <int GROUP, bool PARTITION>
+__global__ __launch_bounds__(256) void fused_decode_attn_kernel(const DecodeAttnArgs a) {
+  constexpr int D = 128;
+  const int slot = blockIdx.x, kvh = blockIdx.y;
+  if (PARTITION && a.block_valid_mask && !a.block_valid_mask[slot]) return;
+  const ChunkInfo ci = decode_chunk<PARTITION>(a, slot);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int sub = lane & 15, grp = lane >> 4;
+  const int pos = a.positions[ci.b];
+  const int q_dim = a.num_qo_heads * D, kv_dim = a.num_kv_heads * D;
+  const Half* row = a.qkv + (size_t)ci.b * (q_dim + 2 * kv_dim);
+  const Half* crow = a.cos_cache + (size_t)pos * D;
+  const Half* srow = a.sin_cache + (size_t)pos * D;
+  u32x4 qv[GROUP];
+#pragma unroll
+  for (int h = 0; h < GROUP; ++h) {
+    const u32x4 x = *reinterpret_cast<const u32x4*>(row + (size_t)(kvh * GROUP + h) * D + sub * 8);
+    qv[h] = head_norm_rope16(x, a.q_norm_w, crow, srow, sub, a.eps);
+  }
+  const bool owns_new = pos >= ci.lo && pos < ci.hi;  // workgroup-uniform
+  if (owns_new) {
+    if (wave == 0 && grp == 0) {
+      const u32x4 xk = *reinterpret_cast<const u32x4*>(row + q_dim + (size_t)kvh * D + sub * 8);
+      const u32x4 kn = head_norm_rope16(xk, a.k_norm_w, crow, srow, sub, a.eps);
+      const u32x4 xv = *reinterpret_cast<const u32x4*>(row + q_dim + kv_dim + (size_t)kvh * D + sub * 8);
+      const int page = a.page_indices[ci.pbase + pos / a.page_size];
+      const long base = (long)page * a.stride_page + ((long)(pos % a.page_size) * a.num_kv_heads + kvh) * D + sub * 8;
+      Half* kvw = const_cast<Half*>(a.kv);
+      *reinterpret_cast<u32x4*>(kvw + base + a.k_off) = kn;
+      *reinterpret_cast<u32x4*>(kvw + base + a.v_off) = xv;
+    }
+    __syncthreads();  // workgroup-scope release/acquire: the new row is visible to the scanning waves
+  }
+  decode_attn_body<D, GROUP, PARTITION>(a, ci, qv, slot, kvh);
+}
+
+// merge of the partition-KV partial states: one wave per (request, q head).  Lanes first fetch all
+// log2-sum-exps of the request's slots in parallel (<= 64 slots), then every lane accumulates its
+// D/64 output dims over the slots with the weights broadcast from registers:
+//   out = sum_s 2^(lse_s - M) v_s / sum_s 2^(lse_s - M)
 template <int D>
 __global__ __launch_bounds__(256) void merge_states_kernel(const Half* __restrict__ tmp_v,
                                                            const float* __restrict__ tmp_s,
@@ -175,18 +248,27 @@ __global__ __launch_bounds__(256) void merge_states_kernel(const Half* __restric
   const int lane = threadIdx.x & 63;
   const int s0 = o_indptr[b], s1 = o_indptr[b + 1];
   constexpr int EPL = D / 64;  // elements per lane (2 or 4)
-  float M = -INFINITY;
-  for (int s = s0; s < s1; ++s) M = fmaxf(M, tmp_s[(size_t)s * num_qo_heads + head]);
   float acc[EPL], wsum = 0.f;
 #pragma unroll
   for (int i = 0; i < EPL; ++i) acc[i] = 0.f;
+  // both split plans cap a request at 64 chunks (batch_decode_buffers.rs:15); launch_decode rejects more
+  const int n = s1 - s0 < 64 ? s1 - s0 : 64;
+  const float lse = lane < n ? tmp_s[(size_t)(s0 + lane) * num_qo_heads + head] : -INFINITY;
+  const float M = wave_max(lse);
   if (M != -INFINITY) {
-    for (int s = s0; s < s1; ++s) {
-      const float w = exp2f(tmp_s[(size_t)s * num_qo_heads + head] - M);
+    const float w_lane = exp2f(lse - M);
+    for (int j = 0; j < n; ++j) {
+      const float w = __shfl(w_lane, j, kWave);
+      const Half* v = tmp_v + ((size_t)(s0 + j) * num_qo_heads + head) * D + lane * EPL;
       wsum += w;
-      const Half* v = tmp_v + ((size_t)s * num_qo_heads + head) * D + lane * EPL;
+      if (EPL == 2) {
+        const uint32_t pv = *reinterpret_cast<const uint32_t*>(v);
+        acc[0] += w * bf_lo(pv);
+        acc[1] += w * bf_hi(pv);
+      } else {
 #pragma unroll
-      for (int i = 0; i < EPL; ++i) acc[i] += w * bf2f(v[i]);
+        for (int i = 0; i < EPL; ++i) acc[i] += w * bf2f(v[i]);
+      }
     }
   }
   Half* dst = out + ((size_t)b * num_qo_heads + head) * D + lane * EPL;
@@ -194,20 +276,29 @@ __global__ __launch_bounds__(256) void merge_states_kernel(const Half* __restric
   for (int i = 0; i < EPL; ++i) dst[i] = f2bf(wsum > 0.f ? acc[i] / wsum : 0.f);
 }
 
-template <int D, bool PARTITION>
-static int launch_decode(const Half* q, Half* output, const Half* kv, long k_off, long v_off, const int* pi,
-                         const int* pip, const int* lpl, const int* ri, const int* kti, const int* kcs,
-                         const int* o_indptr, const uint8_t* mask, Half* tmp_v, float* tmp_s, int hq, int hkv,
-                         int page_size, int batch_size, int slots, long stride_page, float sm_scale,
-                         hipStream_t s) {
-  if (slots <= 0 || hkv <= 0) return 0;
-  const int group = hq / hkv;
-  const float scale_log2 = sm_scale * 1.4426950408889634f;
-  dim3 grid(slots, hkv);
-#define PK_LAUNCH(G)                                                                                   \
-  decode_attn_kernel<D, G, PARTITION><<<grid, 256, 0, s>>>(q, output, kv, k_off, v_off, pi, pip, lpl, ri, kti, \
-                                                           kcs, mask, tmp_v, tmp_s, hq, hkv, page_size,       \
-                                                           stride_page, scale_log2)
+static void fill_args(DecodeAttnArgs& a, const Half* q, Half* output, const Half* kv, long k_off, long v_off,
+                      const int* pi, const int* pip, const int* lpl, const int* ri, const int* kti, const int* kcs,
+                      const uint8_t* mask, Half* tmp_v, float* tmp_s, int hq, int hkv, int page_size,
+                      long stride_page, float sm_scale) {
+  a = DecodeAttnArgs{};
+  a.q = q; a.o_out = output; a.kv = kv; a.k_off = k_off; a.v_off = v_off;
+  a.page_indices = pi; a.page_indptr = pip; a.last_page_len = lpl; a.request_indices = ri;
+  a.kv_tile_indices = kti; a.kv_chunk_size_ptr = kcs; a.block_valid_mask = mask; a.tmp_v = tmp_v; a.tmp_s = tmp_s;
+  a.num_qo_heads = hq; a.num_kv_heads = hkv; a.page_size = page_size; a.stride_page = stride_page;
+  a.scale_log2 = sm_scale * 1.4426950408889634f;
+}
+
+template <int D, bool PARTITION, bool FUSED>
+static int launch_decode(const DecodeAttnArgs& a, const int* o_indptr, int batch_size, int slots, hipStream_t s) {
+  if (slots <= 0 || a.num_kv_heads <= 0) return 0;
+  if (o_indptr && PARTITION && slots > batch_size * 64) return static_cast<int>(hipErrorInvalidValue);
+  const int group = a.num_qo_heads / a.num_kv_heads;
+  dim3 grid(slots, a.num_kv_heads);
+#define PK_LAUNCH(G)                                                                    \
+  do {                                                                                  \
+    if (FUSED) fused_decode_attn_kernel<G, PARTITION><<<grid, 256, 0, s>>>(a);          \
+    else decode_attn_kernel<D, G, PARTITION><<<grid, 256, 0, s>>>(a);                   \
+  } while (0)
   switch (group) {
     case 1: PK_LAUNCH(1); break;
     case 2: PK_LAUNCH(2); break;
@@ -217,8 +308,8 @@ static int launch_decode(const Half* q, Half* output, const Half* kv, long k_off
   }
 #undef PK_LAUNCH
   if (PARTITION)
-    merge_states_kernel<D><<<ceil_div((long)batch_size * hq, 4), 256, 0, s>>>(tmp_v, tmp_s, o_indptr, output,
-                                                                             batch_size, hq);
+    merge_states_kernel<D><<<ceil_div((long)batch_size * a.num_qo_heads, 4), 256, 0, s>>>(
+        a.tmp_v, a.tmp_s, o_indptr, a.o_out, batch_size, a.num_qo_heads);
   return static_cast<int>(hipGetLastError());
 }
 
@@ -236,10 +327,11 @@ int32_t paged_attention_decode_cuda(const Half* q, Half* output, const Half* kv_
                                     int32_t head_dim, int32_t page_size, int32_t batch_size, int64_t stride_page,
                                     float sm_scale, pegainfer_stream_t stream) {
   if (head_dim != 128) return static_cast<int32_t>(hipErrorInvalidValue);  // HEAD_DIM=128 instantiation
-  return launch_decode<128, false>(q, output, kv_data, k_offset_elems, v_offset_elems, page_indices, page_indptr,
-                                   last_page_len_d, request_indices, kv_tile_indices, kv_chunk_size_ptr, nullptr,
-                                   nullptr, nullptr, nullptr, num_qo_heads, num_kv_heads, page_size, batch_size,
-                                   batch_size, stride_page, sm_scale, as_stream(stream));
+  DecodeAttnArgs a;
+  fill_args(a, q, output, kv_data, k_offset_elems, v_offset_elems, page_indices, page_indptr, last_page_len_d,
+            request_indices, kv_tile_indices, kv_chunk_size_ptr, nullptr, nullptr, nullptr, num_qo_heads,
+            num_kv_heads, page_size, stride_page, sm_scale);
+  return launch_decode<128, false, false>(a, nullptr, batch_size, batch_size, as_stream(stream));
 }
 
 int32_t paged_attention_decode_split_kv_cuda(
@@ -250,10 +342,36 @@ int32_t paged_attention_decode_split_kv_cuda(
     int32_t num_kv_heads, int32_t head_dim, int32_t page_size, int32_t batch_size, int32_t padded_batch_size,
     int64_t stride_page, float sm_scale, pegainfer_stream_t stream) {
   if (head_dim != 128) return static_cast<int32_t>(hipErrorInvalidValue);
-  return launch_decode<128, true>(q, output, kv_data, k_offset_elems, v_offset_elems, page_indices, page_indptr,
-                                  last_page_len_d, request_indices, kv_tile_indices, kv_chunk_size_ptr, o_indptr,
-                                  block_valid_mask, tmp_v, tmp_s, num_qo_heads, num_kv_heads, page_size,
-                                  batch_size, padded_batch_size, stride_page, sm_scale, as_stream(stream));
+  DecodeAttnArgs a;
+  fill_args(a, q, output, kv_data, k_offset_elems, v_offset_elems, page_indices, page_indptr, last_page_len_d,
+            request_indices, kv_tile_indices, kv_chunk_size_ptr, block_valid_mask, tmp_v, tmp_s, num_qo_heads,
+            num_kv_heads, page_size, stride_page, sm_scale);
+  return launch_decode<128, true, false>(a, o_indptr, batch_size, padded_batch_size, as_stream(stream));
+}
+
+// Extension (include/pegainfer_kernels_ext.h): qk_norm_rope_batched_decode_cuda + paged_kv_scatter_cuda +
+// paged_attention_decode[_split_kv]_cuda in one launch (+ the merge when partitioned).
+int32_t pegainfer_fused_decode_attention(
+    const Half* qkv, Half* output, const Half* kv_data, int64_t k_offset_elems, int64_t v_offset_elems,
+    const int32_t* page_indices, const int32_t* page_indptr, const int32_t* last_page_len_d,
+    const int32_t* positions, const Half* q_norm_weight, const Half* k_norm_weight, const Half* cos_cache,
+    const Half* sin_cache, float rms_eps, int32_t use_split, const int32_t* split_request_indices,
+    const int32_t* split_kv_tile_indices, const int32_t* split_kv_chunk_size_ptr, const int32_t* split_o_indptr,
+    const uint8_t* split_block_valid_mask, Half* tmp_v, float* tmp_s, int32_t num_qo_heads, int32_t num_kv_heads,
+    int32_t head_dim, int32_t page_size, int32_t batch_size, int32_t split_slots, int64_t stride_page,
+    float sm_scale, pegainfer_stream_t stream) {
+  if (head_dim != 128 || !host_aligned16(qkv) || !host_aligned16(kv_data))
+    return static_cast<int32_t>(hipErrorInvalidValue);
+  DecodeAttnArgs a;
+  fill_args(a, nullptr, output, kv_data, k_offset_elems, v_offset_elems, page_indices, page_indptr, last_page_len_d,
+            use_split ? split_request_indices : nullptr, split_kv_tile_indices, split_kv_chunk_size_ptr,
+            use_split ? split_block_valid_mask : nullptr, tmp_v, tmp_s, num_qo_heads, num_kv_heads, page_size,
+            stride_page, sm_scale);
+  a.qkv = qkv; a.q_norm_w = q_norm_weight; a.k_norm_w = k_norm_weight; a.cos_cache = cos_cache;
+  a.sin_cache = sin_cache; a.positions = positions; a.eps = rms_eps;
+  if (use_split)
+    return launch_decode<128, true, true>(a, split_o_indptr, batch_size, split_slots, as_stream(stream));
+  return launch_decode<128, false, true>(a, nullptr, batch_size, batch_size, as_stream(stream));
 }
 
 }  // extern "C"

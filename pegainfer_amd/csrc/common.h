@@ -31,6 +31,8 @@ __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
   return static_cast<uint32_t>(f2bf(lo)) | (static_cast<uint32_t>(f2bf(hi)) << 16);
 }
 __device__ __forceinline__ float bf16_round_f(float f) { return bf2f(f2bf(f)); }
+// SiLU exactly as the reference writes it: g / (1 + expf(-g))  (csrc/fused_proj.cu:57-62)
+__device__ __forceinline__ float silu_f(float g) { return g / (1.0f + expf(-g)); }
 
 // a.lo*b.lo + a.hi*b.hi + c on packed bf16 pairs (v_dot2c_f32_bf16)
 __device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {

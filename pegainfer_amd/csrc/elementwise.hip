@@ -9,7 +9,6 @@ namespace pk {
 constexpr int kBlock = 256;
 constexpr int kMaxGrid = 256 * 8;  // 256 CUs x 8 blocks (guide: cap + grid-stride)
 
-__device__ __forceinline__ float silu_f(float g) { return g / (1.0f + expf(-g)); }
 
 // ---- add: out = bf16(f32(a)+f32(b))  (reference csrc/elementwise.cu:8-20) ----
 __global__ void add_vec_kernel(const u32x4* __restrict__ a, const u32x4* __restrict__ b,

@@ -1,0 +1,259 @@
+// Decode GEMV core for gfx950 - shared by the reference-ABI GEMM entry points (linear.hip) and the
+// fused decode entry point (pegainfer_gemv_fused).  HBM-bound weight streaming:
+//   * every W element is read exactly once with 16-byte non-temporal loads straight into VGPRs
+//     (no LDS round trip for the streamed operand); U x RPW loads (16 KB per wave) are in flight
+//     and the first group is issued BEFORE the x prologue so HBM latency overlaps it;
+//   * x lives in LDS (K-tiled, shared by the 4 waves); optional prologue builds x on the fly as
+//     rms_norm(X [+ residual]) * w with the canonical summation order of norm_core.h, so the fused
+//     form rounds exactly like "fused_add_rms_norm kernel, then GEMV";
+//   * v_dot2c_f32_bf16 accumulation, wave64 butterfly; K >= 4096 deals the 512-element K blocks
+//     round-robin to the 4 waves (LDS combine in fixed order) so M = 2560 still gives 1280 workgroups;
+//   * optional epilogue applies SwiGLU to (gate row r, up row I + r) pairs computed by the same wave,
+//     rounding gate/up to bf16 first exactly like the unfused GEMM -> silu_mul_fused sequence.
+// The per-(row, token) summation order depends only on (K, KSPLIT): never on T, M, RPW or the
+// prologue/epilogue, which is what makes batch decode == single decode bit-for-bit.
+#pragma once
+
+#include "common.h"
+#include "norm_core.h"
+
+namespace pk {
+
+// x K-tile per token row: 32 KB of LDS for NT <= 8, 64 KB for NT = 16.  KT stays a multiple of 2048
+// (4 waves x 512) so the KSPLIT block->wave deal is identical for every NT.
+template <int NT> struct GemvTile { static constexpr int KT = NT <= 8 ? 16384 / NT : 2048; };
+
+enum { kEpiStore = 0, kEpiSilu = 1 };
+
+struct GemvFusedArgs {
+  const Half* W; const Half* X; Half* Y; int M; int T; int K;
+  const Half* residual;   // optional: x = norm(X + residual), hidden_out = bf16(X + residual)
+  const Half* norm_w;     // optional: non-null enables the RMSNorm prologue
+  Half* hidden_out;       // written by workgroup 0 only (must not alias X)
+  float eps;
+  int I;                  // kEpiSilu: W = [gate(I rows); up(I rows)], Y = [T, I]
+};
+
+template <int NT, int RPW, int KSPLIT, int EPI>
+__global__ __launch_bounds__(256) void gemv_fused_kernel(const GemvFusedArgs a) {
+  constexpr int KT = GemvTile<NT>::KT;
+  constexpr int NW = EPI == kEpiSilu ? 2 : 1;  // weight row sets streamed together
+  constexpr int U = 4;                         // K blocks in flight per wave: U*NW*RPW = 16 loads = 16 KB
+  __shared__ __attribute__((aligned(16))) u32x4 xs[NT * KT / 8];
+  __shared__ float part[KSPLIT == 1 ? 1 : 4 * NW * RPW * NT];
+  __shared__ float red[kNormWaves];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int K = a.K, T = a.T;
+  const int rows_total = EPI == kEpiSilu ? a.I : a.M;
+  const int row0 = (KSPLIT == 1 ? (blockIdx.x * 4 + wave) : blockIdx.x) * RPW;
+  const Half* wrow[NW][RPW];
+#pragma unroll
+  for (int s = 0; s < NW; ++s)
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      int row = row0 + r;
+      row = row < rows_total ? row : rows_total - 1;  // clamp: loads stay in bounds, stores are masked
+      wrow[s][r] = a.W + ((size_t)row + (size_t)s * a.I) * K;
+    }
+  float acc[NW][RPW][NT];
+#pragma unroll
+  for (int s = 0; s < NW; ++s)
+#pragma unroll
+    for (int r = 0; r < RPW; ++r)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[s][r][t] = 0.f;
+
+  u32x4 wv[U][NW][RPW];
+  auto issue = [&](int k0, int kt, int b0) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int kk = (b0 + u * KSPLIT) * 512 + lane * 8;
+      kk = kk < kt ? kk : kt - 8;  // clamped loads read valid weights; their x is zeroed below
+#pragma unroll
+      for (int s = 0; s < NW; ++s)
+#pragma unroll
+        for (int r = 0; r < RPW; ++r)
+          wv[u][s][r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow[s][r] + k0 + kk));
+    }
+  };
+  auto consume = [&](int kt, int nblk, int b0) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int blk = b0 + u * KSPLIT;
+      const int kk = blk * 512 + lane * 8;
+      const bool live = blk < nblk && kk < kt;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        u32x4 xv = xs[t * (KT / 8) + (live ? (kk >> 3) : 0)];
+        if (!live) xv = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int s = 0; s < NW; ++s)
+#pragma unroll
+          for (int r = 0; r < RPW; ++r) acc[s][r][t] = dot8(wv[u][s][r], xv, acc[s][r][t]);
+      }
+    }
+  };
+
+  const int bfirst = KSPLIT == 1 ? 0 : wave;
+  const int kt0 = K < KT ? K : KT;
+  issue(0, kt0, bfirst);  // HBM requests leave before the prologue touches anything
+
+  // ---- prologue: per-token inverse RMS (canonical order), only when a norm weight is given ----
+  float inv[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    inv[t] = 0.f;
+    if (a.norm_w && t < T)
+      inv[t] = row_inv_rms_vec(a.X + (size_t)t * K, a.residual ? a.residual + (size_t)t * K : nullptr, K, a.eps, red);
+  }
+  auto stage = [&](int k0, int kt) {
+    const int nvec = (kt + 7) >> 3;  // lanes beyond kt never read their slot (consume() zeroes them)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      if (t >= T) continue;          // accumulators of absent tokens are never stored
+      for (int c = threadIdx.x; c < nvec; c += 256) {
+        u32x4 v = {0u, 0u, 0u, 0u};
+        {
+          const size_t off = (size_t)t * K + k0 + c * 8;
+          const u32x4 h = *reinterpret_cast<const u32x4*>(a.X + off);
+          if (a.norm_w) {
+            const u32x4 g = *reinterpret_cast<const u32x4*>(a.norm_w + k0 + c * 8);
+            if (a.residual) {
+              const u32x4 r = *reinterpret_cast<const u32x4*>(a.residual + off);
+              u32x4 nh;
+              v = norm_scale8(h, &r, g, inv[t], 0.f, &nh);
+              if (blockIdx.x == 0) *reinterpret_cast<u32x4*>(a.hidden_out + off) = nh;
+            } else {
+              v = norm_scale8(h, nullptr, g, inv[t], 0.f, nullptr);
+            }
+          } else {
+            v = h;
+          }
+        }
+        xs[t * (KT / 8) + c] = v;
+      }
+    }
+  };
+
+  // ---- tile 0 (first block group already in flight) ----
+  stage(0, kt0);
+  __syncthreads();
+  {
+    const int nblk = (kt0 + 511) >> 9;
+    consume(kt0, nblk, bfirst);
+    for (int b0 = bfirst + U * KSPLIT; b0 < nblk; b0 += U * KSPLIT) {
+      issue(0, kt0, b0);
+      consume(kt0, nblk, b0);
+    }
+  }
+  for (int k0 = KT; k0 < K; k0 += KT) {
+    const int kt = (K - k0) < KT ? (K - k0) : KT;
+    __syncthreads();
+    stage(k0, kt);
+    __syncthreads();
+    const int nblk = (kt + 511) >> 9;
+    for (int b0 = bfirst; b0 < nblk; b0 += U * KSPLIT) {
+      issue(k0, kt, b0);
+      consume(kt, nblk, b0);
+    }
+  }
+
+#pragma unroll
+  for (int s = 0; s < NW; ++s)
+#pragma unroll
+    for (int r = 0; r < RPW; ++r)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[s][r][t] = wave_sum(acc[s][r][t]);
+
+  auto emit = [&](int r, int t, float v0, float v1) {
+    const int row = row0 + r;
+    if (row >= rows_total || t >= T) return;
+    if (EPI == kEpiSilu) {
+      const float g = bf16_round_f(v0), u = bf16_round_f(v1);  // the GEMM output is bf16 before SwiGLU
+      a.Y[(size_t)t * a.I + row] = f2bf(silu_f(g) * u);
+    } else {
+      a.Y[(size_t)t * a.M + row] = f2bf(v0);
+    }
+  };
+  if (KSPLIT == 1) {
+    if (lane == 0) {
+#pragma unroll
+      for (int r = 0; r < RPW; ++r)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) emit(r, t, acc[0][r][t], acc[NW - 1][r][t]);
+    }
+  } else {
+    if (lane == 0) {
+#pragma unroll
+      for (int s = 0; s < NW; ++s)
+#pragma unroll
+        for (int r = 0; r < RPW; ++r)
+#pragma unroll
+          for (int t = 0; t < NT; ++t) part[((wave * NW + s) * RPW + r) * NT + t] = acc[s][r][t];
+    }
+    __syncthreads();
+    if (threadIdx.x < RPW * NT) {
+      const int r = threadIdx.x / NT, t = threadIdx.x - r * NT;
+      float tot[NW];
+#pragma unroll
+      for (int s = 0; s < NW; ++s) {
+        float v = part[((0 * NW + s) * RPW + r) * NT + t];
+        v += part[((1 * NW + s) * RPW + r) * NT + t];
+        v += part[((2 * NW + s) * RPW + r) * NT + t];
+        v += part[((3 * NW + s) * RPW + r) * NT + t];
+        tot[s] = v;
+      }
+      emit(r, t, tot[0], tot[NW - 1]);
+    }
+  }
+}
+
+// rows per wave: the largest of {4,2,1} (bounded by max_rpw) whose workgroup count fills the 256 CUs
+// evenly (>= 95 % balance) and reaches >= 512 workgroups; otherwise the best-balanced one.
+inline int gemv_pick_rpw(int rows, int ksplit, int max_rpw) {
+  int best = 1;
+  double best_score = -1.0;
+  for (int rpw = max_rpw; rpw >= 1; rpw >>= 1) {
+    const int per_wg = (ksplit == 1 ? 4 : 1) * rpw;
+    const int nwg = (rows + per_wg - 1) / per_wg;
+    const double bal = (double)nwg / (double)(((nwg + 255) / 256) * 256);
+    if (bal >= 0.95 && nwg >= 512) return rpw;
+    const double score = bal + (nwg >= 256 ? 0.0 : -1.0);
+    if (score > best_score) { best_score = score; best = rpw; }
+  }
+  return best;
+}
+
+template <int NT, int RPW, int EPI>
+inline void gemv_launch_ks(const GemvFusedArgs& a, int ksplit, hipStream_t s) {
+  const int rows = EPI == kEpiSilu ? a.I : a.M;
+  if (ksplit == 4) gemv_fused_kernel<NT, RPW, 4, EPI><<<ceil_div(rows, RPW), 256, 0, s>>>(a);
+  else gemv_fused_kernel<NT, RPW, 1, EPI><<<ceil_div(rows, 4 * RPW), 256, 0, s>>>(a);
+}
+
+template <int NT, int EPI>
+inline void gemv_launch_nt(const GemvFusedArgs& a, hipStream_t s) {
+  const int ksplit = a.K >= 4096 ? 4 : 1;
+  const int rows = EPI == kEpiSilu ? a.I : a.M;
+  constexpr int kMaxRpw = (EPI == kEpiSilu) ? 2 : (NT <= 2 ? 4 : 2);  // keeps <= 16 loads / 32 accumulators per wave
+  const int rpw = gemv_pick_rpw(rows, ksplit, kMaxRpw);
+  if constexpr (kMaxRpw >= 4) {
+    if (rpw == 4) { gemv_launch_ks<NT, 4, EPI>(a, ksplit, s); return; }
+  }
+  if (rpw >= 2) { gemv_launch_ks<NT, 2, EPI>(a, ksplit, s); return; }
+  gemv_launch_ks<NT, 1, EPI>(a, ksplit, s);
+}
+
+// T <= 16, K % 8 == 0, 16-byte aligned W/X (and residual/norm_w/hidden_out when given)
+template <int EPI>
+inline bool gemv_dispatch(const GemvFusedArgs& a, hipStream_t s) {
+  if (a.T < 1 || a.T > 16 || (a.K & 7) != 0) return false;
+  if (a.T == 1) gemv_launch_nt<1, EPI>(a, s);
+  else if (a.T == 2) gemv_launch_nt<2, EPI>(a, s);
+  else if (a.T <= 4) gemv_launch_nt<4, EPI>(a, s);
+  else if (a.T <= 8) gemv_launch_nt<8, EPI>(a, s);
+  else gemv_launch_nt<16, EPI>(a, s);
+  return true;
+}
+
+}  // namespace pk

@@ -87,7 +87,8 @@ struct Model {
   std::vector<KvState> requests;
   // decode buffers
   Half *normed = nullptr, *q = nullptr, *k = nullptr, *v = nullptr, *attn_out = nullptr, *attn_proj = nullptr,
-       *gate_up_out = nullptr, *mlp_act = nullptr, *mlp_out = nullptr, *hidden = nullptr, *logits = nullptr;
+       *gate_up_out = nullptr, *mlp_act = nullptr, *mlp_out = nullptr, *hidden = nullptr, *logits = nullptr,
+       *hidden2 = nullptr, *qkv_out = nullptr;
   Half* split_tmp_v = nullptr;
   float* split_tmp_s = nullptr;
   int32_t* tokens_out_d = nullptr;
@@ -174,6 +175,7 @@ struct Model {
     if (dalloc(&normed, bs * H) || dalloc(&q, bs * q_dim) || dalloc(&k, bs * kv_dim) || dalloc(&v, bs * kv_dim) ||
         dalloc(&attn_out, bs * q_dim) || dalloc(&attn_proj, bs * H) || dalloc(&gate_up_out, bs * 2 * I) ||
         dalloc(&mlp_act, bs * I) || dalloc(&mlp_out, bs * H) || dalloc(&hidden, bs * H) ||
+        dalloc(&hidden2, bs * H) || dalloc(&qkv_out, bs * (size_t)(q_dim + 2 * kv_dim)) ||
         dalloc(&logits, bs * (size_t)V) || dalloc(&split_tmp_v, slots * q_dim) || dalloc(&split_tmp_s, slots * Hq) ||
         dalloc(&tokens_out_d, bs) || dalloc(&top1_state, bs * 16) || dalloc(&probs_scratch, (size_t)V) ||
         dalloc(&top1_value, 1) || dalloc(&row_states, 1024 * 1024) || dalloc(&valid_scratch, 1) ||
@@ -343,7 +345,55 @@ struct Model {
     return 0;
   }
 
+  // decode_mode 1: the MI355X launch-lean form of the same DAG.  Per layer 5 launches (+ merge when the KV
+  // is partitioned) instead of 14: both fused_add_rms_norm ops are folded into the prologue of the GEMV that
+  // consumes them, SwiGLU into the gate_up GEMV epilogue, qk-norm + RoPE + KV append into the attention
+  // kernel.  Every fused kernel shares its arithmetic core with the reference-named op it replaces, so the
+  // logits are bit-identical to decode_mode 0 (tests/test_gpu_fused.py).
+  int decode_kernels_fused(int bs, bool split, int split_slots) {
+    if (embedding_batched_cuda(embed, md<uint32_t>(ml.token_ids), hidden, H, bs, S())) {
+      set_error("embedding_batched_cuda failed");
+      return -1;
+    }
+    Half *cur = hidden, *nxt = hidden2;
+    const Half* resid = nullptr;
+    const float sm = 1.0f / std::sqrt((float)D);
+    for (int li = 0; li < L; ++li) {
+      const Layer& ly = layers[li];
+      int rc = pegainfer_gemv_fused(ly.qkv, cur, qkv_out, q_dim + 2 * kv_dim, bs, H, resid, ly.ln1,
+                                    resid ? nxt : nullptr, eps, 0, S());
+      if (resid) std::swap(cur, nxt);
+      if (!rc)
+        rc = pegainfer_fused_decode_attention(
+            qkv_out, attn_out, kv_buffer, layout.k_offset(li), layout.v_offset(li), md<int32_t>(ml.page_indices),
+            md<int32_t>(ml.page_indptr), md<int32_t>(ml.last_page_len), md<int32_t>(ml.positions), ly.q_norm,
+            ly.k_norm, cos, sin, eps, split ? 1 : 0, md<int32_t>(ml.split_request_indices),
+            md<int32_t>(ml.split_kv_tile_indices), md<int32_t>(ml.split_kv_chunk_size),
+            md<int32_t>(ml.split_o_indptr), md<uint8_t>(ml.split_valid), split_tmp_v, split_tmp_s, Hq, Hkv, D,
+            layout.page_size, bs, split_slots, layout.page_stride, sm, S());
+      if (!rc) rc = pegainfer_gemv_fused(ly.o, attn_out, attn_proj, H, bs, q_dim, nullptr, nullptr, nullptr, 0.f, 0, S());
+      if (!rc) {
+        rc = pegainfer_gemv_fused(ly.gate_up, cur, mlp_act, 2 * I, bs, H, attn_proj, ly.ln2, nxt, eps, I, S());
+        std::swap(cur, nxt);
+      }
+      if (!rc) rc = pegainfer_gemv_fused(ly.down, mlp_act, mlp_out, H, bs, I, nullptr, nullptr, nullptr, 0.f, 0, S());
+      if (rc) { set_error("fused decode layer failed"); return -1; }
+      resid = mlp_out;
+    }
+    if (pegainfer_gemv_fused(lm_head, cur, logits, V, bs, H, resid, final_norm, nxt, eps, 0, S())) {
+      set_error("fused lm_head failed");
+      return -1;
+    }
+    if (pegainfer_batched_top1(logits, V, bs, V, top1_state, tokens_out_d, S())) {
+      set_error("pegainfer_batched_top1 failed");
+      return -1;
+    }
+    return 0;
+  }
+  bool fused_ok(int bs) const { return decode_mode == 1 && bs <= 16 && (H & 7) == 0 && (I & 7) == 0 && D == 128; }
+
   int decode_kernels(int bs, bool split, int split_slots) {
+    if (fused_ok(bs)) return decode_kernels_fused(bs, split, split_slots);
     if (embedding_batched_cuda(embed, md<uint32_t>(ml.token_ids), hidden, H, bs, S())) {
       set_error("embedding_batched_cuda failed");
       return -1;

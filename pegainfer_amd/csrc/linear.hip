@@ -19,6 +19,8 @@
 //       slot swizzle, XCD-aware tile order (each XCD's L2 keeps one W panel hot).
 //   naive_gemm_kernel           any shape the fast paths cannot take (K % 8 != 0, unaligned).
 #include "common.h"
+#include "gemv_core.h"
+#include "pegainfer_kernels_ext.h"
 
 namespace pk {
 
@@ -33,112 +35,6 @@ __global__ __launch_bounds__(256) void naive_gemm_kernel(const Half* __restrict_
   for (int k = lane; k < K; k += 64) acc += bf2f(W[(size_t)m * K + k]) * bf2f(X[(size_t)t * K + k]);
   acc = wave_sum(acc);
   if (lane == 0) Y[(size_t)t * M + m] = f2bf(acc);
-}
-
-// ------------------------------------------------------------------ decode GEMV
-// x K-tile per token row: 32 KB of LDS for NT <= 8, 64 KB for NT = 16.  KT must stay a multiple
-// of 2048 (4 waves x 512) so the KSPLIT block->wave deal is the same for every NT.
-template <int NT> struct GemvTile { static constexpr int KT = NT <= 8 ? 16384 / NT : 2048; };
-
-template <int NT, int RPW, int KSPLIT>
-__global__ __launch_bounds__(256) void gemv_kernel(const Half* __restrict__ W, const Half* __restrict__ X,
-                                                   Half* __restrict__ Y, int M, int T, int K) {
-  constexpr int KT = GemvTile<NT>::KT;  // multiple of 512
-  __shared__ __attribute__((aligned(16))) u32x4 xs[NT * KT / 8];
-  __shared__ float part[KSPLIT == 1 ? 1 : 4 * RPW * NT];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int row0 = (KSPLIT == 1 ? (blockIdx.x * 4 + wave) : blockIdx.x) * RPW;
-  const Half* wrow[RPW];
-#pragma unroll
-  for (int r = 0; r < RPW; ++r) {
-    int row = row0 + r;
-    row = row < M ? row : M - 1;  // clamp: loads stay in bounds, the store is masked
-    wrow[r] = W + (size_t)row * K;
-  }
-  float acc[RPW][NT];
-#pragma unroll
-  for (int r = 0; r < RPW; ++r)
-#pragma unroll
-    for (int t = 0; t < NT; ++t) acc[r][t] = 0.f;
-
-  for (int k0 = 0; k0 < K; k0 += KT) {
-    const int kt = (K - k0) < KT ? (K - k0) : KT;
-    __syncthreads();
-    // stage x[:, k0:k0+KT] -> LDS; zero beyond T and beyond K so clamped weight loads add 0
-    for (int idx = threadIdx.x; idx < NT * (KT / 8); idx += 256) {
-      const int t = idx / (KT / 8), c = idx - t * (KT / 8);
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (t < T && c * 8 < kt) v = *reinterpret_cast<const u32x4*>(X + (size_t)t * K + k0 + c * 8);
-      xs[idx] = v;
-    }
-    __syncthreads();
-    // 512-element blocks of this tile; with KSPLIT the blocks are dealt round-robin to waves
-    const int nblk = (kt + 511) >> 9;
-    constexpr int U = 4;
-    for (int b0 = (KSPLIT == 1 ? 0 : wave); b0 < nblk; b0 += U * KSPLIT) {
-      u32x4 wv[U][RPW];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        int kk = (b0 + u * KSPLIT) * 512 + lane * 8;
-        kk = kk < kt ? kk : kt - 8;  // clamp (x is zero there or the block is skipped below)
-#pragma unroll
-        for (int r = 0; r < RPW; ++r)
-          wv[u][r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow[r] + k0 + kk));
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int blk = b0 + u * KSPLIT;
-        const int kk = blk * 512 + lane * 8;
-        const bool live = blk < nblk && kk < kt;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          u32x4 xv = xs[t * (KT / 8) + (live ? (kk >> 3) : 0)];
-          if (!live) xv = u32x4{0u, 0u, 0u, 0u};
-#pragma unroll
-          for (int r = 0; r < RPW; ++r) acc[r][t] = dot8(wv[u][r], xv, acc[r][t]);
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < RPW; ++r)
-#pragma unroll
-    for (int t = 0; t < NT; ++t) acc[r][t] = wave_sum(acc[r][t]);
-
-  if (KSPLIT == 1) {
-    if (lane == 0) {
-#pragma unroll
-      for (int r = 0; r < RPW; ++r)
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-          if (row0 + r < M && t < T) Y[(size_t)t * M + row0 + r] = f2bf(acc[r][t]);
-    }
-  } else {
-    if (lane == 0) {
-#pragma unroll
-      for (int r = 0; r < RPW; ++r)
-#pragma unroll
-        for (int t = 0; t < NT; ++t) part[(wave * RPW + r) * NT + t] = acc[r][t];
-    }
-    __syncthreads();
-    if (threadIdx.x < RPW * NT) {
-      const int r = threadIdx.x / NT, t = threadIdx.x - r * NT;
-      float s = part[(0 * RPW + r) * NT + t];
-      s += part[(1 * RPW + r) * NT + t];
-      s += part[(2 * RPW + r) * NT + t];
-      s += part[(3 * RPW + r) * NT + t];
-      if (row0 + r < M && t < T) Y[(size_t)t * M + row0 + r] = f2bf(s);
-    }
-  }
-}
-
-template <int NT, int RPW>
-static void launch_gemv(const Half* W, const Half* X, Half* Y, int M, int T, int K, hipStream_t s) {
-  if (K >= 4096) {
-    gemv_kernel<NT, RPW, 4><<<ceil_div(M, RPW), 256, 0, s>>>(W, X, Y, M, T, K);
-  } else {
-    gemv_kernel<NT, RPW, 1><<<ceil_div(M, 4 * RPW), 256, 0, s>>>(W, X, Y, M, T, K);
-  }
 }
 
 // ------------------------------------------------------------------ prefill MFMA GEMM
@@ -247,12 +143,8 @@ static void gemm_dispatch(const Half* W, const Half* X, Half* Y, int M, int T, i
   if (M <= 0 || T <= 0 || K <= 0) return;
   const bool fast = (K & 7) == 0 && host_aligned16(W) && host_aligned16(X);
   if (fast && T <= 16) {
-    if (T == 1) launch_gemv<1, 4>(W, X, Y, M, T, K, s);
-    else if (T == 2) launch_gemv<2, 4>(W, X, Y, M, T, K, s);
-    else if (T <= 4) launch_gemv<4, 2>(W, X, Y, M, T, K, s);
-    else if (T <= 8) launch_gemv<8, 2>(W, X, Y, M, T, K, s);
-    else launch_gemv<16, 2>(W, X, Y, M, T, K, s);
-    return;
+    GemvFusedArgs a{W, X, Y, M, T, K, nullptr, nullptr, nullptr, 0.f, 0};
+    if (gemv_dispatch<kEpiStore>(a, s)) return;
   }
   if (fast && (K % BK) == 0 && (M & 3) == 0 && (reinterpret_cast<uintptr_t>(Y) & 7u) == 0) {
     const int m_tiles = ceil_div(M, BM), t_tiles = ceil_div(T, BT);
@@ -283,6 +175,24 @@ void gemm_cuda(const Half* W, const Half* X, Half* Y, int32_t M, int32_t N, int3
 void gemm_graphsafe_cuda(const Half* W, const Half* X, Half* Y, int32_t M, int32_t N, int32_t K,
                          pegainfer_stream_t stream) {
   pk::gemm_dispatch(W, X, Y, M, N, K, pk::as_stream(stream));
+}
+
+// Fused decode GEMV (extension, include/pegainfer_kernels_ext.h): optional RMSNorm / add+RMSNorm
+// prologue and SwiGLU epilogue around the SAME gemv core that gemm_graphsafe_cuda uses.
+pegainfer_status_t pegainfer_gemv_fused(const Half* W, const Half* X, Half* Y, int32_t M, int32_t T, int32_t K,
+                                        const Half* residual, const Half* norm_weight, Half* hidden_out, float eps,
+                                        int32_t silu_intermediate, pegainfer_stream_t stream) {
+  using namespace pk;
+  if (M <= 0 || T < 1 || T > 16 || K <= 0 || (K & 7) != 0) return (pegainfer_status_t)hipErrorInvalidValue;
+  if (!host_aligned16(W) || !host_aligned16(X) || (residual && !host_aligned16(residual)) ||
+      (norm_weight && !host_aligned16(norm_weight)) || (hidden_out && !host_aligned16(hidden_out)))
+    return (pegainfer_status_t)hipErrorInvalidValue;
+  if (residual && (!norm_weight || !hidden_out || hidden_out == X)) return (pegainfer_status_t)hipErrorInvalidValue;
+  if (silu_intermediate > 0 && M != 2 * silu_intermediate) return (pegainfer_status_t)hipErrorInvalidValue;
+  GemvFusedArgs a{W, X, Y, M, T, K, residual, norm_weight, hidden_out, eps, silu_intermediate};
+  const bool ok = silu_intermediate > 0 ? gemv_dispatch<kEpiSilu>(a, as_stream(stream))
+                                        : gemv_dispatch<kEpiStore>(a, as_stream(stream));
+  return ok ? (pegainfer_status_t)hipGetLastError() : (pegainfer_status_t)hipErrorInvalidValue;
 }
 
 }  // extern "C"

@@ -8,11 +8,9 @@
 //   rms_norm_gated      per head: bf16(x * inv_rms * w_f32 * silu(gate))     (csrc/norm.cu:17-61)
 // Reference: csrc/flashinfer_norm.cu:49-133 (FlashInfer RMSNorm / FusedAddRMSNorm / GemmaRMSNorm).
 #include "common.h"
+#include "norm_core.h"
 
 namespace pk {
-
-constexpr int kNormBlock = 256;
-constexpr int kNormWaves = kNormBlock / 64;
 
 template <bool OFFSET, bool VEC>
 __global__ __launch_bounds__(kNormBlock) void rms_norm_kernel(const Half* __restrict__ x,
@@ -21,39 +19,21 @@ __global__ __launch_bounds__(kNormBlock) void rms_norm_kernel(const Half* __rest
   __shared__ float red[kNormWaves];
   const Half* xr = x + (size_t)blockIdx.x * d;
   Half* orow = out + (size_t)blockIdx.x * d;
-  float ss = 0.f;
+  const float bias = OFFSET ? 1.0f : 0.0f;
   if (VEC) {
+    const float inv = row_inv_rms_vec(xr, nullptr, d, eps, red);
     const int nvec = d >> 3;
-    for (int i = threadIdx.x; i < nvec; i += kNormBlock) {
-      u32x4 v = reinterpret_cast<const u32x4*>(xr)[i];
-      float a;
-      a = bf_lo(v.x); ss += a * a; a = bf_hi(v.x); ss += a * a;
-      a = bf_lo(v.y); ss += a * a; a = bf_hi(v.y); ss += a * a;
-      a = bf_lo(v.z); ss += a * a; a = bf_hi(v.z); ss += a * a;
-      a = bf_lo(v.w); ss += a * a; a = bf_hi(v.w); ss += a * a;
-    }
+    for (int i = threadIdx.x; i < nvec; i += kNormBlock)
+      reinterpret_cast<u32x4*>(orow)[i] = norm_scale8(reinterpret_cast<const u32x4*>(xr)[i], nullptr,
+                                                      reinterpret_cast<const u32x4*>(w)[i], inv, bias, nullptr);
   } else {
+    float ss = 0.f;
     for (int i = threadIdx.x; i < d; i += kNormBlock) {
       float a = bf2f(xr[i]);
       ss += a * a;
     }
-  }
-  ss = block_sum<kNormWaves>(ss, red);
-  const float inv = rsqrtf(ss / (float)d + eps);
-  const float bias = OFFSET ? 1.0f : 0.0f;
-  if (VEC) {
-    const int nvec = d >> 3;
-    for (int i = threadIdx.x; i < nvec; i += kNormBlock) {
-      u32x4 v = reinterpret_cast<const u32x4*>(xr)[i];
-      u32x4 g = reinterpret_cast<const u32x4*>(w)[i];
-      u32x4 o;
-      o.x = pack_bf2(bf_lo(v.x) * inv * (bias + bf_lo(g.x)), bf_hi(v.x) * inv * (bias + bf_hi(g.x)));
-      o.y = pack_bf2(bf_lo(v.y) * inv * (bias + bf_lo(g.y)), bf_hi(v.y) * inv * (bias + bf_hi(g.y)));
-      o.z = pack_bf2(bf_lo(v.z) * inv * (bias + bf_lo(g.z)), bf_hi(v.z) * inv * (bias + bf_hi(g.z)));
-      o.w = pack_bf2(bf_lo(v.w) * inv * (bias + bf_lo(g.w)), bf_hi(v.w) * inv * (bias + bf_hi(g.w)));
-      reinterpret_cast<u32x4*>(orow)[i] = o;
-    }
-  } else {
+    ss = block_sum<kNormWaves>(ss, red);
+    const float inv = rsqrtf(ss / (float)d + eps);
     for (int i = threadIdx.x; i < d; i += kNormBlock)
       orow[i] = f2bf(bf2f(xr[i]) * inv * (bias + bf2f(w[i])));
   }
@@ -69,49 +49,28 @@ __global__ __launch_bounds__(kNormBlock) void fused_add_rms_norm_kernel(Half* __
   Half* hr = hidden + (size_t)blockIdx.x * d;
   const Half* rr = residual + (size_t)blockIdx.x * d;
   Half* orow = out + (size_t)blockIdx.x * d;
-  float ss = 0.f;
-  // pass 1: sum of squares of the UNROUNDED fp32 sum (hidden is not modified yet)
-  if (VEC) {
-    const int nvec = d >> 3;
-    for (int i = threadIdx.x; i < nvec; i += kNormBlock) {
-      u32x4 h = reinterpret_cast<const u32x4*>(hr)[i];
-      u32x4 r = reinterpret_cast<const u32x4*>(rr)[i];
-      float a;
-      a = bf_lo(h.x) + bf_lo(r.x); ss += a * a; a = bf_hi(h.x) + bf_hi(r.x); ss += a * a;
-      a = bf_lo(h.y) + bf_lo(r.y); ss += a * a; a = bf_hi(h.y) + bf_hi(r.y); ss += a * a;
-      a = bf_lo(h.z) + bf_lo(r.z); ss += a * a; a = bf_hi(h.z) + bf_hi(r.z); ss += a * a;
-      a = bf_lo(h.w) + bf_lo(r.w); ss += a * a; a = bf_hi(h.w) + bf_hi(r.w); ss += a * a;
-    }
-  } else {
-    for (int i = threadIdx.x; i < d; i += kNormBlock) {
-      float a = bf2f(hr[i]) + bf2f(rr[i]);
-      ss += a * a;
-    }
-  }
-  ss = block_sum<kNormWaves>(ss, red);
-  const float inv = rsqrtf(ss / (float)d + eps);
   const float bias = OFFSET ? 1.0f : 0.0f;
-  // pass 2: each thread re-reads exactly the elements it will overwrite
   if (VEC) {
+    // pass 1: sum of squares of the UNROUNDED fp32 sum (hidden is not modified yet);
+    // pass 2: each thread re-reads exactly the elements it will overwrite
+    const float inv = row_inv_rms_vec(hr, rr, d, eps, red);
     const int nvec = d >> 3;
     for (int i = threadIdx.x; i < nvec; i += kNormBlock) {
-      u32x4 h = reinterpret_cast<const u32x4*>(hr)[i];
-      u32x4 r = reinterpret_cast<const u32x4*>(rr)[i];
-      u32x4 g = reinterpret_cast<const u32x4*>(w)[i];
-      u32x4 nh, o;
-      float s0, s1;
-      s0 = bf_lo(h.x) + bf_lo(r.x); s1 = bf_hi(h.x) + bf_hi(r.x);
-      nh.x = pack_bf2(s0, s1); o.x = pack_bf2(s0 * inv * (bias + bf_lo(g.x)), s1 * inv * (bias + bf_hi(g.x)));
-      s0 = bf_lo(h.y) + bf_lo(r.y); s1 = bf_hi(h.y) + bf_hi(r.y);
-      nh.y = pack_bf2(s0, s1); o.y = pack_bf2(s0 * inv * (bias + bf_lo(g.y)), s1 * inv * (bias + bf_hi(g.y)));
-      s0 = bf_lo(h.z) + bf_lo(r.z); s1 = bf_hi(h.z) + bf_hi(r.z);
-      nh.z = pack_bf2(s0, s1); o.z = pack_bf2(s0 * inv * (bias + bf_lo(g.z)), s1 * inv * (bias + bf_hi(g.z)));
-      s0 = bf_lo(h.w) + bf_lo(r.w); s1 = bf_hi(h.w) + bf_hi(r.w);
-      nh.w = pack_bf2(s0, s1); o.w = pack_bf2(s0 * inv * (bias + bf_lo(g.w)), s1 * inv * (bias + bf_hi(g.w)));
+      const u32x4 r = reinterpret_cast<const u32x4*>(rr)[i];
+      u32x4 nh;
+      const u32x4 o = norm_scale8(reinterpret_cast<const u32x4*>(hr)[i], &r, reinterpret_cast<const u32x4*>(w)[i],
+                                  inv, bias, &nh);
       reinterpret_cast<u32x4*>(hr)[i] = nh;
       reinterpret_cast<u32x4*>(orow)[i] = o;
     }
   } else {
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < d; i += kNormBlock) {
+      float a = bf2f(hr[i]) + bf2f(rr[i]);
+      ss += a * a;
+    }
+    ss = block_sum<kNormWaves>(ss, red);
+    const float inv = rsqrtf(ss / (float)d + eps);
     for (int i = threadIdx.x; i < d; i += kNormBlock) {
       float s = bf2f(hr[i]) + bf2f(rr[i]);
       hr[i] = f2bf(s);

@@ -7,6 +7,7 @@
 //   out[d]      = bf16(m[d]*c - m[d+half]*s)
 //   out[d+half] = bf16(m[d]*s + m[d+half]*c)          c,s = bf16 table[pos*head_dim + d]
 #include "common.h"
+#include "rope_core.h"
 
 namespace pk {
 
@@ -60,11 +61,38 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(
   }
 }
 
+// head_dim == 128 fast path: 16 lanes per head (one 16-byte load each), 4 heads per wave, 16 per block.
+__global__ __launch_bounds__(256) void qk_norm_rope128_kernel(
+    Half* __restrict__ q, Half* __restrict__ k, const Half* __restrict__ q_w, const Half* __restrict__ k_w,
+    const Half* __restrict__ cos_cache, const Half* __restrict__ sin_cache, int num_q_heads, int num_kv_heads,
+    int tokens, int start_pos, const int* __restrict__ positions, float eps) {
+  const int heads = num_q_heads + num_kv_heads;
+  const long unit = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+  if (unit >= (long)tokens * heads) return;  // whole 16-lane rows drop out together (DPP stays inside a row)
+  const int token = (int)(unit / heads);
+  const int hg = (int)(unit - (long)token * heads);
+  const int sub = threadIdx.x & 15;
+  const bool is_q = hg < num_q_heads;
+  Half* data = is_q ? q + ((size_t)token * num_q_heads + hg) * 128
+                    : k + ((size_t)token * num_kv_heads + (hg - num_q_heads)) * 128;
+  const int pos = positions ? positions[token] : start_pos + token;
+  const u32x4 x = *reinterpret_cast<const u32x4*>(data + sub * 8);
+  const u32x4 r = head_norm_rope16(x, is_q ? q_w : k_w, cos_cache + (size_t)pos * 128, sin_cache + (size_t)pos * 128,
+                                   sub, eps);
+  *reinterpret_cast<u32x4*>(data + sub * 8) = r;
+}
+
 static void launch(Half* q, Half* k, const Half* qw, const Half* kw, const Half* c, const Half* s, int hq,
                    int hkv, int hd, int tokens, int start_pos, const int* positions, float eps,
                    hipStream_t stream) {
   if (tokens <= 0 || hq + hkv <= 0) return;
   const long units = (long)tokens * (hq + hkv);
+  if (hd == 128 && host_aligned16(q) && host_aligned16(k) && host_aligned16(qw) && host_aligned16(kw) &&
+      host_aligned16(c) && host_aligned16(s)) {
+    qk_norm_rope128_kernel<<<ceil_div(units, 16), 256, 0, stream>>>(q, k, qw, kw, c, s, hq, hkv, tokens, start_pos,
+                                                                    positions, eps);
+    return;
+  }
   qk_norm_rope_kernel<<<ceil_div(units, 4), 256, 0, stream>>>(q, k, qw, kw, c, s, hq, hkv, hd, tokens,
                                                               start_pos, positions, eps);
 }

@@ -60,7 +60,7 @@ def declared_symbols(header):
 
 
 class _Lib:
-    def __init__(self, so_name, header):
+    def __init__(self, so_name, *headers):
         path = os.path.join(LIBDIR, so_name)
         if not os.path.exists(path):
             raise ImportError(
@@ -68,7 +68,9 @@ class _Lib:
                 "(hipcc, gfx950). There is no CPU fallback for the product path.")
         self.path = path
         self.cdll = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
-        self.protos = parse_header(os.path.join(INCLUDE, header))
+        self.protos = {}
+        for header in headers:
+            self.protos.update(parse_header(os.path.join(INCLUDE, header)))
         for name, (res, args) in self.protos.items():
             fn = getattr(self.cdll, name)  # AttributeError if a declared symbol is not exported
             fn.restype = res
@@ -82,7 +84,7 @@ _cache = {}
 def lib():
     """libpegainfer_kernels_hip.so (include/pegainfer_kernels.h)."""
     if "k" not in _cache:
-        _cache["k"] = _Lib("libpegainfer_kernels_hip.so", "pegainfer_kernels.h")
+        _cache["k"] = _Lib("libpegainfer_kernels_hip.so", "pegainfer_kernels.h", "pegainfer_kernels_ext.h")
     return _cache["k"]
 
 

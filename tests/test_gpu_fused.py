@@ -1,0 +1,156 @@
+"""The MI355X fused decode kernels (include/pegainfer_kernels_ext.h) must be BIT-IDENTICAL to the sequence
+of reference-named ops they replace - at op level and through the whole model (decode_mode 1 vs 0)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import from_dev, to_dev
+from oracle import ops as O
+from oracle.bf16 import bf16_bits, bf16_round
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def rnd(rng, *shape, scale=1.0):
+    return bf16_round((rng.standard_normal(shape) * scale).astype(np.float32))
+
+
+@pytest.mark.parametrize("T", [1, 2, 3, 8, 16])
+@pytest.mark.parametrize("M,K", [(6144, 2560), (2560, 4096), (512, 256)])
+def test_gemv_fused_prologues_match_unfused(built_libs, T, M, K):
+    import torch
+    import pegainfer_amd.ops as P
+    from pegainfer_amd import ffi
+    rng = np.random.default_rng(T + M + K)
+    W, X, R, g = rnd(rng, M, K, scale=0.05), rnd(rng, T, K, scale=2), rnd(rng, T, K, scale=0.7), bf16_round(1 + rnd(rng, K, scale=0.2))
+    Wd, s = to_dev(W), torch.cuda.current_stream().cuda_stream
+    L = ffi.lib()
+    # (a) plain == gemm_graphsafe
+    y1 = torch.zeros((T, M), dtype=torch.bfloat16, device="cuda")
+    Xd = to_dev(X)
+    assert L.pegainfer_gemv_fused(Wd.data_ptr(), Xd.data_ptr(), y1.data_ptr(), M, T, K, None, None, None, 0.0, 0, s) == 0
+    assert np.array_equal(bf16_bits(from_dev(y1)), bf16_bits(from_dev(P.gemm(Wd, Xd))))
+    # (b) norm prologue == rms_norm_batched + gemm
+    normed = torch.zeros_like(Xd)
+    P.rms_norm_batch_into(Xd, to_dev(g), 1e-6, normed)
+    ref = P.gemm(Wd, normed)
+    gd = to_dev(g)
+    assert L.pegainfer_gemv_fused(Wd.data_ptr(), Xd.data_ptr(), y1.data_ptr(), M, T, K, None, gd.data_ptr(), None, 1e-6, 0, s) == 0
+    assert np.array_equal(bf16_bits(from_dev(y1)), bf16_bits(from_dev(ref)))
+    # (c) add+norm prologue == fused_add_rms_norm_batched + gemm, hidden_out == updated hidden
+    hid, Rd = to_dev(X), to_dev(R)
+    P.fused_add_rms_norm_batch_into(hid, Rd, gd, 1e-6, normed)
+    ref = P.gemm(Wd, normed)
+    hout = torch.zeros_like(Xd)
+    assert L.pegainfer_gemv_fused(Wd.data_ptr(), Xd.data_ptr(), y1.data_ptr(), M, T, K, Rd.data_ptr(), gd.data_ptr(),
+                                  hout.data_ptr(), 1e-6, 0, s) == 0
+    assert np.array_equal(bf16_bits(from_dev(y1)), bf16_bits(from_dev(ref)))
+    assert np.array_equal(bf16_bits(from_dev(hout)), bf16_bits(from_dev(hid)))
+
+
+@pytest.mark.parametrize("T,I,K", [(1, 9728, 2560), (4, 9728, 2560), (16, 512, 256), (2, 1000, 4096)])
+def test_gemv_fused_silu_epilogue_matches_unfused(built_libs, T, I, K):
+    import torch
+    import pegainfer_amd.ops as P
+    from pegainfer_amd import ffi
+    rng = np.random.default_rng(T + I)
+    W, X = rnd(rng, 2 * I, K, scale=0.06), rnd(rng, T, K, scale=1.5)
+    Wd, Xd = to_dev(W), to_dev(X)
+    gu = P.gemm(Wd, Xd)
+    ref = torch.zeros((T, I), dtype=torch.bfloat16, device="cuda")
+    P.silu_mul_fused_batch_into(gu, ref)
+    out = torch.zeros_like(ref)
+    assert ffi.lib().pegainfer_gemv_fused(Wd.data_ptr(), Xd.data_ptr(), out.data_ptr(), 2 * I, T, K, None, None, None,
+                                          0.0, I, torch.cuda.current_stream().cuda_stream) == 0
+    assert np.array_equal(bf16_bits(from_dev(out)), bf16_bits(from_dev(ref)))
+
+
+def test_gemv_fused_rejects_unsupported_shapes(built_libs):
+    import torch
+    from pegainfer_amd import ffi
+    x = torch.zeros(64, dtype=torch.bfloat16, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    L = ffi.lib()
+    assert L.pegainfer_gemv_fused(x.data_ptr(), x.data_ptr(), x.data_ptr(), 4, 17, 8, None, None, None, 0.0, 0, s) != 0
+    assert L.pegainfer_gemv_fused(x.data_ptr(), x.data_ptr(), x.data_ptr(), 4, 1, 12, None, None, None, 0.0, 0, s) != 0
+    assert L.pegainfer_gemv_fused(x.data_ptr(), x.data_ptr(), x.data_ptr(), 4, 1, 8, x.data_ptr(), x.data_ptr(),
+                                  x.data_ptr(), 0.0, 0, s) != 0   # hidden_out aliases X
+
+
+@pytest.mark.parametrize("lens,split", [([1], False), ([17, 300], False), ([1024], True), ([2000, 70], True)])
+def test_fused_decode_attention_matches_unfused(built_libs, lens, split):
+    """qk_norm_rope + scatter + decode attention in one launch == the three reference-named calls:
+    identical attention output bits AND identical KV-cache bytes."""
+    import torch
+    import pegainfer_amd.ops as P
+    from pegainfer_amd import ffi
+    from test_gpu_ops import make_paged
+    rng = np.random.default_rng(sum(lens))
+    bs, Hq, Hkv, D = len(lens), 32, 8, 128
+    lay, kv, pages, indptr, last = make_paged(rng, bs, lens)
+    qkv = rnd(rng, bs, (Hq + 2 * Hkv) * D, scale=1.5)
+    qw, kw = bf16_round(1 + rnd(rng, D, scale=0.2)), bf16_round(1 + rnd(rng, D, scale=0.2))
+    cos, sin = O.precompute_rope(D, 4096, 1e6)
+    pos = np.asarray(lens, np.int32) - 1                   # the new token is the last position
+    i32 = lambda a: torch.tensor(np.asarray(a), dtype=torch.int32, device="cuda")
+    Lk = P.PagedKvLayout(2, Hkv, D, 16)
+    plan = O.split_kv_plan(lens, bs)
+    d = dict(pages=i32(pages), indptr=i32(indptr), last=i32(last), pos=i32(pos), ri=i32(np.arange(bs)),
+             kti=i32(np.zeros(bs)), kcs=i32(lens), sri=i32(plan["request_indices"]), skt=i32(plan["kv_tile_indices"]),
+             skc=i32([plan["kv_chunk_size"]]), soi=i32(plan["o_indptr"]),
+             sva=torch.tensor(plan["block_valid_mask"], dtype=torch.uint8, device="cuda"),
+             qw=to_dev(qw), kw=to_dev(kw), cos=to_dev(cos), sin=to_dev(sin))
+    slots = plan["padded_slots"]
+    tmp_v = torch.zeros(slots * Hq * D, dtype=torch.bfloat16, device="cuda")
+    tmp_s = torch.zeros(slots * Hq, dtype=torch.float32, device="cuda")
+    # ---- unfused reference-named sequence ----
+    kv_a = to_dev(kv)
+    qkvd = to_dev(qkv)
+    q = qkvd[:, :Hq * D].contiguous(); k = qkvd[:, Hq * D:(Hq + Hkv) * D].contiguous(); v = qkvd[:, (Hq + Hkv) * D:].contiguous()
+    P.qk_norm_rope_batch_decode_into(q, k, d["qw"], d["kw"], d["cos"], d["sin"], d["pos"], Hq, Hkv, D, 1e-6)
+    out_a = torch.zeros((bs, Hq * D), dtype=torch.bfloat16, device="cuda")
+    if split:
+        P.paged_attention_batch_decode_split_kv_into(q, k, v, kv_a, Lk, 1, d["pages"], d["indptr"], d["last"], d["pos"],
+                                                     d["ri"], d["sri"], d["skt"], d["skc"], d["soi"], d["sva"], tmp_v,
+                                                     tmp_s, slots, out_a, Hq, bs)
+    else:
+        P.paged_attention_batch_decode_into(q, k, v, kv_a, Lk, 1, d["pages"], d["indptr"], d["last"], d["pos"], d["ri"],
+                                            d["kti"], d["kcs"], out_a, Hq, bs)
+    # ---- fused ----
+    kv_b = to_dev(kv)
+    out_b = torch.zeros_like(out_a)
+    rc = ffi.lib().pegainfer_fused_decode_attention(
+        qkvd.data_ptr(), out_b.data_ptr(), kv_b.data_ptr(), Lk.layer_stride, Lk.layer_stride + Lk.kv_block_len,
+        d["pages"].data_ptr(), d["indptr"].data_ptr(), d["last"].data_ptr(), d["pos"].data_ptr(), d["qw"].data_ptr(),
+        d["kw"].data_ptr(), d["cos"].data_ptr(), d["sin"].data_ptr(), 1e-6, int(split), d["sri"].data_ptr(),
+        d["skt"].data_ptr(), d["skc"].data_ptr(), d["soi"].data_ptr(), d["sva"].data_ptr(), tmp_v.data_ptr(),
+        tmp_s.data_ptr(), Hq, Hkv, D, 16, bs, slots, Lk.page_stride, 1.0 / np.sqrt(128.0),
+        torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    assert np.array_equal(bf16_bits(from_dev(kv_b)), bf16_bits(from_dev(kv_a)))
+    assert np.array_equal(bf16_bits(from_dev(out_b)), bf16_bits(from_dev(out_a)))
+
+
+@pytest.mark.parametrize("split_policy", [0, 1])
+def test_model_fused_decode_bitwise_equals_reference_sequence(built_libs, split_policy):
+    from pegainfer_amd.qwen3 import Qwen3Engine
+    meta = json.load(open(os.path.join(G, "qwen3_tiny_golden.json")))
+    ck = os.path.join(G, "qwen3_tiny.safetensors")
+    rng = np.random.default_rng(1)
+    prompts = [meta["cases"][3]["prompt_tokens"], rng.integers(0, 1024, 1100).tolist()]
+    outs = []
+    for mode in (0, 1):
+        eng = Qwen3Engine(meta["config"], num_kv_pages=256, max_batch_size=4, decode_mode=mode,
+                          split_policy=split_policy).load_safetensors(ck)
+        rids = [eng.new_request() for _ in prompts]
+        toks = np.array([int(eng.prefill([r], [p])[0]) for r, p in zip(rids, prompts)], np.int32)
+        rows = []
+        for _ in range(6):
+            toks, lg = eng.decode(rids, toks, return_logits=True)
+            rows.append(lg.copy())
+        outs.append(np.stack(rows))
+        eng.close()
+    assert np.array_equal(outs[0], outs[1])
