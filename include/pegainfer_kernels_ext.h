@@ -36,8 +36,11 @@ pegainfer_status_t pegainfer_gemv_fused(const Half* W, const Half* X, Half* Y, i
  * reads the raw fused-QKV GEMV output qkv[bs, (Hq + 2 Hkv) * 128], writes the new K (normalised, rotated)
  * and V rows into the paged cache and the attention output [bs, Hq*128].  Bit-identical to
  * qk_norm_rope_batched_decode_cuda + paged_kv_scatter_cuda + paged_attention_decode[_split_kv]_cuda
- * (ops/attention.rs:469-511, 572-796).  use_split selects the partition-KV plan arrays. */
-int32_t pegainfer_fused_decode_attention(const Half* qkv, Half* output, const Half* kv_data, int64_t k_offset_elems, int64_t v_offset_elems, const int32_t* page_indices, const int32_t* page_indptr, const int32_t* last_page_len_d, const int32_t* positions, const Half* q_norm_weight, const Half* k_norm_weight, const Half* cos_cache, const Half* sin_cache, float rms_eps, int32_t use_split, const int32_t* split_request_indices, const int32_t* split_kv_tile_indices, const int32_t* split_kv_chunk_size_ptr, const int32_t* split_o_indptr, const uint8_t* split_block_valid_mask, Half* tmp_v, float* tmp_s, int32_t num_qo_heads, int32_t num_kv_heads, int32_t head_dim, int32_t page_size, int32_t batch_size, int32_t split_slots, int64_t stride_page, float sm_scale, pegainfer_stream_t stream);
+ * (ops/attention.rs:469-511, 572-796).  use_split selects the partition-KV plan arrays.
+ * slot_desc (optional, 16-byte aligned): one record of 8 int32 per slot {b, lo, hi, page_indptr[b], position,
+ * kv_len, 0, 0}, lo < 0 for padding slots - the same plan, pre-resolved on the host so a workgroup needs one
+ * metadata load instead of four dependent ones. */
+int32_t pegainfer_fused_decode_attention(const Half* qkv, Half* output, const Half* kv_data, int64_t k_offset_elems, int64_t v_offset_elems, const int32_t* page_indices, const int32_t* page_indptr, const int32_t* last_page_len_d, const int32_t* positions, const Half* q_norm_weight, const Half* k_norm_weight, const Half* cos_cache, const Half* sin_cache, float rms_eps, int32_t use_split, const int32_t* split_request_indices, const int32_t* split_kv_tile_indices, const int32_t* split_kv_chunk_size_ptr, const int32_t* split_o_indptr, const uint8_t* split_block_valid_mask, Half* tmp_v, float* tmp_s, int32_t num_qo_heads, int32_t num_kv_heads, int32_t head_dim, int32_t page_size, int32_t batch_size, int32_t split_slots, int64_t stride_page, float sm_scale, const int32_t* slot_desc, pegainfer_stream_t stream);
 
 #ifdef __cplusplus
 }

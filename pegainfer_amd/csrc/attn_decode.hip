@@ -38,6 +38,9 @@ struct DecodeAttnArgs {
   // fused form only: raw qkv rows [bs, (Hq + 2 Hkv) * 128], per-head norm weights, RoPE tables, positions
   const Half* qkv; const Half* q_norm_w; const Half* k_norm_w; const Half* cos_cache; const Half* sin_cache;
   const int* positions; float eps;
+  // fused form, optional: one 32-byte record per slot {b, lo, hi, pbase, pos, kv_len, 0, 0} built by the host
+  // (lo < 0 = padding slot) - replaces a 4-deep chain of dependent metadata loads by one load
+  const int* slot_desc;
 };
 
 struct ChunkInfo { int b, pbase, kv_len, lo, hi; };
@@ -92,9 +95,7 @@ __device__ __forceinline__ void decode_attn_body(const DecodeAttnArgs& a, const 
   const long head_off = (long)kvh * D + sub * 8;
   const long row_stride = (long)num_kv_heads * D;
 
-  for (int t0 = (lo / TB) * TB + wave * TB; t0 < hi && lo < hi; t0 += 4 * TB) {
-    u32x4 kx[U], vx[U];
-    bool ok[U];
+  auto load_tile = [&](int t0, u32x4 (&kx)[U], u32x4 (&vx)[U], bool (&ok)[U]) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int t = t0 + u * TPI + grp;
@@ -105,6 +106,8 @@ __device__ __forceinline__ void decode_attn_body(const DecodeAttnArgs& a, const 
       kx[u] = *reinterpret_cast<const u32x4*>(kv + base + k_off);
       vx[u] = *reinterpret_cast<const u32x4*>(kv + base + v_off);
     }
+  };
+  auto compute_tile = [&](const u32x4 (&kx)[U], const u32x4 (&vx)[U], const bool (&ok)[U]) {
     float s[GROUP][U];
 #pragma unroll
     for (int u = 0; u < U; ++u)
@@ -138,6 +141,27 @@ __device__ __forceinline__ void decode_attn_body(const DecodeAttnArgs& a, const 
           o[h][2 * j] += p[u] * bf_lo(w[j]);
           o[h][2 * j + 1] += p[u] * bf_hi(w[j]);
         }
+      }
+    }
+  };
+  // software-pipelined scan: the next tile's 2*U loads are in flight while the current one is reduced
+  {
+    int t0 = (lo / TB) * TB + wave * TB;
+    if (lo < hi && t0 < hi) {
+      u32x4 kA[U], vA[U], kB[U], vB[U];
+      bool okA[U], okB[U];
+      load_tile(t0, kA, vA, okA);
+      for (;;) {
+        int t1 = t0 + 4 * TB;
+        bool more = t1 < hi;
+        if (more) load_tile(t1, kB, vB, okB);
+        compute_tile(kA, vA, okA);
+        if (!more) break;
+        t0 = t1 + 4 * TB;
+        more = t0 < hi;
+        if (more) load_tile(t0, kA, vA, okA);
+        compute_tile(kB, vB, okB);
+        if (!more) break;
       }
     }
   }
@@ -200,11 +224,21 @@ template <int GROUP, bool PARTITION>
 __global__ __launch_bounds__(256) void fused_decode_attn_kernel(const DecodeAttnArgs a) {
   constexpr int D = 128;
   const int slot = blockIdx.x, kvh = blockIdx.y;
-  if (PARTITION && a.block_valid_mask && !a.block_valid_mask[slot]) return;
-  const ChunkInfo ci = decode_chunk<PARTITION>(a, slot);
+  ChunkInfo ci;
+  int pos;
+  if (a.slot_desc) {
+    const u32x4 d0 = *reinterpret_cast<const u32x4*>(a.slot_desc + 8 * slot);
+    const u32x2 d1 = *reinterpret_cast<const u32x2*>(a.slot_desc + 8 * slot + 4);
+    ci.b = (int)d0.x; ci.lo = (int)d0.y; ci.hi = (int)d0.z; ci.pbase = (int)d0.w;
+    pos = (int)d1.x; ci.kv_len = (int)d1.y;
+    if (ci.lo < 0) return;
+  } else {
+    if (PARTITION && a.block_valid_mask && !a.block_valid_mask[slot]) return;
+    ci = decode_chunk<PARTITION>(a, slot);
+    pos = a.positions[ci.b];
+  }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int sub = lane & 15, grp = lane >> 4;
-  const int pos = a.positions[ci.b];
   const int q_dim = a.num_qo_heads * D, kv_dim = a.num_kv_heads * D;
   const Half* row = a.qkv + (size_t)ci.b * (q_dim + 2 * kv_dim);
   const Half* crow = a.cos_cache + (size_t)pos * D;
@@ -359,8 +393,8 @@ int32_t pegainfer_fused_decode_attention(
     const int32_t* split_kv_tile_indices, const int32_t* split_kv_chunk_size_ptr, const int32_t* split_o_indptr,
     const uint8_t* split_block_valid_mask, Half* tmp_v, float* tmp_s, int32_t num_qo_heads, int32_t num_kv_heads,
     int32_t head_dim, int32_t page_size, int32_t batch_size, int32_t split_slots, int64_t stride_page,
-    float sm_scale, pegainfer_stream_t stream) {
-  if (head_dim != 128 || !host_aligned16(qkv) || !host_aligned16(kv_data))
+    float sm_scale, const int32_t* slot_desc, pegainfer_stream_t stream) {
+  if (head_dim != 128 || !host_aligned16(qkv) || !host_aligned16(kv_data) || !host_aligned16(slot_desc))
     return static_cast<int32_t>(hipErrorInvalidValue);
   DecodeAttnArgs a;
   fill_args(a, nullptr, output, kv_data, k_offset_elems, v_offset_elems, page_indices, page_indptr, last_page_len_d,
@@ -368,7 +402,7 @@ int32_t pegainfer_fused_decode_attention(
             use_split ? split_block_valid_mask : nullptr, tmp_v, tmp_s, num_qo_heads, num_kv_heads, page_size,
             stride_page, sm_scale);
   a.qkv = qkv; a.q_norm_w = q_norm_weight; a.k_norm_w = k_norm_weight; a.cos_cache = cos_cache;
-  a.sin_cache = sin_cache; a.positions = positions; a.eps = rms_eps;
+  a.sin_cache = sin_cache; a.positions = positions; a.eps = rms_eps; a.slot_desc = slot_desc;
   if (use_split)
     return launch_decode<128, true, true>(a, split_o_indptr, batch_size, split_slots, as_stream(stream));
   return launch_decode<128, false, true>(a, nullptr, batch_size, batch_size, as_stream(stream));

@@ -25,6 +25,17 @@ template <int NT> struct GemvTile { static constexpr int KT = NT <= 8 ? 16384 / 
 
 enum { kEpiStore = 0, kEpiSilu = 1 };
 
+template <int NT>
+__host__ __device__ inline int gemv_xs_bytes(int K) {
+  const int kt = K < GemvTile<NT>::KT ? K : GemvTile<NT>::KT;
+  return (NT * kt * 2 + 15) & ~15;
+}
+template <int NT, int RPW, int KSPLIT, int EPI>
+inline int gemv_lds_bytes(int K) {
+  constexpr int NW = EPI == kEpiSilu ? 2 : 1;
+  return gemv_xs_bytes<NT>(K) + ((KSPLIT == 1 ? 0 : 4 * NW * RPW * NT) + kNormWaves) * 4;
+}
+
 struct GemvFusedArgs {
   const Half* W; const Half* X; Half* Y; int M; int T; int K;
   const Half* residual;   // optional: x = norm(X + residual), hidden_out = bf16(X + residual)
@@ -39,11 +50,15 @@ __global__ __launch_bounds__(256) void gemv_fused_kernel(const GemvFusedArgs a) 
   constexpr int KT = GemvTile<NT>::KT;
   constexpr int NW = EPI == kEpiSilu ? 2 : 1;  // weight row sets streamed together
   constexpr int U = 4;                         // K blocks in flight per wave: U*NW*RPW = 16 loads = 16 KB
-  __shared__ __attribute__((aligned(16))) u32x4 xs[NT * KT / 8];
-  __shared__ float part[KSPLIT == 1 ? 1 : 4 * NW * RPW * NT];
-  __shared__ float red[kNormWaves];
+  // all LDS is dynamic and sized to the shape (guide G17: one 16-byte aligned carve, no statics): a K = 2560
+  // GEMV needs 5 KB, not the 32 KB tile capacity, which is what lets 5+ workgroups share a CU.
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  u32x4* xs = reinterpret_cast<u32x4*>(smem_raw);
+  float* part = reinterpret_cast<float*>(smem_raw + gemv_xs_bytes<NT>(a.K));
+  float* red = part + (KSPLIT == 1 ? 0 : 4 * NW * RPW * NT);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int K = a.K, T = a.T;
+  const int pitch = (K < KT ? K : KT) >> 3;  // 16-byte vectors per token row of the x tile
   const int rows_total = EPI == kEpiSilu ? a.I : a.M;
   const int row0 = (KSPLIT == 1 ? (blockIdx.x * 4 + wave) : blockIdx.x) * RPW;
   const Half* wrow[NW][RPW];
@@ -84,7 +99,7 @@ __global__ __launch_bounds__(256) void gemv_fused_kernel(const GemvFusedArgs a) 
       const bool live = blk < nblk && kk < kt;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        u32x4 xv = xs[t * (KT / 8) + (live ? (kk >> 3) : 0)];
+        u32x4 xv = xs[t * pitch + (live ? (kk >> 3) : 0)];
         if (!live) xv = u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
         for (int s = 0; s < NW; ++s)
@@ -130,7 +145,7 @@ __global__ __launch_bounds__(256) void gemv_fused_kernel(const GemvFusedArgs a) 
             v = h;
           }
         }
-        xs[t * (KT / 8) + c] = v;
+        xs[t * pitch + c] = v;
       }
     }
   };
@@ -227,8 +242,18 @@ inline int gemv_pick_rpw(int rows, int ksplit, int max_rpw) {
 template <int NT, int RPW, int EPI>
 inline void gemv_launch_ks(const GemvFusedArgs& a, int ksplit, hipStream_t s) {
   const int rows = EPI == kEpiSilu ? a.I : a.M;
-  if (ksplit == 4) gemv_fused_kernel<NT, RPW, 4, EPI><<<ceil_div(rows, RPW), 256, 0, s>>>(a);
-  else gemv_fused_kernel<NT, RPW, 1, EPI><<<ceil_div(rows, 4 * RPW), 256, 0, s>>>(a);
+  // > 64 KB of dynamic LDS (NT = 16 tiles) must be opted into once per kernel
+  if (ksplit == 4) {
+    static const bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_fused_kernel<NT, RPW, 4, EPI>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024), true);
+    (void)once;
+    gemv_fused_kernel<NT, RPW, 4, EPI><<<ceil_div(rows, RPW), 256, gemv_lds_bytes<NT, RPW, 4, EPI>(a.K), s>>>(a);
+  } else {
+    static const bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_fused_kernel<NT, RPW, 1, EPI>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024), true);
+    (void)once;
+    gemv_fused_kernel<NT, RPW, 1, EPI><<<ceil_div(rows, 4 * RPW), 256, gemv_lds_bytes<NT, RPW, 1, EPI>(a.K), s>>>(a);
+  }
 }
 
 template <int NT, int EPI>

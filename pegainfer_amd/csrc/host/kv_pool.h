@@ -98,7 +98,8 @@ struct SplitPlan {
 
 // policy 0: the reference's rule. policy 1: MI355X - split whenever it raises the number of
 // workgroups towards >= 256 (256 CUs): chunks/request = clamp(ceil(256/(bs*kv_heads)), 1, 64),
-// chunk = max(128, round_up16(ceil(L/chunks))).
+// chunk = max(64, round_up16(ceil(L/chunks))); 64 tokens = one 16-token tile per wave, i.e. a workgroup's
+// whole K/V fetch is a single round trip.
 inline SplitPlan make_split_plan(int policy, const std::vector<int>& seq_lens, int padded_bs, int num_kv_heads) {
   SplitPlan p;
   int max_seq = 0;
@@ -110,7 +111,7 @@ inline SplitPlan make_split_plan(int policy, const std::vector<int>& seq_lens, i
     int want = (256 + padded_bs * num_kv_heads - 1) / (padded_bs * num_kv_heads);
     want = std::min(std::max(want, 1), kSplitMaxChunksPerRequest);
     int chunk = (max_seq + want - 1) / want;
-    chunk = std::max(128, (chunk + 15) / 16 * 16);
+    chunk = std::max(64, (chunk + 15) / 16 * 16);
     p.chunk = chunk;
     p.use_split = want > 1 && max_seq > chunk;
   }

@@ -62,7 +62,7 @@ struct Layer {
 struct MetaLayout {
   size_t token_ids, positions, page_indptr, last_page_len, request_indices, kv_tile_indices, kv_chunk_size,
       split_request_indices, split_kv_tile_indices, split_kv_chunk_size, split_o_indptr, split_valid /*u8*/,
-      page_indices, total;
+      slot_desc /*8 x int32 per slot*/, page_indices, total;
 };
 
 struct Model {
@@ -196,6 +196,7 @@ struct Model {
     ml.split_kv_chunk_size = off; off = al(off + 4);
     ml.split_o_indptr = off; off = al(off + (bs + 1) * 4);
     ml.split_valid = off; off = al(off + slots);
+    ml.slot_desc = off; off = al(off + slots * 32);
     ml.page_indices = off; off = al(off + ((size_t)num_pages + bs) * 4);
     ml.total = off;
     PQ_HIP(hipHostMalloc(reinterpret_cast<void**>(&meta_host), ml.total, hipHostMallocDefault));
@@ -370,7 +371,7 @@ struct Model {
             ly.k_norm, cos, sin, eps, split ? 1 : 0, md<int32_t>(ml.split_request_indices),
             md<int32_t>(ml.split_kv_tile_indices), md<int32_t>(ml.split_kv_chunk_size),
             md<int32_t>(ml.split_o_indptr), md<uint8_t>(ml.split_valid), split_tmp_v, split_tmp_s, Hq, Hkv, D,
-            layout.page_size, bs, split_slots, layout.page_stride, sm, S());
+            layout.page_size, bs, split_slots, layout.page_stride, sm, md<int32_t>(ml.slot_desc), S());
       if (!rc) rc = pegainfer_gemv_fused(ly.o, attn_out, attn_proj, H, bs, q_dim, nullptr, nullptr, nullptr, 0.f, 0, S());
       if (!rc) {
         rc = pegainfer_gemv_fused(ly.gate_up, cur, mlp_act, 2 * I, bs, H, attn_proj, ly.ln2, nxt, eps, I, S());
@@ -467,6 +468,26 @@ struct Model {
     mh<int32_t>(ml.split_kv_chunk_size)[0] = plan.chunk;
     std::memcpy(mh<int32_t>(ml.split_o_indptr), plan.o_indptr.data(), (padded + 1) * 4);
     std::memcpy(mh<uint8_t>(ml.split_valid), plan.valid.data(), plan.slots);
+    // host-resolved slot records for the fused attention kernel (one load instead of four dependent ones)
+    {
+      auto* sd = mh<int32_t>(ml.slot_desc);
+      const int nslots = plan.use_split ? plan.slots : padded;
+      for (int sl = 0; sl < nslots; ++sl) {
+        int32_t* r = sd + 8 * sl;
+        int b, lo, hi;
+        if (plan.use_split) {
+          if (!plan.valid[sl]) { r[0] = 0; r[1] = -1; r[2] = -1; r[3] = 0; r[4] = 0; r[5] = 0; r[6] = r[7] = 0; continue; }
+          b = plan.request_indices[sl];
+          const int len = kcs[b];
+          lo = plan.kv_tile_indices[sl] * plan.chunk;
+          hi = std::min(lo + plan.chunk, len);
+          if (lo > hi) lo = hi;
+        } else {
+          b = sl; lo = 0; hi = kcs[b];
+        }
+        r[0] = b; r[1] = lo; r[2] = hi; r[3] = indptr[b]; r[4] = pos[b]; r[5] = kcs[b]; r[6] = r[7] = 0;
+      }
+    }
     const size_t upload = ml.page_indices + (size_t)np * 4;
     PQ_HIP(hipMemcpyAsync(meta_dev, meta_host, upload, hipMemcpyHostToDevice, stream));
     const bool split = plan.use_split;

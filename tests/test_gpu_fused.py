@@ -109,7 +109,7 @@ def test_fused_decode_attention_matches_unfused(built_libs, lens, split):
     # ---- unfused reference-named sequence ----
     kv_a = to_dev(kv)
     qkvd = to_dev(qkv)
-    q = qkvd[:, :Hq * D].contiguous(); k = qkvd[:, Hq * D:(Hq + Hkv) * D].contiguous(); v = qkvd[:, (Hq + Hkv) * D:].contiguous()
+    q = qkvd[:, :Hq * D].clone(); k = qkvd[:, Hq * D:(Hq + Hkv) * D].clone(); v = qkvd[:, (Hq + Hkv) * D:].clone()
     P.qk_norm_rope_batch_decode_into(q, k, d["qw"], d["kw"], d["cos"], d["sin"], d["pos"], Hq, Hkv, D, 1e-6)
     out_a = torch.zeros((bs, Hq * D), dtype=torch.bfloat16, device="cuda")
     if split:
@@ -127,11 +127,35 @@ def test_fused_decode_attention_matches_unfused(built_libs, lens, split):
         d["pages"].data_ptr(), d["indptr"].data_ptr(), d["last"].data_ptr(), d["pos"].data_ptr(), d["qw"].data_ptr(),
         d["kw"].data_ptr(), d["cos"].data_ptr(), d["sin"].data_ptr(), 1e-6, int(split), d["sri"].data_ptr(),
         d["skt"].data_ptr(), d["skc"].data_ptr(), d["soi"].data_ptr(), d["sva"].data_ptr(), tmp_v.data_ptr(),
-        tmp_s.data_ptr(), Hq, Hkv, D, 16, bs, slots, Lk.page_stride, 1.0 / np.sqrt(128.0),
+        tmp_s.data_ptr(), Hq, Hkv, D, 16, bs, slots, Lk.page_stride, 1.0 / np.sqrt(128.0), None,
         torch.cuda.current_stream().cuda_stream)
     assert rc == 0
     assert np.array_equal(bf16_bits(from_dev(kv_b)), bf16_bits(from_dev(kv_a)))
     assert np.array_equal(bf16_bits(from_dev(out_b)), bf16_bits(from_dev(out_a)))
+    # ---- fused with host-resolved slot descriptors: same bits again ----
+    nslots = slots if split else bs
+    desc = np.zeros((nslots, 8), np.int32)
+    desc[:, 1] = -1
+    if split:
+        for sl in range(int(plan["o_indptr"][bs])):
+            b = int(plan["request_indices"][sl]); t = int(plan["kv_tile_indices"][sl]); c = plan["kv_chunk_size"]
+            desc[sl] = [b, t * c, min((t + 1) * c, lens[b]), indptr[b], pos[b], lens[b], 0, 0]
+    else:
+        for b in range(bs):
+            desc[b] = [b, 0, lens[b], indptr[b], pos[b], lens[b], 0, 0]
+    dd = i32(desc.reshape(-1))
+    kv_c = to_dev(kv)
+    out_c = torch.zeros_like(out_a)
+    rc = ffi.lib().pegainfer_fused_decode_attention(
+        qkvd.data_ptr(), out_c.data_ptr(), kv_c.data_ptr(), Lk.layer_stride, Lk.layer_stride + Lk.kv_block_len,
+        d["pages"].data_ptr(), d["indptr"].data_ptr(), d["last"].data_ptr(), d["pos"].data_ptr(), d["qw"].data_ptr(),
+        d["kw"].data_ptr(), d["cos"].data_ptr(), d["sin"].data_ptr(), 1e-6, int(split), d["sri"].data_ptr(),
+        d["skt"].data_ptr(), d["skc"].data_ptr(), d["soi"].data_ptr(), d["sva"].data_ptr(), tmp_v.data_ptr(),
+        tmp_s.data_ptr(), Hq, Hkv, D, 16, bs, slots, Lk.page_stride, 1.0 / np.sqrt(128.0), dd.data_ptr(),
+        torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    assert np.array_equal(bf16_bits(from_dev(kv_c)), bf16_bits(from_dev(kv_a)))
+    assert np.array_equal(bf16_bits(from_dev(out_c)), bf16_bits(from_dev(out_a)))
 
 
 @pytest.mark.parametrize("split_policy", [0, 1])
