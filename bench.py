@@ -116,6 +116,10 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=12, help="decode steps for the CPU baseline (0 = skip)")
     ap.add_argument("--ttft-iters", type=int, default=5)
+    ap.add_argument("--parallelism", default="replicas", choices=["replicas", "tp"],
+                    help="N>1: 'replicas' = one independent request stream per GPU (weak scaling, no data-path "
+                         "collective; default); 'tp' = the reference's Qwen3 tensor parallel over RCCL "
+                         "(strong scaling, 72 all-reduces per step)")
     args = ap.parse_args()
 
     import torch
@@ -131,7 +135,12 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
 
+    from pegainfer_amd import parallel
     cfg = dict(QWEN3_4B if args.model == "qwen3-4b" else QWEN3_8B)
+    full_cfg = dict(cfg)
+    tp = args.parallelism == "tp" and world > 1
+    if tp:
+        cfg = parallel.tp_local_config(cfg, world)
     total_ctx = args.ctx + args.warmup + args.steps + 8
     pages = args.batch * (-(-total_ctx // 16) + 1) + 8
     eng = Qwen3Engine(cfg, num_kv_pages=pages, max_batch_size=max(args.batch, 1), enable_graph=not args.no_graph,
@@ -142,8 +151,10 @@ def main():
         eng.load_safetensors(path)
         data = "synthetic prompt, real weights"
     else:
-        eng.fill_synthetic(seed=42 + rank, std=0.02)
+        eng.fill_synthetic(seed=42 if tp else 42 + rank, std=0.02)   # TP: replicated tensors must agree
         data = "synthetic"
+    if tp:
+        parallel.attach_tp(eng)
 
     prompt = synthetic_prompt(args.ctx)
     # ---- TTFT (submit -> first token): prefill of the ctx-token prompt, fresh request each time ----
@@ -176,27 +187,25 @@ def main():
         dev_ms.append(eng.last_step_ms())
     barrier()
     elapsed = time.perf_counter() - t_start
-    if world > 1:
-        tmax = torch.tensor([elapsed], device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    elapsed = parallel.max_over_ranks(elapsed, device="cuda")
 
-    tokens = args.steps * args.batch * world
+    tokens = args.steps * args.batch * (1 if tp else world)
     value = tokens / elapsed
     ctx_mid = args.ctx + args.warmup + args.steps / 2
-    step_bytes = algorithmic_bytes_per_token(cfg, ctx_mid, args.batch)
+    step_bytes = algorithmic_bytes_per_token(full_cfg, ctx_mid, args.batch)
 
     out = {
         "metric": "decode tokens/sec + TTFT, Qwen3-4B bf16 greedy, 1xMI355X" if args.model == "qwen3-4b"
                   else "decode tokens/sec + TTFT, Qwen3-8B bf16 greedy, 1xMI355X",
         "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+        "scaling": "strong" if tp else "weak",
         "vs_baseline": None, "dtype": "bf16", "data": data,
         "config": {"workload": f"{args.model} greedy decode, hipGraph {'off' if args.no_graph else 'on'}, "
                                f"bs={args.batch}/GPU, ctx {args.ctx}->{args.ctx + args.warmup + args.steps} "
                                f"(reference decode_heavy: synthetic prompt 100+(i%1000))",
                    "batch_per_gpu": args.batch, "ctx": args.ctx, "decode_mode": args.decode_mode,
-                   "split_policy": args.split_policy, "parallelism": "replicas" if world > 1 else "single"},
+                   "split_policy": args.split_policy, "parallelism": ("tp%d" % world if tp else "replicas%d" % world) if world > 1 else "single"},
         "ttft_ms": {"prompt_tokens": args.ctx, "p50": round(float(np.median(ttfts)), 3),
                     "min": round(float(min(ttfts)), 3), "iters": len(ttfts)},
         "tpot_ms": {"p50": round(float(np.median(step_ms)), 4), "p95": round(float(np.percentile(step_ms, 95)), 4),

@@ -48,6 +48,14 @@ int32_t pegainfer_qwen3_load_tensor(pegainfer_qwen3_t m, const char* name, const
 int32_t pegainfer_qwen3_fill_synthetic(pegainfer_qwen3_t m, uint64_t seed, float std);
 int32_t pegainfer_qwen3_finalize(pegainfer_qwen3_t m);
 
+/* Tensor parallel (the reference's Qwen3 TP, weights.rs:121-291,396-405, executor.rs:580-588 - there one
+ * thread per rank with cudarc NCCL; here one PROCESS per GPU with RCCL over xGMI).  Create the model with the
+ * LOCAL head counts / intermediate size, load the rank's weight shards (q/k/v/gate/up row-sharded, o/down
+ * column-sharded, embeddings / norms / lm_head replicated), then attach: every decode/prefill step all-reduces
+ * (sum, bf16, in place, on the model stream) after O-proj and after down-proj.  world == 1 is a no-op. */
+int32_t pegainfer_qwen3_rccl_unique_id(void* out_128_bytes);
+int32_t pegainfer_qwen3_attach_tp(pegainfer_qwen3_t m, int32_t rank, int32_t world, const void* unique_id_128_bytes);
+
 /* requests = KvState handles (kv_pool.rs:147-260) */
 int32_t pegainfer_qwen3_new_request(pegainfer_qwen3_t m);
 int32_t pegainfer_qwen3_drop_request(pegainfer_qwen3_t m, int32_t request_id);

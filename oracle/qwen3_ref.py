@@ -65,7 +65,10 @@ class Qwen3Oracle:
 
     PAGE_SIZE = 16  # weights.rs:309
 
-    def __init__(self, cfg, weights, num_pages=64, rope_positions=4096):
+    def __init__(self, cfg, weights, num_pages=64, rope_positions=4096, all_reduce=None):
+        """all_reduce: optional callable(float32 array) -> summed array; applied to the bf16 O-proj and
+        down-proj outputs exactly where the reference's TP all-reduces (weights.rs:396-405)."""
+        self.all_reduce = all_reduce
         self.cfg = cfg
         self.w = weights
         c = cfg
@@ -126,10 +129,13 @@ class Qwen3Oracle:
         return ops.batch_prefill_paged(q, self.kv, self.layout, li, pages, indptr, last, q_indptr,
                                        c.num_attention_heads, self.sm_scale)
 
+    def _reduce(self, x):
+        return x if self.all_reduce is None else bf16_round(self.all_reduce(x).astype(F32))
+
     def _mlp(self, L, normed):
         gu = ops.gemm(L["gate_up"], normed)
         act = ops.silu_mul_fused(gu, self.cfg.intermediate_size)
-        return ops.gemm(L["down"], act)
+        return self._reduce(ops.gemm(L["down"], act))
 
     # -- prefill (prefill.rs:220-285) ----------------------------------------
     def batch_prefill(self, prompts, states):
@@ -148,7 +154,7 @@ class Qwen3Oracle:
         for li, L in enumerate(self.layers):
             normed = ops.rms_norm(hidden, L["ln1"], c.rms_norm_eps)
             attn = self._attn_block(li, L, normed, positions, batch_indices, meta, False, q_indptr)
-            o = ops.gemm(L["o"], attn)
+            o = self._reduce(ops.gemm(L["o"], attn))
             hidden, normed = ops.fused_add_rms_norm(hidden, o, L["ln2"], c.rms_norm_eps)
             mlp = self._mlp(L, normed)
             hidden = ops.add(hidden, mlp)                        # prefill.rs:183 plain add
@@ -174,7 +180,7 @@ class Qwen3Oracle:
         normed = ops.rms_norm(hidden, self.layers[0]["ln1"], c.rms_norm_eps)
         for li, L in enumerate(self.layers):
             attn = self._attn_block(li, L, normed, positions, batch_indices, meta, True)
-            o = ops.gemm(L["o"], attn)
+            o = self._reduce(ops.gemm(L["o"], attn))
             hidden, normed = ops.fused_add_rms_norm(hidden, o, L["ln2"], c.rms_norm_eps)
             mlp = self._mlp(L, normed)
             nxt = self.layers[li + 1]["ln1"] if li + 1 < len(self.layers) else self.norm

@@ -79,7 +79,8 @@ def build(verbose=False, force=False):
         _run([_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", KERNEL_LIB] + kobjs)
     if hobjs and _newer(hobjs + [KERNEL_LIB], HOST_LIB):
         _run([_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", HOST_LIB] + hobjs +
-             ["-L", LIBDIR, "-lpegainfer_kernels_hip", "-Wl,-rpath,$ORIGIN"])
+             ["-L", LIBDIR, "-lpegainfer_kernels_hip", "-L", "/opt/rocm/lib", "-lrccl", "-Wl,-rpath,$ORIGIN",
+              "-Wl,-rpath,/opt/rocm/lib"])
     if verbose:
         print("built", KERNEL_LIB, HOST_LIB if hobjs else "")
     return KERNEL_LIB, (HOST_LIB if hobjs else None)

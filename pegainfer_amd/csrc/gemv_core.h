@@ -49,7 +49,8 @@ template <int NT, int RPW, int KSPLIT, int EPI>
 __global__ __launch_bounds__(256) void gemv_fused_kernel(const GemvFusedArgs a) {
   constexpr int KT = GemvTile<NT>::KT;
   constexpr int NW = EPI == kEpiSilu ? 2 : 1;  // weight row sets streamed together
-  constexpr int U = 4;                         // K blocks in flight per wave: U*NW*RPW = 16 loads = 16 KB
+  constexpr int U = 4;                         // K blocks in flight per wave: U*NW*RPW loads of 1 KB
+  constexpr int ROWS_PER_GROUP = (KSPLIT == 1 ? 4 : 1) * RPW;
   // all LDS is dynamic and sized to the shape (guide G17: one 16-byte aligned carve, no statics): a K = 2560
   // GEMV needs 5 KB, not the 32 KB tile capacity, which is what lets 5+ workgroups share a CU.
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -60,23 +61,32 @@ __global__ __launch_bounds__(256) void gemv_fused_kernel(const GemvFusedArgs a) 
   const int K = a.K, T = a.T;
   const int pitch = (K < KT ? K : KT) >> 3;  // 16-byte vectors per token row of the x tile
   const int rows_total = EPI == kEpiSilu ? a.I : a.M;
-  const int row0 = (KSPLIT == 1 ? (blockIdx.x * 4 + wave) : blockIdx.x) * RPW;
+  const int ngroups = (rows_total + ROWS_PER_GROUP - 1) / ROWS_PER_GROUP;
+
+  // Persistent over row groups: the launcher sizes the grid to what is co-resident (gridDim <= ngroups) and a
+  // workgroup walks groups g, g + gridDim, ... - x is normalised / staged ONCE per workgroup and the next
+  // group's weight loads are already in flight while the current group is reduced and stored.
   const Half* wrow[NW][RPW];
+  auto set_rows = [&](int g) {
+    const int row0 = (KSPLIT == 1 ? g * 4 + wave : g) * RPW;
 #pragma unroll
-  for (int s = 0; s < NW; ++s)
+    for (int s = 0; s < NW; ++s)
 #pragma unroll
-    for (int r = 0; r < RPW; ++r) {
-      int row = row0 + r;
-      row = row < rows_total ? row : rows_total - 1;  // clamp: loads stay in bounds, stores are masked
-      wrow[s][r] = a.W + ((size_t)row + (size_t)s * a.I) * K;
-    }
+      for (int r = 0; r < RPW; ++r) {
+        int row = row0 + r;
+        row = row < rows_total ? row : rows_total - 1;  // clamp: loads stay in bounds, stores are masked
+        wrow[s][r] = a.W + ((size_t)row + (size_t)s * a.I) * K;
+      }
+  };
   float acc[NW][RPW][NT];
+  auto zero_acc = [&]() {
 #pragma unroll
-  for (int s = 0; s < NW; ++s)
+    for (int s = 0; s < NW; ++s)
 #pragma unroll
-    for (int r = 0; r < RPW; ++r)
+      for (int r = 0; r < RPW; ++r)
 #pragma unroll
-      for (int t = 0; t < NT; ++t) acc[s][r][t] = 0.f;
+        for (int t = 0; t < NT; ++t) acc[s][r][t] = 0.f;
+  };
 
   u32x4 wv[U][NW][RPW];
   auto issue = [&](int k0, int kt, int b0) {
@@ -111,6 +121,8 @@ __global__ __launch_bounds__(256) void gemv_fused_kernel(const GemvFusedArgs a) 
 
   const int bfirst = KSPLIT == 1 ? 0 : wave;
   const int kt0 = K < KT ? K : KT;
+  int g = blockIdx.x;
+  set_rows(g);
   issue(0, kt0, bfirst);  // HBM requests leave before the prologue touches anything
 
   // ---- prologue: per-token inverse RMS (canonical order), only when a norm weight is given ----
@@ -127,146 +139,150 @@ __global__ __launch_bounds__(256) void gemv_fused_kernel(const GemvFusedArgs a) 
     for (int t = 0; t < NT; ++t) {
       if (t >= T) continue;          // accumulators of absent tokens are never stored
       for (int c = threadIdx.x; c < nvec; c += 256) {
-        u32x4 v = {0u, 0u, 0u, 0u};
-        {
-          const size_t off = (size_t)t * K + k0 + c * 8;
-          const u32x4 h = *reinterpret_cast<const u32x4*>(a.X + off);
-          if (a.norm_w) {
-            const u32x4 g = *reinterpret_cast<const u32x4*>(a.norm_w + k0 + c * 8);
-            if (a.residual) {
-              const u32x4 r = *reinterpret_cast<const u32x4*>(a.residual + off);
-              u32x4 nh;
-              v = norm_scale8(h, &r, g, inv[t], 0.f, &nh);
-              if (blockIdx.x == 0) *reinterpret_cast<u32x4*>(a.hidden_out + off) = nh;
-            } else {
-              v = norm_scale8(h, nullptr, g, inv[t], 0.f, nullptr);
-            }
+        u32x4 v;
+        const size_t off = (size_t)t * K + k0 + c * 8;
+        const u32x4 h = *reinterpret_cast<const u32x4*>(a.X + off);
+        if (a.norm_w) {
+          const u32x4 gw = *reinterpret_cast<const u32x4*>(a.norm_w + k0 + c * 8);
+          if (a.residual) {
+            const u32x4 r = *reinterpret_cast<const u32x4*>(a.residual + off);
+            u32x4 nh;
+            v = norm_scale8(h, &r, gw, inv[t], 0.f, &nh);
+            if (blockIdx.x == 0) *reinterpret_cast<u32x4*>(a.hidden_out + off) = nh;
           } else {
-            v = h;
+            v = norm_scale8(h, nullptr, gw, inv[t], 0.f, nullptr);
           }
+        } else {
+          v = h;
         }
         xs[t * pitch + c] = v;
       }
     }
   };
-
-  // ---- tile 0 (first block group already in flight) ----
   stage(0, kt0);
   __syncthreads();
-  {
-    const int nblk = (kt0 + 511) >> 9;
-    consume(kt0, nblk, bfirst);
-    for (int b0 = bfirst + U * KSPLIT; b0 < nblk; b0 += U * KSPLIT) {
-      issue(0, kt0, b0);
-      consume(kt0, nblk, b0);
+
+  for (;;) {
+    zero_acc();
+    // ---- tile 0 (first block group already in flight) ----
+    {
+      const int nblk = (kt0 + 511) >> 9;
+      consume(kt0, nblk, bfirst);
+      for (int b0 = bfirst + U * KSPLIT; b0 < nblk; b0 += U * KSPLIT) {
+        issue(0, kt0, b0);
+        consume(kt0, nblk, b0);
+      }
     }
-  }
-  for (int k0 = KT; k0 < K; k0 += KT) {
-    const int kt = (K - k0) < KT ? (K - k0) : KT;
-    __syncthreads();
-    stage(k0, kt);
-    __syncthreads();
-    const int nblk = (kt + 511) >> 9;
-    for (int b0 = bfirst; b0 < nblk; b0 += U * KSPLIT) {
-      issue(k0, kt, b0);
-      consume(kt, nblk, b0);
+    // ---- further K tiles: only when K > KT, in which case the launcher gives every group its own workgroup ----
+    for (int k0 = KT; k0 < K; k0 += KT) {
+      const int kt = (K - k0) < KT ? (K - k0) : KT;
+      __syncthreads();
+      stage(k0, kt);
+      __syncthreads();
+      const int nblk = (kt + 511) >> 9;
+      for (int b0 = bfirst; b0 < nblk; b0 += U * KSPLIT) {
+        issue(k0, kt, b0);
+        consume(kt, nblk, b0);
+      }
     }
-  }
+    const int g_next = g + gridDim.x;
+    const bool has_next = g_next < ngroups;
+    const int row0 = (KSPLIT == 1 ? g * 4 + wave : g) * RPW;  // rows of the group being finished
+    if (has_next) {
+      set_rows(g_next);
+      issue(0, kt0, bfirst);  // next group's weights stream while this group is reduced
+    }
 
 #pragma unroll
-  for (int s = 0; s < NW; ++s)
-#pragma unroll
-    for (int r = 0; r < RPW; ++r)
-#pragma unroll
-      for (int t = 0; t < NT; ++t) acc[s][r][t] = wave_sum(acc[s][r][t]);
-
-  auto emit = [&](int r, int t, float v0, float v1) {
-    const int row = row0 + r;
-    if (row >= rows_total || t >= T) return;
-    if (EPI == kEpiSilu) {
-      const float g = bf16_round_f(v0), u = bf16_round_f(v1);  // the GEMM output is bf16 before SwiGLU
-      a.Y[(size_t)t * a.I + row] = f2bf(silu_f(g) * u);
-    } else {
-      a.Y[(size_t)t * a.M + row] = f2bf(v0);
-    }
-  };
-  if (KSPLIT == 1) {
-    if (lane == 0) {
+    for (int s = 0; s < NW; ++s)
 #pragma unroll
       for (int r = 0; r < RPW; ++r)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) emit(r, t, acc[0][r][t], acc[NW - 1][r][t]);
-    }
-  } else {
-    if (lane == 0) {
-#pragma unroll
-      for (int s = 0; s < NW; ++s)
+        for (int t = 0; t < NT; ++t) acc[s][r][t] = wave_sum(acc[s][r][t]);
+
+    auto emit = [&](int r, int t, float v0, float v1) {
+      const int row = row0 + r;
+      if (row >= rows_total || t >= T) return;
+      if (EPI == kEpiSilu) {
+        const float gt = bf16_round_f(v0), up = bf16_round_f(v1);  // the GEMM output is bf16 before SwiGLU
+        a.Y[(size_t)t * a.I + row] = f2bf(silu_f(gt) * up);
+      } else {
+        a.Y[(size_t)t * a.M + row] = f2bf(v0);
+      }
+    };
+    if (KSPLIT == 1) {
+      if (lane == 0) {
 #pragma unroll
         for (int r = 0; r < RPW; ++r)
 #pragma unroll
-          for (int t = 0; t < NT; ++t) part[((wave * NW + s) * RPW + r) * NT + t] = acc[s][r][t];
-    }
-    __syncthreads();
-    if (threadIdx.x < RPW * NT) {
-      const int r = threadIdx.x / NT, t = threadIdx.x - r * NT;
-      float tot[NW];
-#pragma unroll
-      for (int s = 0; s < NW; ++s) {
-        float v = part[((0 * NW + s) * RPW + r) * NT + t];
-        v += part[((1 * NW + s) * RPW + r) * NT + t];
-        v += part[((2 * NW + s) * RPW + r) * NT + t];
-        v += part[((3 * NW + s) * RPW + r) * NT + t];
-        tot[s] = v;
+          for (int t = 0; t < NT; ++t) emit(r, t, acc[0][r][t], acc[NW - 1][r][t]);
       }
-      emit(r, t, tot[0], tot[NW - 1]);
+    } else {
+      if (lane == 0) {
+#pragma unroll
+        for (int s = 0; s < NW; ++s)
+#pragma unroll
+          for (int r = 0; r < RPW; ++r)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) part[((wave * NW + s) * RPW + r) * NT + t] = acc[s][r][t];
+      }
+      __syncthreads();
+      if (threadIdx.x < RPW * NT) {
+        const int r = threadIdx.x / NT, t = threadIdx.x - r * NT;
+        float tot[NW];
+#pragma unroll
+        for (int s = 0; s < NW; ++s) {
+          float v = part[((0 * NW + s) * RPW + r) * NT + t];
+          v += part[((1 * NW + s) * RPW + r) * NT + t];
+          v += part[((2 * NW + s) * RPW + r) * NT + t];
+          v += part[((3 * NW + s) * RPW + r) * NT + t];
+          tot[s] = v;
+        }
+        emit(r, t, tot[0], tot[NW - 1]);
+      }
+      if (has_next) __syncthreads();  // `part` is rewritten by the next group
     }
+    if (!has_next) break;
+    g = g_next;
   }
 }
 
-// rows per wave: the largest of {4,2,1} (bounded by max_rpw) whose workgroup count fills the 256 CUs
-// evenly (>= 95 % balance) and reaches >= 512 workgroups; otherwise the best-balanced one.
-inline int gemv_pick_rpw(int rows, int ksplit, int max_rpw) {
-  int best = 1;
-  double best_score = -1.0;
-  for (int rpw = max_rpw; rpw >= 1; rpw >>= 1) {
-    const int per_wg = (ksplit == 1 ? 4 : 1) * rpw;
-    const int nwg = (rows + per_wg - 1) / per_wg;
-    const double bal = (double)nwg / (double)(((nwg + 255) / 256) * 256);
-    if (bal >= 0.95 && nwg >= 512) return rpw;
-    const double score = bal + (nwg >= 256 ? 0.0 : -1.0);
-    if (score > best_score) { best_score = score; best = rpw; }
-  }
-  return best;
-}
-
-template <int NT, int RPW, int EPI>
-inline void gemv_launch_ks(const GemvFusedArgs& a, int ksplit, hipStream_t s) {
+// Grid sizing: every workgroup should be co-resident (no second, half-empty scheduling round) and all of them
+// should walk the same number of row groups.  capacity = occupancy(kernel, lds) x CU count; rounds =
+// ceil(ngroups / capacity); grid = ceil(ngroups / rounds).  K > KT (multi-tile x) needs one group per workgroup.
+template <int NT, int RPW, int KSPLIT, int EPI>
+inline void gemv_launch_one(const GemvFusedArgs& a, hipStream_t s) {
+  constexpr int ROWS_PER_GROUP = (KSPLIT == 1 ? 4 : 1) * RPW;
   const int rows = EPI == kEpiSilu ? a.I : a.M;
-  // > 64 KB of dynamic LDS (NT = 16 tiles) must be opted into once per kernel
-  if (ksplit == 4) {
-    static const bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_fused_kernel<NT, RPW, 4, EPI>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024), true);
-    (void)once;
-    gemv_fused_kernel<NT, RPW, 4, EPI><<<ceil_div(rows, RPW), 256, gemv_lds_bytes<NT, RPW, 4, EPI>(a.K), s>>>(a);
-  } else {
-    static const bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_fused_kernel<NT, RPW, 1, EPI>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024), true);
-    (void)once;
-    gemv_fused_kernel<NT, RPW, 1, EPI><<<ceil_div(rows, 4 * RPW), 256, gemv_lds_bytes<NT, RPW, 1, EPI>(a.K), s>>>(a);
+  const int ngroups = ceil_div(rows, ROWS_PER_GROUP);
+  const int lds = gemv_lds_bytes<NT, RPW, KSPLIT, EPI>(a.K);
+  auto kern = &gemv_fused_kernel<NT, RPW, KSPLIT, EPI>;
+  static const bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024), true);
+  (void)once;
+  static thread_local int cached_lds = -1, cached_cap = 0;
+  if (cached_lds != lds) {
+    int per_cu = 0, dev = 0, cus = 256;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    cached_cap = per_cu * (cus > 0 ? cus : 256);
+    cached_lds = lds;
   }
+  int grid = ngroups;
+  if (a.K <= GemvTile<NT>::KT && ngroups > cached_cap) {
+    const int rounds = ceil_div(ngroups, cached_cap);
+    grid = ceil_div(ngroups, rounds);
+  }
+  kern<<<grid, 256, lds, s>>>(a);
 }
 
 template <int NT, int EPI>
 inline void gemv_launch_nt(const GemvFusedArgs& a, hipStream_t s) {
-  const int ksplit = a.K >= 4096 ? 4 : 1;
-  const int rows = EPI == kEpiSilu ? a.I : a.M;
-  constexpr int kMaxRpw = (EPI == kEpiSilu) ? 2 : (NT <= 2 ? 4 : 2);  // keeps <= 16 loads / 32 accumulators per wave
-  const int rpw = gemv_pick_rpw(rows, ksplit, kMaxRpw);
-  if constexpr (kMaxRpw >= 4) {
-    if (rpw == 4) { gemv_launch_ks<NT, 4, EPI>(a, ksplit, s); return; }
-  }
-  if (rpw >= 2) { gemv_launch_ks<NT, 2, EPI>(a, ksplit, s); return; }
-  gemv_launch_ks<NT, 1, EPI>(a, ksplit, s);
+  // rows per wave: 2 for the plain store (16 KB of loads per wave with U = 4 ... 8 KB), 1 for SwiGLU (two
+  // matrices per wave); both stay <= 96 VGPRs for NT <= 2, i.e. 5 workgroups per CU.  RPW never changes results.
+  constexpr int RPW = EPI == kEpiSilu ? 1 : 2;
+  if (a.K >= 4096) gemv_launch_one<NT, RPW, 4, EPI>(a, s);
+  else gemv_launch_one<NT, RPW, 1, EPI>(a, s);
 }
 
 // T <= 16, K % 8 == 0, 16-byte aligned W/X (and residual/norm_w/hidden_out when given)

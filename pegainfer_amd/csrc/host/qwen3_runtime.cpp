@@ -6,6 +6,7 @@
 // metadata packed into ONE pinned block and uploaded by ONE hipMemcpyAsync before the launch
 // (the reference issues 13 small H2D copies, batch_decode.rs:51-59).
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 
 #include <chrono>
 #include <cmath>
@@ -116,6 +117,9 @@ struct Model {
   Half* pf_last_normed = nullptr;
   Half* pf_logits = nullptr;
   int pf_logits_rows = 0;
+  // tensor parallel (reference TP: weights.rs:121-291,396-405): RCCL communicator, one rank per process/GPU
+  ncclComm_t tp_comm = nullptr;
+  int tp_rank = 0, tp_world = 1;
   // last step
   const Half* last_logits = nullptr;
   int last_rows = 0;
@@ -204,6 +208,25 @@ struct Model {
     if (dalloc(&meta_dev, ml.total)) return -1;
     PQ_HIP(hipHostMalloc(reinterpret_cast<void**>(&tokens_out_host), bs * 4, hipHostMallocDefault));
     PQ_HIP(hipStreamSynchronize(stream));
+    return 0;
+  }
+
+  // Qwen3Model::all_reduce_hidden (weights.rs:396-405): in-place bf16 sum over the TP group, on the model
+  // stream (capturable), after O-proj and down-proj.  No-op without a communicator.
+  int all_reduce_hidden(Half* buf, size_t count) {
+    if (!tp_comm) return 0;
+    ncclResult_t r = ncclAllReduce(buf, buf, count, ncclBfloat16, ncclSum, tp_comm, stream);
+    if (r != ncclSuccess) { set_error(std::string("ncclAllReduce: ") + ncclGetErrorString(r)); return -1; }
+    return 0;
+  }
+  int attach_tp(int rank, int world, const void* unique_id) {
+    if (world < 1 || rank < 0 || rank >= world) { set_error("bad TP rank/world"); return -1; }
+    tp_rank = rank; tp_world = world;
+    if (!unique_id) return world == 1 ? 0 : (set_error("TP world > 1 needs a unique id"), -1);
+    ncclUniqueId id;
+    std::memcpy(&id, unique_id, sizeof(id));
+    ncclResult_t r = ncclCommInitRank(&tp_comm, world, id, rank);
+    if (r != ncclSuccess) { set_error(std::string("ncclCommInitRank: ") + ncclGetErrorString(r)); return -1; }
     return 0;
   }
 
@@ -339,10 +362,12 @@ struct Model {
     }
     if (rc) { set_error("paged attention decode failed"); return -1; }
     gemm_graphsafe_cuda(ly.o, attn_out, attn_proj, H, bs, q_dim, S());
+    if (all_reduce_hidden(attn_proj, (size_t)bs * H)) return -1;  // batch_decode.rs:266
     fused_add_rms_norm_batched_cuda(hidden, attn_proj, ly.ln2, normed, H, bs, eps, S());
     gemm_graphsafe_cuda(ly.gate_up, normed, gate_up_out, 2 * I, bs, H, S());
     silu_mul_fused_cuda(gate_up_out, mlp_act, I, bs, S());
     gemm_graphsafe_cuda(ly.down, mlp_act, mlp_out, H, bs, I, S());
+    if (all_reduce_hidden(mlp_out, (size_t)bs * H)) return -1;    // batch_decode.rs:292
     return 0;
   }
 
@@ -373,11 +398,13 @@ struct Model {
             md<int32_t>(ml.split_o_indptr), md<uint8_t>(ml.split_valid), split_tmp_v, split_tmp_s, Hq, Hkv, D,
             layout.page_size, bs, split_slots, layout.page_stride, sm, md<int32_t>(ml.slot_desc), S());
       if (!rc) rc = pegainfer_gemv_fused(ly.o, attn_out, attn_proj, H, bs, q_dim, nullptr, nullptr, nullptr, 0.f, 0, S());
+      if (!rc) rc = all_reduce_hidden(attn_proj, (size_t)bs * H);
       if (!rc) {
         rc = pegainfer_gemv_fused(ly.gate_up, cur, mlp_act, 2 * I, bs, H, attn_proj, ly.ln2, nxt, eps, I, S());
         std::swap(cur, nxt);
       }
       if (!rc) rc = pegainfer_gemv_fused(ly.down, mlp_act, mlp_out, H, bs, I, nullptr, nullptr, nullptr, 0.f, 0, S());
+      if (!rc) rc = all_reduce_hidden(mlp_out, (size_t)bs * H);
       if (rc) { set_error("fused decode layer failed"); return -1; }
       resid = mlp_out;
     }
@@ -631,10 +658,12 @@ struct Model {
           Ti, n, num_tiles, layout.page_stride, sm, cta, S());
       if (rc) { set_error("batch_prefill_paged_cuda failed"); return -1; }
       G(ly.o, pf_attn, pf_o, H, q_dim);
+      if (all_reduce_hidden(pf_o, (size_t)Ti * H)) return -1;   // prefill.rs:154
       fused_add_rms_norm_batched_cuda(hid, pf_o, ly.ln2, pf_normed, H, Ti, eps, S());
       G(ly.gate_up, pf_normed, pf_gate_up, 2 * I, H);
       silu_mul_fused_cuda(pf_gate_up, pf_act, I, Ti, S());
       G(ly.down, pf_act, pf_o, H, I);
+      if (all_reduce_hidden(pf_o, (size_t)Ti * H)) return -1;   // prefill.rs:180
       if (add_cuda(hid, pf_o, hid_out, Ti * H, S())) { set_error("add_cuda failed"); return -1; }
       std::swap(hid, hid_out);  // prefill.rs:183-185
     }
@@ -665,8 +694,8 @@ struct Model {
   float bench_gemv(int which, int iters, int bs) {
     if (!finalized || iters <= 0 || bs < 1 || bs > max_bs) return -1.f;
     auto launch = [&](int it) {
-      const Layer& ly = layers[it % L];
-      switch (which) {
+      const Layer& ly = layers[which >= 10 ? 0 : it % L];  // which >= 10: same layer every time (cache-warm probe)
+      switch (which % 10) {
         case 0: gemm_graphsafe_cuda(ly.qkv, normed, gate_up_out, q_dim + 2 * kv_dim, bs, H, S()); break;
         case 1: gemm_graphsafe_cuda(ly.o, attn_out, attn_proj, H, bs, q_dim, S()); break;
         case 2: gemm_graphsafe_cuda(ly.gate_up, normed, gate_up_out, 2 * I, bs, H, S()); break;
@@ -703,6 +732,7 @@ struct Model {
 
   ~Model() {
     if (stream) hipStreamSynchronize(stream);
+    if (tp_comm) ncclCommDestroy(tp_comm);
     for (auto& b : graphs)
       for (auto& g : b)
         if (g) hipGraphExecDestroy(g);
@@ -778,6 +808,15 @@ int32_t pegainfer_qwen3_decode(pegainfer_qwen3_t m, int32_t n, const int32_t* id
 int32_t pegainfer_qwen3_sample(pegainfer_qwen3_t m, int32_t column, float temperature, int32_t top_k, float top_p,
                                float random_val, int32_t* out_token) {
   return M(m)->sample(column, temperature, top_k, top_p, random_val, out_token);
+}
+int32_t pegainfer_qwen3_rccl_unique_id(void* out_128_bytes) {
+  ncclUniqueId id;
+  if (ncclGetUniqueId(&id) != ncclSuccess) return -1;
+  std::memcpy(out_128_bytes, &id, sizeof(id));
+  return 0;
+}
+int32_t pegainfer_qwen3_attach_tp(pegainfer_qwen3_t m, int32_t rank, int32_t world, const void* unique_id_128_bytes) {
+  return M(m)->attach_tp(rank, world, unique_id_128_bytes);
 }
 float pegainfer_qwen3_last_step_ms(pegainfer_qwen3_t m) { return M(m)->last_step_ms; }
 float pegainfer_qwen3_bench_gemv(pegainfer_qwen3_t m, int32_t which, int32_t iters, int32_t bs) {

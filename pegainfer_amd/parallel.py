@@ -1,0 +1,193 @@
+"""Multi-GPU pieces of the hot path, one process per GPU over ``torch.distributed``
+(backend "nccl" == RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
+
+What the reference does and where it lives here:
+
+* **Replicas** - independent requests need no data-path collective: ``shard_requests`` deals request
+  indices to ranks, ``max_over_ranks`` is the only collective (timing).  This is what ``bench.py --gpus N`` uses.
+* **Qwen3 tensor parallel** (pegainfer-qwen3-4b/src/weights.rs:121-291): q/k/v/gate/up row-sharded by head /
+  intermediate, o/down column-sharded, embeddings + norms + lm_head replicated, one bf16 sum all-reduce of
+  ``[hidden x T]`` after O-proj and after down-proj (weights.rs:396-405).  ``shard_range`` / ``tp_local_config``
+  / ``shard_qwen3_state`` produce the rank's weights; ``attach_tp`` hands an RCCL communicator to the C++
+  runtime, which issues the all-reduces on the model stream (capturable in the decode hipGraph).
+* **DeepSeek-V4 MP8 collective set** (pegainfer-deepseek-v4/src/runtime/collectives.rs:8-287,
+  moe.rs:1327-1461, core.rs:560-609): ``Comm`` offers the same verbs - in-place all-reduce, the
+  bf16->f32->all-reduce->bf16 hidden reduce, all-gather, reduce-scatter, the decode-MoE AG/RS pair on a
+  separate comm stream fenced by events so shared-expert compute overlaps.  Payloads are tiny (16 KB - 128 KB
+  at bs=1): latency-bound, so each verb is ONE collective call (no bucketing), and xGMI is point-to-point, so
+  nothing here assumes a switch.
+"""
+import numpy as np
+
+
+def shard_range(total, rank, world):
+    """TensorParallel::shard_range (pegainfer-qwen3-4b/src/config.rs): equal contiguous shards."""
+    if total % world != 0:
+        raise ValueError(f"{total} is not divisible by tensor-parallel size {world}")
+    n = total // world
+    return rank * n, n
+
+
+def tp_local_config(cfg, world):
+    """Per-rank model shape: heads and MLP width divide by the TP size, hidden / vocab do not
+    (config.rs local_* helpers).  8 kv heads => world in {1, 2, 4, 8}."""
+    c = dict(cfg)
+    for k in ("num_attention_heads", "num_key_value_heads", "intermediate_size"):
+        if c[k] % world != 0:
+            raise ValueError(f"{k}={c[k]} is not divisible by tensor-parallel size {world}")
+        c[k] = c[k] // world
+    return c
+
+
+def shard_qwen3_state(tensors, cfg, rank, world):
+    """Rank-local weights from a full HF state dict {name: 2-D/1-D array} (any dtype; slicing only).
+    Row shard: q/k/v/gate/up.  Column shard: o/down.  Replicated: everything else (weights.rs:121-291)."""
+    hd = cfg["head_dim"]
+    q0, qn = shard_range(cfg["num_attention_heads"] * hd, rank, world)
+    k0, kn = shard_range(cfg["num_key_value_heads"] * hd, rank, world)
+    i0, inn = shard_range(cfg["intermediate_size"], rank, world)
+    out = {}
+    for name, w in tensors.items():
+        if name.endswith("self_attn.q_proj.weight"):
+            w = w[q0:q0 + qn]
+        elif name.endswith("self_attn.k_proj.weight") or name.endswith("self_attn.v_proj.weight"):
+            w = w[k0:k0 + kn]
+        elif name.endswith("mlp.gate_proj.weight") or name.endswith("mlp.up_proj.weight"):
+            w = w[i0:i0 + inn]
+        elif name.endswith("self_attn.o_proj.weight"):
+            w = w[:, q0:q0 + qn]
+        elif name.endswith("mlp.down_proj.weight"):
+            w = w[:, i0:i0 + inn]
+        out[name] = np.ascontiguousarray(w)
+    return out
+
+
+def shard_requests(n_requests, rank, world):
+    """Replica mode: request i runs on rank i % world (no collective on the data path)."""
+    return [i for i in range(n_requests) if i % world == rank]
+
+
+def max_over_ranks(seconds, device=None):
+    """The bench contract's only collective: elapsed = MAX over ranks."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(seconds)
+    t = torch.tensor([float(seconds)], dtype=torch.float64, device=device or "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def attach_tp(engine, group=None, force_comm=False):
+    """Create the RCCL communicator of the C++ runtime: rank 0 draws the unique id, torch.distributed
+    broadcasts its 128 bytes, every rank calls ncclCommInitRank inside pegainfer_qwen3_attach_tp.
+    world == 1 attaches nothing unless force_comm (used by the single-GPU test to exercise RCCL + capture)."""
+    import ctypes
+
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    uid = (ctypes.c_ubyte * 128)()
+    if world > 1:
+        buf = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            if engine.lib.pegainfer_qwen3_rccl_unique_id(ctypes.addressof(uid)) != 0:
+                raise RuntimeError("ncclGetUniqueId failed")
+            buf = torch.tensor(list(uid), dtype=torch.uint8)
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else "cpu"
+        buf = buf.to(dev)
+        dist.broadcast(buf, src=0, group=group)
+        for i, b in enumerate(buf.cpu().tolist()):
+            uid[i] = b
+    elif force_comm:
+        if engine.lib.pegainfer_qwen3_rccl_unique_id(ctypes.addressof(uid)) != 0:
+            raise RuntimeError("ncclGetUniqueId failed")
+    ptr = ctypes.addressof(uid) if (world > 1 or force_comm) else None
+    engine._chk(engine.lib.pegainfer_qwen3_attach_tp(engine.h, rank, world, ptr), "attach_tp")
+    return rank, world
+
+
+class Comm:
+    """The reference's collective verbs (cudarc ``Comm`` + deepseek-v4 runtime/collectives.rs) over a
+    torch.distributed process group.  Tensors are torch tensors on the group's device."""
+
+    def __init__(self, group=None, comm_stream=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.comm_stream = comm_stream  # torch.cuda.Stream for the overlapped MoE AG/RS (state.rs:129)
+
+    # -- Comm::all_reduce_in_place (TP hidden reduce, indexer scores, prefill MoE) --
+    def all_reduce_in_place(self, t):
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    # -- all_reduce_hidden_fp32_in_place (collectives.rs:123-184): bf16 -> f32, sum in f32, back to bf16 --
+    def all_reduce_hidden_fp32_in_place(self, hidden_bf16):
+        import torch
+        f32 = self._cast(hidden_bf16, torch.float32)
+        self.dist.all_reduce(f32, op=self.dist.ReduceOp.SUM, group=self.group)
+        hidden_bf16.copy_(self._cast(f32, torch.bfloat16))
+        return hidden_bf16
+
+    # -- Comm::all_gather: [n] per rank -> [world * n], rank-major --
+    def all_gather(self, t):
+        import torch
+        out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        self.dist.all_gather_into_tensor(out.view(-1), t.contiguous().view(-1), group=self.group)
+        return out.view((self.world * t.shape[0],) + tuple(t.shape[1:]))
+
+    # -- Comm::reduce_scatter: [world * n] per rank -> this rank's summed [n] --
+    def reduce_scatter(self, t):
+        import torch
+        n = t.shape[0] // self.world
+        out = torch.empty((n,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        self.dist.reduce_scatter_tensor(out.view(-1), t.contiguous().view(-1), op=self.dist.ReduceOp.SUM,
+                                        group=self.group)
+        return out
+
+    # -- all_gather_logits (core.rs:560-609): vocab/world f32 per rank -> full vocab --
+    def all_gather_logits(self, local_logits_f32):
+        return self.all_gather(local_logits_f32)
+
+    # -- decode MoE AG/RS (moe.rs:1327-1461): gather every rank's tokens, run local experts on all of them
+    #    (`expert_fn`), reduce-scatter the f32 partials; `shared_fn` (shared expert) overlaps with the gather --
+    def moe_all_gather_reduce_scatter(self, hidden_bf16, expert_fn, shared_fn=None):
+        import torch
+        if self.comm_stream is not None and hidden_bf16.is_cuda:
+            ready = torch.cuda.Event()
+            ready.record()                                   # compute stream -> comm stream fence
+            with torch.cuda.stream(self.comm_stream):
+                self.comm_stream.wait_event(ready)
+                gathered = self.all_gather(hidden_bf16)
+                done = torch.cuda.Event()
+                done.record()
+            shared = shared_fn(hidden_bf16) if shared_fn else None   # overlaps with the all-gather
+            torch.cuda.current_stream().wait_event(done)
+        else:
+            gathered = self.all_gather(hidden_bf16)
+            shared = shared_fn(hidden_bf16) if shared_fn else None
+        partial_f32 = expert_fn(gathered)                    # [world*T, hidden] f32: this rank's experts only
+        routed = self.reduce_scatter(partial_f32)            # [T, hidden] f32
+        return routed if shared is None else routed + shared.float()
+
+    @staticmethod
+    def _cast(t, dtype):
+        """bf16 <-> f32 around the collectives: the HIP cast kernels (deepseek_bf16_to_f32_cuda /
+        deepseek_f32_to_bf16_cuda, ffi.rs:8-20) on the GPU; plain torch on the CPU test backend."""
+        import torch
+        if not t.is_cuda:
+            return t.to(dtype)
+        from . import ffi
+        out = torch.empty(t.shape, dtype=dtype, device=t.device)
+        s = torch.cuda.current_stream().cuda_stream
+        if dtype == torch.float32:
+            rc = ffi.lib().deepseek_bf16_to_f32_cuda(t.data_ptr(), out.data_ptr(), t.numel(), s)
+        else:
+            rc = ffi.lib().deepseek_f32_to_bf16_cuda(t.data_ptr(), out.data_ptr(), t.numel(), s)
+        if rc != 0:
+            raise RuntimeError(f"cast kernel failed with error {rc}")
+        return out
