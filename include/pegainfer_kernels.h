@@ -88,6 +88,15 @@ int32_t single_prefill_cuda(const Half* q, Half* output, const Half* k_cache, co
 int32_t paged_attention_decode_cuda(const Half* q, Half* output, const Half* kv_data, int64_t k_offset_elems, int64_t v_offset_elems, const int32_t* page_indices, const int32_t* page_indptr, const int32_t* last_page_len_d, const int32_t* request_indices, const int32_t* kv_tile_indices, const int32_t* kv_chunk_size_ptr, int32_t num_qo_heads, int32_t num_kv_heads, int32_t head_dim, int32_t page_size, int32_t batch_size, int64_t stride_page, float sm_scale, pegainfer_stream_t stream);
 int32_t paged_attention_decode_split_kv_cuda(const Half* q, Half* output, const Half* kv_data, int64_t k_offset_elems, int64_t v_offset_elems, const int32_t* page_indices, const int32_t* page_indptr, const int32_t* last_page_len_d, const int32_t* request_indices, const int32_t* kv_tile_indices, const int32_t* kv_chunk_size_ptr, const int32_t* o_indptr, const uint8_t* block_valid_mask, Half* tmp_v, float* tmp_s, int32_t num_qo_heads, int32_t num_kv_heads, int32_t head_dim, int32_t page_size, int32_t batch_size, int32_t padded_batch_size, int64_t stride_page, float sm_scale, pegainfer_stream_t stream);
 
+/* ---- Qwen3.5 hybrid extras (ffi.rs:181-226, 1014-1039, 1286-1334) ---- */
+void prefill_attention_hd256_prep_cuda(const Half* q_full_batch, const Half* k_batch, const Half* v_batch, const Half* q_norm_weight, const Half* k_norm_weight, const Half* cos_cache, const Half* sin_cache, Half* q_batch_out, Half* k_cache, Half* v_cache, int32_t num_q_heads, int32_t num_kv_heads, int32_t seq_len, const int32_t* start_pos_ptr, int32_t rotary_dim, float rms_eps, int32_t max_seq_len, pegainfer_stream_t stream);
+void attention_gate_batch_hd256_cuda(const Half* q_full_batch, Half* attn_out, int32_t num_q_heads, int32_t seq_len, pegainfer_stream_t stream);
+void qk_norm_partial_rope_batched_decode_hd256_cuda(const Half* q_full_batch, Half* k_batch, const Half* q_norm_weight, const Half* k_norm_weight, const Half* cos_cache, const Half* sin_cache, const int32_t* positions, Half* q_batch_out, int32_t num_q_heads, int32_t num_kv_heads, int32_t batch_size, int32_t rotary_dim, float rms_eps, pegainfer_stream_t stream);
+void gated_delta_rule_decode_cuda(const Half* qkv, const Half* b_proj, const Half* a_proj, const Half* dt_bias, const float* A_log, float* state, Half* output, int32_t num_key_heads, int32_t num_value_heads, int32_t key_dim, int32_t val_dim, pegainfer_stream_t stream);
+void conv1d_prefill_cuda(const Half* x_seq, const Half* conv_weight, Half* conv_state, Half* out_seq, int32_t num_channels, int32_t seq_len, int32_t kernel_size, pegainfer_stream_t stream);
+int32_t paged_attention_decode_cuda_hd256(const Half* q, Half* output, const Half* kv_data, int64_t k_offset_elems, int64_t v_offset_elems, const int32_t* page_indices, const int32_t* page_indptr, const int32_t* last_page_len_d, const int32_t* request_indices, const int32_t* kv_tile_indices, const int32_t* kv_chunk_size_ptr, int32_t num_qo_heads, int32_t num_kv_heads, int32_t head_dim, int32_t page_size, int32_t batch_size, int64_t stride_page, float sm_scale, pegainfer_stream_t stream);
+int32_t batch_prefill_paged_cuda_hd256(const Half* q, Half* output, const Half* kv_data, int64_t k_offset_elems, int64_t v_offset_elems, const int32_t* page_indices, const int32_t* page_indptr, const int32_t* last_page_len_d, const int32_t* q_indptr, const int32_t* request_indices, const int32_t* qo_tile_indices, const int32_t* kv_tile_indices, const int32_t* kv_chunk_size_ptr, const uint32_t* total_num_rows, int32_t num_qo_heads, int32_t num_kv_heads, int32_t head_dim, int32_t page_size, int32_t seq_len, int32_t batch_size, int32_t padded_batch_size, int64_t stride_page, float sm_scale, pegainfer_stream_t stream);
+
 /* ---- sampling (ffi.rs:98-120) ---- */
 void argmax_cuda(const Half* x, int32_t* out, int32_t n, pegainfer_stream_t stream);
 void flashinfer_top1_cuda(const Half* logits, Half* top1_value_scratch, uint8_t* row_states_scratch, int32_t* output, int32_t vocab_size, pegainfer_stream_t stream);

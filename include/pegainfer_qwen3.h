@@ -67,6 +67,14 @@ int32_t pegainfer_qwen3_available_pages(pegainfer_qwen3_t m);
 int32_t pegainfer_qwen3_prefill(pegainfer_qwen3_t m, int32_t n_requests, const int32_t* request_ids,
                                 const int32_t* prompt_lens, const uint32_t* tokens_concat, int32_t* out_tokens,
                                 void* out_logits_host);
+/* unified_step (unified_forward.rs:78-198): new prompts arrive while decodes are active.  ids / lens / tokens
+ * list the n_prefill prompt requests first, then n_decode requests with exactly one token each (lens == 1).
+ * All token columns share the GEMMs / norms / RoPE / KV append; attention is one batch-prefill call over the
+ * prompt columns plus one batch-decode call over the trailing decode columns.  Returns one greedy token (and
+ * optionally one logits row) per request, prompts first. */
+int32_t pegainfer_qwen3_unified_step(pegainfer_qwen3_t m, int32_t n_prefill, int32_t n_decode,
+                                     const int32_t* request_ids, const int32_t* lens, const uint32_t* tokens_concat,
+                                     int32_t* out_tokens, void* out_logits_host);
 /* batch_decode (batch_decode.rs:17-80) + greedy token per request; optional logits [n, vocab]. */
 int32_t pegainfer_qwen3_decode(pegainfer_qwen3_t m, int32_t n_requests, const int32_t* request_ids,
                                const uint32_t* token_ids, int32_t* out_tokens, void* out_logits_host);

@@ -483,3 +483,80 @@ def top_k_top_p_support(probs, top_k, top_p):
         pth = probs[order[min(n, len(probs)) - 1]]
         keep &= probs >= pth
     return keep
+
+
+# --------------------------------------------------------------------------
+# Qwen3.5 hybrid extras
+# --------------------------------------------------------------------------
+def conv1d_prefill(x_seq, conv_weight, conv_state):
+    """Causal depthwise conv + bf16 round + SiLU, and the state update (csrc/conv1d.cu:18-98).
+    x_seq [T, C]; conv_weight [C, K]; conv_state [C, K-1] (modified copy returned).
+    Returns (out [T, C], new_state)."""
+    T, C = x_seq.shape
+    K = conv_weight.shape[1]
+    sw = K - 1
+    hist = np.concatenate([conv_state.T.astype(F32), x_seq.astype(F32)], axis=0)       # [sw + T, C]
+    out = np.empty((T, C), dtype=F32)
+    for t in range(T):
+        s = np.zeros(C, dtype=F32)
+        for k in range(K):
+            s = (s + hist[t + k] * conv_weight[:, k].astype(F32)).astype(F32)          # taps in order k = 0..K-1
+        r = bf16_round(s)
+        out[t] = bf16_round(_silu(r))
+    new_state = hist[T:T + sw].T.copy() if sw > 0 else conv_state.copy()
+    return out, bf16_round(new_state)
+
+
+def gated_delta_rule_decode(qkv, b_proj, a_proj, dt_bias, A_log, state, num_key_heads, num_value_heads,
+                            key_dim, val_dim):
+    """One recurrent decode step per value head, all fp32 (csrc/gated_delta_rule.cu:27-190).
+    qkv: [q(kh*key_dim) | k(kh*key_dim) | v(vh*val_dim)]; state [vh, key_dim, val_dim] float32 (updated copy
+    returned).  Returns (out [vh*val_dim] bf16-valued, new_state)."""
+    q_total = key_dim * num_key_heads
+    st = state.astype(np.float64).copy()
+    out = np.empty(num_value_heads * val_dim, dtype=F32)
+    for h in range(num_value_heads):
+        kh = h * num_key_heads // num_value_heads
+        q = qkv[kh * key_dim:(kh + 1) * key_dim].astype(np.float64)
+        k = qkv[q_total + kh * key_dim: q_total + (kh + 1) * key_dim].astype(np.float64)
+        v = qkv[2 * q_total + h * val_dim: 2 * q_total + (h + 1) * val_dim].astype(np.float64)
+        q = q / np.sqrt((q * q).sum() + 1e-12) / np.sqrt(key_dim)
+        k = k / np.sqrt((k * k).sum() + 1e-12)
+        x = float(a_proj[h]) + float(dt_bias[h])
+        softplus = x if x > 20.0 else np.log1p(np.exp(x))
+        g = -np.exp(float(A_log[h])) * softplus
+        beta = 1.0 / (1.0 + np.exp(-float(b_proj[h])))
+        S = st[h] * np.exp(g)
+        kv = S.T @ k
+        delta = (v - kv) * beta
+        S = S + np.outer(k, delta)
+        st[h] = S
+        out[h * val_dim:(h + 1) * val_dim] = (S.T @ q).astype(F32)
+    return bf16_round(out), st.astype(F32)
+
+
+def hd256_norm_partial_rope(x, w, cos, sin, positions, rotary_dim, eps):
+    """(1+w) RMSNorm (one rounding) then partial NeoX RoPE on the first rotary_dim dims; table rows are
+    rotary_dim wide (csrc/prefill_attention_hd256.cu:7-133).  x: [T, heads, 256]."""
+    xs = x.astype(F32)
+    ss = (xs.astype(np.float64) ** 2).sum(-1, keepdims=True)
+    inv = (1.0 / np.sqrt(ss / 256.0 + np.float64(eps))).astype(F32)
+    n = bf16_round(xs * inv * (F32(1.0) + w.astype(F32)))
+    half = rotary_dim // 2
+    pos = np.asarray(positions, dtype=np.int64)
+    c = cos[pos][:, None, :half].astype(F32)
+    s = sin[pos][:, None, :half].astype(F32)
+    out = n.copy()
+    lo, hi = n[..., :half], n[..., half:rotary_dim]
+    out[..., :half] = bf16_round(lo * c - hi * s)
+    out[..., half:rotary_dim] = bf16_round(lo * s + hi * c)
+    return out
+
+
+def attention_gate_hd256(q_full, attn_out, num_q_heads):
+    """attn_out *= sigmoid(gate); gate = second half of each interleaved q_full head
+    (csrc/prefill_attention_hd256.cu:135-157).  q_full [T, Hq*512], attn_out [T, Hq*256]."""
+    T = attn_out.shape[0]
+    gate = q_full.reshape(T, num_q_heads, 2, 256)[:, :, 1, :].reshape(T, -1).astype(F32)
+    sig = (F32(1.0) / (F32(1.0) + np.exp(-gate, dtype=F32))).astype(F32)
+    return bf16_round(attn_out.astype(F32) * sig)

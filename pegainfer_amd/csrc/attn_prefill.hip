@@ -37,13 +37,17 @@ struct ContigAddr {  // HND: cache[head][pos][dim]
   __device__ __forceinline__ long row(int t) const { return head_base + (long)t * D; }
 };
 
-template <int QBLK, typename Addr>
+template <int QBLK, int D, typename Addr>
 __device__ __forceinline__ void prefill_tile(const Half* __restrict__ q_base, Half* __restrict__ o_base,
                                              const Half* __restrict__ kbuf, const Half* __restrict__ vbuf,
                                              const Addr& addr, int qo_len, int kv_len, int tile_row0,
                                              int tile_rows, int group, long q_stride_n, float scale_log2,
-                                             u32x4* ks /*[TKV*16]*/, Half* vt /*[128*VT_PITCH]*/) {
-  constexpr int D = 128;
+                                             u32x4* ks /*[TKV*D/8]*/, Half* vt /*[D*VT_PITCH]*/) {
+  constexpr int KCH = D / 8;               // 16-byte chunks per K/V row
+  constexpr int KS = D / 32;               // MFMA k-steps over the head dim
+  constexpr int DB = D / 16;               // 16-dim output blocks
+  constexpr int KPT = TKV * KCH / 256;     // K chunks staged per thread
+  constexpr int VPT = 16 * KCH / 256;      // V (4-token x 8-dim) units staged per thread
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int l15 = lane & 15, g = lane >> 4;
   const int packed_len = qo_len * group;
@@ -53,7 +57,7 @@ __device__ __forceinline__ void prefill_tile(const Half* __restrict__ q_base, Ha
   // per-lane query rows (one per 16-row block)
   int qtok[QBLK];
   bool qok[QBLK];
-  bf16x8_t qf[QBLK][4];
+  bf16x8_t qf[QBLK][KS];
   long o_off[QBLK];
 #pragma unroll
   for (int qb = 0; qb < QBLK; ++qb) {
@@ -64,7 +68,7 @@ __device__ __forceinline__ void prefill_tile(const Half* __restrict__ q_base, Ha
     const long off = (long)qtok[qb] * q_stride_n + (long)(rc % group) * D;
     o_off[qb] = off;
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+    for (int s = 0; s < KS; ++s)
       qf[qb][s] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(q_base + off + s * 32 + g * 8));
   }
   // wave-uniform bound on the KV positions this wave can attend to
@@ -75,50 +79,61 @@ __device__ __forceinline__ void prefill_tile(const Half* __restrict__ q_base, Ha
   const int cta_kv_end_raw = (tile_end - 1) / group + causal_off + 1;
   const int cta_kv_end = cta_kv_end_raw < kv_len ? cta_kv_end_raw : kv_len;
 
-  f32x4 acc_o[QBLK][8];
+  f32x4 acc_o[QBLK][DB];
   float m_run[QBLK], l_run[QBLK];
 #pragma unroll
   for (int qb = 0; qb < QBLK; ++qb) {
     m_run[qb] = -INFINITY;
     l_run[qb] = 0.f;
 #pragma unroll
-    for (int d = 0; d < 8; ++d) acc_o[qb][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int d = 0; d < DB; ++d) acc_o[qb][d] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
   // staging roles
-  const int k_row[4] = {(int)(threadIdx.x >> 4), (int)(threadIdx.x >> 4) + 16, (int)(threadIdx.x >> 4) + 32,
-                        (int)(threadIdx.x >> 4) + 48};
-  const int k_slot = threadIdx.x & 15;
-  const int v_tq = threadIdx.x >> 4, v_dc = threadIdx.x & 15;
-  u32x4 kreg[4], vreg[4];
+  u32x4 kreg[KPT], vreg[VPT][4];
   auto load_tile = [&](int kv0) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      int t = kv0 + k_row[j];
+    for (int j = 0; j < KPT; ++j) {
+      const int cid = threadIdx.x + j * 256, row = cid / KCH, slot = cid % KCH;
+      int t = kv0 + row;
       t = t < kv_len ? t : kv_len - 1;
-      kreg[j] = *reinterpret_cast<const u32x4*>(kbuf + addr.row(t) + addr.k_off + k_slot * 8);
-      int tv = kv0 + v_tq * 4 + j;
-      tv = tv < kv_len ? tv : kv_len - 1;
-      vreg[j] = *reinterpret_cast<const u32x4*>(vbuf + addr.row(tv) + addr.v_off + v_dc * 8);
+      kreg[j] = *reinterpret_cast<const u32x4*>(kbuf + addr.row(t) + addr.k_off + slot * 8);
+    }
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+      const int uid = threadIdx.x + j * 256, v_tq = uid / KCH, v_dc = uid % KCH;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int tv = kv0 + v_tq * 4 + i;
+        tv = tv < kv_len ? tv : kv_len - 1;
+        vreg[j][i] = *reinterpret_cast<const u32x4*>(vbuf + addr.row(tv) + addr.v_off + v_dc * 8);
+      }
     }
   };
   auto store_tile = [&]() {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) ks[k_row[j] * 16 + (k_slot ^ (k_row[j] & 15))] = kreg[j];
+    for (int j = 0; j < KPT; ++j) {
+      const int cid = threadIdx.x + j * 256, row = cid / KCH, slot = cid % KCH;
+      ks[row * KCH + (slot ^ (row & 15))] = kreg[j];
+    }
     // 4 tokens x 8 dims -> 8 rows of V^T, 4 tokens each
-    const uint32_t w[4][4] = {{vreg[0].x, vreg[0].y, vreg[0].z, vreg[0].w},
-                              {vreg[1].x, vreg[1].y, vreg[1].z, vreg[1].w},
-                              {vreg[2].x, vreg[2].y, vreg[2].z, vreg[2].w},
-                              {vreg[3].x, vreg[3].y, vreg[3].z, vreg[3].w}};
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {  // dims 2c, 2c+1
-      u32x2 lo, hi;
-      lo.x = (w[0][c] & 0xFFFFu) | (w[1][c] << 16);
-      lo.y = (w[2][c] & 0xFFFFu) | (w[3][c] << 16);
-      hi.x = (w[0][c] >> 16) | (w[1][c] & 0xFFFF0000u);
-      hi.y = (w[2][c] >> 16) | (w[3][c] & 0xFFFF0000u);
-      *reinterpret_cast<u32x2*>(vt + (v_dc * 8 + 2 * c) * VT_PITCH + v_tq * 4) = lo;
-      *reinterpret_cast<u32x2*>(vt + (v_dc * 8 + 2 * c + 1) * VT_PITCH + v_tq * 4) = hi;
+    for (int j = 0; j < VPT; ++j) {
+      const int uid = threadIdx.x + j * 256, v_tq = uid / KCH, v_dc = uid % KCH;
+      const uint32_t w[4][4] = {{vreg[j][0].x, vreg[j][0].y, vreg[j][0].z, vreg[j][0].w},
+                                {vreg[j][1].x, vreg[j][1].y, vreg[j][1].z, vreg[j][1].w},
+                                {vreg[j][2].x, vreg[j][2].y, vreg[j][2].z, vreg[j][2].w},
+                                {vreg[j][3].x, vreg[j][3].y, vreg[j][3].z, vreg[j][3].w}};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {  // dims 2c, 2c+1
+        u32x2 lo, hi;
+        lo.x = (w[0][c] & 0xFFFFu) | (w[1][c] << 16);
+        lo.y = (w[2][c] & 0xFFFFu) | (w[3][c] << 16);
+        hi.x = (w[0][c] >> 16) | (w[1][c] & 0xFFFF0000u);
+        hi.y = (w[2][c] >> 16) | (w[3][c] & 0xFFFF0000u);
+        *reinterpret_cast<u32x2*>(vt + (v_dc * 8 + 2 * c) * VT_PITCH + v_tq * 4) = lo;
+        *reinterpret_cast<u32x2*>(vt + (v_dc * 8 + 2 * c + 1) * VT_PITCH + v_tq * 4) = hi;
+      }
     }
   };
 
@@ -140,8 +155,8 @@ __device__ __forceinline__ void prefill_tile(const Half* __restrict__ q_base, Ha
     for (int tb = 0; tb < 4; ++tb) {
       const int row = tb * 16 + l15;
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const bf16x8_t kf = __builtin_bit_cast(bf16x8_t, ks[row * 16 + ((s * 4 + g) ^ (row & 15))]);
+      for (int s = 0; s < KS; ++s) {
+        const bf16x8_t kf = __builtin_bit_cast(bf16x8_t, ks[row * KCH + ((s * 4 + g) ^ (row & 15))]);
 #pragma unroll
         for (int qb = 0; qb < QBLK; ++qb)
           sacc[qb][tb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qb][s], sacc[qb][tb], 0, 0, 0);
@@ -180,7 +195,7 @@ __device__ __forceinline__ void prefill_tile(const Half* __restrict__ q_base, Ha
         }
       l_run[qb] = l_run[qb] * alpha + ps;  // lane-partial; summed over g at the end
 #pragma unroll
-      for (int d = 0; d < 8; ++d) acc_o[qb][d] *= alpha;
+      for (int d = 0; d < DB; ++d) acc_o[qb][d] *= alpha;
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
         u32x4 pk4;
@@ -193,7 +208,7 @@ __device__ __forceinline__ void prefill_tile(const Half* __restrict__ q_base, Ha
     }
     // ---- O^T += V^T . P^T ----
 #pragma unroll
-    for (int db = 0; db < 8; ++db) {
+    for (int db = 0; db < DB; ++db) {
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
         const Half* vrow = vt + (db * 16 + l15) * VT_PITCH + kb * 32 + g * 4;
@@ -215,7 +230,7 @@ __device__ __forceinline__ void prefill_tile(const Half* __restrict__ q_base, Ha
     if (!qok[qb]) continue;
     const float inv = l > 0.f ? 1.0f / l : 0.f;
 #pragma unroll
-    for (int db = 0; db < 8; ++db) {
+    for (int db = 0; db < DB; ++db) {
       u32x2 o;
       o.x = pack_bf2(acc_o[qb][db][0] * inv, acc_o[qb][db][1] * inv);
       o.y = pack_bf2(acc_o[qb][db][2] * inv, acc_o[qb][db][3] * inv);
@@ -224,15 +239,15 @@ __device__ __forceinline__ void prefill_tile(const Half* __restrict__ q_base, Ha
   }
 }
 
-template <int QBLK>
+template <int QBLK, int D>
 __global__ __launch_bounds__(256) void batch_prefill_paged_kernel(
     const Half* __restrict__ q, Half* __restrict__ out, const Half* __restrict__ kv, long k_off, long v_off,
     const int* __restrict__ page_indices, const int* __restrict__ page_indptr,
     const int* __restrict__ last_page_len, const int* __restrict__ q_indptr,
     const int* __restrict__ request_indices, const int* __restrict__ qo_tile_indices, int num_qo_heads,
     int num_kv_heads, int page_size, long stride_page, float scale_log2, int cta_tile_q) {
-  __shared__ __attribute__((aligned(16))) u32x4 ks[TKV * 16];
-  __shared__ __attribute__((aligned(16))) Half vt[128 * VT_PITCH];
+  __shared__ __attribute__((aligned(16))) u32x4 ks[TKV * D / 8];
+  __shared__ __attribute__((aligned(16))) Half vt[D * VT_PITCH];
   const int tile = blockIdx.x, kvh = blockIdx.y;
   const int req = request_indices[tile];
   const int group = num_qo_heads / num_kv_heads;
@@ -243,10 +258,10 @@ __global__ __launch_bounds__(256) void batch_prefill_paged_kernel(
   const int kv_len = npages > 0 ? (npages - 1) * page_size + last_page_len[req] : 0;
   const int row0 = qo_tile_indices[tile] * cta_tile_q;
   if (row0 >= qo_len * group || kv_len <= 0) return;
-  PagedAddr addr{page_indices, pbase, page_size, stride_page, (long)num_kv_heads * 128, (long)kvh * 128, k_off, v_off};
-  const long q_stride_n = (long)num_qo_heads * 128;
-  const long qo_base = (long)q0 * q_stride_n + (long)kvh * group * 128;
-  prefill_tile<QBLK>(q + qo_base, out + qo_base, kv, kv, addr, qo_len, kv_len, row0, cta_tile_q, group,
+  PagedAddr addr{page_indices, pbase, page_size, stride_page, (long)num_kv_heads * D, (long)kvh * D, k_off, v_off};
+  const long q_stride_n = (long)num_qo_heads * D;
+  const long qo_base = (long)q0 * q_stride_n + (long)kvh * group * D;
+  prefill_tile<QBLK, D>(q + qo_base, out + qo_base, kv, kv, addr, qo_len, kv_len, row0, cta_tile_q, group,
                      q_stride_n, scale_log2, ks, vt);
 }
 
@@ -265,7 +280,7 @@ __global__ __launch_bounds__(256) void single_prefill_kernel(const Half* __restr
   ContigAddr addr{(long)kvh * max_seq_len * 128, 128, 0, 0};
   const long q_stride_n = (long)num_qo_heads * 128;
   const long qo_base = (long)kvh * group * 128;
-  prefill_tile<QBLK>(q + qo_base, out + qo_base, k_cache, v_cache, addr, seq_len, kv_len, row0, cta_tile_q,
+  prefill_tile<QBLK, 128>(q + qo_base, out + qo_base, k_cache, v_cache, addr, seq_len, kv_len, row0, cta_tile_q,
                      group, q_stride_n, scale_log2, ks, vt);
 }
 
@@ -326,12 +341,12 @@ int32_t batch_prefill_paged_cuda_with_cta_tile_q(
   dim3 grid(padded_batch_size, num_kv_heads);
   hipStream_t s = as_stream(stream);
   if (cta == 128)
-    batch_prefill_paged_kernel<2><<<grid, 256, 0, s>>>(q, output, kv_data, k_offset_elems, v_offset_elems,
+    batch_prefill_paged_kernel<2, 128><<<grid, 256, 0, s>>>(q, output, kv_data, k_offset_elems, v_offset_elems,
                                                        page_indices, page_indptr, last_page_len_d, q_indptr,
                                                        request_indices, qo_tile_indices, num_qo_heads,
                                                        num_kv_heads, page_size, stride_page, scale_log2, 128);
   else
-    batch_prefill_paged_kernel<1><<<grid, 256, 0, s>>>(q, output, kv_data, k_offset_elems, v_offset_elems,
+    batch_prefill_paged_kernel<1, 128><<<grid, 256, 0, s>>>(q, output, kv_data, k_offset_elems, v_offset_elems,
                                                        page_indices, page_indptr, last_page_len_d, q_indptr,
                                                        request_indices, qo_tile_indices, num_qo_heads,
                                                        num_kv_heads, page_size, stride_page, scale_log2, (int)cta);
@@ -352,6 +367,30 @@ int32_t batch_prefill_paged_cuda(
                                                   kv_chunk_size_ptr, total_num_rows, num_qo_heads, num_kv_heads,
                                                   head_dim, page_size, seq_len, batch_size, padded_batch_size,
                                                   stride_page, sm_scale, 0, stream);
+}
+
+// HEAD_DIM = 256 instantiation for the Qwen3.5 full-attention layers (ffi.rs:1309-1334): tile 64 / 16 only
+// (FA2DetermineCtaTileQ never picks 128 at head_dim 256).
+int32_t batch_prefill_paged_cuda_hd256(
+    const Half* q, Half* output, const Half* kv_data, int64_t k_offset_elems, int64_t v_offset_elems,
+    const int32_t* page_indices, const int32_t* page_indptr, const int32_t* last_page_len_d,
+    const int32_t* q_indptr, const int32_t* request_indices, const int32_t* qo_tile_indices,
+    const int32_t* kv_tile_indices, const int32_t* kv_chunk_size_ptr, const uint32_t* total_num_rows,
+    int32_t num_qo_heads, int32_t num_kv_heads, int32_t head_dim, int32_t page_size, int32_t seq_len,
+    int32_t batch_size, int32_t padded_batch_size, int64_t stride_page, float sm_scale,
+    pegainfer_stream_t stream) {
+  (void)kv_tile_indices; (void)kv_chunk_size_ptr; (void)total_num_rows; (void)batch_size;
+  if (head_dim != 256 || num_kv_heads <= 0 || num_qo_heads % num_kv_heads != 0)
+    return (int32_t)hipErrorInvalidValue;
+  const int group = num_qo_heads / num_kv_heads;
+  const uint32_t cta = fa2_cta_tile_q((int64_t)seq_len * group, head_dim);
+  if (padded_batch_size <= 0) return 0;
+  dim3 grid(padded_batch_size, num_kv_heads);
+  batch_prefill_paged_kernel<1, 256><<<grid, 256, 0, as_stream(stream)>>>(
+      q, output, kv_data, k_offset_elems, v_offset_elems, page_indices, page_indptr, last_page_len_d, q_indptr,
+      request_indices, qo_tile_indices, num_qo_heads, num_kv_heads, page_size, stride_page,
+      sm_scale * 1.4426950408889634f, (int)cta);
+  return (int32_t)hipGetLastError();
 }
 
 int32_t single_prefill_cuda(const Half* q, Half* output, const Half* k_cache, const Half* v_cache,

@@ -574,8 +574,11 @@ struct Model {
     return 0;
   }
 
+  // n_decode_tail > 0 = unified_step (unified_forward.rs:78-198): the last n_decode_tail requests contribute ONE
+  // token each and attend through the decode kernel; everything else (GEMMs, norms, RoPE, KV append, MLP) is
+  // shared by all token columns.
   int prefill(int n, const int32_t* ids, const int32_t* lens, const uint32_t* tokens, int32_t* out_tokens,
-              void* out_logits_host) {
+              void* out_logits_host, int n_decode_tail = 0) {
     if (!finalized) { set_error("model not finalized"); return -1; }
     if (n <= 0) { set_error("empty prefill"); return -1; }
     std::vector<KvState*> st(n);
@@ -593,11 +596,16 @@ struct Model {
       if (!st[i]->ensure_capacity(&pool, starts[i] + lens[i], layout.page_size)) { set_error("KvState: out of pages"); return -2; }
       st[i]->seq_len += lens[i];
     }
+    const int n_pf = n - n_decode_tail;
+    if (n_decode_tail < 0 || n_pf < 1) { set_error("unified step needs >= 1 prefill request"); return -1; }
+    for (int i = n_pf; i < n; ++i)
+      if (lens[i] != 1) { set_error("decode-tail requests must contribute exactly one token"); return -1; }
     if (ensure_prefill_ws(T, n)) return -1;
     // ---- plan (PrefillPagedPlan::new_batch_with_cta_tile_q, ops/attention.rs:208-302; tile 64 = config.rs:5) ----
     const int group = Hq / Hkv;
-    const int cta = batch_prefill_cta_tile_q_with_override((int)T, Hq, Hkv, D, 64);
-    std::vector<int32_t> pages, indptr{0}, lpl, kvc, bidx, pos, qind{0}, rq, qt, kt;
+    const int P = (int)T - n_decode_tail;  // prefill token columns
+    const int cta = batch_prefill_cta_tile_q_with_override(P, Hq, Hkv, D, 64);
+    std::vector<int32_t> pages, indptr{0}, lpl, kvc, bidx, pos, qind{0}, rq, qt, kt, dri;
     for (int i = 0; i < n; ++i) {
       pages.insert(pages.end(), st[i]->pages.begin(), st[i]->pages.end());
       indptr.push_back((int32_t)pages.size());
@@ -605,17 +613,22 @@ struct Model {
       kvc.push_back(starts[i] + lens[i]);
       for (int t = 0; t < lens[i]; ++t) { bidx.push_back(i); pos.push_back(starts[i] + t); }
       qind.push_back(qind.back() + lens[i]);
+      if (i >= n_pf) { dri.push_back(i - n_pf); continue; }  // decode tail: no prefill tiles
       const int tiles = (lens[i] * group + cta - 1) / cta;
       for (int t = 0; t < tiles; ++t) { rq.push_back(i); qt.push_back(t); kt.push_back(0); }
     }
+    if (dri.empty()) dri.push_back(0);
     const int num_tiles = (int)rq.size();
     std::vector<std::pair<const void*, size_t>> parts = {
         {tokens, T * 4}, {pages.data(), pages.size() * 4}, {indptr.data(), indptr.size() * 4},
         {lpl.data(), lpl.size() * 4}, {bidx.data(), bidx.size() * 4}, {pos.data(), pos.size() * 4},
         {qind.data(), qind.size() * 4}, {rq.data(), rq.size() * 4}, {qt.data(), qt.size() * 4},
         {kt.data(), kt.size() * 4}, {kvc.data(), kvc.size() * 4}};
-    uint32_t total_rows = (uint32_t)T;
+    uint32_t total_rows = (uint32_t)P;
     parts.push_back({&total_rows, 4});
+    parts.push_back({dri.data(), dri.size() * 4});                      // [12] decode request_indices 0..n_dec
+    std::vector<int32_t> dzero(dri.size(), 0);
+    parts.push_back({dzero.data(), dzero.size() * 4});                  // [13] decode kv_tile_indices
     std::vector<size_t> offs;
     size_t off = 0;
     for (auto& p : parts) { offs.push_back(off); off = (off + p.second + 63) & ~size_t(63); }
@@ -645,7 +658,7 @@ struct Model {
       G(ly.qkv, pf_normed, pf_q, q_dim, H);
       G(ly.qkv + (size_t)q_dim * H, pf_normed, pf_k, kv_dim, H);
       G(ly.qkv + (size_t)(q_dim + kv_dim) * H, pf_normed, pf_v, kv_dim, H);
-      if (n == 1)
+      if (n == 1 && n_decode_tail == 0)
         prefill_qk_norm_rope_only_cuda(pf_q, pf_k, ly.q_norm, ly.k_norm, cos, sin, Hq, Hkv, D, Ti, starts[0], eps, S());
       else
         qk_norm_rope_batched_decode_cuda(pf_q, pf_k, ly.q_norm, ly.k_norm, cos, sin, D32(5), Hq, Hkv, D, Ti, eps, S());
@@ -655,8 +668,15 @@ struct Model {
       rc = batch_prefill_paged_cuda_with_cta_tile_q(
           pf_q, pf_attn, kv_buffer, layout.k_offset(li), layout.v_offset(li), D32(1), D32(2), D32(3), D32(6), D32(7),
           D32(8), D32(9), D32(10), reinterpret_cast<uint32_t*>(pf_meta_dev + offs[11]), Hq, Hkv, D, layout.page_size,
-          Ti, n, num_tiles, layout.page_stride, sm, cta, S());
+          P, n_pf, num_tiles, layout.page_stride, sm, cta, S());
       if (rc) { set_error("batch_prefill_paged_cuda failed"); return -1; }
+      if (n_decode_tail > 0) {  // trailing decode columns via pointer offsets (unified_forward.rs:392-396,495-496)
+        rc = paged_attention_decode_cuda(pf_q + (size_t)P * q_dim, pf_attn + (size_t)P * q_dim, kv_buffer,
+                                         layout.k_offset(li), layout.v_offset(li), D32(1), D32(2) + n_pf,
+                                         D32(3) + n_pf, D32(12), D32(13), D32(10) + n_pf, Hq, Hkv, D,
+                                         layout.page_size, n_decode_tail, layout.page_stride, sm, S());
+        if (rc) { set_error("paged_attention_decode_cuda (unified) failed"); return -1; }
+      }
       G(ly.o, pf_attn, pf_o, H, q_dim);
       if (all_reduce_hidden(pf_o, (size_t)Ti * H)) return -1;   // prefill.rs:154
       fused_add_rms_norm_batched_cuda(hid, pf_o, ly.ln2, pf_normed, H, Ti, eps, S());
@@ -800,6 +820,11 @@ int32_t pegainfer_qwen3_available_pages(pegainfer_qwen3_t m) { return M(m)->pool
 int32_t pegainfer_qwen3_prefill(pegainfer_qwen3_t m, int32_t n, const int32_t* ids, const int32_t* lens,
                                 const uint32_t* tokens, int32_t* out_tokens, void* out_logits_host) {
   return M(m)->prefill(n, ids, lens, tokens, out_tokens, out_logits_host);
+}
+int32_t pegainfer_qwen3_unified_step(pegainfer_qwen3_t m, int32_t n_prefill, int32_t n_decode, const int32_t* ids,
+                                     const int32_t* lens, const uint32_t* tokens, int32_t* out_tokens,
+                                     void* out_logits_host) {
+  return M(m)->prefill(n_prefill + n_decode, ids, lens, tokens, out_tokens, out_logits_host, n_decode);
 }
 int32_t pegainfer_qwen3_decode(pegainfer_qwen3_t m, int32_t n, const int32_t* ids, const uint32_t* token_ids,
                                int32_t* out_tokens, void* out_logits_host) {

@@ -110,6 +110,20 @@ class Qwen3Engine:
                                                    out.ctypes.data, lg.ctypes.data if return_logits else None), "prefill")
         return (out, lg) if return_logits else out
 
+    def unified_step(self, prefill_ids, prompts, decode_ids, decode_tokens, return_logits=False):
+        """Qwen3Model::unified_step (unified_forward.rs:78-198): prompts + active decodes in one forward."""
+        ids = _i32(list(prefill_ids) + list(decode_ids))
+        lens = _i32([len(p) for p in prompts] + [1] * len(decode_ids))
+        toks = np.ascontiguousarray(np.concatenate([np.asarray(p, dtype=np.uint32) for p in prompts] +
+                                                   [np.asarray(decode_tokens, dtype=np.uint32)]))
+        out = np.zeros(len(ids), dtype=np.int32)
+        lg = np.zeros((len(ids), self.vocab), dtype=np.uint16) if return_logits else None
+        self._chk(self.lib.pegainfer_qwen3_unified_step(self.h, len(prefill_ids), len(decode_ids), ids.ctypes.data,
+                                                        lens.ctypes.data, toks.ctypes.data, out.ctypes.data,
+                                                        lg.ctypes.data if return_logits else None), "unified_step")
+        np_ = len(prefill_ids)
+        return ((out[:np_], out[np_:]), (lg[:np_], lg[np_:])) if return_logits else (out[:np_], out[np_:])
+
     def decode(self, request_ids, token_ids, return_logits=False):
         ids = _i32(request_ids)
         toks = np.ascontiguousarray(token_ids, dtype=np.uint32)

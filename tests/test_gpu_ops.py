@@ -244,7 +244,7 @@ def test_gemv_batch_invariance_and_row_slices(P):
 
 
 # ------------------------------------------------------------------ paged KV + attention
-def make_paged(rng, bs, lens, Hkv=8, D=128, layers=2, ps=16, extra_pages=3):
+def make_paged(rng, bs, lens, Hkv=8, D=128, layers=2, ps=16, extra_pages=3):  # noqa: E501
     lay = O.PagedKvLayout(layers, Hkv, D, ps)
     need = [-(-n // ps) for n in lens]
     total = sum(need) + extra_pages

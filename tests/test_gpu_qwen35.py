@@ -1,0 +1,167 @@
+"""GPU parity of the Qwen3.5-4B hybrid extras against the oracle: causal conv1d (+ state),
+gated-delta-rule decode (+ fp32 state), HD256 prep / partial RoPE / gate, HD256 paged decode and prefill
+attention.  Shapes from docs/models/qwen35/optimization.md:56-76: 16 q / 4 kv heads x 256, rotary 64,
+linear attention 16 k-heads x 128, 32 v-heads x 128, conv k=4 over 8192 channels."""
+import numpy as np
+import pytest
+
+from conftest import bf16_ulp_diff, from_dev, to_dev
+from oracle import ops as O
+from oracle.bf16 import bf16_bits, bf16_round
+
+pytestmark = pytest.mark.gpu
+
+
+def rnd(rng, *shape, scale=1.0):
+    return bf16_round((rng.standard_normal(shape) * scale).astype(np.float32))
+
+
+def S():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+@pytest.mark.parametrize("T,C,K", [(1, 8192, 4), (37, 8192, 4), (2, 100, 4), (5, 64, 2)])
+def test_conv1d_prefill_and_state(built_libs, T, C, K):
+    from pegainfer_amd import ffi
+    rng = np.random.default_rng(T + C)
+    x, w, st = rnd(rng, T, C), rnd(rng, C, K, scale=0.5), rnd(rng, C, K - 1)
+    xd, wd, sd = to_dev(x), to_dev(w), to_dev(st)
+    out = to_dev(np.zeros((T, C), np.float32))
+    ffi.lib().conv1d_prefill_cuda(xd.data_ptr(), wd.data_ptr(), sd.data_ptr(), out.data_ptr(), C, T, K, S())
+    eo, es = O.conv1d_prefill(x, w, st)
+    assert bf16_ulp_diff(from_dev(out), eo) <= 1
+    assert np.array_equal(bf16_bits(from_dev(sd)), bf16_bits(es))          # state = raw inputs: exact
+    # decode continues from the state (recurrent.rs:49-79): one more token
+    x2 = rnd(rng, 1, C)
+    x2d = to_dev(x2)
+    ffi.lib().conv1d_prefill_cuda(x2d.data_ptr(), wd.data_ptr(), sd.data_ptr(), out.data_ptr(), C, 1, K, S())
+    eo2, es2 = O.conv1d_prefill(x2, w, es)
+    assert bf16_ulp_diff(from_dev(out)[:1], eo2) <= 1 and np.array_equal(bf16_bits(from_dev(sd)), bf16_bits(es2))
+
+
+def test_gated_delta_rule_decode(built_libs):
+    import torch
+    from pegainfer_amd import ffi
+    rng = np.random.default_rng(7)
+    kh, vh, kd, vd = 16, 32, 128, 128
+    qkv = rnd(rng, 2 * kh * kd + vh * vd)
+    b, a, dtb = rnd(rng, vh), rnd(rng, vh), rnd(rng, vh, scale=0.5)
+    alog = (rng.standard_normal(vh) * 0.5).astype(np.float32)
+    state = (rng.standard_normal((vh, kd, vd)) * 0.1).astype(np.float32)
+    sd = torch.from_numpy(state.copy()).cuda()
+    out = to_dev(np.zeros(vh * vd, np.float32))
+    ref_state = state
+    bd, ad, dd, ald = to_dev(b), to_dev(a), to_dev(dtb), torch.from_numpy(alog).cuda()   # keep alive
+    for step in range(3):                                   # the state carries across steps
+        qd = to_dev(qkv)
+        ffi.lib().gated_delta_rule_decode_cuda(qd.data_ptr(), bd.data_ptr(), ad.data_ptr(), dd.data_ptr(),
+                                               ald.data_ptr(), sd.data_ptr(), out.data_ptr(), kh, vh, kd, vd, S())
+        eo, ref_state = O.gated_delta_rule_decode(qkv, b, a, dtb, alog, ref_state, kh, vh, kd, vd)
+        got = from_dev(out)
+        assert np.abs(got - eo).max() <= 2.0 ** -7 * max(1.0, np.abs(eo).max())    # bf16 output of an fp32 recurrence
+        assert np.allclose(sd.cpu().numpy(), ref_state, rtol=2e-5, atol=2e-6)
+        qkv = rnd(rng, 2 * kh * kd + vh * vd)
+
+
+@pytest.mark.parametrize("T,prefill", [(1, False), (5, False), (40, True)])
+def test_hd256_prep_and_gate(built_libs, T, prefill):
+    import torch
+    from pegainfer_amd import ffi
+    rng = np.random.default_rng(T)
+    Hq, Hkv, rot, max_seq = 16, 4, 64, 128
+    q_full, k, v = rnd(rng, T, Hq * 512, scale=2), rnd(rng, T, Hkv * 256, scale=2), rnd(rng, T, Hkv * 256)
+    qw, kw = rnd(rng, 256, scale=0.2), rnd(rng, 256, scale=0.2)
+    half = rot // 2
+    inv = (1.0 / np.power(np.float32(1e7), np.arange(half, dtype=np.float32) * 2 / rot)).astype(np.float32)
+    fr = np.arange(256, dtype=np.float32)[:, None] * inv[None, :]
+    cos = bf16_round(np.concatenate([np.cos(fr), np.cos(fr)], 1).astype(np.float32))     # [pos, rotary_dim]
+    sin = bf16_round(np.concatenate([np.sin(fr), np.sin(fr)], 1).astype(np.float32))
+    q_src = q_full.reshape(T, Hq, 2, 256)[:, :, 0, :]
+    L = ffi.lib()
+    q_out = to_dev(np.zeros((T, Hq * 256), np.float32))
+    qd, kd_, vd_ = to_dev(q_full), to_dev(k), to_dev(v)
+    args = (to_dev(qw), to_dev(kw), to_dev(cos), to_dev(sin))
+    if prefill:
+        start = 17
+        pos = np.arange(start, start + T)
+        kc = to_dev(np.zeros((Hkv, max_seq, 256), np.float32)); vc = to_dev(np.zeros((Hkv, max_seq, 256), np.float32))
+        sp = torch.tensor([start], dtype=torch.int32, device="cuda")
+        L.prefill_attention_hd256_prep_cuda(qd.data_ptr(), kd_.data_ptr(), vd_.data_ptr(), args[0].data_ptr(),
+                                            args[1].data_ptr(), args[2].data_ptr(), args[3].data_ptr(),
+                                            q_out.data_ptr(), kc.data_ptr(), vc.data_ptr(), Hq, Hkv, T,
+                                            sp.data_ptr(), rot, 1e-6, max_seq, S())
+        ek = O.hd256_norm_partial_rope(k.reshape(T, Hkv, 256), kw, cos, sin, pos, rot, 1e-6)
+        gk = from_dev(kc)[:, start:start + T].transpose(1, 0, 2)
+        assert bf16_ulp_diff(gk, ek) <= 1
+        assert np.array_equal(from_dev(vc)[:, start:start + T].transpose(1, 0, 2), v.reshape(T, Hkv, 256))
+        assert np.all(from_dev(kc)[:, :start] == 0) and np.all(from_dev(kc)[:, start + T:] == 0)
+    else:
+        pos = rng.integers(0, 200, T)
+        L.qk_norm_partial_rope_batched_decode_hd256_cuda(qd.data_ptr(), kd_.data_ptr(), args[0].data_ptr(),
+                                                         args[1].data_ptr(), args[2].data_ptr(), args[3].data_ptr(),
+                                                         (posd := torch.tensor(pos, dtype=torch.int32, device="cuda")).data_ptr(),
+                                                         q_out.data_ptr(), Hq, Hkv, T, rot, 1e-6, S())
+        ek = O.hd256_norm_partial_rope(k.reshape(T, Hkv, 256), kw, cos, sin, pos, rot, 1e-6)
+        assert bf16_ulp_diff(from_dev(kd_).reshape(T, Hkv, 256), ek) <= 1
+    eq = O.hd256_norm_partial_rope(q_src, qw, cos, sin, pos, rot, 1e-6)
+    assert bf16_ulp_diff(from_dev(q_out).reshape(T, Hq, 256), eq) <= 1
+    assert np.array_equal(from_dev(qd), q_full)                                   # q_full itself is read-only
+    attn = rnd(rng, T, Hq * 256)
+    ad = to_dev(attn)
+    L.attention_gate_batch_hd256_cuda(qd.data_ptr(), ad.data_ptr(), Hq, T, S())
+    assert bf16_ulp_diff(from_dev(ad), O.attention_gate_hd256(q_full, attn, Hq)) <= 1
+
+
+@pytest.mark.parametrize("lens", [[1], [300, 17], [1024]])
+def test_paged_decode_attention_hd256(built_libs, lens):
+    import torch
+    from pegainfer_amd import ffi
+    from test_gpu_ops import attn_tol, make_paged
+    rng = np.random.default_rng(sum(lens))
+    bs, Hq, Hkv, D = len(lens), 16, 4, 256
+    lay, kv, pages, indptr, last = make_paged(rng, bs, lens, Hkv=Hkv, D=D)
+    q = rnd(rng, bs, Hq * D)
+    i32 = lambda a: torch.tensor(np.asarray(a), dtype=torch.int32, device="cuda")
+    keep = [to_dev(q), to_dev(kv), i32(pages), i32(indptr), i32(last), i32(np.arange(bs)), i32(np.zeros(bs)), i32(lens)]
+    out = torch.zeros((bs, Hq * D), dtype=torch.bfloat16, device="cuda")
+    sm = 1.0 / np.sqrt(256.0)
+    rc = ffi.lib().paged_attention_decode_cuda_hd256(keep[0].data_ptr(), out.data_ptr(), keep[1].data_ptr(),
+                                                     lay.layer_stride, lay.layer_stride + lay.kv_block_len,
+                                                     keep[2].data_ptr(), keep[3].data_ptr(), keep[4].data_ptr(),
+                                                     keep[5].data_ptr(), keep[6].data_ptr(), keep[7].data_ptr(), Hq, Hkv,
+                                                     D, 16, bs, lay.page_stride, sm, S())
+    assert rc == 0
+    ref = O.paged_attention_decode(q, kv, lay, 1, pages, indptr, last, Hq, sm)
+    assert np.abs(from_dev(out) - ref).max() <= attn_tol(ref)
+
+
+@pytest.mark.parametrize("seq_lens,starts", [([5], [0]), ([70, 3], [0, 20]), ([130], [0])])
+def test_batch_prefill_paged_hd256(built_libs, seq_lens, starts):
+    import torch
+    from pegainfer_amd import ffi
+    from test_gpu_ops import attn_tol, make_paged
+    rng = np.random.default_rng(sum(seq_lens))
+    Hq, Hkv, D = 16, 4, 256
+    lens = [s + n for s, n in zip(starts, seq_lens)]
+    lay, kv, pages, indptr, last = make_paged(rng, len(lens), lens, Hkv=Hkv, D=D)
+    T = sum(seq_lens)
+    q = rnd(rng, T, Hq * D)
+    page_lists = [pages[indptr[i]:indptr[i + 1]].tolist() for i in range(len(lens))]
+    pl = O.prefill_paged_plan(page_lists, last.tolist(), starts, seq_lens, Hq, Hkv, D, 0)
+    i32 = lambda a: torch.tensor(np.asarray(a), dtype=torch.int32, device="cuda")
+    keep = {k: i32(pl[k]) for k in ("page_indices", "page_indptr", "last_page_len", "q_indptr", "request_indices",
+                                    "qo_tile_indices", "kv_tile_indices", "kv_chunk_size")}
+    tot = i32([T])
+    qd, kvd = to_dev(q), to_dev(kv)
+    out = torch.zeros((T, Hq * D), dtype=torch.bfloat16, device="cuda")
+    sm = 1.0 / np.sqrt(256.0)
+    rc = ffi.lib().batch_prefill_paged_cuda_hd256(
+        qd.data_ptr(), out.data_ptr(), kvd.data_ptr(), lay.layer_stride, lay.layer_stride + lay.kv_block_len,
+        keep["page_indices"].data_ptr(), keep["page_indptr"].data_ptr(), keep["last_page_len"].data_ptr(),
+        keep["q_indptr"].data_ptr(), keep["request_indices"].data_ptr(), keep["qo_tile_indices"].data_ptr(),
+        keep["kv_tile_indices"].data_ptr(), keep["kv_chunk_size"].data_ptr(), tot.data_ptr(), Hq, Hkv, D, 16, T,
+        len(lens), pl["num_tiles"], lay.page_stride, sm, S())
+    assert rc == 0
+    ref = O.batch_prefill_paged(q, kv, lay, 1, pages, indptr, last, pl["q_indptr"], Hq, sm)
+    assert np.abs(from_dev(out) - ref).max() <= 2 * attn_tol(ref)
