@@ -215,14 +215,31 @@ def main():
                           "frac_of_8TBps": round(step_bytes / (np.median(dev_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
     }
     if rank == 0:
-        # ---- roofline of the dominant kernel: the gate_up weight-streaming GEMV (45 % of the step's bytes) ----
+        # ---- roofline of the dominant kernel: the gate_up weight-streaming GEMV (45 % of the step's bytes).
+        # decode_mode 1 launches it with the add+RMSNorm prologue and SwiGLU epilogue fused in; the timing loop
+        # launches exactly that kernel over the 36 layers' weights, hipEvents on the model stream. ----
         H, I = cfg["hidden_size"], cfg["intermediate_size"]
-        gate_up_bytes = 2 * I * H * 2 + args.batch * (H * 2 + 2 * I * 2)   # weights once + x in + y out
-        ms = eng.bench_gemv(2, 360, args.batch)
+        fused = args.decode_mode == 1 and args.batch <= 16
+        # weights once + (hidden, residual, norm weight in; hidden out by one workgroup; act out)
+        gate_up_bytes = 2 * I * H * 2 + args.batch * (2 * H * 2 + H * 2 + I * 2) + H * 2
+        ms = eng.bench_gemv(5 if fused else 2, 360, args.batch)
         achieved = gate_up_bytes / (ms * 1e-3) / 1e9
-        out["roofline"] = {"bound": "hbm", "kernel": "gemv_kernel (gate_up call site, M=%d K=%d N=%d)" % (2 * I, H, args.batch),
+        traffic, traffic_src = None, None
+        prof = os.path.join(ROOT, "profiles", "r1_fused_pmc_FETCH_SIZE.csv")
+        if fused and args.batch == 1 and args.model == "qwen3-4b" and os.path.exists(prof):
+            import csv
+            fetch = {r["kernel"]: float(r["avg_value"]) for r in csv.DictReader(open(prof)) if r["counter"] == "FETCH_SIZE"}
+            wprof = os.path.join(ROOT, "profiles", "r1_fused_pmc_WRITE_SIZE.csv")
+            wr = {r["kernel"]: float(r["avg_value"]) for r in csv.DictReader(open(wprof))} if os.path.exists(wprof) else {}
+            kname = "gemv_fused_kernel<1, 1, 1, 1>"
+            if kname in fetch:   # KiB per dispatch; gfx950 FETCH_SIZE reports 1/2 of a wide coalesced stream -> x2
+                traffic = int(2 * fetch[kname] * 1024 + wr.get(kname, 0.0) * 1024)
+                traffic_src = "profiles/r1_fused_pmc_FETCH_SIZE.csv (x2 gfx950 correction) + WRITE_SIZE, rocprofv3 --pmc"
+        out["roofline"] = {"bound": "hbm",
+                           "kernel": ("gemv_fused_kernel<NT=1,RPW=1,KSPLIT=1,EPI=silu> (gate_up, M=%d K=%d N=%d)" if fused
+                                      else "gemv_fused_kernel<NT,RPW=2,KSPLIT=1,EPI=store> (gate_up, M=%d K=%d N=%d)") % (2 * I, H, args.batch),
                            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                            "bytes_per_launch": gate_up_bytes, "avg_launch_us": round(ms * 1e3, 2)}
         per_site = {}
         for which, name, M, K in [(0, "qkv", (cfg["num_attention_heads"] + 2 * cfg["num_key_value_heads"]) * cfg["head_dim"], H),

@@ -87,7 +87,10 @@ int32_t pegainfer_qwen3_sample(pegainfer_qwen3_t m, int32_t column, float temper
 float pegainfer_qwen3_last_step_ms(pegainfer_qwen3_t m);
 int32_t pegainfer_qwen3_last_attention_path(pegainfer_qwen3_t m); /* 0 non-partition, 1 split-KV */
 /* average ms per launch of one GEMM call site over the layers' real weights, hipEvents on the model
- * stream (bench.py roofline).  which: 0 fused qkv, 1 o, 2 gate_up, 3 down, 4 lm_head; bs = token columns */
+ * stream (bench.py roofline).  which: 0 fused qkv, 1 o, 2 gate_up, 3 down, 4 lm_head (plain GEMM call sites);
+ * 5 gate_up with add+RMSNorm prologue and SwiGLU epilogue, 6 qkv with add+RMSNorm prologue, 7 lm_head with
+ * add+RMSNorm prologue (the fused decode step's kernels); +10 = same layer every launch (cache-warm probe);
+ * bs = token columns */
 float pegainfer_qwen3_bench_gemv(pegainfer_qwen3_t m, int32_t which, int32_t iters, int32_t bs);
 int64_t pegainfer_qwen3_weight_bytes(pegainfer_qwen3_t m);
 void* pegainfer_qwen3_stream(pegainfer_qwen3_t m);

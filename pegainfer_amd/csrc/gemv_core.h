@@ -19,21 +19,27 @@
 
 namespace pk {
 
-// x K-tile per token row: 32 KB of LDS for NT <= 8, 64 KB for NT = 16.  KT stays a multiple of 2048
-// (4 waves x 512) so the KSPLIT block->wave deal is identical for every NT.
-template <int NT> struct GemvTile { static constexpr int KT = NT <= 8 ? 16384 / NT : 2048; };
+// x K-tile: chosen on the host (gemv_pick_kt).  Whenever NT*K*2 bytes fit in 152 KB of LDS the whole x block
+// is resident (single tile) and workgroups persist over row groups; otherwise x is streamed in tiles whose
+// width is a multiple of 2048 (4 waves x 512) so the KSPLIT block->wave deal is identical for every NT.
+constexpr int kGemvMaxLds = 152 * 1024;
+inline int gemv_pick_kt(int NT, int K) {
+  if ((long)NT * K * 2 <= kGemvMaxLds) return K;
+  int kt = (64 * 1024 / (NT * 2)) / 2048 * 2048;
+  return kt < 2048 ? 2048 : kt;
+}
 
 enum { kEpiStore = 0, kEpiSilu = 1 };
 
 template <int NT>
-__host__ __device__ inline int gemv_xs_bytes(int K) {
-  const int kt = K < GemvTile<NT>::KT ? K : GemvTile<NT>::KT;
+__host__ __device__ inline int gemv_xs_bytes(int K, int KT) {
+  const int kt = K < KT ? K : KT;
   return (NT * kt * 2 + 15) & ~15;
 }
 template <int NT, int RPW, int KSPLIT, int EPI>
-inline int gemv_lds_bytes(int K) {
+inline int gemv_lds_bytes(int K, int KT) {
   constexpr int NW = EPI == kEpiSilu ? 2 : 1;
-  return gemv_xs_bytes<NT>(K) + ((KSPLIT == 1 ? 0 : 4 * NW * RPW * NT) + kNormWaves) * 4;
+  return gemv_xs_bytes<NT>(K, KT) + ((KSPLIT == 1 ? 0 : 4 * NW * RPW * NT) + 16) * 4;  // + 16 floats: inv_rms per token
 }
 
 struct GemvFusedArgs {
@@ -43,11 +49,12 @@ struct GemvFusedArgs {
   Half* hidden_out;       // written by workgroup 0 only (must not alias X)
   float eps;
   int I;                  // kEpiSilu: W = [gate(I rows); up(I rows)], Y = [T, I]
+  int KT;                 // x tile width (gemv_pick_kt)
 };
 
 template <int NT, int RPW, int KSPLIT, int EPI>
 __global__ __launch_bounds__(256) void gemv_fused_kernel(const GemvFusedArgs a) {
-  constexpr int KT = GemvTile<NT>::KT;
+  const int KT = a.KT;
   constexpr int NW = EPI == kEpiSilu ? 2 : 1;  // weight row sets streamed together
   constexpr int U = 4;                         // K blocks in flight per wave: U*NW*RPW loads of 1 KB
   constexpr int ROWS_PER_GROUP = (KSPLIT == 1 ? 4 : 1) * RPW;
@@ -55,7 +62,7 @@ __global__ __launch_bounds__(256) void gemv_fused_kernel(const GemvFusedArgs a) 
   // GEMV needs 5 KB, not the 32 KB tile capacity, which is what lets 5+ workgroups share a CU.
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   u32x4* xs = reinterpret_cast<u32x4*>(smem_raw);
-  float* part = reinterpret_cast<float*>(smem_raw + gemv_xs_bytes<NT>(a.K));
+  float* part = reinterpret_cast<float*>(smem_raw + gemv_xs_bytes<NT>(a.K, a.KT));
   float* red = part + (KSPLIT == 1 ? 0 : 4 * NW * RPW * NT);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int K = a.K, T = a.T;
@@ -125,13 +132,20 @@ __global__ __launch_bounds__(256) void gemv_fused_kernel(const GemvFusedArgs a) 
   set_rows(g);
   issue(0, kt0, bfirst);  // HBM requests leave before the prologue touches anything
 
-  // ---- prologue: per-token inverse RMS (canonical order), only when a norm weight is given ----
+  // ---- prologue: per-token inverse RMS (canonical one-wave-per-row order), only when a norm weight is given:
+  //      wave w takes tokens t == w (mod 4), results meet in LDS, one barrier ----
   float inv[NT];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    inv[t] = 0.f;
-    if (a.norm_w && t < T)
-      inv[t] = row_inv_rms_vec(a.X + (size_t)t * K, a.residual ? a.residual + (size_t)t * K : nullptr, K, a.eps, red);
+  for (int t = 0; t < NT; ++t) inv[t] = 0.f;
+  if (a.norm_w) {
+    for (int t = wave; t < T; t += 4) {
+      const float v = wave_row_inv_rms(a.X + (size_t)t * K, a.residual ? a.residual + (size_t)t * K : nullptr, K, a.eps);
+      if (lane == 0) red[t] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+      if (t < T) inv[t] = red[t];
   }
   auto stage = [&](int k0, int kt) {
     const int nvec = (kt + 7) >> 3;  // lanes beyond kt never read their slot (consume() zeroes them)
@@ -255,10 +269,10 @@ inline void gemv_launch_one(const GemvFusedArgs& a, hipStream_t s) {
   constexpr int ROWS_PER_GROUP = (KSPLIT == 1 ? 4 : 1) * RPW;
   const int rows = EPI == kEpiSilu ? a.I : a.M;
   const int ngroups = ceil_div(rows, ROWS_PER_GROUP);
-  const int lds = gemv_lds_bytes<NT, RPW, KSPLIT, EPI>(a.K);
+  const int lds = gemv_lds_bytes<NT, RPW, KSPLIT, EPI>(a.K, a.KT);
   auto kern = &gemv_fused_kernel<NT, RPW, KSPLIT, EPI>;
   static const bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024), true);
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
   (void)once;
   static thread_local int cached_lds = -1, cached_cap = 0;
   if (cached_lds != lds) {
@@ -269,7 +283,7 @@ inline void gemv_launch_one(const GemvFusedArgs& a, hipStream_t s) {
     cached_lds = lds;
   }
   int grid = ngroups;
-  if (a.K <= GemvTile<NT>::KT && ngroups > cached_cap) {
+  if (a.K <= a.KT && ngroups > cached_cap) {
     const int rounds = ceil_div(ngroups, cached_cap);
     grid = ceil_div(ngroups, rounds);
   }
@@ -287,12 +301,27 @@ inline void gemv_launch_nt(const GemvFusedArgs& a, hipStream_t s) {
 
 // T <= 16, K % 8 == 0, 16-byte aligned W/X (and residual/norm_w/hidden_out when given)
 template <int EPI>
-inline bool gemv_dispatch(const GemvFusedArgs& a, hipStream_t s) {
-  if (a.T < 1 || a.T > 16 || (a.K & 7) != 0) return false;
-  if (a.T == 1) gemv_launch_nt<1, EPI>(a, s);
-  else if (a.T == 2) gemv_launch_nt<2, EPI>(a, s);
-  else if (a.T <= 4) gemv_launch_nt<4, EPI>(a, s);
-  else if (a.T <= 8) gemv_launch_nt<8, EPI>(a, s);
+inline bool gemv_dispatch(const GemvFusedArgs& a_in, hipStream_t s) {
+  if (a_in.T < 1 || a_in.T > 16 || (a_in.K & 7) != 0) return false;
+  GemvFusedArgs a = a_in;
+  if (a.T > 8 && (long)16 * a.K * 2 > kGemvMaxLds) {
+    // 9..16 tokens but x[16][K] would not be LDS-resident: two resident 8-token passes instead (the second
+    // pass streams the weights out of the 256 MB Infinity Cache); per-token arithmetic is unchanged.
+    GemvFusedArgs lo = a, hi = a;
+    lo.T = 8;
+    hi.T = a.T - 8;
+    hi.X = a.X + (size_t)8 * a.K;
+    if (a.residual) hi.residual = a.residual + (size_t)8 * a.K;
+    if (a.hidden_out) hi.hidden_out = a.hidden_out + (size_t)8 * a.K;
+    hi.Y = a.Y + (size_t)8 * (EPI == kEpiSilu ? a.I : a.M);
+    return gemv_dispatch<EPI>(lo, s) && gemv_dispatch<EPI>(hi, s);
+  }
+  const int nt = a.T == 1 ? 1 : a.T == 2 ? 2 : a.T <= 4 ? 4 : a.T <= 8 ? 8 : 16;
+  a.KT = gemv_pick_kt(nt, a.K);
+  if (nt == 1) gemv_launch_nt<1, EPI>(a, s);
+  else if (nt == 2) gemv_launch_nt<2, EPI>(a, s);
+  else if (nt == 4) gemv_launch_nt<4, EPI>(a, s);
+  else if (nt == 8) gemv_launch_nt<8, EPI>(a, s);
   else gemv_launch_nt<16, EPI>(a, s);
   return true;
 }

@@ -418,7 +418,7 @@ struct Model {
     }
     return 0;
   }
-  bool fused_ok(int bs) const { return decode_mode == 1 && bs <= 16 && (H & 7) == 0 && (I & 7) == 0 && D == 128; }
+  bool fused_ok(int bs) const { return decode_mode == 1 && bs <= 64 && (H & 31) == 0 && (I & 31) == 0 && D == 128; }
 
   int decode_kernels(int bs, bool split, int split_slots) {
     if (fused_ok(bs)) return decode_kernels_fused(bs, split, split_slots);
@@ -720,7 +720,11 @@ struct Model {
         case 1: gemm_graphsafe_cuda(ly.o, attn_out, attn_proj, H, bs, q_dim, S()); break;
         case 2: gemm_graphsafe_cuda(ly.gate_up, normed, gate_up_out, 2 * I, bs, H, S()); break;
         case 3: gemm_graphsafe_cuda(ly.down, mlp_act, mlp_out, H, bs, I, S()); break;
-        default: gemm_graphsafe_cuda(lm_head, normed, logits, V, bs, H, S()); break;
+        case 4: gemm_graphsafe_cuda(lm_head, normed, logits, V, bs, H, S()); break;
+        // the kernels the fused decode step really launches (decode_mode 1):
+        case 5: pegainfer_gemv_fused(ly.gate_up, hidden, mlp_act, 2 * I, bs, H, attn_proj, ly.ln2, hidden2, eps, I, S()); break;
+        case 6: pegainfer_gemv_fused(ly.qkv, hidden, qkv_out, q_dim + 2 * kv_dim, bs, H, mlp_out, ly.ln1, hidden2, eps, 0, S()); break;
+        default: pegainfer_gemv_fused(lm_head, hidden, logits, V, bs, H, mlp_out, final_norm, hidden2, eps, 0, S()); break;
       }
     };
     for (int i = 0; i < 3; ++i) launch(i);

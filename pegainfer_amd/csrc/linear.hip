@@ -18,8 +18,11 @@
 //       4x4 blocks of v_mfma_f32_16x16x32_bf16, register-staged double-buffered LDS with an XOR
 //       slot swizzle, XCD-aware tile order (each XCD's L2 keeps one W panel hot).
 //   naive_gemm_kernel           any shape the fast paths cannot take (K % 8 != 0, unaligned).
+#include <cstdlib>
+
 #include "common.h"
 #include "gemv_core.h"
+#include "gemm_skinny.h"
 #include "pegainfer_kernels_ext.h"
 
 namespace pk {
@@ -139,12 +142,31 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(const Half* __restrict__
   }
 }
 
+// Decode-shaped GEMM routing (T <= 64 columns, weights streamed once), by shape only (measured on MI355X,
+// Qwen3-4B step: dot2 wins up to 4 columns, the matrix-core kernel from 5):
+//   T <= 4            -> dot2 GEMV (gemv_core.h)            [PEGAINFER_GEMV_T1=mfma routes everything to MFMA]
+//   5 <= T <= 64      -> skinny MFMA GEMM (gemm_skinny.h)   when K % 32 == 0
+//   otherwise         -> dot2 GEMV for T <= 16 (K % 8 == 0), else not taken
+// Within each family a column's result does not depend on the batch size (bitwise batch invariance).
+static bool t1_uses_mfma() {
+  static const bool v = [] { const char* e = getenv("PEGAINFER_GEMV_T1"); return e && e[0] == 'm'; }();
+  return v;
+}
+template <int EPI>
+static bool decode_gemm_dispatch(const GemvFusedArgs& a, hipStream_t s) {
+  if ((a.T >= 5 || t1_uses_mfma()) && a.T <= 64 && (a.K & 31) == 0) {
+    if (a.T == 1) { skinny_launch<1, EPI>(a, s); return true; }
+    return skinny_dispatch<EPI>(a, s);
+  }
+  return gemv_dispatch<EPI>(a, s);
+}
+
 static void gemm_dispatch(const Half* W, const Half* X, Half* Y, int M, int T, int K, hipStream_t s) {
   if (M <= 0 || T <= 0 || K <= 0) return;
   const bool fast = (K & 7) == 0 && host_aligned16(W) && host_aligned16(X);
-  if (fast && T <= 16) {
-    GemvFusedArgs a{W, X, Y, M, T, K, nullptr, nullptr, nullptr, 0.f, 0};
-    if (gemv_dispatch<kEpiStore>(a, s)) return;
+  if (fast && T <= 64) {
+    GemvFusedArgs a{W, X, Y, M, T, K, nullptr, nullptr, nullptr, 0.f, 0, 0};
+    if (decode_gemm_dispatch<kEpiStore>(a, s)) return;
   }
   if (fast && (K % BK) == 0 && (M & 3) == 0 && (reinterpret_cast<uintptr_t>(Y) & 7u) == 0) {
     const int m_tiles = ceil_div(M, BM), t_tiles = ceil_div(T, BT);
@@ -183,15 +205,15 @@ pegainfer_status_t pegainfer_gemv_fused(const Half* W, const Half* X, Half* Y, i
                                         const Half* residual, const Half* norm_weight, Half* hidden_out, float eps,
                                         int32_t silu_intermediate, pegainfer_stream_t stream) {
   using namespace pk;
-  if (M <= 0 || T < 1 || T > 16 || K <= 0 || (K & 7) != 0) return (pegainfer_status_t)hipErrorInvalidValue;
+  if (M <= 0 || T < 1 || T > 64 || K <= 0 || (K & 7) != 0) return (pegainfer_status_t)hipErrorInvalidValue;
   if (!host_aligned16(W) || !host_aligned16(X) || (residual && !host_aligned16(residual)) ||
       (norm_weight && !host_aligned16(norm_weight)) || (hidden_out && !host_aligned16(hidden_out)))
     return (pegainfer_status_t)hipErrorInvalidValue;
   if (residual && (!norm_weight || !hidden_out || hidden_out == X)) return (pegainfer_status_t)hipErrorInvalidValue;
   if (silu_intermediate > 0 && M != 2 * silu_intermediate) return (pegainfer_status_t)hipErrorInvalidValue;
-  GemvFusedArgs a{W, X, Y, M, T, K, residual, norm_weight, hidden_out, eps, silu_intermediate};
-  const bool ok = silu_intermediate > 0 ? gemv_dispatch<kEpiSilu>(a, as_stream(stream))
-                                        : gemv_dispatch<kEpiStore>(a, as_stream(stream));
+  GemvFusedArgs a{W, X, Y, M, T, K, residual, norm_weight, hidden_out, eps, silu_intermediate, 0};
+  const bool ok = silu_intermediate > 0 ? decode_gemm_dispatch<kEpiSilu>(a, as_stream(stream))
+                                        : decode_gemm_dispatch<kEpiStore>(a, as_stream(stream));
   return ok ? (pegainfer_status_t)hipGetLastError() : (pegainfer_status_t)hipErrorInvalidValue;
 }
 

@@ -1,6 +1,6 @@
-// RMSNorm family for gfx950.  One 256-thread workgroup (4 waves) per row, 16-byte loads,
-// fp32 sum of squares reduced with DPP/bpermute butterflies, the row re-read from L1/L2 for
-// the scale pass (rows are <= 16 KB).  Rounding points follow the reference exactly:
+// RMSNorm family for gfx950.  One wave64 per row (4 rows per 256-thread workgroup), 16-byte loads,
+// fp32 sum of squares reduced with a DPP/bpermute butterfly (norm_core.h), the row re-read from L1/L2
+// for the scale pass (rows are <= 16 KB); no LDS, no barrier.  Rounding points follow the reference exactly:
 //   rms_norm            out = bf16(f32(x) * inv_rms * f32(w))                (single rounding)
 //   rms_norm_offset     same with (1 + w)                                     (Gemma / Qwen3.5)
 //   fused_add_rms_norm  hidden = bf16(h + r);  out = bf16((h + r)_fp32 * inv_rms * w)
@@ -12,70 +12,91 @@
 
 namespace pk {
 
-template <bool OFFSET, bool VEC>
-__global__ __launch_bounds__(kNormBlock) void rms_norm_kernel(const Half* __restrict__ x,
-                                                              const Half* __restrict__ w,
-                                                              Half* __restrict__ out, int d, float eps) {
+// VEC kernels: one wave per row, 4 rows per 256-thread block.  Scalar fallback (d % 8 != 0): one block per row.
+template <bool OFFSET>
+__global__ __launch_bounds__(kNormBlock) void rms_norm_vec_kernel(const Half* __restrict__ x,
+                                                                  const Half* __restrict__ w,
+                                                                  Half* __restrict__ out, int d, int rows, float eps) {
+  const int row = blockIdx.x * kNormWaves + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const Half* xr = x + (size_t)row * d;
+  Half* orow = out + (size_t)row * d;
+  const float bias = OFFSET ? 1.0f : 0.0f;
+  const float inv = wave_row_inv_rms(xr, nullptr, d, eps);
+  const int nvec = d >> 3;
+  for (int i = lane; i < nvec; i += 64)
+    reinterpret_cast<u32x4*>(orow)[i] = norm_scale8(reinterpret_cast<const u32x4*>(xr)[i], nullptr,
+                                                    reinterpret_cast<const u32x4*>(w)[i], inv, bias, nullptr);
+}
+
+template <bool OFFSET>
+__global__ __launch_bounds__(kNormBlock) void rms_norm_scalar_kernel(const Half* __restrict__ x,
+                                                                     const Half* __restrict__ w,
+                                                                     Half* __restrict__ out, int d, float eps) {
   __shared__ float red[kNormWaves];
   const Half* xr = x + (size_t)blockIdx.x * d;
   Half* orow = out + (size_t)blockIdx.x * d;
   const float bias = OFFSET ? 1.0f : 0.0f;
-  if (VEC) {
-    const float inv = row_inv_rms_vec(xr, nullptr, d, eps, red);
-    const int nvec = d >> 3;
-    for (int i = threadIdx.x; i < nvec; i += kNormBlock)
-      reinterpret_cast<u32x4*>(orow)[i] = norm_scale8(reinterpret_cast<const u32x4*>(xr)[i], nullptr,
-                                                      reinterpret_cast<const u32x4*>(w)[i], inv, bias, nullptr);
-  } else {
-    float ss = 0.f;
-    for (int i = threadIdx.x; i < d; i += kNormBlock) {
-      float a = bf2f(xr[i]);
-      ss += a * a;
-    }
-    ss = block_sum<kNormWaves>(ss, red);
-    const float inv = rsqrtf(ss / (float)d + eps);
-    for (int i = threadIdx.x; i < d; i += kNormBlock)
-      orow[i] = f2bf(bf2f(xr[i]) * inv * (bias + bf2f(w[i])));
+  float ss = 0.f;
+  for (int i = threadIdx.x; i < d; i += kNormBlock) {
+    float a = bf2f(xr[i]);
+    ss += a * a;
+  }
+  ss = block_sum<kNormWaves>(ss, red);
+  const float inv = rsqrtf(ss / (float)d + eps);
+  for (int i = threadIdx.x; i < d; i += kNormBlock) orow[i] = f2bf(bf2f(xr[i]) * inv * (bias + bf2f(w[i])));
+}
+
+// hidden = bf16(h + r); out = bf16((h + r)_fp32 * inv * w): the sum of squares uses the UNROUNDED fp32 sum and is
+// taken before hidden is modified; each lane then re-reads exactly the elements it overwrites.
+template <bool OFFSET>
+__global__ __launch_bounds__(kNormBlock) void fused_add_rms_norm_vec_kernel(Half* __restrict__ hidden,
+                                                                            const Half* __restrict__ residual,
+                                                                            const Half* __restrict__ w,
+                                                                            Half* __restrict__ out, int d, int rows,
+                                                                            float eps) {
+  const int row = blockIdx.x * kNormWaves + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  Half* hr = hidden + (size_t)row * d;
+  const Half* rr = residual + (size_t)row * d;
+  Half* orow = out + (size_t)row * d;
+  const float bias = OFFSET ? 1.0f : 0.0f;
+  const float inv = wave_row_inv_rms(hr, rr, d, eps);
+  const int nvec = d >> 3;
+  for (int i = lane; i < nvec; i += 64) {
+    const u32x4 r = reinterpret_cast<const u32x4*>(rr)[i];
+    u32x4 nh;
+    const u32x4 o = norm_scale8(reinterpret_cast<const u32x4*>(hr)[i], &r, reinterpret_cast<const u32x4*>(w)[i], inv,
+                                bias, &nh);
+    reinterpret_cast<u32x4*>(hr)[i] = nh;
+    reinterpret_cast<u32x4*>(orow)[i] = o;
   }
 }
 
-template <bool OFFSET, bool VEC>
-__global__ __launch_bounds__(kNormBlock) void fused_add_rms_norm_kernel(Half* __restrict__ hidden,
-                                                                        const Half* __restrict__ residual,
-                                                                        const Half* __restrict__ w,
-                                                                        Half* __restrict__ out, int d,
-                                                                        float eps) {
+template <bool OFFSET>
+__global__ __launch_bounds__(kNormBlock) void fused_add_rms_norm_scalar_kernel(Half* __restrict__ hidden,
+                                                                               const Half* __restrict__ residual,
+                                                                               const Half* __restrict__ w,
+                                                                               Half* __restrict__ out, int d,
+                                                                               float eps) {
   __shared__ float red[kNormWaves];
   Half* hr = hidden + (size_t)blockIdx.x * d;
   const Half* rr = residual + (size_t)blockIdx.x * d;
   Half* orow = out + (size_t)blockIdx.x * d;
   const float bias = OFFSET ? 1.0f : 0.0f;
-  if (VEC) {
-    // pass 1: sum of squares of the UNROUNDED fp32 sum (hidden is not modified yet);
-    // pass 2: each thread re-reads exactly the elements it will overwrite
-    const float inv = row_inv_rms_vec(hr, rr, d, eps, red);
-    const int nvec = d >> 3;
-    for (int i = threadIdx.x; i < nvec; i += kNormBlock) {
-      const u32x4 r = reinterpret_cast<const u32x4*>(rr)[i];
-      u32x4 nh;
-      const u32x4 o = norm_scale8(reinterpret_cast<const u32x4*>(hr)[i], &r, reinterpret_cast<const u32x4*>(w)[i],
-                                  inv, bias, &nh);
-      reinterpret_cast<u32x4*>(hr)[i] = nh;
-      reinterpret_cast<u32x4*>(orow)[i] = o;
-    }
-  } else {
-    float ss = 0.f;
-    for (int i = threadIdx.x; i < d; i += kNormBlock) {
-      float a = bf2f(hr[i]) + bf2f(rr[i]);
-      ss += a * a;
-    }
-    ss = block_sum<kNormWaves>(ss, red);
-    const float inv = rsqrtf(ss / (float)d + eps);
-    for (int i = threadIdx.x; i < d; i += kNormBlock) {
-      float s = bf2f(hr[i]) + bf2f(rr[i]);
-      hr[i] = f2bf(s);
-      orow[i] = f2bf(s * inv * (bias + bf2f(w[i])));
-    }
+  float ss = 0.f;
+  for (int i = threadIdx.x; i < d; i += kNormBlock) {
+    float a = bf2f(hr[i]) + bf2f(rr[i]);
+    ss += a * a;
+  }
+  ss = block_sum<kNormWaves>(ss, red);
+  const float inv = rsqrtf(ss / (float)d + eps);
+  for (int i = threadIdx.x; i < d; i += kNormBlock) {
+    float s = bf2f(hr[i]) + bf2f(rr[i]);
+    hr[i] = f2bf(s);
+    orow[i] = f2bf(s * inv * (bias + bf2f(w[i])));
   }
 }
 
@@ -107,8 +128,8 @@ template <bool OFFSET>
 static void launch_rms(const Half* x, const Half* w, Half* out, int d, int rows, float eps, hipStream_t s) {
   if (d <= 0 || rows <= 0) return;
   const bool vec = (d & 7) == 0 && host_aligned16(x) && host_aligned16(w) && host_aligned16(out);
-  if (vec) rms_norm_kernel<OFFSET, true><<<rows, kNormBlock, 0, s>>>(x, w, out, d, eps);
-  else rms_norm_kernel<OFFSET, false><<<rows, kNormBlock, 0, s>>>(x, w, out, d, eps);
+  if (vec) rms_norm_vec_kernel<OFFSET><<<ceil_div(rows, kNormWaves), kNormBlock, 0, s>>>(x, w, out, d, rows, eps);
+  else rms_norm_scalar_kernel<OFFSET><<<rows, kNormBlock, 0, s>>>(x, w, out, d, eps);
 }
 
 static void launch_fused(Half* hidden, const Half* residual, const Half* w, Half* out, int d, int rows,
@@ -116,8 +137,10 @@ static void launch_fused(Half* hidden, const Half* residual, const Half* w, Half
   if (d <= 0 || rows <= 0) return;
   const bool vec = (d & 7) == 0 && host_aligned16(hidden) && host_aligned16(residual) &&
                    host_aligned16(w) && host_aligned16(out);
-  if (vec) fused_add_rms_norm_kernel<false, true><<<rows, kNormBlock, 0, s>>>(hidden, residual, w, out, d, eps);
-  else fused_add_rms_norm_kernel<false, false><<<rows, kNormBlock, 0, s>>>(hidden, residual, w, out, d, eps);
+  if (vec)
+    fused_add_rms_norm_vec_kernel<false><<<ceil_div(rows, kNormWaves), kNormBlock, 0, s>>>(hidden, residual, w, out, d,
+                                                                                          rows, eps);
+  else fused_add_rms_norm_scalar_kernel<false><<<rows, kNormBlock, 0, s>>>(hidden, residual, w, out, d, eps);
 }
 
 }  // namespace pk

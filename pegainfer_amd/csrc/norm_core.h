@@ -1,7 +1,9 @@
-// Canonical fp32 sum-of-squares of one token row for a 256-thread workgroup.  Shared by the
-// stand-alone norm kernels (norm.hip) and the GEMV prologues (gemv_core.h) so that
-// "fused_add_rms_norm then GEMV" and "GEMV with the norm folded into its prologue" round
-// identically: same per-thread element order, same wave butterfly, same 4-wave combine.
+// Canonical fp32 sum-of-squares of one token row, computed by ONE wave64: lane l folds the 16-byte vectors
+// l, l+64, l+128, ... in order, then a wave butterfly (4 DPP steps + 2 bpermutes).  Shared by the stand-alone
+// norm kernels (norm.hip) and the GEMV / skinny-GEMM prologues so that "fused_add_rms_norm then GEMM" and
+// "GEMM with the norm folded into its prologue" round identically.  One wave per row means a workgroup
+// normalises several token rows concurrently with no barrier (a 256-thread-per-row reduction serialised the
+// prologue over the batch: T x (loads + 2 barriers)).
 #pragma once
 
 #include "common.h"
@@ -26,18 +28,19 @@ __device__ __forceinline__ void add_sq8(const u32x4& h, const u32x4& r, float& s
   a = bf_lo(h.w) + bf_lo(r.w); ss += a * a; a = bf_hi(h.w) + bf_hi(r.w); ss += a * a;
 }
 
-// inv_rms of row `hr` (+ `rr` when non-null), d % 8 == 0, all 256 threads participate.
-__device__ __forceinline__ float row_inv_rms_vec(const Half* __restrict__ hr, const Half* __restrict__ rr, int d,
-                                                 float eps, float* red /* >= 4 floats of LDS */) {
+// inv_rms of row `hr` (+ `rr` when non-null), d % 8 == 0; call from ALL 64 lanes of one wave.
+__device__ __forceinline__ float wave_row_inv_rms(const Half* __restrict__ hr, const Half* __restrict__ rr, int d,
+                                                  float eps) {
   float ss = 0.f;
   const int nvec = d >> 3;
+  const int lane = threadIdx.x & 63;
   if (rr) {
-    for (int i = threadIdx.x; i < nvec; i += kNormBlock)
+    for (int i = lane; i < nvec; i += 64)
       add_sq8(reinterpret_cast<const u32x4*>(hr)[i], reinterpret_cast<const u32x4*>(rr)[i], ss);
   } else {
-    for (int i = threadIdx.x; i < nvec; i += kNormBlock) sq8(reinterpret_cast<const u32x4*>(hr)[i], ss);
+    for (int i = lane; i < nvec; i += 64) sq8(reinterpret_cast<const u32x4*>(hr)[i], ss);
   }
-  ss = block_sum<kNormWaves>(ss, red);
+  ss = wave_sum(ss);
   return rsqrtf(ss / (float)d + eps);
 }
 
