@@ -33,6 +33,13 @@ pegainfer_status_t pegainfer_batched_top1(const Half* logits, int32_t vocab_size
  * fall back to the unfused sequence. */
 pegainfer_status_t pegainfer_gemv_fused(const Half* W, const Half* X, Half* Y, int32_t M, int32_t T, int32_t K, const Half* residual, const Half* norm_weight, Half* hidden_out, float eps, int32_t silu_intermediate, pegainfer_stream_t stream);
 
+/* Prefill q/k/v projection as ONE GEMM over the row-stacked weight W[M0 + M1 + M2, K] (q_proj; k_proj; v_proj
+ * rows), writing the three contiguous buffers the reference's prefill kernels take: Y0[T, M0], Y1[T, M1],
+ * Y2[T, M2].  Replaces the three gemm_cuda calls of prefill.rs:120-129 (the k/v projections alone cover a
+ * quarter of the chip); every element equals the separate call bit for bit.  Falls back to three calls for
+ * shapes the tiled kernel does not take. */
+pegainfer_status_t pegainfer_gemm_split3(const Half* W, const Half* X, Half* Y0, int32_t M0, Half* Y1, int32_t M1, Half* Y2, int32_t M2, int32_t T, int32_t K, pegainfer_stream_t stream);
+
 /* Decode attention with the per-head q/k RMSNorm + RoPE and the KV append folded in (head_dim 128):
  * reads the raw fused-QKV GEMV output qkv[bs, (Hq + 2 Hkv) * 128], writes the new K (normalised, rotated)
  * and V rows into the paged cache and the attention output [bs, Hq*128].  Bit-identical to

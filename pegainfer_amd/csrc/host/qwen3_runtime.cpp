@@ -655,9 +655,15 @@ struct Model {
         if (Ti == 1) gemm_graphsafe_cuda(w, x, y, M, 1, K, S());
         else gemm_cuda(w, x, y, M, Ti, K, S());
       };
-      G(ly.qkv, pf_normed, pf_q, q_dim, H);
-      G(ly.qkv + (size_t)q_dim * H, pf_normed, pf_k, kv_dim, H);
-      G(ly.qkv + (size_t)(q_dim + kv_dim) * H, pf_normed, pf_v, kv_dim, H);
+      if (Ti > 64) {  // one launch over the stacked q/k/v rows, three outputs (bit-identical to three calls)
+        if (pegainfer_gemm_split3(ly.qkv, pf_normed, pf_q, q_dim, pf_k, kv_dim, pf_v, kv_dim, Ti, H, S())) {
+          set_error("pegainfer_gemm_split3 failed"); return -1;
+        }
+      } else {
+        G(ly.qkv, pf_normed, pf_q, q_dim, H);
+        G(ly.qkv + (size_t)q_dim * H, pf_normed, pf_k, kv_dim, H);
+        G(ly.qkv + (size_t)(q_dim + kv_dim) * H, pf_normed, pf_v, kv_dim, H);
+      }
       if (n == 1 && n_decode_tail == 0)
         prefill_qk_norm_rope_only_cuda(pf_q, pf_k, ly.q_norm, ly.k_norm, cos, sin, Hq, Hkv, D, Ti, starts[0], eps, S());
       else

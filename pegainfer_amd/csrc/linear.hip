@@ -142,6 +142,146 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(const Half* __restrict__
   }
 }
 
+// Same tiling and the same per-element K order (so results are bit-identical to mfma_gemm_kernel), but
+// the tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4): no staging VGPRs, no ds_write pass.  The
+// DMA writes LDS lane-linearly (base + lane*16), so the bank swizzle is applied to each lane's SOURCE
+// address: lane l of row-group rg fetches global slot (l%8) ^ (row&7) of row rg*8 + l/8, and readers use
+// lds_slot() unchanged.  TT = token-tile width (128, or 64 when M is small and 128-wide tiles would leave
+// CUs idle).
+// Optional row-segmented output: W rows [0,M0) -> Y[T][M0], [M0,M0+M1) -> Y1[T][M1], the rest -> Y2[T][M-M0-M1]
+// (one GEMM over a stacked q/k/v weight writing the three buffers the attention kernels take).  Y1 == nullptr
+// means a plain [T][M] output.  M0 and M1 are multiples of 4 (a lane stores 4 consecutive rows).
+struct SplitOut { Half* Y1; Half* Y2; int M0; int M1; };
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int TT, int ST>
+__global__ __launch_bounds__(256) void mfma_gemm_glds_kernel(const Half* __restrict__ W, const Half* __restrict__ X,
+                                                             Half* __restrict__ Y, int M, int T, int K,
+                                                             int m_tiles, int t_tiles, SplitOut so) {
+  constexpr int TJ = TT / 32;       // 16-token blocks per wave
+  constexpr int XG = TT / 32;       // X row-groups (8 rows) staged per wave
+  constexpr int NG = 4 + XG;        // LDS-DMA instructions per wave per K tile
+  extern __shared__ __attribute__((aligned(16))) u32x4 glds_smem[];   // ST x (W tile | X tile)
+  u32x4(*ws)[BM * 8] = reinterpret_cast<u32x4(*)[BM * 8]>(glds_smem);
+  u32x4(*xs)[TT * 8] = reinterpret_cast<u32x4(*)[TT * 8]>(glds_smem + ST * BM * 8);
+  const int ntiles = m_tiles * t_tiles;
+  int tile = blockIdx.x;
+  {
+    const int q = ntiles / 8, r = ntiles % 8, xcd = tile % 8, idx = tile / 8;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int mt = tile / t_tiles, tt = tile - mt * t_tiles;
+  const int m0 = mt * BM, t0 = tt * TT;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int wm = (wave >> 1) * 64, wt = (wave & 1) * (TT / 2);
+  const int l15 = lane & 15, g = lane >> 4;
+
+  // per-lane DMA sources: W row-groups wave, wave+4, wave+8, wave+12; X row-groups wave + 4*j
+  const Half* wsrc[4];
+  const Half* xsrc[XG];
+  const int lr = lane >> 3, ls = lane & 7;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = (wave + 4 * j) * 8 + lr;
+    int mr = m0 + row; mr = mr < M ? mr : M - 1;
+    wsrc[j] = W + (size_t)mr * K + ((ls ^ (row & 7)) << 3);
+  }
+#pragma unroll
+  for (int j = 0; j < XG; ++j) {
+    const int row = (wave + 4 * j) * 8 + lr;
+    int tr = t0 + row; tr = tr < T ? tr : T - 1;
+    xsrc[j] = X + (size_t)tr * K + ((ls ^ (row & 7)) << 3);
+  }
+  f32x4 acc[4][TJ];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // The DMA is issued from inline asm on purpose: hipcc orders every later ds_read behind a compiler-visible
+  // LDS-DMA with s_waitcnt vmcnt(0) (it cannot tell the two halves of ws/xs apart), which would serialise
+  // load and math.  The hand-placed vmcnt(0) below, just before the barrier, is the only wait the DMA needs:
+  // buffer cur^1 was last read before the previous barrier and is first read after the next one.
+  const uint32_t ws_lds = (uint32_t)(uintptr_t)(lptr_t)&ws[0][0], xs_lds = (uint32_t)(uintptr_t)(lptr_t)&xs[0][0];
+  auto stage = [&](int buf, int kt) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t dst = __builtin_amdgcn_readfirstlane(ws_lds + (uint32_t)(buf * BM * 8 + (wave + 4 * j) * 64) * 16u);
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                   :: "v"(wsrc[j] + (size_t)kt * BK), "s"(dst) : "memory", "m0");
+    }
+#pragma unroll
+    for (int j = 0; j < XG; ++j) {
+      const uint32_t dst = __builtin_amdgcn_readfirstlane(xs_lds + (uint32_t)(buf * TT * 8 + (wave + 4 * j) * 64) * 16u);
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                   :: "v"(xsrc[j] + (size_t)kt * BK), "s"(dst) : "memory", "m0");
+    }
+  };
+  // ST-deep ring, prefetch distance ST-1.  Tile kt+ST-1 goes into the buffer tile kt-1 was read from (every wave
+  // left that compute before the barrier that ended iteration kt-1).  A wave's vmcnt counts its own DMAs in
+  // issue order, so "at most (ST-2)*NG outstanding" == tile kt+1 has landed; the barrier extends that to all waves.
+  const int nk = K / BK;
+#pragma unroll
+  for (int p = 0; p < ST - 1; ++p)
+    if (p < nk) stage(p, p);
+  if (nk > ST - 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((ST - 2) * NG) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int cur = 0, nxt = ST - 1;  // ring slots of tile kt and tile kt+ST-1
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool more = kt + ST - 1 < nk;
+    if (more) stage(nxt, kt + ST - 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t a[4], b[TJ];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        a[i] = __builtin_bit_cast(bf16x8_t, ws[cur][lds_slot(wm + i * 16 + l15, ks * 4 + g)]);
+#pragma unroll
+      for (int j = 0; j < TJ; ++j)
+        b[j] = __builtin_bit_cast(bf16x8_t, xs[cur][lds_slot(wt + j * 16 + l15, ks * 4 + g)]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((ST - 2) * NG) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cur = cur + 1 == ST ? 0 : cur + 1;
+    nxt = nxt + 1 == ST ? 0 : nxt + 1;
+  }
+#pragma unroll
+  for (int j = 0; j < TJ; ++j) {
+    const int t = t0 + wt + j * 16 + l15;
+    if (t >= T) continue;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + wm + i * 16 + g * 4;
+      Half* dst = Y;
+      int ld = M, mm = m, mlim = M;
+      if (so.Y1) {
+        if (m < so.M0) { ld = mlim = so.M0; }
+        else if (m < so.M0 + so.M1) { dst = so.Y1; ld = mlim = so.M1; mm = m - so.M0; }
+        else { dst = so.Y2; ld = mlim = M - so.M0 - so.M1; mm = m - so.M0 - so.M1; }
+      }
+      if (mm + 3 < mlim) {
+        u32x2 o;
+        o.x = pack_bf2(acc[i][j][0], acc[i][j][1]);
+        o.y = pack_bf2(acc[i][j][2], acc[i][j][3]);
+        *reinterpret_cast<u32x2*>(dst + (size_t)t * ld + mm) = o;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (mm + e < mlim) dst[(size_t)t * ld + mm + e] = f2bf(acc[i][j][e]);
+      }
+    }
+  }
+}
+
 // Decode-shaped GEMM routing (T <= 64 columns, weights streamed once), by shape only (measured on MI355X,
 // Qwen3-4B step: dot2 wins up to 4 columns, the matrix-core kernel from 5):
 //   T <= 4            -> dot2 GEMV (gemv_core.h)            [PEGAINFER_GEMV_T1=mfma routes everything to MFMA]
@@ -161,6 +301,41 @@ static bool decode_gemm_dispatch(const GemvFusedArgs& a, hipStream_t s) {
   return gemv_dispatch<EPI>(a, s);
 }
 
+static bool glds_gemm_ok(const Half* W, const Half* X, const Half* Y, int M, int K) {
+  return (K & 7) == 0 && host_aligned16(W) && host_aligned16(X) && (K % BK) == 0 && (M & 3) == 0 &&
+         (reinterpret_cast<uintptr_t>(Y) & 7u) == 0;
+}
+template <int TT, int ST>
+static void glds_gemm_launch_t(const Half* W, const Half* X, Half* Y, int M, int T, int K, SplitOut so, hipStream_t s) {
+  constexpr int kLds = ST * (BM + TT) * 8 * 16;
+  static const bool once = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_gemm_glds_kernel<TT, ST>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+    return true;
+  }();
+  (void)once;
+  const int m_tiles = ceil_div(M, BM), t_tiles = ceil_div(T, TT);
+  mfma_gemm_glds_kernel<TT, ST><<<m_tiles * t_tiles, 256, kLds, s>>>(W, X, Y, M, T, K, m_tiles, t_tiles, so);
+}
+// variant: 0 = by shape; else 10*tile + stages with tile 1 = 128-token, 2 = 64-token (A/B probe only)
+static void glds_gemm_launch(const Half* W, const Half* X, Half* Y, int M, int T, int K, SplitOut so, int variant,
+                             hipStream_t s) {
+  if (variant == 0) {
+    // Measured on MI355X (tools/bench_prefill_gemm.py, T = 1024): co-resident workgroups hide DMA latency better
+    // than a deeper ring, so the ring only goes to 3 when every 64-token tile is resident at once (<= 2 per CU);
+    // 128-token tiles (half the LDS reads per MFMA) once they give each CU >= 1.5 workgroups.
+    const long m_tiles = ceil_div(M, BM), wide = m_tiles * ceil_div(T, 128), narrow = m_tiles * ceil_div(T, 64);
+    variant = narrow <= 512 ? 23 : wide >= 384 ? 12 : 22;
+  }
+  switch (variant) {
+    case 12: glds_gemm_launch_t<128, 2>(W, X, Y, M, T, K, so, s); break;
+    case 13: glds_gemm_launch_t<128, 3>(W, X, Y, M, T, K, so, s); break;
+    case 22: glds_gemm_launch_t<64, 2>(W, X, Y, M, T, K, so, s); break;
+    case 24: glds_gemm_launch_t<64, 4>(W, X, Y, M, T, K, so, s); break;
+    default: glds_gemm_launch_t<64, 3>(W, X, Y, M, T, K, so, s); break;
+  }
+}
+
 static void gemm_dispatch(const Half* W, const Half* X, Half* Y, int M, int T, int K, hipStream_t s) {
   if (M <= 0 || T <= 0 || K <= 0) return;
   const bool fast = (K & 7) == 0 && host_aligned16(W) && host_aligned16(X);
@@ -168,9 +343,22 @@ static void gemm_dispatch(const Half* W, const Half* X, Half* Y, int M, int T, i
     GemvFusedArgs a{W, X, Y, M, T, K, nullptr, nullptr, nullptr, 0.f, 0, 0};
     if (decode_gemm_dispatch<kEpiStore>(a, s)) return;
   }
-  if (fast && (K % BK) == 0 && (M & 3) == 0 && (reinterpret_cast<uintptr_t>(Y) & 7u) == 0) {
-    const int m_tiles = ceil_div(M, BM), t_tiles = ceil_div(T, BT);
-    mfma_gemm_kernel<<<m_tiles * t_tiles, 256, 0, s>>>(W, X, Y, M, T, K, m_tiles, t_tiles);
+  if (glds_gemm_ok(W, X, Y, M, K)) {
+    // PEGAINFER_GEMM=reg keeps the register-staged kernel; w2 w3 n2 n3 n4 force a 128 / 64-token LDS-DMA tile
+    // with that ring depth (A/B probes, tools/bench_prefill_gemm.py); default picks by shape.
+    static const int mode = [] {
+      const char* e = getenv("PEGAINFER_GEMM");
+      if (!e) return 0;
+      if (e[0] == 'r') return -1;
+      if ((e[0] == 'w' || e[0] == 'n') && e[1] >= '2' && e[1] <= '4') return (e[0] == 'w' ? 10 : 20) + (e[1] - '0');
+      return 0;
+    }();
+    if (mode < 0) {
+      const int m_tiles = ceil_div(M, BM), t_tiles = ceil_div(T, BT);
+      mfma_gemm_kernel<<<m_tiles * t_tiles, 256, 0, s>>>(W, X, Y, M, T, K, m_tiles, t_tiles);
+    } else {
+      glds_gemm_launch(W, X, Y, M, T, K, SplitOut{nullptr, nullptr, 0, 0}, mode, s);
+    }
     return;
   }
   naive_gemm_kernel<<<ceil_div((long)M * T, 4), 256, 0, s>>>(W, X, Y, M, T, K);
@@ -215,6 +403,26 @@ pegainfer_status_t pegainfer_gemv_fused(const Half* W, const Half* X, Half* Y, i
   const bool ok = silu_intermediate > 0 ? decode_gemm_dispatch<kEpiSilu>(a, as_stream(stream))
                                         : decode_gemm_dispatch<kEpiStore>(a, as_stream(stream));
   return ok ? (pegainfer_status_t)hipGetLastError() : (pegainfer_status_t)hipErrorInvalidValue;
+}
+
+// One GEMM over a row-stacked weight [M0 + M1 + M2, K] writing three outputs Y0[T][M0], Y1[T][M1], Y2[T][M2]
+// (extension): what prefill's q_proj / k_proj / v_proj calls (prefill.rs:120-129) compute, in one launch that
+// fills the chip.  Each element is bit-identical to the separate gemm_cuda call (same kernel, same K order).
+pegainfer_status_t pegainfer_gemm_split3(const Half* W, const Half* X, Half* Y0, int32_t M0, Half* Y1, int32_t M1,
+                                         Half* Y2, int32_t M2, int32_t T, int32_t K, pegainfer_stream_t stream) {
+  using namespace pk;
+  if (M0 <= 0 || M1 <= 0 || M2 <= 0 || T <= 0 || K <= 0) return (pegainfer_status_t)hipErrorInvalidValue;
+  const int M = M0 + M1 + M2;
+  const bool ok = T > 64 && ((M0 | M1 | M2) & 3) == 0 && glds_gemm_ok(W, X, Y0, M, K) &&
+                  (reinterpret_cast<uintptr_t>(Y1) & 7u) == 0 && (reinterpret_cast<uintptr_t>(Y2) & 7u) == 0;
+  if (ok) {
+    glds_gemm_launch(W, X, Y0, M, T, K, SplitOut{Y1, Y2, M0, M1}, 0, as_stream(stream));
+  } else {  // shapes the tiled kernel does not take: three reference-ABI calls
+    gemm_dispatch(W, X, Y0, M0, T, K, as_stream(stream));
+    gemm_dispatch(W + (size_t)M0 * K, X, Y1, M1, T, K, as_stream(stream));
+    gemm_dispatch(W + (size_t)(M0 + M1) * K, X, Y2, M2, T, K, as_stream(stream));
+  }
+  return (pegainfer_status_t)hipGetLastError();
 }
 
 }  // extern "C"

@@ -148,6 +148,16 @@ def gemm_into(weight, x, out):
     fn(_p(weight), _p(x), _p(out), weight.shape[0], x.shape[0], weight.shape[1], _stream())
 
 
+def gemm_split3_into(weight, x, out0, out1, out2):
+    """One GEMM over the row-stacked weight, three outputs (pegainfer_kernels_ext.h: pegainfer_gemm_split3)."""
+    m0, m1, m2 = out0.shape[1], out1.shape[1], out2.shape[1]
+    assert weight.shape == (m0 + m1 + m2, x.shape[1])
+    assert out0.shape[0] == out1.shape[0] == out2.shape[0] == x.shape[0]
+    _bf16(weight, x, out0, out1, out2)
+    _chk(ffi.lib().pegainfer_gemm_split3(_p(weight), _p(x), _p(out0), m0, _p(out1), m1, _p(out2), m2, x.shape[0],
+                                         weight.shape[1], _stream()), "pegainfer_gemm_split3")
+
+
 def gemm(weight, x):
     out = torch.empty((x.shape[0], weight.shape[0]), dtype=torch.bfloat16, device=x.device)
     gemm_into(weight, x, out)

@@ -229,6 +229,26 @@ def test_gemm_lm_head_shape(P):
     gemm_check(P, 151936, 1, 2560)
 
 
+@pytest.mark.parametrize("T,K,ms", [(1024, 2560, (4096, 1024, 1024)), (200, 512, (256, 64, 192)),
+                                    (65, 128, (132, 4, 8)), (40, 256, (128, 64, 64))])
+def test_gemm_split3_equals_three_gemms(P, T, K, ms):
+    """Stacked q/k/v projection in one launch == the three reference-ABI gemm_cuda calls, bit for bit
+    (prefill.rs:120-129); also pins the LDS-DMA tiled GEMM against the oracle GEMM."""
+    import torch
+    rng = np.random.default_rng(5)
+    W, X = rnd(rng, sum(ms), K, scale=0.05), rnd(rng, T, K)
+    Wd, Xd = to_dev(W), to_dev(X)
+    outs = [torch.empty((T, m), dtype=torch.bfloat16, device=Xd.device) for m in ms]
+    P.gemm_split3_into(Wd, Xd, *outs)
+    r0 = 0
+    for m, o in zip(ms, outs):
+        sep = P.gemm(Wd[r0:r0 + m], Xd)
+        assert np.array_equal(bf16_bits(from_dev(o)), bf16_bits(from_dev(sep))), (ms, m)
+        ref = O.gemm(W[r0:r0 + m], X)
+        assert np.abs(from_dev(o) - ref).max() <= 2.0 ** -6 * max(1.0, np.abs(ref).max())
+        r0 += m
+
+
 def test_decode_gemm_batch_invariance_and_row_slices(P):
     """Decode GEMM: within a kernel family (dot2 GEMV: 1..4 columns, skinny MFMA: 5..64 columns) column t of a
     batched call == the same column in any other batch size, bit for bit; a row slice of the fused matrix == the
