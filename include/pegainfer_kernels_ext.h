@@ -47,8 +47,12 @@ pegainfer_status_t pegainfer_gemm_split3(const Half* W, const Half* X, Half* Y0,
  * (ops/attention.rs:469-511, 572-796).  use_split selects the partition-KV plan arrays.
  * slot_desc (optional, 16-byte aligned): one record of 8 int32 per slot {b, lo, hi, page_indptr[b], position,
  * kv_len, 0, 0}, lo < 0 for padding slots - the same plan, pre-resolved on the host so a workgroup needs one
- * metadata load instead of four dependent ones. */
-int32_t pegainfer_fused_decode_attention(const Half* qkv, Half* output, const Half* kv_data, int64_t k_offset_elems, int64_t v_offset_elems, const int32_t* page_indices, const int32_t* page_indptr, const int32_t* last_page_len_d, const int32_t* positions, const Half* q_norm_weight, const Half* k_norm_weight, const Half* cos_cache, const Half* sin_cache, float rms_eps, int32_t use_split, const int32_t* split_request_indices, const int32_t* split_kv_tile_indices, const int32_t* split_kv_chunk_size_ptr, const int32_t* split_o_indptr, const uint8_t* split_block_valid_mask, Half* tmp_v, float* tmp_s, int32_t num_qo_heads, int32_t num_kv_heads, int32_t head_dim, int32_t page_size, int32_t batch_size, int32_t split_slots, int64_t stride_page, float sm_scale, const int32_t* slot_desc, pegainfer_stream_t stream);
+ * metadata load instead of four dependent ones.
+ * merge_counters (optional, use_split only): batch_size * num_kv_heads int32, zero before the first call.  When
+ * given, the last workgroup of each (request, kv head) to finish merges that head group's partials in the
+ * same launch (agent-scope release/acquire around one atomic) and re-arms the counter; no merge launch.  Output
+ * rows of requests that own no slot (padding columns) are then left untouched.  Same bits either way. */
+int32_t pegainfer_fused_decode_attention(const Half* qkv, Half* output, const Half* kv_data, int64_t k_offset_elems, int64_t v_offset_elems, const int32_t* page_indices, const int32_t* page_indptr, const int32_t* last_page_len_d, const int32_t* positions, const Half* q_norm_weight, const Half* k_norm_weight, const Half* cos_cache, const Half* sin_cache, float rms_eps, int32_t use_split, const int32_t* split_request_indices, const int32_t* split_kv_tile_indices, const int32_t* split_kv_chunk_size_ptr, const int32_t* split_o_indptr, const uint8_t* split_block_valid_mask, Half* tmp_v, float* tmp_s, int32_t num_qo_heads, int32_t num_kv_heads, int32_t head_dim, int32_t page_size, int32_t batch_size, int32_t split_slots, int64_t stride_page, float sm_scale, const int32_t* slot_desc, int32_t* merge_counters, pegainfer_stream_t stream);
 
 #ifdef __cplusplus
 }

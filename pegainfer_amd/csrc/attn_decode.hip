@@ -17,6 +17,8 @@
 // caller's tmp_v / tmp_s exactly like FlashInfer, and merge_states_kernel combines slots
 // o_indptr[b]..o_indptr[b+1].  kv_len always comes from the page table
 // ((pages-1)*page_size + last_page_len), kv_chunk_size_ptr[0] is read only when partitioning.
+#include <type_traits>
+
 #include "common.h"
 #include "pegainfer_kernels_ext.h"
 #include "rope_core.h"
@@ -41,6 +43,10 @@ struct DecodeAttnArgs {
   // fused form, optional: one 32-byte record per slot {b, lo, hi, pbase, pos, kv_len, 0, 0} built by the host
   // (lo < 0 = padding slot) - replaces a 4-deep chain of dependent metadata loads by one load
   const int* slot_desc;
+  // partition form, optional: when merge_counters is non-null the LAST workgroup of a (request, kv head) to
+  // finish merges that head group's partials itself (no merge_states_kernel launch).  One int per
+  // (request, kv head), zero before the first launch; the merging workgroup leaves it zero again.
+  int* merge_counters; const int* o_indptr;
 };
 
 struct ChunkInfo { int b, pbase, kv_len, lo, hi; };
@@ -61,6 +67,54 @@ __device__ __forceinline__ ChunkInfo decode_chunk(const DecodeAttnArgs& a, int s
     if (c.lo > c.hi) c.lo = c.hi;
   }
   return c;
+}
+
+// One wave merges the partition-KV partials of one (request, q head): lanes first fetch all log2-sum-exps of
+// the request's slots in parallel (<= 64 slots), then every lane accumulates its D/64 output dims over the
+// slots with the weights broadcast from registers:  out = sum_s 2^(lse_s - M) v_s / sum_s 2^(lse_s - M).
+// Shared by merge_states_kernel and the in-kernel merge so both round identically.
+template <int D, bool COHERENT>
+__device__ __forceinline__ void merge_one(const Half* __restrict__ tmp_v, const float* __restrict__ tmp_s, int s0,
+                                          int s1, int head, int num_qo_heads, Half* __restrict__ dst_row) {
+  // COHERENT: the partials were published write-through by other workgroups of this launch -> agent-scope
+  // relaxed atomic loads (global_load ... sc1), which are served past this CU's L1.
+  const int lane = threadIdx.x & 63;
+  constexpr int EPL = D / 64;  // elements per lane (2 or 4)
+  typedef typename std::conditional<EPL == 2, uint32_t, uint64_t>::type word_t;
+  float acc[EPL], wsum = 0.f;
+#pragma unroll
+  for (int i = 0; i < EPL; ++i) acc[i] = 0.f;
+  // both split plans cap a request at 64 chunks (batch_decode_buffers.rs:15); launch_decode rejects more
+  const int n = s1 - s0 < 64 ? s1 - s0 : 64;
+  float lse = -INFINITY;
+  if (lane < n) {
+    const float* ps = tmp_s + (size_t)(s0 + lane) * num_qo_heads + head;
+    if (COHERENT)
+      lse = __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<const uint32_t*>(ps), __ATOMIC_RELAXED,
+                                                        __HIP_MEMORY_SCOPE_AGENT));
+    else
+      lse = *ps;
+  }
+  const float M = wave_max(lse);
+  if (M != -INFINITY) {
+    const float w_lane = exp2f(lse - M);
+    for (int j = 0; j < n; ++j) {
+      const float w = __shfl(w_lane, j, kWave);
+      const word_t* v = reinterpret_cast<const word_t*>(tmp_v + ((size_t)(s0 + j) * num_qo_heads + head) * D + lane * EPL);
+      const word_t pv = COHERENT ? __hip_atomic_load(v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *v;
+      wsum += w;
+      acc[0] += w * bf_lo((uint32_t)pv);
+      acc[1] += w * bf_hi((uint32_t)pv);
+      if (EPL == 4) {
+        const uint32_t hi = (uint32_t)((uint64_t)pv >> 32);
+        acc[2] += w * bf_lo(hi);
+        acc[3] += w * bf_hi(hi);
+      }
+    }
+  }
+  Half* dst = dst_row + lane * EPL;
+#pragma unroll
+  for (int i = 0; i < EPL; ++i) dst[i] = f2bf(wsum > 0.f ? acc[i] / wsum : 0.f);
 }
 
 // The KV scan + in-workgroup merge, given the (already normalised / rotated) bf16 q fragments.
@@ -176,27 +230,70 @@ __device__ __forceinline__ void decode_attn_body(const DecodeAttnArgs& a, const 
     *reinterpret_cast<f32x4*>(&sm_o[part][h][sub * 8 + 4]) = c;
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < GROUP * D; e += 256) {
-    const int h = e / D, d = e - h * D;
+  // one thread per (head, 8 output dims): 16-byte stores.  With merge_counters the partials are published
+  // write-through (sc1): they are read by a workgroup on another XCD later in this same launch.
+  const bool publish = PARTITION && a.merge_counters != nullptr;
+  for (int e = threadIdx.x; e < GROUP * (D / 8); e += 256) {
+    const int h = e / (D / 8), d0 = (e - h * (D / 8)) * 8;
     float M = -INFINITY;
 #pragma unroll
     for (int p = 0; p < NPART; ++p) M = fmaxf(M, sm_m[p][h]);
-    float L = 0.f, O = 0.f;
+    float L = 0.f, O[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) O[i] = 0.f;
     if (M != -INFINITY) {
 #pragma unroll
       for (int p = 0; p < NPART; ++p) {
         const float w = exp2f(sm_m[p][h] - M);
         L += sm_l[p][h] * w;
-        O += sm_o[p][h][d] * w;
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(&sm_o[p][h][d0]);
+        const f32x4 x1 = *reinterpret_cast<const f32x4*>(&sm_o[p][h][d0 + 4]);
+        O[0] += x0[0] * w; O[1] += x0[1] * w; O[2] += x0[2] * w; O[3] += x0[3] * w;
+        O[4] += x1[0] * w; O[5] += x1[1] * w; O[6] += x1[2] * w; O[7] += x1[3] * w;
       }
     }
-    const float val = L > 0.f ? O / L : 0.f;
+    u32x4 pk;
+    pk.x = pack_bf2(L > 0.f ? O[0] / L : 0.f, L > 0.f ? O[1] / L : 0.f);
+    pk.y = pack_bf2(L > 0.f ? O[2] / L : 0.f, L > 0.f ? O[3] / L : 0.f);
+    pk.z = pack_bf2(L > 0.f ? O[4] / L : 0.f, L > 0.f ? O[5] / L : 0.f);
+    pk.w = pack_bf2(L > 0.f ? O[6] / L : 0.f, L > 0.f ? O[7] / L : 0.f);
     const int head = kvh * GROUP + h;
     if (PARTITION) {
-      a.tmp_v[((size_t)slot * num_qo_heads + head) * D + d] = f2bf(val);
-      if (d == 0) a.tmp_s[(size_t)slot * num_qo_heads + head] = L > 0.f ? M + log2f(L) : -INFINITY;
+      Half* pv = a.tmp_v + ((size_t)slot * num_qo_heads + head) * D + d0;
+      float* ps = a.tmp_s + (size_t)slot * num_qo_heads + head;
+      const float lse = L > 0.f ? M + log2f(L) : -INFINITY;
+      if (publish) {
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(pv), "v"(pk) : "memory");
+        if (d0 == 0) asm volatile("global_store_dword %0, %1, off sc1" :: "v"(ps), "v"(lse) : "memory");
+      } else {
+        *reinterpret_cast<u32x4*>(pv) = pk;
+        if (d0 == 0) *ps = lse;
+      }
     } else {
-      a.o_out[((size_t)b * num_qo_heads + head) * D + d] = f2bf(val);
+      *reinterpret_cast<u32x4*>(a.o_out + ((size_t)b * num_qo_heads + head) * D + d0) = pk;
+    }
+  }
+  if (publish) {
+    // "last workgroup done" merge without cache-wide fences (guide: sc1 payload -> vmcnt(0) -> counter; the
+    // reader uses sc1 loads): every chunk's partials are write-through, the ticket is a relaxed agent atomic,
+    // and the workgroup that draws n-1 merges this head group and re-arms the counter for the next launch.
+    __shared__ int sm_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int s0 = a.o_indptr[b], s1 = a.o_indptr[b + 1];
+    if (threadIdx.x == 0) {
+      int* ctr = a.merge_counters + b * num_kv_heads + kvh;
+      const int last = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == s1 - s0 - 1;
+      if (last) __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      sm_last = last;
+    }
+    __syncthreads();
+    if (sm_last) {
+      for (int h = wave; h < GROUP; h += 4) {
+        const int head = kvh * GROUP + h;
+        merge_one<D, true>(a.tmp_v, a.tmp_s, s0, s1, head, num_qo_heads,
+                           a.o_out + ((size_t)b * num_qo_heads + head) * D);
+      }
     }
   }
 }
@@ -279,35 +376,8 @@ __global__ __launch_bounds__(256) void merge_states_kernel(const Half* __restric
   const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (unit >= batch_size * num_qo_heads) return;
   const int b = unit / num_qo_heads, head = unit - b * num_qo_heads;
-  const int lane = threadIdx.x & 63;
-  const int s0 = o_indptr[b], s1 = o_indptr[b + 1];
-  constexpr int EPL = D / 64;  // elements per lane (2 or 4)
-  float acc[EPL], wsum = 0.f;
-#pragma unroll
-  for (int i = 0; i < EPL; ++i) acc[i] = 0.f;
-  // both split plans cap a request at 64 chunks (batch_decode_buffers.rs:15); launch_decode rejects more
-  const int n = s1 - s0 < 64 ? s1 - s0 : 64;
-  const float lse = lane < n ? tmp_s[(size_t)(s0 + lane) * num_qo_heads + head] : -INFINITY;
-  const float M = wave_max(lse);
-  if (M != -INFINITY) {
-    const float w_lane = exp2f(lse - M);
-    for (int j = 0; j < n; ++j) {
-      const float w = __shfl(w_lane, j, kWave);
-      const Half* v = tmp_v + ((size_t)(s0 + j) * num_qo_heads + head) * D + lane * EPL;
-      wsum += w;
-      if (EPL == 2) {
-        const uint32_t pv = *reinterpret_cast<const uint32_t*>(v);
-        acc[0] += w * bf_lo(pv);
-        acc[1] += w * bf_hi(pv);
-      } else {
-#pragma unroll
-        for (int i = 0; i < EPL; ++i) acc[i] += w * bf2f(v[i]);
-      }
-    }
-  }
-  Half* dst = out + ((size_t)b * num_qo_heads + head) * D + lane * EPL;
-#pragma unroll
-  for (int i = 0; i < EPL; ++i) dst[i] = f2bf(wsum > 0.f ? acc[i] / wsum : 0.f);
+  merge_one<D, false>(tmp_v, tmp_s, o_indptr[b], o_indptr[b + 1], head, num_qo_heads,
+               out + ((size_t)b * num_qo_heads + head) * D);
 }
 
 static void fill_args(DecodeAttnArgs& a, const Half* q, Half* output, const Half* kv, long k_off, long v_off,
@@ -341,7 +411,7 @@ static int launch_decode(const DecodeAttnArgs& a, const int* o_indptr, int batch
     default: return static_cast<int>(hipErrorInvalidValue);
   }
 #undef PK_LAUNCH
-  if (PARTITION)
+  if (PARTITION && !a.merge_counters)
     merge_states_kernel<D><<<ceil_div((long)batch_size * a.num_qo_heads, 4), 256, 0, s>>>(
         a.tmp_v, a.tmp_s, o_indptr, a.o_out, batch_size, a.num_qo_heads);
   return static_cast<int>(hipGetLastError());
@@ -411,7 +481,7 @@ int32_t pegainfer_fused_decode_attention(
     const int32_t* split_kv_tile_indices, const int32_t* split_kv_chunk_size_ptr, const int32_t* split_o_indptr,
     const uint8_t* split_block_valid_mask, Half* tmp_v, float* tmp_s, int32_t num_qo_heads, int32_t num_kv_heads,
     int32_t head_dim, int32_t page_size, int32_t batch_size, int32_t split_slots, int64_t stride_page,
-    float sm_scale, const int32_t* slot_desc, pegainfer_stream_t stream) {
+    float sm_scale, const int32_t* slot_desc, int32_t* merge_counters, pegainfer_stream_t stream) {
   if (head_dim != 128 || !host_aligned16(qkv) || !host_aligned16(kv_data) || !host_aligned16(slot_desc))
     return static_cast<int32_t>(hipErrorInvalidValue);
   DecodeAttnArgs a;
@@ -421,8 +491,10 @@ int32_t pegainfer_fused_decode_attention(
             stride_page, sm_scale);
   a.qkv = qkv; a.q_norm_w = q_norm_weight; a.k_norm_w = k_norm_weight; a.cos_cache = cos_cache;
   a.sin_cache = sin_cache; a.positions = positions; a.eps = rms_eps; a.slot_desc = slot_desc;
-  if (use_split)
+  if (use_split) {
+    a.merge_counters = merge_counters; a.o_indptr = split_o_indptr;
     return launch_decode<128, true, true>(a, split_o_indptr, batch_size, split_slots, as_stream(stream));
+  }
   return launch_decode<128, false, true>(a, nullptr, batch_size, batch_size, as_stream(stream));
 }
 

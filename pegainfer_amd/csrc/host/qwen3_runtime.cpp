@@ -94,6 +94,12 @@ struct Model {
   float* split_tmp_s = nullptr;
   int32_t* tokens_out_d = nullptr;
   uint8_t* top1_state = nullptr;
+  // PEGAINFER_FUSED_MERGE=1: the split-KV partials are merged by the last workgroup of each (request, kv head)
+  // inside the attention launch instead of by merge_states_kernel.  Same bits; measured a wash on MI355X
+  // (2.418 vs 2.426 ms/step: the write-through publish + ticket + cross-XCD reads cost what the launch did),
+  // so the default keeps the separate launch, which cannot leave a counter armed if a launch is aborted.
+  bool fused_merge = [] { const char* e = getenv("PEGAINFER_FUSED_MERGE"); return e && e[0] == '1'; }();
+  int32_t* merge_ctr = nullptr;  // per (request, kv head) arrival counters of the in-kernel split-KV merge
   // sampling scratch (ops/sampling.rs)
   float* probs_scratch = nullptr;
   Half* top1_value = nullptr;
@@ -181,7 +187,7 @@ struct Model {
         dalloc(&mlp_act, bs * I) || dalloc(&mlp_out, bs * H) || dalloc(&hidden, bs * H) ||
         dalloc(&hidden2, bs * H) || dalloc(&qkv_out, bs * (size_t)(q_dim + 2 * kv_dim)) ||
         dalloc(&logits, bs * (size_t)V) || dalloc(&split_tmp_v, slots * q_dim) || dalloc(&split_tmp_s, slots * Hq) ||
-        dalloc(&tokens_out_d, bs) || dalloc(&top1_state, bs * 16) || dalloc(&probs_scratch, (size_t)V) ||
+        dalloc(&tokens_out_d, bs) || dalloc(&top1_state, bs * 16) || dalloc(&merge_ctr, bs * (size_t)Hkv) || dalloc(&probs_scratch, (size_t)V) ||
         dalloc(&top1_value, 1) || dalloc(&row_states, 1024 * 1024) || dalloc(&valid_scratch, 1) ||
         dalloc(&sample_out_d, 1))
       return -1;
@@ -396,7 +402,8 @@ struct Model {
             ly.k_norm, cos, sin, eps, split ? 1 : 0, md<int32_t>(ml.split_request_indices),
             md<int32_t>(ml.split_kv_tile_indices), md<int32_t>(ml.split_kv_chunk_size),
             md<int32_t>(ml.split_o_indptr), md<uint8_t>(ml.split_valid), split_tmp_v, split_tmp_s, Hq, Hkv, D,
-            layout.page_size, bs, split_slots, layout.page_stride, sm, md<int32_t>(ml.slot_desc), S());
+            layout.page_size, bs, split_slots, layout.page_stride, sm, md<int32_t>(ml.slot_desc),
+            fused_merge ? merge_ctr : nullptr, S());
       if (!rc) rc = pegainfer_gemv_fused(ly.o, attn_out, attn_proj, H, bs, q_dim, nullptr, nullptr, nullptr, 0.f, 0, S());
       if (!rc) rc = all_reduce_hidden(attn_proj, (size_t)bs * H);
       if (!rc) {

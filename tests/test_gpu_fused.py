@@ -127,7 +127,7 @@ def test_fused_decode_attention_matches_unfused(built_libs, lens, split):
         d["pages"].data_ptr(), d["indptr"].data_ptr(), d["last"].data_ptr(), d["pos"].data_ptr(), d["qw"].data_ptr(),
         d["kw"].data_ptr(), d["cos"].data_ptr(), d["sin"].data_ptr(), 1e-6, int(split), d["sri"].data_ptr(),
         d["skt"].data_ptr(), d["skc"].data_ptr(), d["soi"].data_ptr(), d["sva"].data_ptr(), tmp_v.data_ptr(),
-        tmp_s.data_ptr(), Hq, Hkv, D, 16, bs, slots, Lk.page_stride, 1.0 / np.sqrt(128.0), None,
+        tmp_s.data_ptr(), Hq, Hkv, D, 16, bs, slots, Lk.page_stride, 1.0 / np.sqrt(128.0), None, None,
         torch.cuda.current_stream().cuda_stream)
     assert rc == 0
     assert np.array_equal(bf16_bits(from_dev(kv_b)), bf16_bits(from_dev(kv_a)))
@@ -151,11 +151,29 @@ def test_fused_decode_attention_matches_unfused(built_libs, lens, split):
         d["pages"].data_ptr(), d["indptr"].data_ptr(), d["last"].data_ptr(), d["pos"].data_ptr(), d["qw"].data_ptr(),
         d["kw"].data_ptr(), d["cos"].data_ptr(), d["sin"].data_ptr(), 1e-6, int(split), d["sri"].data_ptr(),
         d["skt"].data_ptr(), d["skc"].data_ptr(), d["soi"].data_ptr(), d["sva"].data_ptr(), tmp_v.data_ptr(),
-        tmp_s.data_ptr(), Hq, Hkv, D, 16, bs, slots, Lk.page_stride, 1.0 / np.sqrt(128.0), dd.data_ptr(),
+        tmp_s.data_ptr(), Hq, Hkv, D, 16, bs, slots, Lk.page_stride, 1.0 / np.sqrt(128.0), dd.data_ptr(), None,
         torch.cuda.current_stream().cuda_stream)
     assert rc == 0
     assert np.array_equal(bf16_bits(from_dev(kv_c)), bf16_bits(from_dev(kv_a)))
     assert np.array_equal(bf16_bits(from_dev(out_c)), bf16_bits(from_dev(out_a)))
+    # ---- partials merged by the last workgroup of each (request, kv head) instead of a merge launch: same bits,
+    #      counters re-armed (run twice on the same counters) ----
+    if split:
+        ctr = torch.zeros(bs * Hkv, dtype=torch.int32, device="cuda")
+        for _ in range(2):
+            kv_d = to_dev(kv)
+            out_d = torch.zeros_like(out_a)
+            rc = ffi.lib().pegainfer_fused_decode_attention(
+                qkvd.data_ptr(), out_d.data_ptr(), kv_d.data_ptr(), Lk.layer_stride, Lk.layer_stride + Lk.kv_block_len,
+                d["pages"].data_ptr(), d["indptr"].data_ptr(), d["last"].data_ptr(), d["pos"].data_ptr(),
+                d["qw"].data_ptr(), d["kw"].data_ptr(), d["cos"].data_ptr(), d["sin"].data_ptr(), 1e-6, 1,
+                d["sri"].data_ptr(), d["skt"].data_ptr(), d["skc"].data_ptr(), d["soi"].data_ptr(), d["sva"].data_ptr(),
+                tmp_v.data_ptr(), tmp_s.data_ptr(), Hq, Hkv, D, 16, bs, slots, Lk.page_stride, 1.0 / np.sqrt(128.0),
+                dd.data_ptr(), ctr.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            assert rc == 0
+            assert np.array_equal(bf16_bits(from_dev(kv_d)), bf16_bits(from_dev(kv_a)))
+            assert np.array_equal(bf16_bits(from_dev(out_d)), bf16_bits(from_dev(out_a)))
+            assert int(ctr.abs().sum().item()) == 0
 
 
 @pytest.mark.parametrize("split_policy", [0, 1])
