@@ -97,6 +97,19 @@ void conv1d_prefill_cuda(const Half* x_seq, const Half* conv_weight, Half* conv_
 int32_t paged_attention_decode_cuda_hd256(const Half* q, Half* output, const Half* kv_data, int64_t k_offset_elems, int64_t v_offset_elems, const int32_t* page_indices, const int32_t* page_indptr, const int32_t* last_page_len_d, const int32_t* request_indices, const int32_t* kv_tile_indices, const int32_t* kv_chunk_size_ptr, int32_t num_qo_heads, int32_t num_kv_heads, int32_t head_dim, int32_t page_size, int32_t batch_size, int64_t stride_page, float sm_scale, pegainfer_stream_t stream);
 int32_t batch_prefill_paged_cuda_hd256(const Half* q, Half* output, const Half* kv_data, int64_t k_offset_elems, int64_t v_offset_elems, const int32_t* page_indices, const int32_t* page_indptr, const int32_t* last_page_len_d, const int32_t* q_indptr, const int32_t* request_indices, const int32_t* qo_tile_indices, const int32_t* kv_tile_indices, const int32_t* kv_chunk_size_ptr, const uint32_t* total_num_rows, int32_t num_qo_heads, int32_t num_kv_heads, int32_t head_dim, int32_t page_size, int32_t seq_len, int32_t batch_size, int32_t padded_batch_size, int64_t stride_page, float sm_scale, pegainfer_stream_t stream);
 
+/* ---- Qwen3.5 gated delta rule, chunk-wise prefill (ffi.rs:1041-1137; Triton-AOT in the reference, source
+ * tools/triton/gated_delta_rule_chunkwise_kernels.py).  Fixed chunk 64, key_dim = value_dim = 128.  Token-major:
+ * q,k,w [T,H,128] bf16; v,u,v_new,output [T,H,128] bf16; g,beta [T,H] f32; a_tril [T,H,64] f32; a_inv [T,H,64]
+ * bf16; state [H,K,V] f32 (V contiguous); chunk_state [ceil(T/64),H,K,V] f32.  Operator order:
+ * recurrent.rs:368-470.  CUresult-style status. ---- */
+pegainfer_status_t gated_delta_rule_prefill_chunk_prepare_cuda(const Half* qkv, const Half* b_proj, const Half* a_proj, const Half* dt_bias, const float* a_log, Half* q_out, Half* k_out, Half* v_out, float* g_out, float* beta_out, int32_t num_key_heads, int32_t num_value_heads, int32_t qkv_dim, int32_t seq_len, pegainfer_stream_t stream);
+pegainfer_status_t gated_delta_rule_prefill_chunk_cumsum_cuda(const float* g_in, float* g_out, int32_t seq_len, int32_t num_value_heads, pegainfer_stream_t stream);
+pegainfer_status_t gated_delta_rule_prefill_chunk_a_cuda(const Half* k, const float* g_cumsum, const float* beta, float* a_tril, int32_t seq_len, int32_t num_value_heads, pegainfer_stream_t stream);
+pegainfer_status_t gated_delta_rule_prefill_chunk_solve_cuda(const float* a_tril, Half* a_inv, int32_t seq_len, int32_t num_value_heads, pegainfer_stream_t stream);
+pegainfer_status_t gated_delta_rule_prefill_chunk_recompute_cuda(const Half* k, const Half* v, const float* beta, Half* w, Half* u, const Half* a_inv, const float* g_cumsum, int32_t seq_len, int32_t num_value_heads, pegainfer_stream_t stream);
+pegainfer_status_t gated_delta_rule_prefill_chunk_state_cuda(const Half* k, const Half* w, const Half* u, const float* g_cumsum, const float* initial_state, float* chunk_state, Half* v_new, float* final_state, int32_t seq_len, int32_t num_value_heads, pegainfer_stream_t stream);
+pegainfer_status_t gated_delta_rule_prefill_chunk_o_cuda(const Half* q, const Half* k, const Half* v_new, const float* chunk_state, const float* g_cumsum, Half* output, int32_t seq_len, int32_t num_value_heads, float scale, pegainfer_stream_t stream);
+
 /* ---- sampling (ffi.rs:98-120) ---- */
 void argmax_cuda(const Half* x, int32_t* out, int32_t n, pegainfer_stream_t stream);
 void flashinfer_top1_cuda(const Half* logits, Half* top1_value_scratch, uint8_t* row_states_scratch, int32_t* output, int32_t vocab_size, pegainfer_stream_t stream);

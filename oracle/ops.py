@@ -560,3 +560,153 @@ def attention_gate_hd256(q_full, attn_out, num_q_heads):
     gate = q_full.reshape(T, num_q_heads, 2, 256)[:, :, 1, :].reshape(T, -1).astype(F32)
     sig = (F32(1.0) / (F32(1.0) + np.exp(-gate, dtype=F32))).astype(F32)
     return bf16_round(attn_out.astype(F32) * sig)
+
+
+# --------------------------------------------------------------------------
+# Qwen3.5 gated delta rule, chunk-wise prefill (7 stages; chunk 64)
+# Follows pegainfer-kernels/tools/triton/gated_delta_rule_chunkwise_kernels.py (the Triton-AOT kernels behind
+# ffi.rs gated_delta_rule_prefill_chunk_*_cuda) stage by stage, with its bf16 rounding points, and the
+# operator order of pegainfer-qwen35-4b/src/recurrent.rs:368-470.  Matrix products accumulate in float64
+# here (the GPU accumulates in fp32: parity by tolerance).
+# --------------------------------------------------------------------------
+GDR_CHUNK = 64
+
+
+def gdr_chunk_prepare(qkv, b_proj, a_proj, dt_bias, A_log, num_key_heads, num_value_heads, key_dim, val_dim):
+    """(kernels.py:29-84)  qkv [T, 2*kh*K + vh*V]; returns q,k [T, vh, K] bf16 (L2-normalised, head-expanded),
+    v [T, vh, V] (raw), g [T, vh] f32 (= -exp(A_log)*softplus(a+dt_bias)), beta [T, vh] f32 (= sigmoid(b))."""
+    T = qkv.shape[0]
+    qk_total = num_key_heads * key_dim
+    kh_of = (np.arange(num_value_heads) * num_key_heads) // num_value_heads
+    q_src = qkv[:, :qk_total].reshape(T, num_key_heads, key_dim).astype(F32)[:, kh_of]
+    k_src = qkv[:, qk_total:2 * qk_total].reshape(T, num_key_heads, key_dim).astype(F32)[:, kh_of]
+    v = qkv[:, 2 * qk_total:].reshape(T, num_value_heads, val_dim).astype(F32).copy()
+
+    def l2(x):
+        ss = (x.astype(np.float64) ** 2).sum(-1, keepdims=True)
+        return bf16_round((x * (1.0 / np.sqrt(ss + 1e-12))).astype(F32))
+
+    x = a_proj.astype(F32) + dt_bias.astype(F32)[None, :]
+    with np.errstate(over="ignore"):
+        softplus = np.where(x > 20.0, x, np.log1p(np.exp(x.astype(np.float64)))).astype(F32)
+    g = (-np.exp(A_log.astype(F32))[None, :] * softplus).astype(F32)
+    beta = (1.0 / (1.0 + np.exp(-b_proj.astype(np.float64)))).astype(F32)
+    return l2(q_src), l2(k_src), v, g, beta
+
+
+def gdr_chunk_cumsum(g):
+    """Chunk-local inclusive prefix sum over tokens (kernels.py:143-159).  g [T, vh] f32."""
+    out = np.empty_like(g, dtype=F32)
+    for c0 in range(0, g.shape[0], GDR_CHUNK):
+        out[c0:c0 + GDR_CHUNK] = np.cumsum(g[c0:c0 + GDR_CHUNK].astype(np.float64), axis=0).astype(F32)
+    return out
+
+
+def gdr_chunk_a(k, g_cumsum, beta):
+    """A[t, h, j] = beta_t * exp(g_t - g_j) * <k_t, k_j> for j < t inside the chunk, else 0 (kernels.py:162-215).
+    k [T, vh, K] -> a_tril [T, vh, 64] f32."""
+    T, H, _ = k.shape
+    A = np.zeros((T, H, GDR_CHUNK), dtype=F32)
+    for c0 in range(0, T, GDR_CHUNK):
+        n = min(GDR_CHUNK, T - c0)
+        for h in range(H):
+            kc = k[c0:c0 + n, h].astype(np.float64)
+            gc = g_cumsum[c0:c0 + n, h].astype(np.float64)
+            a = (kc @ kc.T) * beta[c0:c0 + n, h].astype(np.float64)[:, None] * np.exp(gc[:, None] - gc[None, :])
+            A[c0:c0 + n, h, :n] = np.tril(a, -1).astype(F32)
+    return A
+
+
+def gdr_chunk_solve(a_tril):
+    """A_inv = (I + A)^-1 per (chunk, head), rounded to bf16 (kernels.py:218-330).  Rows of a partial last chunk
+    beyond seq_len do not exist; columns beyond the chunk length are zero."""
+    T, H, _ = a_tril.shape
+    out = np.zeros((T, H, GDR_CHUNK), dtype=F32)
+    for c0 in range(0, T, GDR_CHUNK):
+        n = min(GDR_CHUNK, T - c0)
+        for h in range(H):
+            M = np.eye(n) + a_tril[c0:c0 + n, h, :n].astype(np.float64)
+            out[c0:c0 + n, h, :n] = bf16_round(np.linalg.inv(M).astype(F32))
+    return out
+
+
+def gdr_chunk_recompute(k, v, beta, a_inv, g_cumsum):
+    """u = A_inv @ bf16(v * bf16(beta)), w = A_inv @ bf16(bf16(k * bf16(beta)) * bf16(exp(g)))  (kernels.py:333-430).
+    Returns (w [T, vh, K], u [T, vh, V]) bf16."""
+    T, H, _ = k.shape
+    w = np.zeros_like(k, dtype=F32)
+    u = np.zeros_like(v, dtype=F32)
+    for c0 in range(0, T, GDR_CHUNK):
+        n = min(GDR_CHUNK, T - c0)
+        for h in range(H):
+            ai = a_inv[c0:c0 + n, h, :n].astype(np.float64)
+            bb = bf16_round(beta[c0:c0 + n, h].astype(F32))[:, None]
+            eg = bf16_round(np.exp(g_cumsum[c0:c0 + n, h].astype(F32)))[:, None]
+            vb = bf16_round(v[c0:c0 + n, h].astype(F32) * bb)
+            kb = bf16_round(bf16_round(k[c0:c0 + n, h].astype(F32) * bb) * eg)
+            u[c0:c0 + n, h] = bf16_round((ai @ vb.astype(np.float64)).astype(F32))
+            w[c0:c0 + n, h] = bf16_round((ai @ kb.astype(np.float64)).astype(F32))
+    return w, u
+
+
+def gdr_chunk_state(k, w, u, g_cumsum, state):
+    """Sequential over chunks (kernels.py:433-600): snapshot h; v_new = u - w @ bf16(h); store bf16(v_new);
+    h = h*exp(g_last) + k^T @ bf16(v_new * exp(g_last - g)).  state [vh, K, V] f32.
+    Returns (chunk_state [nchunks, vh, K, V] f32, v_new [T, vh, V] bf16, final_state)."""
+    T, H, K = k.shape
+    V = u.shape[2]
+    nchunks = (T + GDR_CHUNK - 1) // GDR_CHUNK
+    chunk_state = np.zeros((nchunks, H, K, V), dtype=F32)
+    v_new = np.zeros((T, H, V), dtype=F32)
+    h_all = state.astype(F32).copy()
+    for ci in range(nchunks):
+        c0 = ci * GDR_CHUNK
+        n = min(GDR_CHUNK, T - c0)
+        chunk_state[ci] = h_all
+        for h in range(H):
+            hh = h_all[h]
+            vn = u[c0:c0 + n, h].astype(np.float64) - w[c0:c0 + n, h].astype(np.float64) @ bf16_round(hh).astype(np.float64)
+            vn = vn.astype(F32)
+            v_new[c0:c0 + n, h] = bf16_round(vn)
+            gc = g_cumsum[c0:c0 + n, h].astype(F32)
+            g_last = gc[n - 1]
+            gate = np.exp(g_last - gc).astype(F32)
+            vg = bf16_round(vn * gate[:, None])
+            hh = (hh * np.exp(g_last).astype(F32)).astype(F32)
+            hh = (hh.astype(np.float64) + k[c0:c0 + n, h].astype(np.float64).T @ vg.astype(np.float64)).astype(F32)
+            h_all[h] = hh
+    return chunk_state, v_new, h_all
+
+
+def gdr_chunk_o(q, k, v_new, chunk_state, g_cumsum, scale):
+    """out = (exp(g) * (q @ bf16(h_chunk)) + bf16(tril(q k^T * exp(g_i - g_j))) @ v_new) * scale  (kernels.py:603-709).
+    Returns [T, vh*V] bf16."""
+    T, H, K = q.shape
+    V = v_new.shape[2]
+    out = np.zeros((T, H, V), dtype=F32)
+    for c0 in range(0, T, GDR_CHUNK):
+        n = min(GDR_CHUNK, T - c0)
+        ci = c0 // GDR_CHUNK
+        for h in range(H):
+            qc = q[c0:c0 + n, h].astype(np.float64)
+            kc = k[c0:c0 + n, h].astype(np.float64)
+            gc = g_cumsum[c0:c0 + n, h].astype(np.float64)
+            acc_o = (qc @ bf16_round(chunk_state[ci, h]).astype(np.float64)) * np.exp(gc)[:, None]
+            acc_a = np.tril((qc @ kc.T) * np.exp(gc[:, None] - gc[None, :]))
+            a_bf = bf16_round(acc_a.astype(F32)).astype(np.float64)
+            out[c0:c0 + n, h] = bf16_round(((acc_o + a_bf @ v_new[c0:c0 + n, h].astype(np.float64)) * scale).astype(F32))
+    return out.reshape(T, H * V)
+
+
+def gated_delta_rule_prefill_chunkwise(qkv, b_proj, a_proj, dt_bias, A_log, state, num_key_heads, num_value_heads,
+                                       key_dim, val_dim):
+    """The 7-stage operator (recurrent.rs:368-470).  Returns (out [T, vh*V] bf16, new_state [vh, K, V] f32)."""
+    q, k, v, g, beta = gdr_chunk_prepare(qkv, b_proj, a_proj, dt_bias, A_log, num_key_heads, num_value_heads,
+                                         key_dim, val_dim)
+    gc = gdr_chunk_cumsum(g)
+    a_tril = gdr_chunk_a(k, gc, beta)
+    a_inv = gdr_chunk_solve(a_tril)
+    w, u = gdr_chunk_recompute(k, v, beta, a_inv, gc)
+    chunk_state, v_new, final_state = gdr_chunk_state(k, w, u, gc, state)
+    out = gdr_chunk_o(q, k, v_new, chunk_state, gc, 1.0 / np.sqrt(float(key_dim)))
+    return out, final_state

@@ -318,3 +318,52 @@ def gpu_sample(logits, probs_scratch, top1_value_scratch, row_states_scratch, te
     out = torch.zeros(1, dtype=torch.int32, device=logits.device)
     return gpu_sample_into(logits, probs_scratch, top1_value_scratch, row_states_scratch, valid, out,
                            temperature, top_k, top_p, random_val)
+
+
+# ------------------------------------------------------------------ Qwen3.5 gated delta rule, chunk-wise prefill
+class GdrChunkwiseScratch35:
+    """Pre-allocated scratch of the 7-stage operator (pegainfer-qwen35-4b/src/prefill_buffers.rs:8-95)."""
+    CHUNK_SIZE = 64
+
+    def __init__(self, num_value_heads, key_dim, value_dim, seq_len, device="cuda"):
+        f32 = dict(dtype=torch.float32, device=device)
+        bf = dict(dtype=torch.bfloat16, device=device)
+        H, T, C = num_value_heads, seq_len, self.CHUNK_SIZE
+        self.num_chunks = (T + C - 1) // C
+        self.g_cumsum = torch.zeros(T * H, **f32)
+        self.beta = torch.zeros(T * H, **f32)
+        self.q_expanded = torch.zeros((T, H * key_dim), **bf)
+        self.k_expanded = torch.zeros((T, H * key_dim), **bf)
+        self.v_raw = torch.zeros((T, H * value_dim), **bf)
+        self.a_tril = torch.zeros(T * H * C, **f32)
+        self.a_inv = torch.zeros(T * H * C, **bf)
+        self.w = torch.zeros((T, H * key_dim), **bf)
+        self.u = torch.zeros((T, H * value_dim), **bf)
+        self.v_new = torch.zeros((T, H * value_dim), **bf)
+        self.chunk_state = torch.zeros(self.num_chunks * H * value_dim * key_dim, **f32)
+
+
+def gated_delta_rule_prefill_chunkwise_into(qkv, b_proj, a_proj, dt_bias, a_log, state, scratch, output,
+                                            num_key_heads, num_value_heads, key_dim, val_dim):
+    """recurrent.rs:368-470: prepare -> cumsum (in place) -> a -> solve -> recompute -> state -> o."""
+    L, s, st = ffi.lib(), scratch, _stream()
+    T = qkv.shape[0]
+    assert key_dim == 128 and val_dim == 128 and output.shape == (T, num_value_heads * val_dim)
+    assert s.q_expanded.shape == (T, num_value_heads * key_dim) and state.dtype == torch.float32
+    _chk(L.gated_delta_rule_prefill_chunk_prepare_cuda(
+        _p(qkv), _p(b_proj), _p(a_proj), _p(dt_bias), _p(a_log), _p(s.q_expanded), _p(s.k_expanded), _p(s.v_raw),
+        _p(s.g_cumsum), _p(s.beta), num_key_heads, num_value_heads, qkv.shape[1], T, st), "gdr prepare")
+    _chk(L.gated_delta_rule_prefill_chunk_cumsum_cuda(_p(s.g_cumsum), _p(s.g_cumsum), T, num_value_heads, st),
+         "gdr cumsum")
+    _chk(L.gated_delta_rule_prefill_chunk_a_cuda(_p(s.k_expanded), _p(s.g_cumsum), _p(s.beta), _p(s.a_tril), T,
+                                                 num_value_heads, st), "gdr a")
+    _chk(L.gated_delta_rule_prefill_chunk_solve_cuda(_p(s.a_tril), _p(s.a_inv), T, num_value_heads, st), "gdr solve")
+    _chk(L.gated_delta_rule_prefill_chunk_recompute_cuda(_p(s.k_expanded), _p(s.v_raw), _p(s.beta), _p(s.w), _p(s.u),
+                                                         _p(s.a_inv), _p(s.g_cumsum), T, num_value_heads, st),
+         "gdr recompute")
+    _chk(L.gated_delta_rule_prefill_chunk_state_cuda(_p(s.k_expanded), _p(s.w), _p(s.u), _p(s.g_cumsum), _p(state),
+                                                     _p(s.chunk_state), _p(s.v_new), _p(state), T, num_value_heads,
+                                                     st), "gdr state")
+    _chk(L.gated_delta_rule_prefill_chunk_o_cuda(_p(s.q_expanded), _p(s.k_expanded), _p(s.v_new), _p(s.chunk_state),
+                                                 _p(s.g_cumsum), _p(output), T, num_value_heads,
+                                                 1.0 / float(key_dim) ** 0.5, st), "gdr o")

@@ -165,3 +165,96 @@ def test_batch_prefill_paged_hd256(built_libs, seq_lens, starts):
     assert rc == 0
     ref = O.batch_prefill_paged(q, kv, lay, 1, pages, indptr, last, pl["q_indptr"], Hq, sm)
     assert np.abs(from_dev(out) - ref).max() <= 2 * attn_tol(ref)
+
+
+def _gdr_inputs(rng, T, kh, vh):
+    import torch
+    qkv = rnd(rng, T, 2 * kh * 128 + vh * 128)
+    b, a, dtb = rnd(rng, T, vh), rnd(rng, T, vh), rnd(rng, vh, scale=0.5)
+    alog = (rng.standard_normal(vh) * 0.5).astype(np.float32)
+    state = (rng.standard_normal((vh, 128, 128)) * 0.1).astype(np.float32)
+    return qkv, b, a, dtb, alog, state
+
+
+@pytest.mark.parametrize("T,kh,vh", [(64, 2, 4), (150, 2, 4), (1, 1, 2), (333, 16, 32)])
+def test_gdr_chunkwise_prefill_stages_and_operator(built_libs, T, kh, vh):
+    """The seven chunk-wise stages (ffi.rs:1041-1137) against the oracle restatement of the Triton kernels, stage by
+    stage on the oracle's own inputs (so one stage's rounding noise is not amplified by the next), then the whole
+    operator, then chunk-wise == token-by-token decode recurrence (the property the reference relies on when a
+    prefilled state is handed to decode).  Tolerances: fp32 stages 1e-5 relative; bf16 outputs 2^-7 of the tensor's
+    max (the GPU accumulates in fp32, the oracle in fp64, both round at the same points)."""
+    import torch
+    import pegainfer_amd.ops as P
+    from pegainfer_amd import ffi
+    L = ffi.lib()
+    rng = np.random.default_rng(T * 7 + vh)
+    qkv, b, a, dtb, alog, state = _gdr_inputs(rng, T, kh, vh)
+    f32d = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).cuda()
+    bfd = lambda x: to_dev(np.ascontiguousarray(x).reshape(x.shape[0], -1))
+    close = lambda got, ref, tol: np.abs(got - ref).max() <= tol * max(1e-6, np.abs(ref).max())
+    # oracle stages
+    q, k, v, g, beta = O.gdr_chunk_prepare(qkv, b, a, dtb, alog, kh, vh, 128, 128)
+    gc = O.gdr_chunk_cumsum(g)
+    A = O.gdr_chunk_a(k, gc, beta)
+    Ai = O.gdr_chunk_solve(A)
+    w, u = O.gdr_chunk_recompute(k, v, beta, Ai, gc)
+    cs, vn, fs = O.gdr_chunk_state(k, w, u, gc, state)
+    out = O.gdr_chunk_o(q, k, vn, cs, gc, 1.0 / np.sqrt(128.0))
+    sc = P.GdrChunkwiseScratch35(vh, 128, 128, T)
+    qkvd, bd, ad, dd, ald = to_dev(qkv), to_dev(b), to_dev(a), to_dev(dtb), f32d(alog)
+    # 1 prepare
+    assert L.gated_delta_rule_prefill_chunk_prepare_cuda(
+        qkvd.data_ptr(), bd.data_ptr(), ad.data_ptr(), dd.data_ptr(), ald.data_ptr(), sc.q_expanded.data_ptr(),
+        sc.k_expanded.data_ptr(), sc.v_raw.data_ptr(), sc.g_cumsum.data_ptr(), sc.beta.data_ptr(), kh, vh,
+        qkv.shape[1], T, S()) == 0
+    assert bf16_ulp_diff(from_dev(sc.q_expanded), q.reshape(T, -1)) <= 1
+    assert bf16_ulp_diff(from_dev(sc.k_expanded), k.reshape(T, -1)) <= 1
+    assert np.array_equal(bf16_bits(from_dev(sc.v_raw)), bf16_bits(v.reshape(T, -1)))
+    assert close(sc.g_cumsum.cpu().numpy().reshape(T, vh), g, 1e-5)
+    assert close(sc.beta.cpu().numpy().reshape(T, vh), beta, 1e-5)
+    # 2 cumsum (in place, like recurrent.rs:165-183)
+    gd = f32d(g)
+    assert L.gated_delta_rule_prefill_chunk_cumsum_cuda(gd.data_ptr(), gd.data_ptr(), T, vh, S()) == 0
+    assert close(gd.cpu().numpy(), gc, 1e-5)
+    # 3 A
+    kd, gcd, betad = bfd(k), f32d(gc), f32d(beta)
+    assert L.gated_delta_rule_prefill_chunk_a_cuda(kd.data_ptr(), gcd.data_ptr(), betad.data_ptr(),
+                                                   sc.a_tril.data_ptr(), T, vh, S()) == 0
+    assert close(sc.a_tril.cpu().numpy().reshape(T, vh, 64), A, 1e-4)
+    # 4 solve
+    Ad = f32d(A)
+    assert L.gated_delta_rule_prefill_chunk_solve_cuda(Ad.data_ptr(), sc.a_inv.data_ptr(), T, vh, S()) == 0
+    got_ai = from_dev(sc.a_inv).reshape(T, vh, 64)
+    assert close(got_ai, Ai, 2.0 ** -7)
+    # 5 recompute
+    vd_, aid = bfd(v), bfd(Ai)
+    assert L.gated_delta_rule_prefill_chunk_recompute_cuda(kd.data_ptr(), vd_.data_ptr(), betad.data_ptr(),
+                                                           sc.w.data_ptr(), sc.u.data_ptr(), aid.data_ptr(),
+                                                           gcd.data_ptr(), T, vh, S()) == 0
+    assert close(from_dev(sc.w), w.reshape(T, -1), 2.0 ** -7) and close(from_dev(sc.u), u.reshape(T, -1), 2.0 ** -7)
+    # 6 state (in place on the state buffer, recurrent.rs:290-330)
+    wd, ud, std = bfd(w), bfd(u), f32d(state)
+    assert L.gated_delta_rule_prefill_chunk_state_cuda(kd.data_ptr(), wd.data_ptr(), ud.data_ptr(), gcd.data_ptr(),
+                                                       std.data_ptr(), sc.chunk_state.data_ptr(),
+                                                       sc.v_new.data_ptr(), std.data_ptr(), T, vh, S()) == 0
+    assert close(from_dev(sc.v_new), vn.reshape(T, -1), 2.0 ** -6)
+    assert close(sc.chunk_state.cpu().numpy().reshape(cs.shape), cs, 2.0 ** -6)
+    assert close(std.cpu().numpy(), fs, 2.0 ** -6)
+    # 7 output
+    qd, vnd, csd = bfd(q), bfd(vn), f32d(cs)
+    outd = torch.zeros((T, vh * 128), dtype=torch.bfloat16, device="cuda")
+    assert L.gated_delta_rule_prefill_chunk_o_cuda(qd.data_ptr(), kd.data_ptr(), vnd.data_ptr(), csd.data_ptr(),
+                                                   gcd.data_ptr(), outd.data_ptr(), T, vh,
+                                                   1.0 / float(np.sqrt(128.0)), S()) == 0
+    assert close(from_dev(outd), out, 2.0 ** -6)
+    # whole operator through the Rust-shaped wrapper, vs the oracle operator and vs the decode recurrence
+    std2 = f32d(state)
+    out2 = torch.zeros((T, vh * 128), dtype=torch.bfloat16, device="cuda")
+    P.gated_delta_rule_prefill_chunkwise_into(qkvd, bd, ad, dd, ald, std2, sc, out2, kh, vh, 128, 128)
+    assert close(from_dev(out2), out, 2.0 ** -5) and close(std2.cpu().numpy(), fs, 2.0 ** -5)
+    if T <= 150:
+        s_seq, rows = state.copy(), []
+        for i in range(T):
+            o, s_seq = O.gated_delta_rule_decode(qkv[i], b[i], a[i], dtb, alog, s_seq, kh, vh, 128, 128)
+            rows.append(o)
+        assert close(from_dev(out2), np.stack(rows), 2.0 ** -4) and close(std2.cpu().numpy(), s_seq, 2.0 ** -4)
