@@ -1,0 +1,61 @@
+/*
+ * pegainfer_qwen35.h - C ABI of the Qwen3.5 hybrid (linear + full attention) host runtime inside
+ * libpegainfer_qwen3.so.  Mirrors, for the forward pass only:
+ *
+ *   pegainfer-qwen35-4b/src/config.rs            -> the create() arguments
+ *   pegainfer-qwen35-4b/src/weights.rs:102-296   -> tensor names (prefix model.language_model), f32 A_log / norm
+ *   pegainfer-qwen35-4b/src/recurrent_state.rs   -> per-request conv_state (bf16) + GDR state (f32) per linear layer
+ *   pegainfer-qwen35-4b/src/prefill.rs:21-449    -> prefill (one request per call, chunk-wise GDR, HD256 paged attn)
+ *   pegainfer-qwen35-4b/src/batch_decode.rs      -> batched decode with per-slot recurrent updates
+ *   pegainfer-qwen35-4b/src/batch_decode_graph.rs-> hipGraph replay of the decode step
+ *
+ * Scheduler / sampling params / tokenizer are out of scope.  0 on success, negative on error.
+ */
+#ifndef PEGAINFER_QWEN35_H
+#define PEGAINFER_QWEN35_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* pegainfer_qwen35_t;
+
+/* layer_is_full[num_layers]: 1 = full attention layer, 0 = linear attention (config.rs layer_types).
+ * linear key_dim = value_dim = 128 (the chunk-wise kernels' fixed shape).  enable_graph: capture the decode step
+ * (re-captured when the set of request ids in the batch changes - the recurrent state addresses are per request). */
+pegainfer_qwen35_t pegainfer_qwen35_create(int32_t device_ordinal, int32_t hidden_size, int32_t intermediate_size,
+                                           int32_t num_layers, int32_t vocab_size, int32_t num_attention_heads,
+                                           int32_t num_kv_heads, int32_t head_dim, int32_t linear_num_key_heads,
+                                           int32_t linear_num_value_heads, int32_t linear_conv_kernel_dim,
+                                           float rms_norm_eps, float rope_theta, int32_t rotary_dim,
+                                           const int32_t* layer_is_full, int32_t max_position_embeddings,
+                                           int32_t num_kv_pages, int32_t max_batch_size, int32_t enable_graph);
+void pegainfer_qwen35_destroy(pegainfer_qwen35_t m);
+const char* pegainfer_qwen35_last_error(pegainfer_qwen35_t m);
+
+/* is_f32 = 1 for ...linear_attn.A_log and ...linear_attn.norm.weight (host float32), else host bf16 bits */
+int32_t pegainfer_qwen35_load_tensor(pegainfer_qwen35_t m, const char* name, const void* host, int64_t numel,
+                                     int32_t is_f32);
+int32_t pegainfer_qwen35_fill_synthetic(pegainfer_qwen35_t m, uint64_t seed, float std);
+int32_t pegainfer_qwen35_finalize(pegainfer_qwen35_t m);
+
+int32_t pegainfer_qwen35_new_request(pegainfer_qwen35_t m);
+int32_t pegainfer_qwen35_drop_request(pegainfer_qwen35_t m, int32_t request_id);
+int32_t pegainfer_qwen35_request_seq_len(pegainfer_qwen35_t m, int32_t request_id);
+
+/* prefill_forward (prefill.rs:21-120): appends n_tokens to the request (recurrent + conv state carried over),
+ * returns the greedy token of the last position and optionally its logits (bf16 bits [vocab]). */
+int32_t pegainfer_qwen35_prefill(pegainfer_qwen35_t m, int32_t request_id, int32_t n_tokens, const uint32_t* tokens,
+                                 int32_t* out_token, void* out_logits_host);
+/* batch_decode_graph (batch_decode.rs:113-196): one token per request; greedy tokens + optional logits [n, vocab] */
+int32_t pegainfer_qwen35_decode(pegainfer_qwen35_t m, int32_t n_requests, const int32_t* request_ids,
+                                const uint32_t* token_ids, int32_t* out_tokens, void* out_logits_host);
+float pegainfer_qwen35_last_step_ms(pegainfer_qwen35_t m);
+int64_t pegainfer_qwen35_weight_bytes(pegainfer_qwen35_t m);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PEGAINFER_QWEN35_H */

@@ -1,0 +1,663 @@
+// C++ host runtime for the Qwen3.5 hybrid forward pass on MI355X (include/pegainfer_qwen35.h lists the reference
+// files each piece mirrors).  Same shape as the Qwen3 runtime: one model = one device + one in-order HIP stream,
+// every op goes through the C ABI of libpegainfer_kernels_hip.so in the reference's order
+// (prefill.rs:121-449, batch_decode.rs:43-365), decode metadata travels as ONE pinned block, and the decode
+// step is captured into a hipGraph.  The linear-attention layers own per-request state (conv window + fp32
+// delta-rule matrix), so the graph is keyed by the list of request ids and re-captured when it changes.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kv_pool.h"
+#include "pegainfer_kernels.h"
+#include "pegainfer_kernels_ext.h"
+#include "pegainfer_qwen35.h"
+
+namespace pq35 {
+
+using pq::KvLayout;
+using pq::KvState;
+using pq::PagePool;
+
+#define P35_HIP(expr)                                                                        \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess) {                                                                  \
+      set_error(std::string(#expr) + ": " + hipGetErrorString(e_));                          \
+      return -1;                                                                             \
+    }                                                                                        \
+  } while (0)
+
+static inline uint16_t host_f2bf(float f) {
+  uint32_t u;
+  std::memcpy(&u, &f, 4);
+  if ((u & 0x7FFFFFFFu) > 0x7F800000u) return 0x7FC0;
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return static_cast<uint16_t>(u >> 16);
+}
+
+template <typename T>
+static __global__ void fill_normal35_kernel(T* out, long n, uint64_t seed, float std, float mean) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    uint64_t z = (uint64_t)i * 0x9E3779B97F4A7C15ull + seed;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    const float u1 = ((float)(z >> 40) + 1.0f) * (1.0f / 16777217.0f);
+    const float u2 = (float)((z >> 16) & 0xFFFFFF) * (1.0f / 16777216.0f);
+    const float g = mean + std * sqrtf(-2.0f * logf(u1)) * cosf(6.2831853f * u2);
+    if constexpr (sizeof(T) == 2) out[i] = __builtin_bit_cast(uint16_t, static_cast<__bf16>(g));
+    else out[i] = g;
+  }
+}
+
+constexpr int LK = 128;  // linear key_dim == value_dim (fixed by the chunk-wise kernels)
+
+struct Layer35 {
+  bool full = false;
+  Half *ln1 = nullptr, *ln2 = nullptr, *gate = nullptr, *up = nullptr, *down = nullptr;
+  Half *q_proj = nullptr, *k_proj = nullptr, *v_proj = nullptr, *o_proj = nullptr, *q_norm = nullptr, *k_norm = nullptr;
+  Half *in_qkv = nullptr, *in_z = nullptr, *in_b = nullptr, *in_a = nullptr, *conv_w = nullptr, *dt_bias = nullptr,
+       *out_proj = nullptr;
+  float *a_log = nullptr, *norm_w = nullptr;
+};
+
+struct Request35 {
+  KvState kv;
+  std::vector<Half*> conv;     // per linear layer [C * (K-1)] bf16
+  std::vector<float*> state;   // per linear layer [vh, 128, 128] f32
+  bool allocated = false;
+};
+
+struct Model35 {
+  int device, H, I, L, V, Hq, Hkv, D, kh, vh, convK, rotary, max_pos, num_pages, max_bs, enable_graph;
+  float eps, theta;
+  int q_dim, kv_dim, C, Z, n_full = 0, n_lin = 0;
+  std::string err;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::vector<Layer35> layers;
+  Half *embed = nullptr, *final_norm = nullptr, *cos = nullptr, *sin = nullptr;
+  std::vector<void*> owned;
+  int64_t weight_bytes = 0;
+  KvLayout layout;
+  PagePool pool;
+  Half* kv_buffer = nullptr;
+  std::vector<Request35> requests;
+  // decode buffers (decode_buffers.rs:22-140)
+  Half *hidden = nullptr, *hidden_mid = nullptr, *normed = nullptr, *attn_res = nullptr, *q_full = nullptr,
+       *q_attn = nullptr, *k_attn = nullptr, *v_attn = nullptr, *attn_out = nullptr, *qkv = nullptr,
+       *qkv_conv = nullptr, *z = nullptr, *b_proj = nullptr, *a_proj = nullptr, *gdr_out = nullptr,
+       *normed_gated = nullptr, *gate_out = nullptr, *up_out = nullptr, *act_out = nullptr, *mlp_out = nullptr,
+       *logits = nullptr;
+  int32_t* tokens_out_d = nullptr;
+  uint8_t* top1_state = nullptr;
+  int32_t* tokens_out_host = nullptr;
+  uint8_t *meta_host = nullptr, *meta_dev = nullptr;
+  size_t m_tok, m_pos, m_indptr, m_lpl, m_ri, m_kti, m_kcs, m_pages, m_total;
+  hipGraphExec_t graph = nullptr;
+  std::vector<int> graph_ids;
+  // prefill workspace (grow-only)
+  size_t pf_cap = 0;
+  std::vector<void*> pf_owned;
+  Half *pf_hidden = nullptr, *pf_mid = nullptr, *pf_normed = nullptr, *pf_attn_res = nullptr, *pf_big0 = nullptr,
+       *pf_big1 = nullptr, *pf_big2 = nullptr, *pf_q_prep = nullptr, *pf_k = nullptr, *pf_v = nullptr, *pf_kc = nullptr,
+       *pf_vc = nullptr, *pf_attn = nullptr, *pf_z = nullptr, *pf_b = nullptr, *pf_a = nullptr, *pf_gdr = nullptr;
+  // GDR chunk-wise scratch (prefill_buffers.rs)
+  float *g_cumsum = nullptr, *beta = nullptr, *a_tril = nullptr, *chunk_state = nullptr;
+  Half *q_exp = nullptr, *k_exp = nullptr, *v_raw = nullptr, *a_inv = nullptr, *w = nullptr, *u = nullptr, *v_new = nullptr;
+  uint8_t *pf_meta_dev = nullptr, *pf_meta_host = nullptr;
+  size_t pf_meta_cap = 0;
+  Half *pf_last = nullptr, *pf_last_normed = nullptr, *pf_logits = nullptr;
+  int32_t* start_pos_d = nullptr;
+  float last_step_ms = 0.f;
+
+  Model35(int dev, int h, int inter, int l, int v, int hq, int hkv, int d, int kh_, int vh_, int ck, float e, float th,
+          int rot, const int32_t* is_full, int mp, int pages, int mbs, int graph_)
+      : device(dev), H(h), I(inter), L(l), V(v), Hq(hq), Hkv(hkv), D(d), kh(kh_), vh(vh_), convK(ck), rotary(rot),
+        max_pos(mp), num_pages(pages), max_bs(mbs), enable_graph(graph_), eps(e), theta(th), q_dim(hq * d),
+        kv_dim(hkv * d), C(2 * kh_ * LK + vh_ * LK), Z(vh_ * LK), layout(1, hkv, d, 16), pool(pages) {
+    layers.resize(l);
+    for (int i = 0; i < l; ++i) {
+      layers[i].full = is_full[i] != 0;
+      (layers[i].full ? n_full : n_lin)++;
+    }
+    layout = KvLayout(n_full > 0 ? n_full : 1, hkv, d, 16);
+  }
+
+  void set_error(const std::string& s) { err = s; }
+  void* S() const { return reinterpret_cast<void*>(stream); }
+
+  template <typename T>
+  int dalloc(T** p, size_t count, bool zero = true, std::vector<void*>* owner = nullptr) {
+    void* raw = nullptr;
+    P35_HIP(hipMalloc(&raw, (count ? count : 1) * sizeof(T)));
+    if (zero) P35_HIP(hipMemsetAsync(raw, 0, (count ? count : 1) * sizeof(T), stream));
+    (owner ? owner : &owned)->push_back(raw);
+    *p = static_cast<T*>(raw);
+    return 0;
+  }
+
+  int init() {
+    if (D != 256) { set_error("Qwen3.5 full attention needs head_dim 256"); return -1; }
+    P35_HIP(hipSetDevice(device));
+    cublas_init();
+    P35_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    P35_HIP(hipEventCreate(&ev0));
+    P35_HIP(hipEventCreate(&ev1));
+    auto W = [&](Half** p, size_t n) { weight_bytes += (int64_t)n * 2; return dalloc(p, n, false); };
+    auto WF = [&](float** p, size_t n) { weight_bytes += (int64_t)n * 4; return dalloc(p, n, false); };
+    if (W(&embed, (size_t)V * H) || W(&final_norm, H)) return -1;
+    for (auto& ly : layers) {
+      if (W(&ly.ln1, H) || W(&ly.ln2, H) || W(&ly.gate, (size_t)I * H) || W(&ly.up, (size_t)I * H) ||
+          W(&ly.down, (size_t)H * I))
+        return -1;
+      if (ly.full) {
+        if (W(&ly.q_proj, (size_t)2 * q_dim * H) || W(&ly.k_proj, (size_t)kv_dim * H) ||
+            W(&ly.v_proj, (size_t)kv_dim * H) || W(&ly.o_proj, (size_t)H * q_dim) || W(&ly.q_norm, D) ||
+            W(&ly.k_norm, D))
+          return -1;
+      } else {
+        if (W(&ly.in_qkv, (size_t)C * H) || W(&ly.in_z, (size_t)Z * H) || W(&ly.in_b, (size_t)vh * H) ||
+            W(&ly.in_a, (size_t)vh * H) || W(&ly.conv_w, (size_t)C * convK) || W(&ly.dt_bias, vh) ||
+            W(&ly.out_proj, (size_t)H * Z) || WF(&ly.a_log, vh) || WF(&ly.norm_w, LK))
+          return -1;
+      }
+    }
+    if (dalloc(&cos, (size_t)max_pos * rotary, false) || dalloc(&sin, (size_t)max_pos * rotary, false)) return -1;
+    if (dalloc(&kv_buffer, (size_t)num_pages * layout.page_stride)) return -1;
+    std::vector<int32_t> pad;
+    if (!pool.acquire(1, &pad)) { set_error("pool must have at least 1 page"); return -1; }  // padding page 0
+    const size_t bs = max_bs;
+    if (dalloc(&hidden, bs * H) || dalloc(&hidden_mid, bs * H) || dalloc(&normed, bs * H) ||
+        dalloc(&attn_res, bs * H) || dalloc(&q_full, bs * 2 * q_dim) || dalloc(&q_attn, bs * q_dim) ||
+        dalloc(&k_attn, bs * kv_dim) || dalloc(&v_attn, bs * kv_dim) || dalloc(&attn_out, bs * q_dim) ||
+        dalloc(&qkv, bs * C) || dalloc(&qkv_conv, bs * C) || dalloc(&z, bs * Z) || dalloc(&b_proj, bs * vh) ||
+        dalloc(&a_proj, bs * vh) || dalloc(&gdr_out, bs * Z) || dalloc(&normed_gated, bs * Z) ||
+        dalloc(&gate_out, bs * I) || dalloc(&up_out, bs * I) || dalloc(&act_out, bs * I) ||
+        dalloc(&mlp_out, bs * H) || dalloc(&logits, bs * (size_t)V) || dalloc(&tokens_out_d, bs) ||
+        dalloc(&top1_state, bs * 16) || dalloc(&start_pos_d, 1) || dalloc(&pf_last, H) ||
+        dalloc(&pf_last_normed, H) || dalloc(&pf_logits, V))
+      return -1;
+    auto al = [](size_t x) { return (x + 63) & ~size_t(63); };
+    size_t off = 0;
+    m_tok = off; off = al(off + bs * 4);
+    m_pos = off; off = al(off + bs * 4);
+    m_indptr = off; off = al(off + (bs + 1) * 4);
+    m_lpl = off; off = al(off + bs * 4);
+    m_ri = off; off = al(off + bs * 4);
+    m_kti = off; off = al(off + bs * 4);
+    m_kcs = off; off = al(off + bs * 4);
+    m_pages = off; off = al(off + ((size_t)num_pages + bs) * 4);
+    m_total = off;
+    P35_HIP(hipHostMalloc(reinterpret_cast<void**>(&meta_host), m_total, hipHostMallocDefault));
+    std::memset(meta_host, 0, m_total);
+    if (dalloc(&meta_dev, m_total)) return -1;
+    P35_HIP(hipHostMalloc(reinterpret_cast<void**>(&tokens_out_host), bs * 4, hipHostMallocDefault));
+    P35_HIP(hipStreamSynchronize(stream));
+    return 0;
+  }
+
+  // ------------------------------------------------------------------ weights (weights.rs:118-296)
+  int load_tensor(const char* name_c, const void* host, int64_t numel, int is_f32) {
+    std::string name(name_c);
+    const std::string wp = "model.language_model.";
+    if (name.rfind(wp, 0) != 0) { set_error("tensor outside " + wp + ": " + name); return -1; }
+    name = name.substr(wp.size());
+    void* dst = nullptr;
+    int64_t expect = 0;
+    bool f32 = false;
+    auto set = [&](void* p, int64_t n, bool isf = false) { dst = p; expect = n; f32 = isf; };
+    if (name == "embed_tokens.weight") set(embed, (int64_t)V * H);
+    else if (name == "norm.weight") set(final_norm, H);
+    else if (name.rfind("layers.", 0) == 0) {
+      const size_t p0 = 7, p1 = name.find('.', p0);
+      const int li = std::stoi(name.substr(p0, p1 - p0));
+      if (li < 0 || li >= L) { set_error("layer index out of range: " + name); return -1; }
+      const std::string r = name.substr(p1 + 1);
+      Layer35& ly = layers[li];
+      if (r == "input_layernorm.weight") set(ly.ln1, H);
+      else if (r == "post_attention_layernorm.weight") set(ly.ln2, H);
+      else if (r == "mlp.gate_proj.weight") set(ly.gate, (int64_t)I * H);
+      else if (r == "mlp.up_proj.weight") set(ly.up, (int64_t)I * H);
+      else if (r == "mlp.down_proj.weight") set(ly.down, (int64_t)H * I);
+      else if (ly.full) {
+        if (r == "self_attn.q_proj.weight") set(ly.q_proj, (int64_t)2 * q_dim * H);
+        else if (r == "self_attn.k_proj.weight") set(ly.k_proj, (int64_t)kv_dim * H);
+        else if (r == "self_attn.v_proj.weight") set(ly.v_proj, (int64_t)kv_dim * H);
+        else if (r == "self_attn.o_proj.weight") set(ly.o_proj, (int64_t)H * q_dim);
+        else if (r == "self_attn.q_norm.weight") set(ly.q_norm, D);
+        else if (r == "self_attn.k_norm.weight") set(ly.k_norm, D);
+      } else {
+        if (r == "linear_attn.in_proj_qkv.weight") set(ly.in_qkv, (int64_t)C * H);
+        else if (r == "linear_attn.in_proj_z.weight") set(ly.in_z, (int64_t)Z * H);
+        else if (r == "linear_attn.in_proj_b.weight") set(ly.in_b, (int64_t)vh * H);
+        else if (r == "linear_attn.in_proj_a.weight") set(ly.in_a, (int64_t)vh * H);
+        else if (r == "linear_attn.conv1d.weight") set(ly.conv_w, (int64_t)C * convK);
+        else if (r == "linear_attn.dt_bias") set(ly.dt_bias, vh);
+        else if (r == "linear_attn.A_log") set(ly.a_log, vh, true);
+        else if (r == "linear_attn.norm.weight") set(ly.norm_w, LK, true);
+        else if (r == "linear_attn.out_proj.weight") set(ly.out_proj, (int64_t)H * Z);
+      }
+    }
+    if (!dst) { set_error("unknown tensor name: " + std::string(name_c)); return -1; }
+    if (numel != expect || (is_f32 != 0) != f32) { set_error("shape/dtype mismatch for " + std::string(name_c)); return -1; }
+    P35_HIP(hipMemcpy(dst, host, (size_t)numel * (f32 ? 4 : 2), hipMemcpyHostToDevice));
+    return 0;
+  }
+
+  void fill(Half* p, size_t n, uint64_t seed, float std, float mean) {
+    fill_normal35_kernel<Half><<<2048, 256, 0, stream>>>(p, (long)n, seed, std, mean);
+  }
+  void fillf(float* p, size_t n, uint64_t seed, float std, float mean) {
+    fill_normal35_kernel<float><<<64, 256, 0, stream>>>(p, (long)n, seed, std, mean);
+  }
+  int fill_synthetic(uint64_t seed, float std) {
+    uint64_t s = seed * 1000003ull;
+    fill(embed, (size_t)V * H, ++s, std, 0.f);
+    fill(final_norm, H, ++s, 0.1f, 0.f);
+    for (auto& ly : layers) {
+      fill(ly.ln1, H, ++s, 0.1f, 0.f);
+      fill(ly.ln2, H, ++s, 0.1f, 0.f);
+      fill(ly.gate, (size_t)I * H, ++s, std, 0.f);
+      fill(ly.up, (size_t)I * H, ++s, std, 0.f);
+      fill(ly.down, (size_t)H * I, ++s, std, 0.f);
+      if (ly.full) {
+        fill(ly.q_proj, (size_t)2 * q_dim * H, ++s, std, 0.f);
+        fill(ly.k_proj, (size_t)kv_dim * H, ++s, std, 0.f);
+        fill(ly.v_proj, (size_t)kv_dim * H, ++s, std, 0.f);
+        fill(ly.o_proj, (size_t)H * q_dim, ++s, std, 0.f);
+        fill(ly.q_norm, D, ++s, 0.1f, 0.f);
+        fill(ly.k_norm, D, ++s, 0.1f, 0.f);
+      } else {
+        fill(ly.in_qkv, (size_t)C * H, ++s, std, 0.f);
+        fill(ly.in_z, (size_t)Z * H, ++s, std, 0.f);
+        fill(ly.in_b, (size_t)vh * H, ++s, std, 0.f);
+        fill(ly.in_a, (size_t)vh * H, ++s, std, 0.f);
+        fill(ly.conv_w, (size_t)C * convK, ++s, 0.3f, 0.f);
+        fill(ly.dt_bias, vh, ++s, 0.5f, 0.f);
+        fill(ly.out_proj, (size_t)H * Z, ++s, std, 0.f);
+        fillf(ly.a_log, vh, ++s, 0.5f, 0.f);
+        fillf(ly.norm_w, LK, ++s, 0.1f, 1.f);
+      }
+    }
+    P35_HIP(hipStreamSynchronize(stream));
+    return 0;
+  }
+  // partial-RoPE tables: rows of rotary_dim, cos/sin duplicated in both halves (weights.rs:296-297 ->
+  // weight_loader.rs:210-244 with head_dim = rotary_dim)
+  int finalize() {
+    const int half = rotary / 2;
+    std::vector<float> inv(half);
+    for (int i = 0; i < half; ++i) inv[i] = 1.0f / std::pow(theta, (float)i * 2.0f / (float)rotary);
+    std::vector<uint16_t> c((size_t)max_pos * rotary), s((size_t)max_pos * rotary);
+    for (int pos = 0; pos < max_pos; ++pos)
+      for (int i = 0; i < half; ++i) {
+        const float f = (float)pos * inv[i];
+        const uint16_t cv = host_f2bf(std::cos(f)), sv = host_f2bf(std::sin(f));
+        c[(size_t)pos * rotary + i] = c[(size_t)pos * rotary + i + half] = cv;
+        s[(size_t)pos * rotary + i] = s[(size_t)pos * rotary + i + half] = sv;
+      }
+    P35_HIP(hipMemcpy(cos, c.data(), c.size() * 2, hipMemcpyHostToDevice));
+    P35_HIP(hipMemcpy(sin, s.data(), s.size() * 2, hipMemcpyHostToDevice));
+    return 0;
+  }
+
+  // ------------------------------------------------------------------ requests
+  int new_request() {
+    int id = -1;
+    for (size_t i = 0; i < requests.size(); ++i)
+      if (!requests[i].kv.live) { id = (int)i; break; }
+    if (id < 0) { requests.emplace_back(); id = (int)requests.size() - 1; }
+    Request35& r = requests[id];
+    if (!r.allocated) {
+      r.conv.resize(n_lin);
+      r.state.resize(n_lin);
+      for (int i = 0; i < n_lin; ++i)
+        if (dalloc(&r.conv[i], (size_t)C * (convK - 1), false) || dalloc(&r.state[i], (size_t)vh * LK * LK, false)) return -1;
+      r.allocated = true;
+    }
+    for (int i = 0; i < n_lin; ++i) {
+      P35_HIP(hipMemsetAsync(r.conv[i], 0, (size_t)C * (convK - 1) * 2, stream));
+      P35_HIP(hipMemsetAsync(r.state[i], 0, (size_t)vh * LK * LK * 4, stream));
+    }
+    r.kv = KvState();
+    r.kv.live = true;
+    return id;
+  }
+  Request35* req(int id) {
+    if (id < 0 || id >= (int)requests.size() || !requests[id].kv.live) { set_error("bad request id"); return nullptr; }
+    return &requests[id];
+  }
+  int drop_request(int id) {
+    Request35* r = req(id);
+    if (!r) return -1;
+    r->kv.reset(&pool);
+    r->kv.live = false;
+    return 0;
+  }
+
+  void G(const Half* wt, const Half* x, Half* y, int M, int T, int K) {
+    if (T == 1) gemm_graphsafe_cuda(wt, x, y, M, 1, K, S());
+    else gemm_cuda(wt, x, y, M, T, K, S());
+  }
+  int mlp(const Layer35& ly, const Half* x, Half* g, Half* up_, Half* act, Half* out, int T) {
+    G(ly.gate, x, g, I, T, H);
+    G(ly.up, x, up_, I, T, H);
+    if (silu_mul_triton_aot_cuda(g, up_, act, T * I, S())) { set_error("silu_mul failed"); return -1; }
+    G(ly.down, act, out, H, T, I);
+    return 0;
+  }
+
+  // ------------------------------------------------------------------ decode (batch_decode.rs:198-365)
+  int decode_kernels(int bs, const std::vector<Request35*>& rs) {
+    auto md = [&](size_t off) { return reinterpret_cast<int32_t*>(meta_dev + off); };
+    if (embedding_batched_cuda(embed, reinterpret_cast<uint32_t*>(meta_dev + m_tok), hidden, H, bs, S())) {
+      set_error("embedding failed"); return -1;
+    }
+    const float sm = 1.0f / std::sqrt((float)D);
+    int lin = 0, full = 0;
+    for (const Layer35& ly : layers) {
+      rms_norm_batched_offset_cuda(hidden, ly.ln1, normed, H, bs, eps, S());
+      if (ly.full) {
+        G(ly.q_proj, normed, q_full, 2 * q_dim, bs, H);
+        G(ly.k_proj, normed, k_attn, kv_dim, bs, H);
+        G(ly.v_proj, normed, v_attn, kv_dim, bs, H);
+        qk_norm_partial_rope_batched_decode_hd256_cuda(q_full, k_attn, ly.q_norm, ly.k_norm, cos, sin, md(m_pos), q_attn,
+                                                       Hq, Hkv, bs, rotary, eps, S());
+        int rc = paged_kv_scatter_cuda(kv_buffer, layout.k_offset(full), layout.v_offset(full), md(m_pages), md(m_indptr),
+                                       md(m_lpl), k_attn, v_attn, md(m_ri), md(m_pos), bs, Hkv, D, layout.page_size,
+                                       layout.page_stride, kv_dim, D, S());
+        if (!rc)
+          rc = paged_attention_decode_cuda_hd256(q_attn, attn_out, kv_buffer, layout.k_offset(full), layout.v_offset(full),
+                                                 md(m_pages), md(m_indptr), md(m_lpl), md(m_ri), md(m_kti), md(m_kcs), Hq,
+                                                 Hkv, D, layout.page_size, bs, layout.page_stride, sm, S());
+        if (rc) { set_error("hd256 decode attention failed"); return -1; }
+        attention_gate_batch_hd256_cuda(q_full, attn_out, Hq, bs, S());
+        G(ly.o_proj, attn_out, attn_res, H, bs, q_dim);
+        ++full;
+      } else {
+        G(ly.in_qkv, normed, qkv, C, bs, H);
+        G(ly.in_z, normed, z, Z, bs, H);
+        G(ly.in_b, normed, b_proj, vh, bs, H);
+        G(ly.in_a, normed, a_proj, vh, bs, H);
+        // per slot (batch_decode.rs:315-345); the reference copies each column out and back, the kernels take
+        // the column pointers directly - same kernels, same bits
+        for (int i = 0; i < bs; ++i) {
+          conv1d_prefill_cuda(qkv + (size_t)i * C, ly.conv_w, rs[i]->conv[lin], qkv_conv + (size_t)i * C, C, 1, convK, S());
+          gated_delta_rule_decode_cuda(qkv_conv + (size_t)i * C, b_proj + (size_t)i * vh, a_proj + (size_t)i * vh,
+                                       ly.dt_bias, ly.a_log, rs[i]->state[lin], gdr_out + (size_t)i * Z, kh, vh, LK, LK, S());
+        }
+        rms_norm_gated_cuda(gdr_out, ly.norm_w, z, normed_gated, bs * vh, LK, eps, S());
+        G(ly.out_proj, normed_gated, attn_res, H, bs, Z);
+        ++lin;
+      }
+      if (add_cuda(hidden, attn_res, hidden_mid, bs * H, S())) { set_error("add failed"); return -1; }
+      rms_norm_batched_offset_cuda(hidden_mid, ly.ln2, normed, H, bs, eps, S());
+      if (mlp(ly, normed, gate_out, up_out, act_out, mlp_out, bs)) return -1;
+      if (add_cuda(hidden_mid, mlp_out, hidden, bs * H, S())) { set_error("add failed"); return -1; }
+    }
+    rms_norm_batched_offset_cuda(hidden, final_norm, normed, H, bs, eps, S());
+    G(embed, normed, logits, V, bs, H);
+    if (pegainfer_batched_top1(logits, V, bs, V, top1_state, tokens_out_d, S())) { set_error("top1 failed"); return -1; }
+    return 0;
+  }
+
+  int decode(int n, const int32_t* ids, const uint32_t* toks, int32_t* out_tokens, void* out_logits_host) {
+    if (n < 1 || n > max_bs) { set_error("decode batch size out of range"); return -1; }
+    std::vector<Request35*> rs(n);
+    std::vector<int> key(ids, ids + n);
+    for (int i = 0; i < n; ++i) {
+      rs[i] = req(ids[i]);
+      if (!rs[i]) return -1;
+      for (int j = 0; j < i; ++j)
+        if (ids[j] == ids[i]) { set_error("duplicate request id in decode batch"); return -1; }
+    }
+    auto mh = [&](size_t off) { return reinterpret_cast<int32_t*>(meta_host + off); };
+    int np = 0;
+    mh(m_indptr)[0] = 0;
+    for (int i = 0; i < n; ++i) {
+      KvState& kv = rs[i]->kv;
+      const int pos = kv.seq_len;
+      if (pos + 1 > max_pos) { set_error("position beyond the RoPE table"); return -1; }
+      if (!kv.ensure_capacity(&pool, pos + 1, layout.page_size)) { set_error("KV pool exhausted"); return -1; }
+      kv.seq_len += 1;
+      mh(m_tok)[i] = (int32_t)toks[i];
+      mh(m_pos)[i] = pos;
+      for (int32_t p : kv.pages) mh(m_pages)[np++] = p;
+      mh(m_indptr)[i + 1] = np;
+      mh(m_lpl)[i] = kv.last_page_len(layout.page_size);
+      mh(m_ri)[i] = i;
+      mh(m_kti)[i] = 0;
+      mh(m_kcs)[i] = kv.seq_len;
+    }
+    P35_HIP(hipMemcpyAsync(meta_dev, meta_host, m_total, hipMemcpyHostToDevice, stream));
+    P35_HIP(hipEventRecord(ev0, stream));
+    if (enable_graph) {
+      if (!graph || graph_ids != key) {
+        if (graph) { P35_HIP(hipGraphExecDestroy(graph)); graph = nullptr; }
+        hipGraph_t g = nullptr;
+        P35_HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+        const int rc = decode_kernels(n, rs);
+        hipError_t e = hipStreamEndCapture(stream, &g);
+        if (rc || e != hipSuccess) { if (!rc) set_error("graph capture failed"); return -1; }
+        P35_HIP(hipGraphInstantiate(&graph, g, nullptr, nullptr, 0));
+        P35_HIP(hipGraphDestroy(g));
+        graph_ids = key;
+      }
+      P35_HIP(hipGraphLaunch(graph, stream));
+    } else if (decode_kernels(n, rs)) {
+      return -1;
+    }
+    P35_HIP(hipEventRecord(ev1, stream));
+    P35_HIP(hipMemcpyAsync(tokens_out_host, tokens_out_d, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
+    if (out_logits_host)
+      P35_HIP(hipMemcpyAsync(out_logits_host, logits, (size_t)n * V * 2, hipMemcpyDeviceToHost, stream));
+    P35_HIP(hipStreamSynchronize(stream));
+    P35_HIP(hipEventElapsedTime(&last_step_ms, ev0, ev1));
+    if (out_tokens) std::memcpy(out_tokens, tokens_out_host, (size_t)n * 4);
+    return 0;
+  }
+
+  // ------------------------------------------------------------------ prefill (prefill.rs:21-449)
+  int ensure_prefill_ws(size_t T) {
+    if (T <= pf_cap) return 0;
+    P35_HIP(hipStreamSynchronize(stream));
+    for (void* p : pf_owned) P35_HIP(hipFree(p));
+    pf_owned.clear();
+    const size_t cap = std::max<size_t>(T, 64);
+    const size_t big = std::max<size_t>({(size_t)2 * q_dim, (size_t)C, (size_t)I});
+    const size_t nch = (cap + 63) / 64;
+    auto A = [&](auto** p, size_t n) { return dalloc(p, n, true, &pf_owned); };
+    if (A(&pf_hidden, cap * H) || A(&pf_mid, cap * H) || A(&pf_normed, cap * H) || A(&pf_attn_res, cap * H) ||
+        A(&pf_big0, cap * big) || A(&pf_big1, cap * big) || A(&pf_big2, cap * big) || A(&pf_q_prep, cap * q_dim) ||
+        A(&pf_k, cap * kv_dim) || A(&pf_v, cap * kv_dim) || A(&pf_kc, cap * kv_dim) || A(&pf_vc, cap * kv_dim) ||
+        A(&pf_attn, cap * q_dim) || A(&pf_z, cap * Z) || A(&pf_b, cap * vh) || A(&pf_a, cap * vh) ||
+        A(&pf_gdr, cap * Z) || A(&g_cumsum, cap * vh) || A(&beta, cap * vh) || A(&a_tril, cap * vh * 64) ||
+        A(&chunk_state, nch * vh * LK * LK) || A(&q_exp, cap * Z) || A(&k_exp, cap * Z) || A(&v_raw, cap * Z) ||
+        A(&a_inv, cap * vh * 64) || A(&w, cap * Z) || A(&u, cap * Z) || A(&v_new, cap * Z))
+      return -1;
+    pf_cap = cap;
+    return 0;
+  }
+
+  int prefill(int id, int T, const uint32_t* tokens, int32_t* out_token, void* out_logits_host) {
+    Request35* r = req(id);
+    if (!r) return -1;
+    if (T < 1) { set_error("prefill needs at least one token"); return -1; }
+    KvState& kv = r->kv;
+    const int base = kv.seq_len;
+    if (base + T > max_pos) { set_error("prompt beyond the RoPE table"); return -1; }
+    if (!kv.ensure_capacity(&pool, base + T, layout.page_size)) { set_error("KV pool exhausted"); return -1; }
+    kv.seq_len += T;
+    if (ensure_prefill_ws(T)) return -1;
+    // PrefillPagedPlan::new (ops/attention.rs:17-130), one request
+    const int group = Hq / Hkv;
+    const int cta = batch_prefill_cta_tile_q(T, Hq, Hkv, D);
+    const int tiles = (T * group + cta - 1) / cta;
+    std::vector<int32_t> indptr{0, (int32_t)kv.pages.size()}, lpl{kv.last_page_len(layout.page_size)}, kcs{base + T},
+        bidx(T, 0), pos(T), qind{0, T}, rq(tiles, 0), qt(tiles), kt(tiles, 0);
+    for (int t = 0; t < T; ++t) pos[t] = base + t;
+    for (int t = 0; t < tiles; ++t) qt[t] = t;
+    uint32_t total_rows = (uint32_t)T;
+    int32_t start_pos = base;
+    std::vector<std::pair<const void*, size_t>> parts = {
+        {tokens, (size_t)T * 4}, {kv.pages.data(), kv.pages.size() * 4}, {indptr.data(), 8}, {lpl.data(), 4},
+        {bidx.data(), (size_t)T * 4}, {pos.data(), (size_t)T * 4}, {qind.data(), 8}, {rq.data(), rq.size() * 4},
+        {qt.data(), qt.size() * 4}, {kt.data(), kt.size() * 4}, {kcs.data(), 4}, {&total_rows, 4}, {&start_pos, 4}};
+    std::vector<size_t> offs;
+    size_t off = 0;
+    for (auto& p : parts) { offs.push_back(off); off = (off + p.second + 63) & ~size_t(63); }
+    if (off > pf_meta_cap) {
+      P35_HIP(hipStreamSynchronize(stream));
+      if (pf_meta_dev) { P35_HIP(hipFree(pf_meta_dev)); P35_HIP(hipHostFree(pf_meta_host)); }
+      pf_meta_cap = off * 2;
+      P35_HIP(hipMalloc(reinterpret_cast<void**>(&pf_meta_dev), pf_meta_cap));
+      P35_HIP(hipHostMalloc(reinterpret_cast<void**>(&pf_meta_host), pf_meta_cap, hipHostMallocDefault));
+    }
+    for (size_t i = 0; i < parts.size(); ++i) std::memcpy(pf_meta_host + offs[i], parts[i].first, parts[i].second);
+    P35_HIP(hipMemcpyAsync(pf_meta_dev, pf_meta_host, off, hipMemcpyHostToDevice, stream));
+    auto D32 = [&](int i) { return reinterpret_cast<int32_t*>(pf_meta_dev + offs[i]); };
+
+    if (embedding_batched_cuda(embed, reinterpret_cast<uint32_t*>(pf_meta_dev + offs[0]), pf_hidden, H, T, S())) {
+      set_error("embedding failed"); return -1;
+    }
+    Half *hid = pf_hidden, *alt = pf_mid;  // hidden_batch / hidden_plus_attn ping-pong
+    const float sm = 1.0f / std::sqrt((float)D);
+    int lin = 0, full = 0;
+    for (const Layer35& ly : layers) {
+      rms_norm_batched_offset_cuda(hid, ly.ln1, pf_normed, H, T, eps, S());
+      if (ly.full) {
+        Half* qf = pf_big0;  // q_full_batch [T, 2*q_dim]
+        G(ly.q_proj, pf_normed, qf, 2 * q_dim, T, H);
+        G(ly.k_proj, pf_normed, pf_k, kv_dim, T, H);
+        G(ly.v_proj, pf_normed, pf_v, kv_dim, T, H);
+        // prep writes the processed K/V into an HND buffer [Hkv][max_seq][256] at rows start_pos + t; here the
+        // buffer holds only this call's T rows, so its origin is shifted back by start_pos rows
+        Half* kc0 = pf_kc - (size_t)base * D;
+        Half* vc0 = pf_vc - (size_t)base * D;
+        prefill_attention_hd256_prep_cuda(qf, pf_k, pf_v, ly.q_norm, ly.k_norm, cos, sin, pf_q_prep, kc0, vc0, Hq, Hkv, T,
+                                          D32(12), rotary, eps, T, S());
+        int rc = paged_kv_scatter_cuda(kv_buffer, layout.k_offset(full), layout.v_offset(full), D32(1), D32(2), D32(3),
+                                       pf_kc, pf_vc, D32(4), D32(5), T, Hkv, D, layout.page_size, layout.page_stride, D,
+                                       (int64_t)T * D, S());
+        if (!rc)
+          rc = batch_prefill_paged_cuda_hd256(pf_q_prep, pf_attn, kv_buffer, layout.k_offset(full), layout.v_offset(full),
+                                              D32(1), D32(2), D32(3), D32(6), D32(7), D32(8), D32(9), D32(10),
+                                              reinterpret_cast<uint32_t*>(pf_meta_dev + offs[11]), Hq, Hkv, D,
+                                              layout.page_size, T, 1, tiles, layout.page_stride, sm, S());
+        if (rc) { set_error("hd256 prefill attention failed"); return -1; }
+        attention_gate_batch_hd256_cuda(qf, pf_attn, Hq, T, S());
+        G(ly.o_proj, pf_attn, pf_attn_res, H, T, q_dim);
+        ++full;
+      } else {
+        Half *qkv_b = pf_big0, *qkv_c = pf_big1;
+        G(ly.in_qkv, pf_normed, qkv_b, C, T, H);
+        G(ly.in_z, pf_normed, pf_z, Z, T, H);
+        G(ly.in_b, pf_normed, pf_b, vh, T, H);
+        G(ly.in_a, pf_normed, pf_a, vh, T, H);
+        conv1d_prefill_cuda(qkv_b, ly.conv_w, r->conv[lin], qkv_c, C, T, convK, S());
+        // gated_delta_rule_prefill_chunkwise_into (recurrent.rs:368-470)
+        float* st = r->state[lin];
+        int rc = gated_delta_rule_prefill_chunk_prepare_cuda(qkv_c, pf_b, pf_a, ly.dt_bias, ly.a_log, q_exp, k_exp, v_raw,
+                                                             g_cumsum, beta, kh, vh, C, T, S());
+        if (!rc) rc = gated_delta_rule_prefill_chunk_cumsum_cuda(g_cumsum, g_cumsum, T, vh, S());
+        if (!rc) rc = gated_delta_rule_prefill_chunk_a_cuda(k_exp, g_cumsum, beta, a_tril, T, vh, S());
+        if (!rc) rc = gated_delta_rule_prefill_chunk_solve_cuda(a_tril, a_inv, T, vh, S());
+        if (!rc) rc = gated_delta_rule_prefill_chunk_recompute_cuda(k_exp, v_raw, beta, w, u, a_inv, g_cumsum, T, vh, S());
+        if (!rc) rc = gated_delta_rule_prefill_chunk_state_cuda(k_exp, w, u, g_cumsum, st, chunk_state, v_new, st, T, vh, S());
+        if (!rc) rc = gated_delta_rule_prefill_chunk_o_cuda(q_exp, k_exp, v_new, chunk_state, g_cumsum, pf_gdr, T, vh,
+                                                            1.0f / std::sqrt((float)LK), S());
+        if (rc) { set_error("chunk-wise gated delta rule failed"); return -1; }
+        rms_norm_gated_cuda(pf_gdr, ly.norm_w, pf_z, qkv_b /* normed_out */, T * vh, LK, eps, S());
+        G(ly.out_proj, qkv_b, pf_attn_res, H, T, Z);
+        ++lin;
+      }
+      if (add_cuda(hid, pf_attn_res, alt, T * H, S())) { set_error("add failed"); return -1; }
+      rms_norm_batched_offset_cuda(alt, ly.ln2, pf_normed, H, T, eps, S());
+      if (mlp(ly, pf_normed, pf_big0, pf_big1, pf_big2, pf_attn_res, T)) return -1;
+      if (add_cuda(alt, pf_attn_res, hid, T * H, S())) { set_error("add failed"); return -1; }
+    }
+    P35_HIP(hipMemcpyAsync(pf_last, hid + (size_t)(T - 1) * H, (size_t)H * 2, hipMemcpyDeviceToDevice, stream));
+    rms_norm_offset_cuda(pf_last, final_norm, pf_last_normed, H, eps, S());
+    gemm_graphsafe_cuda(embed, pf_last_normed, pf_logits, V, 1, H, S());
+    if (pegainfer_batched_top1(pf_logits, V, 1, V, top1_state, tokens_out_d, S())) { set_error("top1 failed"); return -1; }
+    P35_HIP(hipMemcpyAsync(tokens_out_host, tokens_out_d, 4, hipMemcpyDeviceToHost, stream));
+    if (out_logits_host) P35_HIP(hipMemcpyAsync(out_logits_host, pf_logits, (size_t)V * 2, hipMemcpyDeviceToHost, stream));
+    P35_HIP(hipStreamSynchronize(stream));
+    if (out_token) *out_token = tokens_out_host[0];
+    return 0;
+  }
+
+  ~Model35() {
+    (void)hipSetDevice(device);
+    if (stream) (void)hipStreamSynchronize(stream);
+    if (graph) (void)hipGraphExecDestroy(graph);
+    for (void* p : owned) (void)hipFree(p);
+    for (void* p : pf_owned) (void)hipFree(p);
+    if (pf_meta_dev) (void)hipFree(pf_meta_dev);
+    if (pf_meta_host) (void)hipHostFree(pf_meta_host);
+    if (meta_host) (void)hipHostFree(meta_host);
+    if (tokens_out_host) (void)hipHostFree(tokens_out_host);
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+};
+
+}  // namespace pq35
+
+using pq35::Model35;
+static Model35* M35(pegainfer_qwen35_t m) { return static_cast<Model35*>(m); }
+
+extern "C" {
+
+pegainfer_qwen35_t pegainfer_qwen35_create(int32_t device_ordinal, int32_t hidden_size, int32_t intermediate_size,
+                                           int32_t num_layers, int32_t vocab_size, int32_t num_attention_heads,
+                                           int32_t num_kv_heads, int32_t head_dim, int32_t linear_num_key_heads,
+                                           int32_t linear_num_value_heads, int32_t linear_conv_kernel_dim,
+                                           float rms_norm_eps, float rope_theta, int32_t rotary_dim,
+                                           const int32_t* layer_is_full, int32_t max_position_embeddings,
+                                           int32_t num_kv_pages, int32_t max_batch_size, int32_t enable_graph) {
+  if (!layer_is_full || num_layers < 1 || num_kv_pages < 2 || max_batch_size < 1) return nullptr;
+  Model35* m = new Model35(device_ordinal, hidden_size, intermediate_size, num_layers, vocab_size, num_attention_heads,
+                           num_kv_heads, head_dim, linear_num_key_heads, linear_num_value_heads, linear_conv_kernel_dim,
+                           rms_norm_eps, rope_theta, rotary_dim, layer_is_full, max_position_embeddings, num_kv_pages,
+                           max_batch_size, enable_graph);
+  if (m->init()) {
+    fprintf(stderr, "pegainfer_qwen35_create: %s\n", m->err.c_str());
+    delete m;
+    return nullptr;
+  }
+  return m;
+}
+void pegainfer_qwen35_destroy(pegainfer_qwen35_t m) { delete M35(m); }
+const char* pegainfer_qwen35_last_error(pegainfer_qwen35_t m) { return M35(m)->err.c_str(); }
+int32_t pegainfer_qwen35_load_tensor(pegainfer_qwen35_t m, const char* name, const void* host, int64_t numel,
+                                     int32_t is_f32) {
+  return M35(m)->load_tensor(name, host, numel, is_f32);
+}
+int32_t pegainfer_qwen35_fill_synthetic(pegainfer_qwen35_t m, uint64_t seed, float std) { return M35(m)->fill_synthetic(seed, std); }
+int32_t pegainfer_qwen35_finalize(pegainfer_qwen35_t m) { return M35(m)->finalize(); }
+int32_t pegainfer_qwen35_new_request(pegainfer_qwen35_t m) { return M35(m)->new_request(); }
+int32_t pegainfer_qwen35_drop_request(pegainfer_qwen35_t m, int32_t id) { return M35(m)->drop_request(id); }
+int32_t pegainfer_qwen35_request_seq_len(pegainfer_qwen35_t m, int32_t id) {
+  auto* r = M35(m)->req(id);
+  return r ? r->kv.seq_len : -1;
+}
+int32_t pegainfer_qwen35_prefill(pegainfer_qwen35_t m, int32_t request_id, int32_t n_tokens, const uint32_t* tokens,
+                                 int32_t* out_token, void* out_logits_host) {
+  return M35(m)->prefill(request_id, n_tokens, tokens, out_token, out_logits_host);
+}
+int32_t pegainfer_qwen35_decode(pegainfer_qwen35_t m, int32_t n_requests, const int32_t* request_ids,
+                                const uint32_t* token_ids, int32_t* out_tokens, void* out_logits_host) {
+  return M35(m)->decode(n_requests, request_ids, token_ids, out_tokens, out_logits_host);
+}
+float pegainfer_qwen35_last_step_ms(pegainfer_qwen35_t m) { return M35(m)->last_step_ms; }
+int64_t pegainfer_qwen35_weight_bytes(pegainfer_qwen35_t m) { return M35(m)->weight_bytes; }
+
+}  // extern "C"

@@ -18,7 +18,8 @@ _SCALARS = {
     "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "uint32_t": ctypes.c_uint32,
     "uint64_t": ctypes.c_uint64, "float": ctypes.c_float, "int": ctypes.c_int,
     "pegainfer_stream_t": ctypes.c_void_p, "pegainfer_status_t": ctypes.c_int32,
-    "pegainfer_qwen3_t": ctypes.c_void_p, "size_t": ctypes.c_size_t, "double": ctypes.c_double,
+    "pegainfer_qwen3_t": ctypes.c_void_p, "pegainfer_qwen35_t": ctypes.c_void_p, "size_t": ctypes.c_size_t,
+    "double": ctypes.c_double,
 }
 
 _PROTO = re.compile(r"^\s*([A-Za-z_][\w\s\*]*?)\s*\b([a-z_][a-z0-9_]*)\s*\(([^;{}]*)\)\s*;", re.M)
@@ -89,8 +90,8 @@ def lib():
 
 
 def host_lib():
-    """libpegainfer_qwen3.so (include/pegainfer_qwen3.h)."""
+    """libpegainfer_qwen3.so (include/pegainfer_qwen3.h + pegainfer_qwen35.h)."""
     if "h" not in _cache:
         lib()
-        _cache["h"] = _Lib("libpegainfer_qwen3.so", "pegainfer_qwen3.h")
+        _cache["h"] = _Lib("libpegainfer_qwen3.so", "pegainfer_qwen3.h", "pegainfer_qwen35.h")
     return _cache["h"]
