@@ -102,6 +102,96 @@ def cpu_baseline(cfg, steps, threads):
                       f"{dt:.1f} s timed, {setup_s:.0f} s untimed setup"}
 
 
+
+def qwen35_bytes_per_token(c, ctx, batch):
+    """Algorithmic HBM bytes of one Qwen3.5 decode step: every weight once (bf16; A_log / gated-norm f32), the KV of
+    the full-attention layers (2 * Hkv * 256 * 2 B per token per layer), and per request the fp32 delta-rule state
+    read + written (2 * vh*128*128*4 B per linear layer) plus the conv window."""
+    H, I, V = c["hidden_size"], c["intermediate_size"], c["vocab_size"]
+    qd, kvd = c["num_attention_heads"] * c["head_dim"], c["num_key_value_heads"] * c["head_dim"]
+    kh, vh = c["linear_num_key_heads"], c["linear_num_value_heads"]
+    C, Z = 2 * kh * 128 + vh * 128, vh * 128
+    n_full = sum(t == "full_attention" for t in c["layer_types"])
+    n_lin = len(c["layer_types"]) - n_full
+    mlp = 3 * I * H
+    full = 2 * qd * H + 2 * kvd * H + H * qd
+    lin = C * H + Z * H + 2 * vh * H + H * Z + C * c.get("linear_conv_kernel_dim", 4)
+    params = V * H + n_full * (full + mlp) + n_lin * (lin + mlp)
+    kv = n_full * 2 * kvd * 2 * ctx
+    state = n_lin * (2 * vh * 128 * 128 * 4 + 2 * C * 3 * 2)
+    return 2.0 * params + batch * (kv + state)
+
+
+def run_qwen35(args, rank, world, local, dist, torch):
+    """configs[3]: Qwen3.5-4B hybrid (24 linear + 8 full-attention layers) - same decode_heavy profile, one
+    independent request stream per GPU (the reference supports exactly one device for this model: replicas)."""
+    from pegainfer_amd import parallel
+    from pegainfer_amd.qwen35 import QWEN35_4B, Qwen35Engine
+    cfg = dict(QWEN35_4B)
+    total_ctx = args.ctx + args.warmup + args.steps + 8
+    pages = (args.batch + 1) * (-(-total_ctx // 16) + 1) + 8
+    eng = Qwen35Engine(cfg, num_kv_pages=pages, max_batch_size=max(args.batch, 1) + 1, enable_graph=not args.no_graph,
+                       device=local, max_positions=max(4096, total_ctx + 16))
+    eng.fill_synthetic(seed=42 + rank, std=0.02)
+    prompt = synthetic_prompt(args.ctx)
+    ttfts = []
+    for _ in range(1 + args.ttft_iters):
+        r = eng.new_request()
+        t0 = time.perf_counter()
+        eng.prefill(r, prompt)
+        ttfts.append((time.perf_counter() - t0) * 1e3)
+        eng.drop_request(r)
+    ttfts = sorted(ttfts[1:]) if len(ttfts) > 1 else ttfts
+    rids = [eng.new_request() for _ in range(args.batch)]
+    toks = np.array([eng.prefill(r, prompt) for r in rids], np.int32)
+    for _ in range(args.warmup):
+        toks = eng.decode(rids, toks)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    step_ms, dev_ms = [], []
+    barrier()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        t0 = time.perf_counter()
+        toks = eng.decode(rids, toks)
+        step_ms.append((time.perf_counter() - t0) * 1e3)
+        dev_ms.append(eng.last_step_ms())
+    barrier()
+    elapsed = parallel.max_over_ranks(time.perf_counter() - t_start, device="cuda")
+    value = args.steps * args.batch * world / elapsed
+    step_bytes = qwen35_bytes_per_token(cfg, args.ctx + args.warmup + args.steps / 2, args.batch)
+    out = {
+        "metric": "decode tokens/sec + TTFT, Qwen3.5-4B bf16 greedy, 1xMI355X",
+        "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"qwen3.5-4b hybrid (24 linear + 8 full-attention layers) greedy decode, hipGraph "
+                               f"{'off' if args.no_graph else 'on'}, bs={args.batch}/GPU, ctx {args.ctx}->"
+                               f"{args.ctx + args.warmup + args.steps}, reference op sequence",
+                   "batch_per_gpu": args.batch, "ctx": args.ctx,
+                   "parallelism": "replicas%d" % world if world > 1 else "single"},
+        "ttft_ms": {"prompt_tokens": args.ctx, "p50": round(float(np.median(ttfts)), 3),
+                    "min": round(float(min(ttfts)), 3), "iters": len(ttfts)},
+        "tpot_ms": {"p50": round(float(np.median(step_ms)), 4), "p95": round(float(np.percentile(step_ms, 95)), 4),
+                    "device_p50": round(float(np.median(dev_ms)), 4)},
+        "roofline": {"bound": "hbm", "kernel": "whole decode step (graph)", "achieved": round(
+            step_bytes / (np.median(dev_ms) * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(step_bytes / (np.median(dev_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+            "bytes_per_launch": int(step_bytes)},
+        "cpu_baseline": None,
+    }
+    if rank == 0:
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -109,7 +199,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--ctx", type=int, default=1024, help="prompt length before the timed decode steps")
     ap.add_argument("--batch", type=int, default=1, help="requests decoded together per rank")
-    ap.add_argument("--model", default="qwen3-4b", choices=["qwen3-4b", "qwen3-8b"])
+    ap.add_argument("--model", default="qwen3-4b", choices=["qwen3-4b", "qwen3-8b", "qwen3.5-4b"])
     ap.add_argument("--decode-mode", type=int, default=int(os.environ.get("PEGAINFER_DECODE_MODE", "1")),
                     help="0 = reference op sequence 1:1, 1 = fused MI355X decode kernels (bit-identical)")
     ap.add_argument("--split-policy", type=int, default=1)
@@ -136,6 +226,8 @@ def main():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
 
     from pegainfer_amd import parallel
+    if args.model == "qwen3.5-4b":
+        return run_qwen35(args, rank, world, local, dist, torch)
     cfg = dict(QWEN3_4B if args.model == "qwen3-4b" else QWEN3_8B)
     full_cfg = dict(cfg)
     tp = args.parallelism == "tp" and world > 1

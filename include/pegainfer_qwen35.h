@@ -24,14 +24,17 @@ typedef void* pegainfer_qwen35_t;
 
 /* layer_is_full[num_layers]: 1 = full attention layer, 0 = linear attention (config.rs layer_types).
  * linear key_dim = value_dim = 128 (the chunk-wise kernels' fixed shape).  enable_graph: capture the decode step
- * (re-captured when the set of request ids in the batch changes - the recurrent state addresses are per request). */
+ * (re-captured when the set of request ids in the batch changes - the recurrent state addresses are per request).
+ * split_policy: 0 = the reference's call (non-partition HD256 decode attention), 1 = partition the KV scan of the
+ * full-attention layers towards >= 256 workgroups (pegainfer_paged_attention_decode_split_kv_hd256). */
 pegainfer_qwen35_t pegainfer_qwen35_create(int32_t device_ordinal, int32_t hidden_size, int32_t intermediate_size,
                                            int32_t num_layers, int32_t vocab_size, int32_t num_attention_heads,
                                            int32_t num_kv_heads, int32_t head_dim, int32_t linear_num_key_heads,
                                            int32_t linear_num_value_heads, int32_t linear_conv_kernel_dim,
                                            float rms_norm_eps, float rope_theta, int32_t rotary_dim,
                                            const int32_t* layer_is_full, int32_t max_position_embeddings,
-                                           int32_t num_kv_pages, int32_t max_batch_size, int32_t enable_graph);
+                                           int32_t num_kv_pages, int32_t max_batch_size, int32_t enable_graph,
+                                           int32_t split_policy);
 void pegainfer_qwen35_destroy(pegainfer_qwen35_t m);
 const char* pegainfer_qwen35_last_error(pegainfer_qwen35_t m);
 

@@ -471,6 +471,24 @@ int32_t paged_attention_decode_cuda_hd256(const Half* q, Half* output, const Hal
   return launch_decode<256, false, false>(a, nullptr, batch_size, batch_size, as_stream(stream));
 }
 
+// Extension: partition-KV decode at head_dim 256.  The reference has no split symbol for the Qwen3.5 full-attention
+// layers (ffi.rs:1286-1306 is non-partition only), which leaves bs = 1 with num_kv_heads = 4 workgroups on a
+// 256-CU part; same plan arrays and scratch contract as paged_attention_decode_split_kv_cuda.
+int32_t pegainfer_paged_attention_decode_split_kv_hd256(
+    const Half* q, Half* output, const Half* kv_data, int64_t k_offset_elems, int64_t v_offset_elems,
+    const int32_t* page_indices, const int32_t* page_indptr, const int32_t* last_page_len_d,
+    const int32_t* request_indices, const int32_t* kv_tile_indices, const int32_t* kv_chunk_size_ptr,
+    const int32_t* o_indptr, const uint8_t* block_valid_mask, Half* tmp_v, float* tmp_s, int32_t num_qo_heads,
+    int32_t num_kv_heads, int32_t head_dim, int32_t page_size, int32_t batch_size, int32_t padded_batch_size,
+    int64_t stride_page, float sm_scale, pegainfer_stream_t stream) {
+  if (head_dim != 256) return static_cast<int32_t>(hipErrorInvalidValue);
+  DecodeAttnArgs a;
+  fill_args(a, q, output, kv_data, k_offset_elems, v_offset_elems, page_indices, page_indptr, last_page_len_d,
+            request_indices, kv_tile_indices, kv_chunk_size_ptr, block_valid_mask, tmp_v, tmp_s, num_qo_heads,
+            num_kv_heads, page_size, stride_page, sm_scale);
+  return launch_decode<256, true, false>(a, o_indptr, batch_size, padded_batch_size, as_stream(stream));
+}
+
 // Extension (include/pegainfer_kernels_ext.h): qk_norm_rope_batched_decode_cuda + paged_kv_scatter_cuda +
 // paged_attention_decode[_split_kv]_cuda in one launch (+ the merge when partitioned).
 int32_t pegainfer_fused_decode_attention(

@@ -74,7 +74,7 @@ struct Request35 {
 };
 
 struct Model35 {
-  int device, H, I, L, V, Hq, Hkv, D, kh, vh, convK, rotary, max_pos, num_pages, max_bs, enable_graph;
+  int device, H, I, L, V, Hq, Hkv, D, kh, vh, convK, rotary, max_pos, num_pages, max_bs, enable_graph, split_policy;
   float eps, theta;
   int q_dim, kv_dim, C, Z, n_full = 0, n_lin = 0;
   std::string err;
@@ -98,9 +98,12 @@ struct Model35 {
   uint8_t* top1_state = nullptr;
   int32_t* tokens_out_host = nullptr;
   uint8_t *meta_host = nullptr, *meta_dev = nullptr;
-  size_t m_tok, m_pos, m_indptr, m_lpl, m_ri, m_kti, m_kcs, m_pages, m_total;
+  size_t m_tok, m_pos, m_indptr, m_lpl, m_ri, m_kti, m_kcs, m_sri, m_skt, m_skc, m_soi, m_sva, m_pages, m_total;
+  // partition-KV decode for the full-attention layers (MI355X policy of kv_pool.h: fill the 256 CUs)
+  Half* split_tmp_v = nullptr;
+  float* split_tmp_s = nullptr;
   hipGraphExec_t graph = nullptr;
-  std::vector<int> graph_ids;
+  std::vector<int> graph_ids;   // request ids of the captured step, then the attention path
   // prefill workspace (grow-only)
   size_t pf_cap = 0;
   std::vector<void*> pf_owned;
@@ -117,9 +120,10 @@ struct Model35 {
   float last_step_ms = 0.f;
 
   Model35(int dev, int h, int inter, int l, int v, int hq, int hkv, int d, int kh_, int vh_, int ck, float e, float th,
-          int rot, const int32_t* is_full, int mp, int pages, int mbs, int graph_)
+          int rot, const int32_t* is_full, int mp, int pages, int mbs, int graph_, int split_)
       : device(dev), H(h), I(inter), L(l), V(v), Hq(hq), Hkv(hkv), D(d), kh(kh_), vh(vh_), convK(ck), rotary(rot),
-        max_pos(mp), num_pages(pages), max_bs(mbs), enable_graph(graph_), eps(e), theta(th), q_dim(hq * d),
+        max_pos(mp), num_pages(pages), max_bs(mbs), enable_graph(graph_), split_policy(split_), eps(e), theta(th),
+        q_dim(hq * d),
         kv_dim(hkv * d), C(2 * kh_ * LK + vh_ * LK), Z(vh_ * LK), layout(1, hkv, d, 16), pool(pages) {
     layers.resize(l);
     for (int i = 0; i < l; ++i) {
@@ -180,7 +184,9 @@ struct Model35 {
         dalloc(&a_proj, bs * vh) || dalloc(&gdr_out, bs * Z) || dalloc(&normed_gated, bs * Z) ||
         dalloc(&gate_out, bs * I) || dalloc(&up_out, bs * I) || dalloc(&act_out, bs * I) ||
         dalloc(&mlp_out, bs * H) || dalloc(&logits, bs * (size_t)V) || dalloc(&tokens_out_d, bs) ||
-        dalloc(&top1_state, bs * 16) || dalloc(&start_pos_d, 1) || dalloc(&pf_last, H) ||
+        dalloc(&top1_state, bs * 16) || dalloc(&start_pos_d, 1) ||
+        dalloc(&split_tmp_v, bs * pq::kSplitMaxChunksPerRequest * q_dim) ||
+        dalloc(&split_tmp_s, bs * pq::kSplitMaxChunksPerRequest * Hq) || dalloc(&pf_last, H) ||
         dalloc(&pf_last_normed, H) || dalloc(&pf_logits, V))
       return -1;
     auto al = [](size_t x) { return (x + 63) & ~size_t(63); };
@@ -192,6 +198,12 @@ struct Model35 {
     m_ri = off; off = al(off + bs * 4);
     m_kti = off; off = al(off + bs * 4);
     m_kcs = off; off = al(off + bs * 4);
+    const size_t slots = bs * pq::kSplitMaxChunksPerRequest;
+    m_sri = off; off = al(off + slots * 4);
+    m_skt = off; off = al(off + slots * 4);
+    m_skc = off; off = al(off + 4);
+    m_soi = off; off = al(off + (bs + 1) * 4);
+    m_sva = off; off = al(off + slots);
     m_pages = off; off = al(off + ((size_t)num_pages + bs) * 4);
     m_total = off;
     P35_HIP(hipHostMalloc(reinterpret_cast<void**>(&meta_host), m_total, hipHostMallocDefault));
@@ -354,7 +366,7 @@ struct Model35 {
   }
 
   // ------------------------------------------------------------------ decode (batch_decode.rs:198-365)
-  int decode_kernels(int bs, const std::vector<Request35*>& rs) {
+  int decode_kernels(int bs, const std::vector<Request35*>& rs, bool split) {
     auto md = [&](size_t off) { return reinterpret_cast<int32_t*>(meta_dev + off); };
     if (embedding_batched_cuda(embed, reinterpret_cast<uint32_t*>(meta_dev + m_tok), hidden, H, bs, S())) {
       set_error("embedding failed"); return -1;
@@ -372,7 +384,12 @@ struct Model35 {
         int rc = paged_kv_scatter_cuda(kv_buffer, layout.k_offset(full), layout.v_offset(full), md(m_pages), md(m_indptr),
                                        md(m_lpl), k_attn, v_attn, md(m_ri), md(m_pos), bs, Hkv, D, layout.page_size,
                                        layout.page_stride, kv_dim, D, S());
-        if (!rc)
+        if (!rc && split)
+          rc = pegainfer_paged_attention_decode_split_kv_hd256(
+              q_attn, attn_out, kv_buffer, layout.k_offset(full), layout.v_offset(full), md(m_pages), md(m_indptr),
+              md(m_lpl), md(m_sri), md(m_skt), md(m_skc), md(m_soi), meta_dev + m_sva, split_tmp_v, split_tmp_s, Hq, Hkv,
+              D, layout.page_size, bs, bs * pq::kSplitMaxChunksPerRequest, layout.page_stride, sm, S());
+        else if (!rc)
           rc = paged_attention_decode_cuda_hd256(q_attn, attn_out, kv_buffer, layout.k_offset(full), layout.v_offset(full),
                                                  md(m_pages), md(m_indptr), md(m_lpl), md(m_ri), md(m_kti), md(m_kcs), Hq,
                                                  Hkv, D, layout.page_size, bs, layout.page_stride, sm, S());
@@ -435,6 +452,18 @@ struct Model35 {
       mh(m_kti)[i] = 0;
       mh(m_kcs)[i] = kv.seq_len;
     }
+    // split-KV plan for the full-attention layers (split_policy 0 = the reference's non-partition call only)
+    const bool allow_split = split_policy != 0;
+    std::vector<int> seq_lens(n);
+    for (int i = 0; i < n; ++i) seq_lens[i] = rs[i]->kv.seq_len;
+    const pq::SplitPlan plan = pq::make_split_plan(1, seq_lens, n, Hkv);
+    const bool split = allow_split && plan.use_split;
+    std::memcpy(mh(m_sri), plan.request_indices.data(), (size_t)plan.slots * 4);
+    std::memcpy(mh(m_skt), plan.kv_tile_indices.data(), (size_t)plan.slots * 4);
+    mh(m_skc)[0] = plan.chunk;
+    std::memcpy(mh(m_soi), plan.o_indptr.data(), (size_t)(n + 1) * 4);
+    std::memcpy(meta_host + m_sva, plan.valid.data(), (size_t)plan.slots);
+    key.push_back(split ? 1 : 0);
     P35_HIP(hipMemcpyAsync(meta_dev, meta_host, m_total, hipMemcpyHostToDevice, stream));
     P35_HIP(hipEventRecord(ev0, stream));
     if (enable_graph) {
@@ -442,7 +471,7 @@ struct Model35 {
         if (graph) { P35_HIP(hipGraphExecDestroy(graph)); graph = nullptr; }
         hipGraph_t g = nullptr;
         P35_HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-        const int rc = decode_kernels(n, rs);
+        const int rc = decode_kernels(n, rs, split);
         hipError_t e = hipStreamEndCapture(stream, &g);
         if (rc || e != hipSuccess) { if (!rc) set_error("graph capture failed"); return -1; }
         P35_HIP(hipGraphInstantiate(&graph, g, nullptr, nullptr, 0));
@@ -450,7 +479,7 @@ struct Model35 {
         graph_ids = key;
       }
       P35_HIP(hipGraphLaunch(graph, stream));
-    } else if (decode_kernels(n, rs)) {
+    } else if (decode_kernels(n, rs, split)) {
       return -1;
     }
     P35_HIP(hipEventRecord(ev1, stream));
@@ -622,12 +651,13 @@ pegainfer_qwen35_t pegainfer_qwen35_create(int32_t device_ordinal, int32_t hidde
                                            int32_t linear_num_value_heads, int32_t linear_conv_kernel_dim,
                                            float rms_norm_eps, float rope_theta, int32_t rotary_dim,
                                            const int32_t* layer_is_full, int32_t max_position_embeddings,
-                                           int32_t num_kv_pages, int32_t max_batch_size, int32_t enable_graph) {
+                                           int32_t num_kv_pages, int32_t max_batch_size, int32_t enable_graph,
+                                           int32_t split_policy) {
   if (!layer_is_full || num_layers < 1 || num_kv_pages < 2 || max_batch_size < 1) return nullptr;
   Model35* m = new Model35(device_ordinal, hidden_size, intermediate_size, num_layers, vocab_size, num_attention_heads,
                            num_kv_heads, head_dim, linear_num_key_heads, linear_num_value_heads, linear_conv_kernel_dim,
                            rms_norm_eps, rope_theta, rotary_dim, layer_is_full, max_position_embeddings, num_kv_pages,
-                           max_batch_size, enable_graph);
+                           max_batch_size, enable_graph, split_policy);
   if (m->init()) {
     fprintf(stderr, "pegainfer_qwen35_create: %s\n", m->err.c_str());
     delete m;

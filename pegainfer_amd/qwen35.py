@@ -20,7 +20,8 @@ QWEN35_4B = dict(hidden_size=2560, intermediate_size=9216, num_hidden_layers=32,
 
 
 class Qwen35Engine:
-    def __init__(self, config, num_kv_pages=1024, max_batch_size=8, enable_graph=True, device=0, max_positions=4096):
+    def __init__(self, config, num_kv_pages=1024, max_batch_size=8, enable_graph=True, device=0, max_positions=4096,
+                 split_policy=1):
         self.lib = ffi.host_lib()
         self.cfg = c = dict(config)
         if c.get("linear_key_head_dim", 128) != 128 or c.get("linear_value_head_dim", 128) != 128:
@@ -33,7 +34,7 @@ class Qwen35Engine:
             c["num_attention_heads"], c["num_key_value_heads"], c["head_dim"], c["linear_num_key_heads"],
             c["linear_num_value_heads"], c.get("linear_conv_kernel_dim", 4), float(c.get("rms_norm_eps", 1e-6)),
             float(c.get("rope_theta", 1e7)), rotary, is_full.ctypes.data, int(max_positions), int(num_kv_pages),
-            int(max_batch_size), int(bool(enable_graph)))
+            int(max_batch_size), int(bool(enable_graph)), int(split_policy))
         if not self.h:
             raise RuntimeError("pegainfer_qwen35_create failed")
         self.vocab = c["vocab_size"]

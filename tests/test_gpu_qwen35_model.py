@@ -44,10 +44,10 @@ def teacher_forced(eng, case):
     return np.stack(rows)
 
 
-@pytest.mark.parametrize("graph", [True, False])
-def test_qwen35_matches_hf_golden(built_libs, golden35, graph):
+@pytest.mark.parametrize("graph,split", [(True, 1), (False, 1), (True, 0)])
+def test_qwen35_matches_hf_golden(built_libs, golden35, graph, split):
     meta, hf = golden35
-    eng = make_engine(meta, enable_graph=graph)
+    eng = make_engine(meta, enable_graph=graph, split_policy=split)
     for case in meta["cases"]:
         L, H = teacher_forced(eng, case), hf[case["name"]]
         cos = (L * H).sum(-1) / np.linalg.norm(L, axis=-1) / np.linalg.norm(H, axis=-1)
@@ -79,7 +79,9 @@ def test_qwen35_graph_eager_batch_and_handoff(built_libs, golden35):
     prompts = [c["prompt_tokens"] for c in meta["cases"][:3]]
     runs = {}
     for graph in (True, False):
-        eng = make_engine(meta, enable_graph=graph)
+        # split_policy 0: the partition plan depends on the batch size, so bitwise batch invariance is a property of
+        # the reference's non-partition call; graph == eager holds for both (checked with policy 1 below)
+        eng = make_engine(meta, enable_graph=graph, split_policy=0)
         rids = [eng.new_request() for _ in prompts]
         toks = np.array([eng.prefill(r, p) for r, p in zip(rids, prompts)], np.int32)
         rows = []
@@ -99,6 +101,20 @@ def test_qwen35_graph_eager_batch_and_handoff(built_libs, golden35):
                 eng.drop_request(r)
         eng.close()
     assert np.array_equal(runs[True].view(np.uint32), runs[False].view(np.uint32))      # graph == eager
+    long_prompt = (meta["cases"][3]["prompt_tokens"] * 3)[:300]                          # >= 2 KV chunks -> split path
+    outs = []
+    for graph in (True, False):
+        eng = make_engine(meta, enable_graph=graph, split_policy=1)
+        r = eng.new_request()
+        t = eng.prefill(r, long_prompt)
+        rows = []
+        for _ in range(4):
+            o, lg = eng.decode([r], [t], want_logits=True)
+            rows.append(lg[0].copy())
+            t = int(o[0])
+        outs.append(np.stack(rows))
+        eng.close()
+    assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
     # prefill hand-off: 70 tokens as 41 + 29 vs in one call
     eng = make_engine(meta)
     p = meta["cases"][2]["prompt_tokens"]
