@@ -128,6 +128,7 @@ def run_qwen35(args, rank, world, local, dist, torch):
     from pegainfer_amd import parallel
     from pegainfer_amd.qwen35 import QWEN35_4B, Qwen35Engine
     cfg = dict(QWEN35_4B)
+    q35_mode = int(os.environ.get("PEGAINFER_Q35_DECODE_MODE", "1"))
     total_ctx = args.ctx + args.warmup + args.steps + 8
     pages = (args.batch + 1) * (-(-total_ctx // 16) + 1) + 8
     eng = Qwen35Engine(cfg, num_kv_pages=pages, max_batch_size=max(args.batch, 1) + 1, enable_graph=not args.no_graph,
@@ -171,8 +172,9 @@ def run_qwen35(args, rank, world, local, dist, torch):
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"qwen3.5-4b hybrid (24 linear + 8 full-attention layers) greedy decode, hipGraph "
                                f"{'off' if args.no_graph else 'on'}, bs={args.batch}/GPU, ctx {args.ctx}->"
-                               f"{args.ctx + args.warmup + args.steps}, reference op sequence",
-                   "batch_per_gpu": args.batch, "ctx": args.ctx,
+                               f"{args.ctx + args.warmup + args.steps}, "
+                               + ("fused bs=1 decode kernels" if q35_mode == 1 and args.batch == 1 else "reference op sequence"),
+                   "batch_per_gpu": args.batch, "ctx": args.ctx, "decode_mode": q35_mode,
                    "parallelism": "replicas%d" % world if world > 1 else "single"},
         "ttft_ms": {"prompt_tokens": args.ctx, "p50": round(float(np.median(ttfts)), 3),
                     "min": round(float(min(ttfts)), 3), "iters": len(ttfts)},

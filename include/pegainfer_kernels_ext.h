@@ -33,6 +33,13 @@ pegainfer_status_t pegainfer_batched_top1(const Half* logits, int32_t vocab_size
  * fall back to the unfused sequence. */
 pegainfer_status_t pegainfer_gemv_fused(const Half* W, const Half* X, Half* Y, int32_t M, int32_t T, int32_t K, const Half* residual, const Half* norm_weight, Half* hidden_out, float eps, int32_t silu_intermediate, pegainfer_stream_t stream);
 
+/* pegainfer_gemv_fused with the Qwen3.5 rounding points (T <= 4): flags bit 0 = the norm weight is (1 + w)
+ * (rms_norm_batched_offset_cuda), bit 1 = hidden_out = bf16(X + residual) and the norm runs over that ROUNDED sum
+ * (add_cuda then rms_norm_batched_offset_cuda, batch_decode.rs:246-262) instead of FlashInfer's fused add+norm,
+ * bit 2 = SwiGLU as bf16(bf16(silu(gate)) * up) (silu_mul_triton_aot_cuda, elementwise.cu:28-42).  Bit-identical to
+ * those unfused sequences. */
+pegainfer_status_t pegainfer_gemv_fused_ex(const Half* W, const Half* X, Half* Y, int32_t M, int32_t T, int32_t K, const Half* residual, const Half* norm_weight, Half* hidden_out, float eps, int32_t silu_intermediate, int32_t flags, pegainfer_stream_t stream);
+
 /* Prefill q/k/v projection as ONE GEMM over the row-stacked weight W[M0 + M1 + M2, K] (q_proj; k_proj; v_proj
  * rows), writing the three contiguous buffers the reference's prefill kernels take: Y0[T, M0], Y1[T, M1],
  * Y2[T, M2].  Replaces the three gemm_cuda calls of prefill.rs:120-129 (the k/v projections alone cover a

@@ -50,7 +50,11 @@ struct GemvFusedArgs {
   float eps;
   int I;                  // kEpiSilu: W = [gate(I rows); up(I rows)], Y = [T, I]
   int KT;                 // x tile width (gemv_pick_kt)
+  int flags;              // kGemvNormOffset | kGemvRoundSum | kGemvSiluRound (dot2 GEMV path only)
 };
+// Qwen3.5 forms of the fused pieces (pegainfer_gemv_fused_ex): (1 + w) norm weight; residual sum rounded to bf16
+// before the norm ("add, then norm" instead of FlashInfer's fused add+norm); silu rounded to bf16 before * up
+enum { kGemvNormOffset = 1, kGemvRoundSum = 2, kGemvSiluRound = 4 };
 
 template <int NT, int RPW, int KSPLIT, int EPI>
 __global__ __launch_bounds__(256) void gemv_fused_kernel(const GemvFusedArgs a) {
@@ -139,7 +143,8 @@ __global__ __launch_bounds__(256) void gemv_fused_kernel(const GemvFusedArgs a) 
   for (int t = 0; t < NT; ++t) inv[t] = 0.f;
   if (a.norm_w) {
     for (int t = wave; t < T; t += 4) {
-      const float v = wave_row_inv_rms(a.X + (size_t)t * K, a.residual ? a.residual + (size_t)t * K : nullptr, K, a.eps);
+      const float v = wave_row_inv_rms(a.X + (size_t)t * K, a.residual ? a.residual + (size_t)t * K : nullptr, K, a.eps,
+                                       (a.flags & kGemvRoundSum) != 0);
       if (lane == 0) red[t] = v;
     }
     __syncthreads();
@@ -147,6 +152,8 @@ __global__ __launch_bounds__(256) void gemv_fused_kernel(const GemvFusedArgs a) 
     for (int t = 0; t < NT; ++t)
       if (t < T) inv[t] = red[t];
   }
+  const float nbias = (a.flags & kGemvNormOffset) ? 1.f : 0.f;
+  const bool round_sum = (a.flags & kGemvRoundSum) != 0;
   auto stage = [&](int k0, int kt) {
     const int nvec = (kt + 7) >> 3;  // lanes beyond kt never read their slot (consume() zeroes them)
 #pragma unroll
@@ -161,10 +168,10 @@ __global__ __launch_bounds__(256) void gemv_fused_kernel(const GemvFusedArgs a) 
           if (a.residual) {
             const u32x4 r = *reinterpret_cast<const u32x4*>(a.residual + off);
             u32x4 nh;
-            v = norm_scale8(h, &r, gw, inv[t], 0.f, &nh);
+            v = norm_scale8(h, &r, gw, inv[t], nbias, &nh, round_sum);
             if (blockIdx.x == 0) *reinterpret_cast<u32x4*>(a.hidden_out + off) = nh;
           } else {
-            v = norm_scale8(h, nullptr, gw, inv[t], 0.f, nullptr);
+            v = norm_scale8(h, nullptr, gw, inv[t], nbias, nullptr);
           }
         } else {
           v = h;
@@ -219,7 +226,8 @@ __global__ __launch_bounds__(256) void gemv_fused_kernel(const GemvFusedArgs a) 
       if (row >= rows_total || t >= T) return;
       if (EPI == kEpiSilu) {
         const float gt = bf16_round_f(v0), up = bf16_round_f(v1);  // the GEMM output is bf16 before SwiGLU
-        a.Y[(size_t)t * a.I + row] = f2bf(silu_f(gt) * up);
+        const float sg = (a.flags & kGemvSiluRound) ? bf16_round_f(silu_f(gt)) : silu_f(gt);
+        a.Y[(size_t)t * a.I + row] = f2bf(sg * up);
       } else {
         a.Y[(size_t)t * a.M + row] = f2bf(v0);
       }

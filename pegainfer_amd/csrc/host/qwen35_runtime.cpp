@@ -6,8 +6,10 @@
 // delta-rule matrix), so the graph is keyed by the list of request ids and re-captured when it changes.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -75,6 +77,7 @@ struct Request35 {
 
 struct Model35 {
   int device, H, I, L, V, Hq, Hkv, D, kh, vh, convK, rotary, max_pos, num_pages, max_bs, enable_graph, split_policy;
+  int decode_mode = [] { const char* e = getenv("PEGAINFER_Q35_DECODE_MODE"); return e ? atoi(e) : 1; }();
   float eps, theta;
   int q_dim, kv_dim, C, Z, n_full = 0, n_lin = 0;
   std::string err;
@@ -93,7 +96,7 @@ struct Model35 {
        *q_attn = nullptr, *k_attn = nullptr, *v_attn = nullptr, *attn_out = nullptr, *qkv = nullptr,
        *qkv_conv = nullptr, *z = nullptr, *b_proj = nullptr, *a_proj = nullptr, *gdr_out = nullptr,
        *normed_gated = nullptr, *gate_out = nullptr, *up_out = nullptr, *act_out = nullptr, *mlp_out = nullptr,
-       *logits = nullptr;
+       *logits = nullptr, *wide = nullptr;  // wide: one token's stacked projection output (fused path)
   int32_t* tokens_out_d = nullptr;
   uint8_t* top1_state = nullptr;
   int32_t* tokens_out_host = nullptr;
@@ -157,19 +160,23 @@ struct Model35 {
     auto WF = [&](float** p, size_t n) { weight_bytes += (int64_t)n * 4; return dalloc(p, n, false); };
     if (W(&embed, (size_t)V * H) || W(&final_norm, H)) return -1;
     for (auto& ly : layers) {
-      if (W(&ly.ln1, H) || W(&ly.ln2, H) || W(&ly.gate, (size_t)I * H) || W(&ly.up, (size_t)I * H) ||
-          W(&ly.down, (size_t)H * I))
-        return -1;
+      // projections that read the same activation are stored row-stacked (gate|up, q|k|v, qkv|z|b|a) so the fused
+      // decode path can stream them with ONE GEMV; the reference-order path uses the sub-matrices in place
+      if (W(&ly.ln1, H) || W(&ly.ln2, H) || W(&ly.gate, (size_t)2 * I * H) || W(&ly.down, (size_t)H * I)) return -1;
+      ly.up = ly.gate + (size_t)I * H;
       if (ly.full) {
-        if (W(&ly.q_proj, (size_t)2 * q_dim * H) || W(&ly.k_proj, (size_t)kv_dim * H) ||
-            W(&ly.v_proj, (size_t)kv_dim * H) || W(&ly.o_proj, (size_t)H * q_dim) || W(&ly.q_norm, D) ||
-            W(&ly.k_norm, D))
+        if (W(&ly.q_proj, (size_t)(2 * q_dim + 2 * kv_dim) * H) || W(&ly.o_proj, (size_t)H * q_dim) ||
+            W(&ly.q_norm, D) || W(&ly.k_norm, D))
           return -1;
+        ly.k_proj = ly.q_proj + (size_t)2 * q_dim * H;
+        ly.v_proj = ly.k_proj + (size_t)kv_dim * H;
       } else {
-        if (W(&ly.in_qkv, (size_t)C * H) || W(&ly.in_z, (size_t)Z * H) || W(&ly.in_b, (size_t)vh * H) ||
-            W(&ly.in_a, (size_t)vh * H) || W(&ly.conv_w, (size_t)C * convK) || W(&ly.dt_bias, vh) ||
+        if (W(&ly.in_qkv, (size_t)(C + Z + 2 * vh) * H) || W(&ly.conv_w, (size_t)C * convK) || W(&ly.dt_bias, vh) ||
             W(&ly.out_proj, (size_t)H * Z) || WF(&ly.a_log, vh) || WF(&ly.norm_w, LK))
           return -1;
+        ly.in_z = ly.in_qkv + (size_t)C * H;
+        ly.in_b = ly.in_z + (size_t)Z * H;
+        ly.in_a = ly.in_b + (size_t)vh * H;
       }
     }
     if (dalloc(&cos, (size_t)max_pos * rotary, false) || dalloc(&sin, (size_t)max_pos * rotary, false)) return -1;
@@ -185,6 +192,7 @@ struct Model35 {
         dalloc(&gate_out, bs * I) || dalloc(&up_out, bs * I) || dalloc(&act_out, bs * I) ||
         dalloc(&mlp_out, bs * H) || dalloc(&logits, bs * (size_t)V) || dalloc(&tokens_out_d, bs) ||
         dalloc(&top1_state, bs * 16) || dalloc(&start_pos_d, 1) ||
+        dalloc(&wide, (size_t)std::max(C + Z + 2 * vh, 2 * q_dim + 2 * kv_dim)) ||
         dalloc(&split_tmp_v, bs * pq::kSplitMaxChunksPerRequest * q_dim) ||
         dalloc(&split_tmp_s, bs * pq::kSplitMaxChunksPerRequest * Hq) || dalloc(&pf_last, H) ||
         dalloc(&pf_last_normed, H) || dalloc(&pf_logits, V))
@@ -424,6 +432,75 @@ struct Model35 {
     return 0;
   }
 
+  // bs == 1 fused step (decode_mode 1): 8-10 launches per layer instead of 16-17, every result bit-identical to
+  // decode_kernels().  The two norms and both residual adds ride in GEMV prologues (pegainfer_gemv_fused_ex with the
+  // Qwen3.5 rounding points), SwiGLU in the gate|up GEMV epilogue, and the stacked qkv|z|b|a / q|k|v / gate|up
+  // weights are streamed by one GEMV each.  Batches > 1 use the reference-order path (the consumers of the
+  // stacked outputs take contiguous [bs, dim] tensors in the reference ABI).
+  int decode_kernels_fused1(Request35* r, bool split) {
+    auto md = [&](size_t off) { return reinterpret_cast<int32_t*>(meta_dev + off); };
+    if (embedding_batched_cuda(embed, reinterpret_cast<uint32_t*>(meta_dev + m_tok), hidden, H, 1, S())) {
+      set_error("embedding failed"); return -1;
+    }
+    const float sm = 1.0f / std::sqrt((float)D);
+    const int OFF = 1, RSUM = 2, SILU2 = 4;
+    Half *cur = hidden, *nxt = hidden_mid;
+    const Half* resid = nullptr;
+    int lin = 0, full = 0, rc = 0;
+    for (const Layer35& ly : layers) {
+      if (ly.full) {
+        rc = pegainfer_gemv_fused_ex(ly.q_proj, cur, wide, 2 * q_dim + 2 * kv_dim, 1, H, resid, ly.ln1,
+                                     resid ? nxt : nullptr, eps, 0, OFF | (resid ? RSUM : 0), S());
+        if (resid) std::swap(cur, nxt);
+        Half *qf = wide, *kk = wide + 2 * q_dim, *vv = kk + kv_dim;   // [q|gate per head | k | v] of this token
+        if (!rc) {
+          qk_norm_partial_rope_batched_decode_hd256_cuda(qf, kk, ly.q_norm, ly.k_norm, cos, sin, md(m_pos), q_attn, Hq,
+                                                         Hkv, 1, rotary, eps, S());
+          rc = paged_kv_scatter_cuda(kv_buffer, layout.k_offset(full), layout.v_offset(full), md(m_pages), md(m_indptr),
+                                     md(m_lpl), kk, vv, md(m_ri), md(m_pos), 1, Hkv, D, layout.page_size,
+                                     layout.page_stride, kv_dim, D, S());
+        }
+        if (!rc && split)
+          rc = pegainfer_paged_attention_decode_split_kv_hd256(
+              q_attn, attn_out, kv_buffer, layout.k_offset(full), layout.v_offset(full), md(m_pages), md(m_indptr),
+              md(m_lpl), md(m_sri), md(m_skt), md(m_skc), md(m_soi), meta_dev + m_sva, split_tmp_v, split_tmp_s, Hq, Hkv,
+              D, layout.page_size, 1, pq::kSplitMaxChunksPerRequest, layout.page_stride, sm, S());
+        else if (!rc)
+          rc = paged_attention_decode_cuda_hd256(q_attn, attn_out, kv_buffer, layout.k_offset(full), layout.v_offset(full),
+                                                 md(m_pages), md(m_indptr), md(m_lpl), md(m_ri), md(m_kti), md(m_kcs), Hq,
+                                                 Hkv, D, layout.page_size, 1, layout.page_stride, sm, S());
+        if (rc) { set_error("fused full-attention layer failed"); return -1; }
+        attention_gate_batch_hd256_cuda(qf, attn_out, Hq, 1, S());
+        gemm_graphsafe_cuda(ly.o_proj, attn_out, attn_res, H, 1, q_dim, S());
+        ++full;
+      } else {
+        rc = pegainfer_gemv_fused_ex(ly.in_qkv, cur, wide, C + Z + 2 * vh, 1, H, resid, ly.ln1, resid ? nxt : nullptr,
+                                     eps, 0, OFF | (resid ? RSUM : 0), S());
+        if (rc) { set_error("fused linear-attention projection failed"); return -1; }
+        if (resid) std::swap(cur, nxt);
+        conv1d_prefill_cuda(wide, ly.conv_w, r->conv[lin], qkv_conv, C, 1, convK, S());
+        gated_delta_rule_decode_cuda(qkv_conv, wide + C + Z, wide + C + Z + vh, ly.dt_bias, ly.a_log, r->state[lin],
+                                     gdr_out, kh, vh, LK, LK, S());
+        rms_norm_gated_cuda(gdr_out, ly.norm_w, wide + C, normed_gated, vh, LK, eps, S());
+        gemm_graphsafe_cuda(ly.out_proj, normed_gated, attn_res, H, 1, Z, S());
+        ++lin;
+      }
+      // mid = bf16(cur + attn_res) -> nxt; act = silu_mul(gate, up) of norm_offset(mid)
+      rc = pegainfer_gemv_fused_ex(ly.gate, cur, act_out, 2 * I, 1, H, attn_res, ly.ln2, nxt, eps, I, OFF | RSUM | SILU2, S());
+      if (rc) { set_error("fused gate|up GEMV failed"); return -1; }
+      std::swap(cur, nxt);
+      gemm_graphsafe_cuda(ly.down, act_out, mlp_out, H, 1, I, S());
+      resid = mlp_out;
+    }
+    rc = pegainfer_gemv_fused_ex(embed, cur, logits, V, 1, H, resid, final_norm, nxt, eps, 0, OFF | RSUM, S());
+    if (rc || pegainfer_batched_top1(logits, V, 1, V, top1_state, tokens_out_d, S())) { set_error("fused lm_head failed"); return -1; }
+    return 0;
+  }
+  int run_decode_kernels(int n, const std::vector<Request35*>& rs, bool split) {
+    if (decode_mode == 1 && n == 1 && (H & 7) == 0) return decode_kernels_fused1(rs[0], split);
+    return decode_kernels(n, rs, split);
+  }
+
   int decode(int n, const int32_t* ids, const uint32_t* toks, int32_t* out_tokens, void* out_logits_host) {
     if (n < 1 || n > max_bs) { set_error("decode batch size out of range"); return -1; }
     std::vector<Request35*> rs(n);
@@ -464,6 +541,7 @@ struct Model35 {
     std::memcpy(mh(m_soi), plan.o_indptr.data(), (size_t)(n + 1) * 4);
     std::memcpy(meta_host + m_sva, plan.valid.data(), (size_t)plan.slots);
     key.push_back(split ? 1 : 0);
+    key.push_back(decode_mode);
     P35_HIP(hipMemcpyAsync(meta_dev, meta_host, m_total, hipMemcpyHostToDevice, stream));
     P35_HIP(hipEventRecord(ev0, stream));
     if (enable_graph) {
@@ -471,7 +549,7 @@ struct Model35 {
         if (graph) { P35_HIP(hipGraphExecDestroy(graph)); graph = nullptr; }
         hipGraph_t g = nullptr;
         P35_HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-        const int rc = decode_kernels(n, rs, split);
+        const int rc = run_decode_kernels(n, rs, split);
         hipError_t e = hipStreamEndCapture(stream, &g);
         if (rc || e != hipSuccess) { if (!rc) set_error("graph capture failed"); return -1; }
         P35_HIP(hipGraphInstantiate(&graph, g, nullptr, nullptr, 0));
@@ -479,7 +557,7 @@ struct Model35 {
         graph_ids = key;
       }
       P35_HIP(hipGraphLaunch(graph, stream));
-    } else if (decode_kernels(n, rs, split)) {
+    } else if (run_decode_kernels(n, rs, split)) {
       return -1;
     }
     P35_HIP(hipEventRecord(ev1, stream));

@@ -340,7 +340,7 @@ static void gemm_dispatch(const Half* W, const Half* X, Half* Y, int M, int T, i
   if (M <= 0 || T <= 0 || K <= 0) return;
   const bool fast = (K & 7) == 0 && host_aligned16(W) && host_aligned16(X);
   if (fast && T <= 64) {
-    GemvFusedArgs a{W, X, Y, M, T, K, nullptr, nullptr, nullptr, 0.f, 0, 0};
+    GemvFusedArgs a{W, X, Y, M, T, K, nullptr, nullptr, nullptr, 0.f, 0, 0, 0};
     if (decode_gemm_dispatch<kEpiStore>(a, s)) return;
   }
   if (glds_gemm_ok(W, X, Y, M, K)) {
@@ -389,9 +389,9 @@ void gemm_graphsafe_cuda(const Half* W, const Half* X, Half* Y, int32_t M, int32
 
 // Fused decode GEMV (extension, include/pegainfer_kernels_ext.h): optional RMSNorm / add+RMSNorm
 // prologue and SwiGLU epilogue around the SAME gemv core that gemm_graphsafe_cuda uses.
-pegainfer_status_t pegainfer_gemv_fused(const Half* W, const Half* X, Half* Y, int32_t M, int32_t T, int32_t K,
-                                        const Half* residual, const Half* norm_weight, Half* hidden_out, float eps,
-                                        int32_t silu_intermediate, pegainfer_stream_t stream) {
+static pegainfer_status_t gemv_fused_impl(const Half* W, const Half* X, Half* Y, int32_t M, int32_t T, int32_t K,
+                                          const Half* residual, const Half* norm_weight, Half* hidden_out, float eps,
+                                          int32_t silu_intermediate, int32_t flags, pegainfer_stream_t stream) {
   using namespace pk;
   if (M <= 0 || T < 1 || T > 64 || K <= 0 || (K & 7) != 0) return (pegainfer_status_t)hipErrorInvalidValue;
   if (!host_aligned16(W) || !host_aligned16(X) || (residual && !host_aligned16(residual)) ||
@@ -399,10 +399,25 @@ pegainfer_status_t pegainfer_gemv_fused(const Half* W, const Half* X, Half* Y, i
     return (pegainfer_status_t)hipErrorInvalidValue;
   if (residual && (!norm_weight || !hidden_out || hidden_out == X)) return (pegainfer_status_t)hipErrorInvalidValue;
   if (silu_intermediate > 0 && M != 2 * silu_intermediate) return (pegainfer_status_t)hipErrorInvalidValue;
-  GemvFusedArgs a{W, X, Y, M, T, K, residual, norm_weight, hidden_out, eps, silu_intermediate, 0};
+  if (flags != 0 && (T > 4 || t1_uses_mfma())) return (pegainfer_status_t)hipErrorInvalidValue;  // dot2 path only
+  GemvFusedArgs a{W, X, Y, M, T, K, residual, norm_weight, hidden_out, eps, silu_intermediate, 0, flags};
   const bool ok = silu_intermediate > 0 ? decode_gemm_dispatch<kEpiSilu>(a, as_stream(stream))
                                         : decode_gemm_dispatch<kEpiStore>(a, as_stream(stream));
   return ok ? (pegainfer_status_t)hipGetLastError() : (pegainfer_status_t)hipErrorInvalidValue;
+}
+
+pegainfer_status_t pegainfer_gemv_fused(const Half* W, const Half* X, Half* Y, int32_t M, int32_t T, int32_t K,
+                                        const Half* residual, const Half* norm_weight, Half* hidden_out, float eps,
+                                        int32_t silu_intermediate, pegainfer_stream_t stream) {
+  return gemv_fused_impl(W, X, Y, M, T, K, residual, norm_weight, hidden_out, eps, silu_intermediate, 0, stream);
+}
+
+// Qwen3.5 forms (flags: 1 = (1 + w) norm weight, 2 = residual sum rounded to bf16 before the norm, 4 = silu rounded
+// to bf16 before the multiply); T <= 4 only.
+pegainfer_status_t pegainfer_gemv_fused_ex(const Half* W, const Half* X, Half* Y, int32_t M, int32_t T, int32_t K,
+                                           const Half* residual, const Half* norm_weight, Half* hidden_out, float eps,
+                                           int32_t silu_intermediate, int32_t flags, pegainfer_stream_t stream) {
+  return gemv_fused_impl(W, X, Y, M, T, K, residual, norm_weight, hidden_out, eps, silu_intermediate, flags, stream);
 }
 
 // One GEMM over a row-stacked weight [M0 + M1 + M2, K] writing three outputs Y0[T][M0], Y1[T][M1], Y2[T][M2]

@@ -27,14 +27,26 @@ __device__ __forceinline__ void add_sq8(const u32x4& h, const u32x4& r, float& s
   a = bf_lo(h.z) + bf_lo(r.z); ss += a * a; a = bf_hi(h.z) + bf_hi(r.z); ss += a * a;
   a = bf_lo(h.w) + bf_lo(r.w); ss += a * a; a = bf_hi(h.w) + bf_hi(r.w); ss += a * a;
 }
+// same with the sum rounded to bf16 first: "add_cuda, then rms_norm on its bf16 output" (the Qwen3.5 residual
+// chain, batch_decode.rs:246-262) as opposed to FlashInfer's fused add+norm over the un-rounded sum
+__device__ __forceinline__ void add_round_sq8(const u32x4& h, const u32x4& r, float& ss) {
+  float a;
+  a = bf16_round_f(bf_lo(h.x) + bf_lo(r.x)); ss += a * a; a = bf16_round_f(bf_hi(h.x) + bf_hi(r.x)); ss += a * a;
+  a = bf16_round_f(bf_lo(h.y) + bf_lo(r.y)); ss += a * a; a = bf16_round_f(bf_hi(h.y) + bf_hi(r.y)); ss += a * a;
+  a = bf16_round_f(bf_lo(h.z) + bf_lo(r.z)); ss += a * a; a = bf16_round_f(bf_hi(h.z) + bf_hi(r.z)); ss += a * a;
+  a = bf16_round_f(bf_lo(h.w) + bf_lo(r.w)); ss += a * a; a = bf16_round_f(bf_hi(h.w) + bf_hi(r.w)); ss += a * a;
+}
 
 // inv_rms of row `hr` (+ `rr` when non-null), d % 8 == 0; call from ALL 64 lanes of one wave.
 __device__ __forceinline__ float wave_row_inv_rms(const Half* __restrict__ hr, const Half* __restrict__ rr, int d,
-                                                  float eps) {
+                                                  float eps, bool round_sum = false) {
   float ss = 0.f;
   const int nvec = d >> 3;
   const int lane = threadIdx.x & 63;
-  if (rr) {
+  if (rr && round_sum) {
+    for (int i = lane; i < nvec; i += 64)
+      add_round_sq8(reinterpret_cast<const u32x4*>(hr)[i], reinterpret_cast<const u32x4*>(rr)[i], ss);
+  } else if (rr) {
     for (int i = lane; i < nvec; i += 64)
       add_sq8(reinterpret_cast<const u32x4*>(hr)[i], reinterpret_cast<const u32x4*>(rr)[i], ss);
   } else {
@@ -46,7 +58,7 @@ __device__ __forceinline__ float wave_row_inv_rms(const Half* __restrict__ hr, c
 
 // out = bf16(s * inv * (bias + w)) on 8 packed elements; s = h (+ r).  Also returns bf16(s) in `nh`.
 __device__ __forceinline__ u32x4 norm_scale8(const u32x4& h, const u32x4* r, const u32x4& g, float inv, float bias,
-                                             u32x4* nh) {
+                                             u32x4* nh, bool round_sum = false) {
   u32x4 o, n;
   const uint32_t hw[4] = {h.x, h.y, h.z, h.w}, gw[4] = {g.x, g.y, g.z, g.w};
   uint32_t rw[4] = {0u, 0u, 0u, 0u};
@@ -56,6 +68,7 @@ __device__ __forceinline__ u32x4 norm_scale8(const u32x4& h, const u32x4* r, con
   for (int j = 0; j < 4; ++j) {
     float s0 = bf_lo(hw[j]), s1 = bf_hi(hw[j]);
     if (r) { s0 += bf_lo(rw[j]); s1 += bf_hi(rw[j]); }
+    if (round_sum) { s0 = bf16_round_f(s0); s1 = bf16_round_f(s1); }
     nw[j] = pack_bf2(s0, s1);
     ow[j] = pack_bf2(s0 * inv * (bias + bf_lo(gw[j])), s1 * inv * (bias + bf_hi(gw[j])));
   }

@@ -40,6 +40,21 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const Half* __restrict__ x,
   }
 }
 
+// T == 1 (decode, recurrent.rs:49-79): output and window shift in one pass, same arithmetic as conv1d_kernel
+__global__ __launch_bounds__(256) void conv1d_step_kernel(const Half* __restrict__ x, const Half* __restrict__ w,
+                                                          Half* __restrict__ state, Half* __restrict__ out, int C,
+                                                          int K) {
+  const int sw = K - 1;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  Half win[kConvMaxK];
+  for (int i = 0; i < sw; ++i) win[i] = state[(size_t)c * sw + i];
+  win[sw] = x[c];
+  float sum = 0.f;
+  for (int k = 0; k < K; ++k) sum += bf2f(win[k]) * bf2f(w[(size_t)c * K + k]);
+  out[c] = f2bf(silu_f(bf16_round_f(sum)));
+  for (int i = 0; i < sw; ++i) state[(size_t)c * sw + i] = win[i + 1];
+}
 __global__ __launch_bounds__(256) void conv1d_state_kernel(const Half* __restrict__ x, Half* __restrict__ state,
                                                            int C, int T, int K) {
   const int sw = K - 1;
@@ -287,6 +302,11 @@ void conv1d_prefill_cuda(const Half* x_seq, const Half* conv_weight, Half* conv_
                          int32_t num_channels, int32_t seq_len, int32_t kernel_size, pegainfer_stream_t stream) {
   if (num_channels <= 0 || seq_len <= 0 || kernel_size < 1 || kernel_size > kConvMaxK) return;
   hipStream_t s = as_stream(stream);
+  if (seq_len == 1 && kernel_size > 1) {  // decode step: a channel's window is private to one lane -> one launch
+    conv1d_step_kernel<<<ceil_div(num_channels, 256), 256, 0, s>>>(x_seq, conv_weight, conv_state, out_seq,
+                                                                   num_channels, kernel_size);
+    return;
+  }
   conv1d_kernel<<<grid_cap((long)num_channels * seq_len, 256), 256, 0, s>>>(x_seq, conv_weight, conv_state, out_seq,
                                                                            num_channels, seq_len, kernel_size);
   if (kernel_size > 1)

@@ -128,3 +128,27 @@ def test_qwen35_graph_eager_batch_and_handoff(built_libs, golden35):
     _, again = eng.prefill(eng.new_request(), p, want_logits=True)                      # rerun determinism
     assert np.array_equal(one.view(np.uint32), again.view(np.uint32))
     eng.close()
+
+
+@pytest.mark.parametrize("split", [0, 1])
+def test_qwen35_fused_decode_bitwise_equals_reference_sequence(built_libs, golden35, split, monkeypatch):
+    """bs = 1 fused step (stacked-projection GEMVs with the norm / residual-add prologues and the SwiGLU epilogue in
+    their Qwen3.5 rounding forms, single-launch conv step) == the reference-order op sequence, logits bit for bit,
+    across prompts that end inside / across KV chunks and GDR chunks."""
+    meta, _ = golden35
+    runs = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("PEGAINFER_Q35_DECODE_MODE", mode)
+        eng = make_engine(meta, split_policy=split)
+        rows = []
+        for case in meta["cases"]:
+            r = eng.new_request()
+            t = eng.prefill(r, case["prompt_tokens"])
+            for _ in range(6):
+                o, lg = eng.decode([r], [t], want_logits=True)
+                rows.append(lg[0].copy())
+                t = int(o[0])
+            eng.drop_request(r)
+        runs.append(np.stack(rows))
+        eng.close()
+    assert np.array_equal(runs[0].view(np.uint32), runs[1].view(np.uint32))
