@@ -47,6 +47,10 @@ pegainfer_status_t pegainfer_gemv_fused_ex(const Half* W, const Half* X, Half* Y
  * shapes the tiled kernel does not take. */
 pegainfer_status_t pegainfer_gemm_split3(const Half* W, const Half* X, Half* Y0, int32_t M0, Half* Y1, int32_t M1, Half* Y2, int32_t M2, int32_t T, int32_t K, pegainfer_stream_t stream);
 
+/* General form of pegainfer_gemm_split3: n_out in 2..4 outputs Y[i][T, Ms[i]] from the row-stacked weight
+ * W[sum Ms, K] (Qwen3.5: in_proj_qkv | z | b | a, and gate_proj | up_proj).  Host arrays of n_out entries. */
+pegainfer_status_t pegainfer_gemm_split(const Half* W, const Half* X, int32_t n_out, Half* const* Y, const int32_t* Ms, int32_t T, int32_t K, pegainfer_stream_t stream);
+
 /* Decode attention with the per-head q/k RMSNorm + RoPE and the KV append folded in (head_dim 128):
  * reads the raw fused-QKV GEMV output qkv[bs, (Hq + 2 Hkv) * 128], writes the new K (normalised, rotated)
  * and V rows into the paged cache and the attention output [bs, Hq*128].  Bit-identical to

@@ -365,9 +365,20 @@ struct Model35 {
     if (T == 1) gemm_graphsafe_cuda(wt, x, y, M, 1, K, S());
     else gemm_cuda(wt, x, y, M, T, K, S());
   }
+  // stacked projections of one activation: one multi-output GEMM when prefill-sized, else the reference's calls
+  int GS(const Half* wt, const Half* x, int n_out, Half* const* ys, const int32_t* ms, int T, int K) {
+    if (T > 64) {
+      if (pegainfer_gemm_split(wt, x, n_out, ys, ms, T, K, S())) { set_error("pegainfer_gemm_split failed"); return -1; }
+      return 0;
+    }
+    size_t row = 0;
+    for (int i = 0; i < n_out; ++i) { G(wt + row * K, x, ys[i], ms[i], T, K); row += ms[i]; }
+    return 0;
+  }
   int mlp(const Layer35& ly, const Half* x, Half* g, Half* up_, Half* act, Half* out, int T) {
-    G(ly.gate, x, g, I, T, H);
-    G(ly.up, x, up_, I, T, H);
+    Half* ys[2] = {g, up_};
+    const int32_t ms[2] = {I, I};
+    if (GS(ly.gate, x, 2, ys, ms, T, H)) return -1;
     if (silu_mul_triton_aot_cuda(g, up_, act, T * I, S())) { set_error("silu_mul failed"); return -1; }
     G(ly.down, act, out, H, T, I);
     return 0;
@@ -640,9 +651,11 @@ struct Model35 {
       rms_norm_batched_offset_cuda(hid, ly.ln1, pf_normed, H, T, eps, S());
       if (ly.full) {
         Half* qf = pf_big0;  // q_full_batch [T, 2*q_dim]
-        G(ly.q_proj, pf_normed, qf, 2 * q_dim, T, H);
-        G(ly.k_proj, pf_normed, pf_k, kv_dim, T, H);
-        G(ly.v_proj, pf_normed, pf_v, kv_dim, T, H);
+        {
+          Half* ys[3] = {qf, pf_k, pf_v};
+          const int32_t ms[3] = {2 * q_dim, kv_dim, kv_dim};
+          if (GS(ly.q_proj, pf_normed, 3, ys, ms, T, H)) return -1;
+        }
         // prep writes the processed K/V into an HND buffer [Hkv][max_seq][256] at rows start_pos + t; here the
         // buffer holds only this call's T rows, so its origin is shifted back by start_pos rows
         Half* kc0 = pf_kc - (size_t)base * D;
@@ -663,10 +676,11 @@ struct Model35 {
         ++full;
       } else {
         Half *qkv_b = pf_big0, *qkv_c = pf_big1;
-        G(ly.in_qkv, pf_normed, qkv_b, C, T, H);
-        G(ly.in_z, pf_normed, pf_z, Z, T, H);
-        G(ly.in_b, pf_normed, pf_b, vh, T, H);
-        G(ly.in_a, pf_normed, pf_a, vh, T, H);
+        {
+          Half* ys[4] = {qkv_b, pf_z, pf_b, pf_a};
+          const int32_t ms[4] = {C, Z, vh, vh};
+          if (GS(ly.in_qkv, pf_normed, 4, ys, ms, T, H)) return -1;
+        }
         conv1d_prefill_cuda(qkv_b, ly.conv_w, r->conv[lin], qkv_c, C, T, convK, S());
         // gated_delta_rule_prefill_chunkwise_into (recurrent.rs:368-470)
         float* st = r->state[lin];

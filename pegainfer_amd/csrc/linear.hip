@@ -148,10 +148,11 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(const Half* __restrict__
 // address: lane l of row-group rg fetches global slot (l%8) ^ (row&7) of row rg*8 + l/8, and readers use
 // lds_slot() unchanged.  TT = token-tile width (128, or 64 when M is small and 128-wide tiles would leave
 // CUs idle).
-// Optional row-segmented output: W rows [0,M0) -> Y[T][M0], [M0,M0+M1) -> Y1[T][M1], the rest -> Y2[T][M-M0-M1]
-// (one GEMM over a stacked q/k/v weight writing the three buffers the attention kernels take).  Y1 == nullptr
-// means a plain [T][M] output.  M0 and M1 are multiples of 4 (a lane stores 4 consecutive rows).
-struct SplitOut { Half* Y1; Half* Y2; int M0; int M1; };
+// Optional row-segmented output (up to 4 segments): W rows [0,M0) -> Y[T][M0], [M0,M0+M1) -> Y1[T][M1],
+// [M0+M1,M0+M1+M2) -> Y2[T][M2], the rest -> Y3 (one GEMM over a stacked weight writing the separate contiguous
+// buffers the downstream kernels take).  Y1 == nullptr means a plain [T][M] output; unused trailing segments have
+// size 0.  Segment sizes are multiples of 4 (a lane stores 4 consecutive rows).
+struct SplitOut { Half* Y1; Half* Y2; Half* Y3; int M0; int M1; int M2; };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -264,9 +265,11 @@ __global__ __launch_bounds__(256) void mfma_gemm_glds_kernel(const Half* __restr
       Half* dst = Y;
       int ld = M, mm = m, mlim = M;
       if (so.Y1) {
+        const int b1 = so.M0 + so.M1, b2 = b1 + so.M2;
         if (m < so.M0) { ld = mlim = so.M0; }
-        else if (m < so.M0 + so.M1) { dst = so.Y1; ld = mlim = so.M1; mm = m - so.M0; }
-        else { dst = so.Y2; ld = mlim = M - so.M0 - so.M1; mm = m - so.M0 - so.M1; }
+        else if (m < b1) { dst = so.Y1; ld = mlim = so.M1; mm = m - so.M0; }
+        else if (m < b2) { dst = so.Y2; ld = mlim = so.M2; mm = m - b1; }
+        else { dst = so.Y3; ld = mlim = M - b2; mm = m - b2; }
       }
       if (mm + 3 < mlim) {
         u32x2 o;
@@ -357,7 +360,7 @@ static void gemm_dispatch(const Half* W, const Half* X, Half* Y, int M, int T, i
       const int m_tiles = ceil_div(M, BM), t_tiles = ceil_div(T, BT);
       mfma_gemm_kernel<<<m_tiles * t_tiles, 256, 0, s>>>(W, X, Y, M, T, K, m_tiles, t_tiles);
     } else {
-      glds_gemm_launch(W, X, Y, M, T, K, SplitOut{nullptr, nullptr, 0, 0}, mode, s);
+      glds_gemm_launch(W, X, Y, M, T, K, SplitOut{nullptr, nullptr, nullptr, 0, 0, 0}, mode, s);
     }
     return;
   }
@@ -420,24 +423,43 @@ pegainfer_status_t pegainfer_gemv_fused_ex(const Half* W, const Half* X, Half* Y
   return gemv_fused_impl(W, X, Y, M, T, K, residual, norm_weight, hidden_out, eps, silu_intermediate, flags, stream);
 }
 
-// One GEMM over a row-stacked weight [M0 + M1 + M2, K] writing three outputs Y0[T][M0], Y1[T][M1], Y2[T][M2]
-// (extension): what prefill's q_proj / k_proj / v_proj calls (prefill.rs:120-129) compute, in one launch that
-// fills the chip.  Each element is bit-identical to the separate gemm_cuda call (same kernel, same K order).
-pegainfer_status_t pegainfer_gemm_split3(const Half* W, const Half* X, Half* Y0, int32_t M0, Half* Y1, int32_t M1,
-                                         Half* Y2, int32_t M2, int32_t T, int32_t K, pegainfer_stream_t stream) {
+// One GEMM over a row-stacked weight writing 2..4 separate outputs Y_i[T][M_i] (extension): what prefill's
+// q_proj / k_proj / v_proj calls (prefill.rs:120-129), Qwen3.5's in_proj_qkv / z / b / a (qwen35 prefill.rs:373-376)
+// and gate_proj / up_proj (:187-188) compute, in one launch that fills the chip.  Each element is bit-identical to
+// the separate gemm_cuda call (same kernel, same K order).
+pegainfer_status_t pegainfer_gemm_split(const Half* W, const Half* X, int32_t n_out, Half* const* Y, const int32_t* Ms,
+                                        int32_t T, int32_t K, pegainfer_stream_t stream) {
   using namespace pk;
-  if (M0 <= 0 || M1 <= 0 || M2 <= 0 || T <= 0 || K <= 0) return (pegainfer_status_t)hipErrorInvalidValue;
-  const int M = M0 + M1 + M2;
-  const bool ok = T > 64 && ((M0 | M1 | M2) & 3) == 0 && glds_gemm_ok(W, X, Y0, M, K) &&
-                  (reinterpret_cast<uintptr_t>(Y1) & 7u) == 0 && (reinterpret_cast<uintptr_t>(Y2) & 7u) == 0;
+  if (n_out < 2 || n_out > 4 || T <= 0 || K <= 0) return (pegainfer_status_t)hipErrorInvalidValue;
+  int M = 0, m[4] = {0, 0, 0, 0};
+  Half* y[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool ok = T > 64;
+  for (int i = 0; i < n_out; ++i) {
+    if (Ms[i] <= 0 || !Y[i]) return (pegainfer_status_t)hipErrorInvalidValue;
+    m[i] = Ms[i]; y[i] = Y[i]; M += Ms[i];
+    ok = ok && (Ms[i] & 3) == 0 && (reinterpret_cast<uintptr_t>(Y[i]) & 7u) == 0;
+  }
+  ok = ok && glds_gemm_ok(W, X, y[0], M, K);
   if (ok) {
-    glds_gemm_launch(W, X, Y0, M, T, K, SplitOut{Y1, Y2, M0, M1}, 0, as_stream(stream));
-  } else {  // shapes the tiled kernel does not take: three reference-ABI calls
-    gemm_dispatch(W, X, Y0, M0, T, K, as_stream(stream));
-    gemm_dispatch(W + (size_t)M0 * K, X, Y1, M1, T, K, as_stream(stream));
-    gemm_dispatch(W + (size_t)(M0 + M1) * K, X, Y2, M2, T, K, as_stream(stream));
+    // the last present segment is "the rest"; with fewer than 4 outputs the unused boundaries collapse onto M
+    SplitOut so{y[1], y[2] ? y[2] : y[1], y[3] ? y[3] : (y[2] ? y[2] : y[1]), m[0], m[1], n_out > 2 ? m[2] : 0};
+    if (n_out == 2) { so.M1 = m[1]; so.M2 = 0; }
+    glds_gemm_launch(W, X, y[0], M, T, K, so, 0, as_stream(stream));
+  } else {  // shapes the tiled kernel does not take: separate reference-ABI calls
+    size_t row = 0;
+    for (int i = 0; i < n_out; ++i) {
+      gemm_dispatch(W + row * K, X, y[i], m[i], T, K, as_stream(stream));
+      row += m[i];
+    }
   }
   return (pegainfer_status_t)hipGetLastError();
+}
+
+pegainfer_status_t pegainfer_gemm_split3(const Half* W, const Half* X, Half* Y0, int32_t M0, Half* Y1, int32_t M1,
+                                         Half* Y2, int32_t M2, int32_t T, int32_t K, pegainfer_stream_t stream) {
+  Half* ys[3] = {Y0, Y1, Y2};
+  const int32_t ms[3] = {M0, M1, M2};
+  return pegainfer_gemm_split(W, X, 3, ys, ms, T, K, stream);
 }
 
 }  // extern "C"

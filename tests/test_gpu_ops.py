@@ -249,6 +249,27 @@ def test_gemm_split3_equals_three_gemms(P, T, K, ms):
         r0 += m
 
 
+@pytest.mark.parametrize("ms", [(8192, 4096, 32, 32), (512, 512), (64, 8, 4, 12)])
+def test_gemm_split_n_outputs_equals_separate_gemms(P, ms):
+    """2- and 4-output stacked GEMM (Qwen3.5 gate|up and qkv|z|b|a) == separate gemm_cuda calls, bit for bit."""
+    import ctypes
+    import torch
+    from pegainfer_amd import ffi
+    rng = np.random.default_rng(9)
+    T, K = 130, 256
+    W, X = rnd(rng, sum(ms), K, scale=0.05), rnd(rng, T, K)
+    Wd, Xd = to_dev(W), to_dev(X)
+    outs = [torch.empty((T, m), dtype=torch.bfloat16, device=Xd.device) for m in ms]
+    ys = (ctypes.c_void_p * len(ms))(*[o.data_ptr() for o in outs])
+    mm = (ctypes.c_int32 * len(ms))(*ms)
+    assert ffi.lib().pegainfer_gemm_split(Wd.data_ptr(), Xd.data_ptr(), len(ms), ys, mm, T, K,
+                                          torch.cuda.current_stream().cuda_stream) == 0
+    r0 = 0
+    for m, o in zip(ms, outs):
+        assert np.array_equal(bf16_bits(from_dev(o)), bf16_bits(from_dev(P.gemm(Wd[r0:r0 + m], Xd)))), (ms, m)
+        r0 += m
+
+
 def test_decode_gemm_batch_invariance_and_row_slices(P):
     """Decode GEMM: within a kernel family (dot2 GEMV: 1..4 columns, skinny MFMA: 5..64 columns) column t of a
     batched call == the same column in any other batch size, bit for bit; a row slice of the fused matrix == the
