@@ -285,6 +285,10 @@ def main():
 
     tokens = args.steps * args.batch * (1 if tp else world)
     value = tokens / elapsed
+    # configs[4] side measurement (not part of `value`): the DeepSeek-V4 MP8 collective verbs over the N ranks
+    mp8 = None
+    if world > 1:
+        mp8 = parallel.bench_mp8_collectives(parallel.Comm(), device=torch.device("cuda", local))
     ctx_mid = args.ctx + args.warmup + args.steps / 2
     step_bytes = algorithmic_bytes_per_token(full_cfg, ctx_mid, args.batch)
 
@@ -304,6 +308,7 @@ def main():
                     "min": round(float(min(ttfts)), 3), "iters": len(ttfts)},
         "tpot_ms": {"p50": round(float(np.median(step_ms)), 4), "p95": round(float(np.percentile(step_ms, 95)), 4),
                     "device_p50": round(float(np.median(dev_ms)), 4)},
+        "mp8_collectives_us": mp8,
         "step_roofline": {"algorithmic_bytes_per_step": int(step_bytes),
                           "achieved_GBps": round(step_bytes / (np.median(dev_ms) * 1e-3) / 1e9, 1),
                           "frac_of_8TBps": round(step_bytes / (np.median(dev_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},

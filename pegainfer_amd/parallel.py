@@ -191,3 +191,40 @@ class Comm:
         if rc != 0:
             raise RuntimeError(f"cast kernel failed with error {rc}")
         return out
+
+
+def bench_mp8_collectives(comm, hidden=4096, token_counts=(1, 8, 32, 256, 4096), iters=10, device="cuda"):
+    """BASELINE.json configs[4] (DeepSeek-V4 MP8, collectives only, synthetic): per-layer f32 all-reduce of
+    [T, hidden], bf16 all-gather [T, hidden] -> x world, f32 reduce-scatter of [world*T, hidden]; average us per
+    collective over the group (RCCL over xGMI when the group is nccl).  Returns {verb: {T: us}}."""
+    import torch
+    out = {"all_reduce_f32": {}, "all_gather_bf16": {}, "reduce_scatter_f32": {}}
+    cuda = str(device).startswith("cuda")
+
+    def timed(fn):
+        fn()
+        if cuda:
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            comm.dist.barrier(group=comm.group)
+            e0.record()
+            for _ in range(iters):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) * 1e3 / iters
+        import time
+        comm.dist.barrier(group=comm.group)
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        return (time.perf_counter() - t0) * 1e6 / iters
+
+    for T in token_counts:
+        ar = torch.ones((T, hidden), dtype=torch.float32, device=device)
+        ag = torch.ones((T, hidden), dtype=torch.bfloat16, device=device)
+        rs = torch.ones((comm.world * T, hidden), dtype=torch.float32, device=device)
+        out["all_reduce_f32"][str(T)] = round(timed(lambda: comm.all_reduce_in_place(ar)), 1)
+        out["all_gather_bf16"][str(T)] = round(timed(lambda: comm.all_gather(ag)), 1)
+        out["reduce_scatter_f32"][str(T)] = round(timed(lambda: comm.reduce_scatter(rs)), 1)
+    return out

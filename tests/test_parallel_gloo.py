@@ -153,3 +153,18 @@ def test_tp2_sharded_oracle_matches_unsharded():
     cos = (a * ref).sum(-1) / np.linalg.norm(a, axis=-1) / np.linalg.norm(ref, axis=-1)
     # partial sums are rounded to bf16 before the reduce (bf16 all-reduce): a few ulp on the logits
     assert cos.min() > 0.9995 and np.abs(a - ref).max() <= 0.5, (cos.min(), np.abs(a - ref).max())
+
+
+# ------------------------------------------------------------------ MP8 collective microbench (bench.py, N > 1)
+def _mp8_bench(rank):
+    out = P.bench_mp8_collectives(P.Comm(), hidden=64, token_counts=(1, 8), iters=2, device="cpu")
+    return out
+
+
+def test_mp8_collective_bench_runs_on_gloo():
+    """The side measurement bench.py adds at N > 1 (BASELINE.json configs[4]): every verb x token count yields a
+    positive time on both ranks."""
+    for r in run2(_mp8_bench):
+        assert set(r) == {"all_reduce_f32", "all_gather_bf16", "reduce_scatter_f32"}
+        for verb in r.values():
+            assert set(verb) == {"1", "8"} and all(v > 0 for v in verb.values())
