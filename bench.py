@@ -208,6 +208,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=12, help="decode steps for the CPU baseline (0 = skip)")
     ap.add_argument("--ttft-iters", type=int, default=5)
+    ap.add_argument("--sampling", default="greedy", choices=["greedy", "topk_topp", "topp"],
+                    help="configs[2]: per-request gpu_sample after every step (ops_embedding_sampling_bench.rs:49-90): "
+                         "topk_topp = T 0.8, top_k 50, top_p 0.95; topp = T 0.8, top_k -1, top_p 0.9")
     ap.add_argument("--parallelism", default="replicas", choices=["replicas", "tp"],
                     help="N>1: 'replicas' = one independent request stream per GPU (weak scaling, no data-path "
                          "collective; default); 'tp' = the reference's Qwen3 tensor parallel over RCCL "
@@ -274,9 +277,14 @@ def main():
     step_ms, dev_ms = [], []
     barrier()
     t_start = time.perf_counter()
+    samp = {"greedy": None, "topk_topp": (0.8, 50, 0.95), "topp": (0.8, -1, 0.9)}[args.sampling]
+    srng = np.random.default_rng(42 + rank)
     for _ in range(args.steps):
         t0 = time.perf_counter()
         toks = eng.decode(rids, toks)
+        if samp:   # the reference samples request by request after the step (executor.rs:324-328)
+            toks = np.array([eng.sample(i, samp[0], samp[1], samp[2], float(srng.random())) for i in range(len(rids))],
+                            dtype=np.int32)
         step_ms.append((time.perf_counter() - t0) * 1e3)
         dev_ms.append(eng.last_step_ms())
     barrier()
@@ -303,7 +311,7 @@ def main():
                                f"bs={args.batch}/GPU, ctx {args.ctx}->{args.ctx + args.warmup + args.steps} "
                                f"(reference decode_heavy: synthetic prompt 100+(i%1000))",
                    "batch_per_gpu": args.batch, "ctx": args.ctx, "decode_mode": args.decode_mode,
-                   "split_policy": args.split_policy, "parallelism": ("tp%d" % world if tp else "replicas%d" % world) if world > 1 else "single"},
+                   "sampling": args.sampling, "split_policy": args.split_policy, "parallelism": ("tp%d" % world if tp else "replicas%d" % world) if world > 1 else "single"},
         "ttft_ms": {"prompt_tokens": args.ctx, "p50": round(float(np.median(ttfts)), 3),
                     "min": round(float(min(ttfts)), 3), "iters": len(ttfts)},
         "tpot_ms": {"p50": round(float(np.median(step_ms)), 4), "p95": round(float(np.percentile(step_ms, 95)), 4),

@@ -122,7 +122,16 @@ __global__ __launch_bounds__(256) void batched_top1_kernel(const Half* __restric
 }
 
 // ---------------------------------------------------------------- temperature / top-k / top-p
+// One workgroup of 1024 lanes, 7 vectorised sweeps of the vocabulary (L2-resident after the first):
+//   softmax: max, sum, write  |  3 radix passes that build the top-k COUNT and the top-p MASS histograms together
+//   |  one sweep that folds the kept mass into 256-token chunk sums, then a block scan over the chunks and a wave
+//   scan inside the chosen chunk give the inverse-CDF draw in index order.
+// Histograms are integer (counts u32, masses as floor(p * 2^44) in u64): native LDS atomics, and an
+// order-independent sum, so the thresholds - hence the support set - are reproducible run to run.  The bin that
+// crosses the target is found with a block-wide suffix scan, not a serial walk.
 constexpr int kSampleBlock = 1024;
+constexpr int kSampleWaves = kSampleBlock / 64;
+constexpr float kMassScale = 17592186044416.0f;  // 2^44
 
 __device__ __forceinline__ float block_reduce_f(float v, bool is_max, float* smem16) {
   v = is_max ? wave_max(v) : wave_sum(v);
@@ -130,44 +139,57 @@ __device__ __forceinline__ float block_reduce_f(float v, bool is_max, float* sme
   if ((threadIdx.x & 63) == 0) smem16[threadIdx.x >> 6] = v;
   __syncthreads();
   float r = smem16[0];
-  for (int i = 1; i < kSampleBlock / 64; ++i) r = is_max ? fmaxf(r, smem16[i]) : r + smem16[i];
+  for (int i = 1; i < kSampleWaves; ++i) r = is_max ? fmaxf(r, smem16[i]) : r + smem16[i];
   return r;
 }
 
-// Largest fp32 bit pattern v such that  weight(p >= v) >= target  (weight = count or mass).
-__device__ uint32_t radix_threshold(const float* __restrict__ probs, int n, float target, bool by_mass,
-                                    float* hist /* 2048 */, uint32_t* sh_prefix, float* sh_above) {
-  if (threadIdx.x == 0) { *sh_prefix = 0u; *sh_above = 0.f; }
-  int shift = 32;
-  for (int pass = 0; pass < 3; ++pass) {
-    const int bits = pass < 2 ? 11 : 10;
-    const int hi_shift = shift;  // bits above this pass
-    shift -= bits;
-    const int nb = 1 << bits;
-    for (int i = threadIdx.x; i < nb; i += kSampleBlock) hist[i] = 0.f;
-    __syncthreads();
-    const uint32_t prefix = *sh_prefix;
-    for (int i = threadIdx.x; i < n; i += kSampleBlock) {
-      const float p = probs[i];
-      const uint32_t u = __builtin_bit_cast(uint32_t, p);
-      const bool match = pass == 0 || (u >> hi_shift) == (prefix >> hi_shift);
-      if (match) atomicAdd(&hist[(u >> shift) & (nb - 1)], by_mass ? p : 1.0f);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      float acc = *sh_above;
-      int chosen = 0;
-      for (int b = nb - 1; b >= 0; --b) {
-        const float h = hist[b];
-        if (acc + h >= target) { chosen = b; break; }
-        acc += h;
-      }
-      *sh_above = acc;
-      *sh_prefix = prefix | ((uint32_t)chosen << shift);
-    }
-    __syncthreads();
+// inclusive scan of one value per thread in thread order; *total = sum over the block
+template <typename T>
+__device__ __forceinline__ T block_scan_incl(T v, T* wave_tot /* 16 */, T* total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const T o = __shfl_up(v, off, kWave);
+    if (lane >= off) v += o;
   }
-  return *sh_prefix;
+  __syncthreads();
+  if (lane == 63) wave_tot[w] = v;
+  __syncthreads();
+  T base = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < kSampleWaves; ++i) {
+    const T x = wave_tot[i];
+    if (i < w) base += x;
+    tot += x;
+  }
+  *total = tot;
+  return base + v;
+}
+
+// Walk the histogram from the top bin down: the bin b with  above + S(b+1) < target <= above + S(b)
+// (S = suffix sum) is written to *chosen and *above += S(b+1).  Thread t owns bins nb-1-t*per .. (descending).
+template <typename T>
+__device__ __forceinline__ void select_bin(const T* hist, int nb, T target_total, int* chosen, T* above, T* wave_tot) {
+  const int t = threadIdx.x, per = nb / kSampleBlock;  // 2 (11-bit pass) or 1 (10-bit pass)
+  const T prev = *above;
+  const T target = target_total > prev ? target_total - prev : 0;
+  const T h0 = hist[nb - 1 - t * per], h1 = per == 2 ? hist[nb - 2 - t * per] : (T)0;
+  if (t == 0) *chosen = 0;  // target beyond the total (rounding): lowest bin, keeps everything below
+  T total;
+  const T incl = block_scan_incl<T>(h0 + h1, wave_tot, &total);
+  const T excl = incl - (h0 + h1);
+  if (target == 0) {
+    if (t == 0) *chosen = nb - 1;
+  } else if (excl < target && target <= excl + h0) {
+    *chosen = nb - 1 - t * per;
+    *above = prev + excl;
+  } else if (per == 2 && excl + h0 < target && target <= incl) {
+    *chosen = nb - 2 - t * per;
+    *above = prev + excl + h0;
+  } else if (t == 0 && target > total) {
+    *above = prev + total - hist[0];
+  }
+  __syncthreads();
 }
 
 __device__ __forceinline__ float uniform01(uint64_t seed) {
@@ -178,91 +200,171 @@ __device__ __forceinline__ float uniform01(uint64_t seed) {
   return (float)(z >> 40) * (1.0f / 16777216.0f);  // 24 random bits -> [0,1)
 }
 
+// f(value, index) over logits*inv_t, 8 per 16-byte load when aligned
+template <typename F>
+__device__ __forceinline__ void for_logits(const Half* __restrict__ logits, int n, float inv_t, F f) {
+  const int tid = threadIdx.x;
+  int done = 0;
+  if (aligned16(logits)) {
+    const int nvec = n >> 3;
+    for (int i = tid; i < nvec; i += kSampleBlock) {
+      const u32x4 v = reinterpret_cast<const u32x4*>(logits)[i];
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f(bf_lo(w[j]) * inv_t, i * 8 + 2 * j);
+        f(bf_hi(w[j]) * inv_t, i * 8 + 2 * j + 1);
+      }
+    }
+    done = nvec << 3;
+  }
+  for (int i = done + tid; i < n; i += kSampleBlock) f(bf2f(logits[i]) * inv_t, i);
+}
+// f(prob) over probs, 4 per 16-byte load when aligned (order of visits is irrelevant to the callers)
+template <typename F>
+__device__ __forceinline__ void for_probs(const float* __restrict__ probs, int n, F f) {
+  const int tid = threadIdx.x;
+  int done = 0;
+  if (aligned16(probs)) {
+    const int nvec = n >> 2;
+    for (int i = tid; i < nvec; i += kSampleBlock) {
+      const f32x4 v = reinterpret_cast<const f32x4*>(probs)[i];
+      f(v[0]); f(v[1]); f(v[2]); f(v[3]);
+    }
+    done = nvec << 2;
+  }
+  for (int i = done + tid; i < n; i += kSampleBlock) f(probs[i]);
+}
+
 __global__ __launch_bounds__(kSampleBlock) void sample_kernel(const Half* __restrict__ logits,
                                                                float* __restrict__ probs,
                                                                uint8_t* __restrict__ valid, int* __restrict__ out,
                                                                int n, float inv_t, int top_k, float top_p,
                                                                uint64_t seed) {
-  __shared__ float red[16];
-  __shared__ float hist[2048];
-  __shared__ uint32_t sh_prefix;
-  __shared__ float sh_above;
-  __shared__ float sh_run;
-  __shared__ int sh_pick;
-  const int tid = threadIdx.x;
-  // softmax (reference logits_to_probs_kernel)
+  __shared__ float red[kSampleWaves];
+  __shared__ uint32_t cnt[2048];
+  __shared__ unsigned long long mass[2048];
+  __shared__ uint32_t wt32[kSampleWaves];
+  __shared__ unsigned long long wt64[kSampleWaves];
+  __shared__ float wtf[kSampleWaves];
+  __shared__ float chunk_sum[kSampleBlock];
+  __shared__ uint32_t above_k;
+  __shared__ unsigned long long above_p;
+  __shared__ int chosen_k, chosen_p, sh_chunk, sh_pick, sh_last;
+  __shared__ float sh_rem;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  // ---- softmax (reference logits_to_probs_kernel): p = expf(v - max) / sum ----
   float m = -INFINITY;
-  for (int i = tid; i < n; i += kSampleBlock) {
-    const float v = bf2f(logits[i]) * inv_t;
-    probs[i] = v;
-    m = fmaxf(m, v);
-  }
+  for_logits(logits, n, inv_t, [&](float v, int) { m = fmaxf(m, v); });
   m = block_reduce_f(m, true, red);
   float s = 0.f;
-  for (int i = tid; i < n; i += kSampleBlock) {
-    const float e = expf(probs[i] - m);
-    probs[i] = e;
-    s += e;
-  }
+  for_logits(logits, n, inv_t, [&](float v, int) { s += expf(v - m); });
   s = block_reduce_f(s, false, red);
   const float inv_sum = 1.0f / s;
-  for (int i = tid; i < n; i += kSampleBlock) probs[i] *= inv_sum;
+  for_logits(logits, n, inv_t, [&](float v, int i) { probs[i] = expf(v - m) * inv_sum; });
   __syncthreads();
 
-  // joint filter thresholds on the ORIGINAL distribution
-  uint32_t thr = 0u;
-  if (top_k > 0 && top_k < n) thr = radix_threshold(probs, n, (float)top_k, false, hist, &sh_prefix, &sh_above);
-  if (top_p < 1.0f) {
-    const uint32_t tp = radix_threshold(probs, n, top_p, true, hist, &sh_prefix, &sh_above);
-    thr = tp > thr ? tp : thr;
+  // ---- joint filter thresholds on the ORIGINAL distribution: largest bit pattern v with count(p >= v) >= top_k,
+  //      resp. mass(p >= v) >= top_p; 11 + 11 + 10 bit radix passes, both histograms per sweep ----
+  const bool do_k = top_k > 0 && top_k < n, do_p = top_p < 1.0f;
+  uint32_t pk = 0u, pp = 0u;
+  if (do_k || do_p) {
+    if (tid == 0) { above_k = 0u; above_p = 0ull; }
+    const unsigned long long target_p = (unsigned long long)((double)top_p * (double)kMassScale);
+    int shift = 32;
+    for (int pass = 0; pass < 3; ++pass) {
+      const int bits = pass < 2 ? 11 : 10, hi = shift, nb = 1 << bits;
+      shift -= bits;
+      for (int i = tid; i < nb; i += kSampleBlock) { cnt[i] = 0u; mass[i] = 0ull; }
+      __syncthreads();
+      for_probs(probs, n, [&](float p) {
+        const uint32_t u = __builtin_bit_cast(uint32_t, p);
+        const int bin = (u >> shift) & (nb - 1);
+        if (do_k && (pass == 0 || (u >> hi) == (pk >> hi))) atomicAdd(&cnt[bin], 1u);
+        if (do_p && (pass == 0 || (u >> hi) == (pp >> hi))) atomicAdd(&mass[bin], (unsigned long long)(p * kMassScale));
+      });
+      __syncthreads();
+      if (do_k) { select_bin<uint32_t>(cnt, nb, (uint32_t)top_k, &chosen_k, &above_k, wt32); pk |= (uint32_t)chosen_k << shift; }
+      if (do_p) { select_bin<unsigned long long>(mass, nb, target_p, &chosen_p, &above_p, wt64); pp |= (uint32_t)chosen_p << shift; }
+    }
   }
+  const uint32_t thr = (do_k ? pk : 0u) > (do_p ? pp : 0u) ? (do_k ? pk : 0u) : (do_p ? pp : 0u);
   const float thr_f = __builtin_bit_cast(float, thr);
 
-  float kept = 0.f;
-  for (int i = tid; i < n; i += kSampleBlock) kept += probs[i] >= thr_f ? probs[i] : 0.f;
-  kept = block_reduce_f(kept, false, red);
-  const float target = uniform01(seed) * kept;
-
-  // inverse CDF in index order: chunks of 1024 consecutive tokens, wave scan + wave offsets
-  if (tid == 0) { sh_run = 0.f; sh_pick = 0x7FFFFFFF; }
-  __syncthreads();
-  int last_kept = -1;
-  for (int base = 0; base < n; base += kSampleBlock) {
-    const int i = base + tid;
-    const float p = (i < n && probs[i] >= thr_f) ? probs[i] : 0.f;
-    if (p > 0.f) last_kept = i;
-    float incl = p;  // inclusive scan inside the wave
+  // ---- kept mass per chunk of cw consecutive tokens (wave w owns chunks w, w+16, ...) ----
+  const int cw = 256 * ((n + 256 * kSampleBlock - 1) / (256 * kSampleBlock));
+  const int nchunks = (n + cw - 1) / cw;
+  const bool vec = aligned16(probs);
+  auto chunk_vals = [&](int c, int j, float (&a)[4]) {  // 4 consecutive kept-filtered probs of this lane
+    const int i0 = c * cw + j * 256 + lane * 4;
+    if (vec && i0 + 3 < n) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(probs + i0);
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const float o = __shfl_up(incl, off, kWave);
-      if ((tid & 63) >= off) incl += o;
+      for (int e = 0; e < 4; ++e) a[e] = v[e] >= thr_f ? v[e] : 0.f;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[e] = (i0 + e < n && probs[i0 + e] >= thr_f) ? probs[i0 + e] : 0.f;
     }
-    if ((tid & 63) == 63) red[tid >> 6] = incl;
-    __syncthreads();
-    float woff = sh_run;
-    for (int w = 0; w < (tid >> 6); ++w) woff += red[w];
-    const float cum = woff + incl;
-    if (p > 0.f && cum > target && cum - p <= target) atomicMin(&sh_pick, i);
-    __syncthreads();
-    if (sh_pick != 0x7FFFFFFF) break;
-    if (tid == 0) {
-      float t = sh_run;
-      for (int w = 0; w < kSampleBlock / 64; ++w) t += red[w];
-      sh_run = t;
+    return i0;
+  };
+  for (int c = wave; c < nchunks; c += kSampleWaves) {
+    float t = 0.f;
+    for (int j = 0; j < cw / 256; ++j) {
+      float a[4];
+      chunk_vals(c, j, a);
+      t += (a[0] + a[1]) + (a[2] + a[3]);
     }
-    __syncthreads();
+    t = wave_sum(t);
+    if (lane == 0) chunk_sum[c] = t;
   }
-  if (sh_pick == 0x7FFFFFFF) {  // rounding left the target above the running sum: take the last kept token
-    __shared__ int sh_last;
-    if (tid == 0) sh_last = -1;
-    __syncthreads();
-    if (last_kept >= 0) atomicMax(&sh_last, last_kept);
-    __syncthreads();
-    if (tid == 0) sh_pick = sh_last < 0 ? 0 : sh_last;
-    __syncthreads();
+  if (tid == 0) { sh_chunk = -1; sh_pick = 0x7FFFFFFF; sh_last = -1; }
+  __syncthreads();
+  const float mine = tid < nchunks ? chunk_sum[tid] : 0.f;
+  float kept;
+  const float incl = block_scan_incl<float>(mine, wtf, &kept);
+  const float target = uniform01(seed) * kept;
+  if (mine > 0.f) {
+    if (incl > target && incl - mine <= target) { sh_chunk = tid; sh_rem = target - (incl - mine); }
+    atomicMax(&sh_last, tid);  // last chunk holding kept mass (fallback when rounding leaves target >= kept)
   }
+  __syncthreads();
+  const bool fallback = sh_chunk < 0;
+  const int c = fallback ? sh_last : sh_chunk;
+  if (c >= 0 && wave == 0) {  // inverse CDF inside the chunk, index order
+    const float rem = sh_rem;
+    float run = 0.f;
+    int last_kept = -1;
+    for (int j = 0; j < cw / 256; ++j) {
+      float a[4];
+      const int i0 = chunk_vals(c, j, a);
+      const float lt = (a[0] + a[1]) + (a[2] + a[3]);
+      float inc = lt;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const float o = __shfl_up(inc, off, kWave);
+        if (lane >= off) inc += o;
+      }
+      float cum = run + inc - lt;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (a[e] > 0.f) {
+          last_kept = i0 + e;
+          if (!fallback && cum + a[e] > rem && cum <= rem) atomicMin(&sh_pick, i0 + e);
+        }
+        cum += a[e];
+      }
+      run += __shfl(inc, 63, kWave);
+    }
+    // not found inside the chunk (summation order differs from the chunk total by an ulp) or fallback: last kept
+    int lk = last_kept;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(lk, off, kWave); lk = lk > o ? lk : o; }
+    if (lane == 0 && sh_pick == 0x7FFFFFFF) sh_pick = lk < 0 ? 0 : lk;
+  }
+  __syncthreads();
   if (tid == 0) {
-    out[0] = sh_pick;
+    out[0] = sh_pick == 0x7FFFFFFF ? 0 : sh_pick;
     if (valid) valid[0] = 1;
   }
 }
