@@ -37,7 +37,7 @@ struct ContigAddr {  // HND: cache[head][pos][dim]
   __device__ __forceinline__ long row(int t) const { return head_base + (long)t * D; }
 };
 
-template <int QBLK, int D, typename Addr>
+template <int QBLK, int D, int NW, typename Addr>
 __device__ __forceinline__ void prefill_tile(const Half* __restrict__ q_base, Half* __restrict__ o_base,
                                              const Half* __restrict__ kbuf, const Half* __restrict__ vbuf,
                                              const Addr& addr, int qo_len, int kv_len, int tile_row0,
@@ -46,8 +46,12 @@ __device__ __forceinline__ void prefill_tile(const Half* __restrict__ q_base, Ha
   constexpr int KCH = D / 8;               // 16-byte chunks per K/V row
   constexpr int KS = D / 32;               // MFMA k-steps over the head dim
   constexpr int DB = D / 16;               // 16-dim output blocks
-  constexpr int KPT = TKV * KCH / 256;     // K chunks staged per thread
-  constexpr int VPT = 16 * KCH / 256;      // V (4-token x 8-dim) units staged per thread
+  // NW waves x QBLK x 16 packed rows per workgroup.  Measured on MI355X (TTFT 1024 / 8192 tokens, ms): 4 waves x
+  // 16 rows 17.0 / 164.5, 2 waves x 32 rows (each LDS fragment feeds two MFMAs) 17.6 / 184.5, 1 wave x 64 rows
+  // 19.8 / 195.1 - occupancy, not LDS reads, is what the 64-row tile is short of.
+  constexpr int NT = NW * 64;
+  constexpr int KPT = TKV * KCH / NT;      // K chunks staged per thread
+  constexpr int VPT = 16 * KCH / NT;       // V (4-token x 8-dim) units staged per thread
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int l15 = lane & 15, g = lane >> 4;
   const int packed_len = qo_len * group;
@@ -94,14 +98,14 @@ __device__ __forceinline__ void prefill_tile(const Half* __restrict__ q_base, Ha
   auto load_tile = [&](int kv0) {
 #pragma unroll
     for (int j = 0; j < KPT; ++j) {
-      const int cid = threadIdx.x + j * 256, row = cid / KCH, slot = cid % KCH;
+      const int cid = threadIdx.x + j * NT, row = cid / KCH, slot = cid % KCH;
       int t = kv0 + row;
       t = t < kv_len ? t : kv_len - 1;
       kreg[j] = *reinterpret_cast<const u32x4*>(kbuf + addr.row(t) + addr.k_off + slot * 8);
     }
 #pragma unroll
     for (int j = 0; j < VPT; ++j) {
-      const int uid = threadIdx.x + j * 256, v_tq = uid / KCH, v_dc = uid % KCH;
+      const int uid = threadIdx.x + j * NT, v_tq = uid / KCH, v_dc = uid % KCH;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         int tv = kv0 + v_tq * 4 + i;
@@ -113,13 +117,13 @@ __device__ __forceinline__ void prefill_tile(const Half* __restrict__ q_base, Ha
   auto store_tile = [&]() {
 #pragma unroll
     for (int j = 0; j < KPT; ++j) {
-      const int cid = threadIdx.x + j * 256, row = cid / KCH, slot = cid % KCH;
+      const int cid = threadIdx.x + j * NT, row = cid / KCH, slot = cid % KCH;
       ks[row * KCH + (slot ^ (row & 15))] = kreg[j];
     }
     // 4 tokens x 8 dims -> 8 rows of V^T, 4 tokens each
 #pragma unroll
     for (int j = 0; j < VPT; ++j) {
-      const int uid = threadIdx.x + j * 256, v_tq = uid / KCH, v_dc = uid % KCH;
+      const int uid = threadIdx.x + j * NT, v_tq = uid / KCH, v_dc = uid % KCH;
       const uint32_t w[4][4] = {{vreg[j][0].x, vreg[j][0].y, vreg[j][0].z, vreg[j][0].w},
                                 {vreg[j][1].x, vreg[j][1].y, vreg[j][1].z, vreg[j][1].w},
                                 {vreg[j][2].x, vreg[j][2].y, vreg[j][2].z, vreg[j][2].w},
@@ -239,8 +243,8 @@ __device__ __forceinline__ void prefill_tile(const Half* __restrict__ q_base, Ha
   }
 }
 
-template <int QBLK, int D>
-__global__ __launch_bounds__(256) void batch_prefill_paged_kernel(
+template <int QBLK, int D, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void batch_prefill_paged_kernel(
     const Half* __restrict__ q, Half* __restrict__ out, const Half* __restrict__ kv, long k_off, long v_off,
     const int* __restrict__ page_indices, const int* __restrict__ page_indptr,
     const int* __restrict__ last_page_len, const int* __restrict__ q_indptr,
@@ -261,7 +265,7 @@ __global__ __launch_bounds__(256) void batch_prefill_paged_kernel(
   PagedAddr addr{page_indices, pbase, page_size, stride_page, (long)num_kv_heads * D, (long)kvh * D, k_off, v_off};
   const long q_stride_n = (long)num_qo_heads * D;
   const long qo_base = (long)q0 * q_stride_n + (long)kvh * group * D;
-  prefill_tile<QBLK, D>(q + qo_base, out + qo_base, kv, kv, addr, qo_len, kv_len, row0, cta_tile_q, group,
+  prefill_tile<QBLK, D, NW>(q + qo_base, out + qo_base, kv, kv, addr, qo_len, kv_len, row0, cta_tile_q, group,
                      q_stride_n, scale_log2, ks, vt);
 }
 
@@ -280,7 +284,7 @@ __global__ __launch_bounds__(256) void single_prefill_kernel(const Half* __restr
   ContigAddr addr{(long)kvh * max_seq_len * 128, 128, 0, 0};
   const long q_stride_n = (long)num_qo_heads * 128;
   const long qo_base = (long)kvh * group * 128;
-  prefill_tile<QBLK, 128>(q + qo_base, out + qo_base, k_cache, v_cache, addr, seq_len, kv_len, row0, cta_tile_q,
+  prefill_tile<QBLK, 128, 4>(q + qo_base, out + qo_base, k_cache, v_cache, addr, seq_len, kv_len, row0, cta_tile_q,
                      group, q_stride_n, scale_log2, ks, vt);
 }
 
