@@ -38,30 +38,39 @@ inline int skinny_pick_kt(int T, int K) {
   return kt > kr ? kr : kt;
 }
 
-template <int NB, int EPI>
+// RB = 16-row blocks of W per workgroup.  The x tile width shrinks as T grows (T*KT*2 <= 64 KB), so at T = 32 / 64 a
+// wave has only 4 / 2 K steps of one row block per tile: too few loads in flight, and x re-staged by every 16 rows.
+// RB = 2 / 4 row blocks per workgroup keep 8 fragment loads per weight set in flight per wave and cut the x
+// staging traffic by RB.  The pair -> wave mapping and the per-wave accumulation order are unchanged, so results
+// are bit-identical to RB = 1.
+template <int NB, int EPI, int RB>
 __global__ __launch_bounds__(kSkinnyThreads) void skinny_mfma_kernel(const GemvFusedArgs a) {
-  constexpr int TP = NB * 16;
   constexpr int NW = EPI == kEpiSilu ? 2 : 1;
-  constexpr int MAXS = 8;  // K steps per wave per tile = KT / 256 <= 8
+  constexpr int JM = 8 / RB;  // K steps per wave per tile per row block; host guarantees KT <= JM * 256
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   u32x4* xs = reinterpret_cast<u32x4*>(smem_raw);
   const int KT = a.KT, K = a.K, T = a.T;
   const int pitch = KT >> 3;  // 16-byte chunks per token row
-  float* sm_inv = reinterpret_cast<float*>(smem_raw + a.M * 0 + (size_t)skinny_xs_bytes(NB, T, KT));  // [64] inverse RMS per token
+  float* sm_inv = reinterpret_cast<float*>(smem_raw + (size_t)skinny_xs_bytes(NB, T, KT));  // [64] inverse RMS per token
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
   const int rows_total = EPI == kEpiSilu ? a.I : a.M;
-  const int row0 = blockIdx.x * 16;
-  int row = row0 + l15;
-  row = row < rows_total ? row : rows_total - 1;
-  const Half* wptr[NW];
+  const int row0 = blockIdx.x * 16 * RB;
+  const Half* wptr[NW][RB];
 #pragma unroll
-  for (int s = 0; s < NW; ++s) wptr[s] = a.W + ((size_t)row + (size_t)s * a.I) * K + g * 8;
+  for (int rb = 0; rb < RB; ++rb) {
+    int row = row0 + rb * 16 + l15;
+    row = row < rows_total ? row : rows_total - 1;
+#pragma unroll
+    for (int s = 0; s < NW; ++s) wptr[s][rb] = a.W + ((size_t)row + (size_t)s * a.I) * K + g * 8;
+  }
 
-  f32x4 acc[NW][NB];
+  f32x4 acc[NW][RB][NB];
 #pragma unroll
   for (int s = 0; s < NW; ++s)
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) acc[s][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc[s][rb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // ---- prologue: per-token inverse RMS, canonical one-wave-per-row order, 8 tokens at a time ----
   if (a.norm_w) {
@@ -76,18 +85,20 @@ __global__ __launch_bounds__(kSkinnyThreads) void skinny_mfma_kernel(const GemvF
     const int kt = (K - k0) < KT ? (K - k0) : KT;
     const int nsteps = kt >> 5;  // K % 32 == 0 (dispatch guarantees)
     // ---- this tile's weight fragments: all loads leave before the x tile is staged ----
-    u32x4 av[NW][MAXS];
+    u32x4 av[NW][RB][JM];
     const int jmax = KT >> 8;  // steps per wave in a full tile (uniform): no wasted loads on narrow tiles
 #pragma unroll
-    for (int j = 0; j < MAXS; ++j) {
-      if (j < jmax) {
-        int s = 2 * (wave + kSkinnyWaves * (j >> 1)) + (j & 1);  // steps of pair wave + 8*(j/2)
-        s = s < nsteps ? s : nsteps - 1;  // clamp on the last, shorter tile (result unused)
+    for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-        for (int w = 0; w < NW; ++w)
-          av[w][j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wptr[w] + k0 + s * 32));
+      for (int j = 0; j < JM; ++j) {
+        if (j < jmax) {
+          int s = 2 * (wave + kSkinnyWaves * (j >> 1)) + (j & 1);  // steps of pair wave + 8*(j/2)
+          s = s < nsteps ? s : nsteps - 1;  // clamp on the last, shorter tile (result unused)
+#pragma unroll
+          for (int w = 0; w < NW; ++w)
+            av[w][rb][j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wptr[w][rb] + k0 + s * 32));
+        }
       }
-    }
     // ---- stage x[:, k0:k0+kt] (optionally normalised on the fly) ----
     __syncthreads();
     const int nvec = kt >> 3;
@@ -114,7 +125,7 @@ __global__ __launch_bounds__(kSkinnyThreads) void skinny_mfma_kernel(const GemvF
     }
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < MAXS; ++j) {
+    for (int j = 0; j < JM; ++j) {
       const int s = 2 * (wave + kSkinnyWaves * (j >> 1)) + (j & 1);
       if (j < jmax && s < nsteps) {
 #pragma unroll
@@ -123,42 +134,48 @@ __global__ __launch_bounds__(kSkinnyThreads) void skinny_mfma_kernel(const GemvF
           t = t < T ? t : T - 1;  // absent token columns re-read a staged row; their results are never stored
           const bf16x8_t b = __builtin_bit_cast(bf16x8_t, xs[t * pitch + ((s * 4 + g) ^ l15)]);
 #pragma unroll
-          for (int w = 0; w < NW; ++w)
-            acc[w][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, av[w][j]), b, acc[w][nb], 0, 0, 0);
+          for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int w = 0; w < NW; ++w)
+              acc[w][rb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, av[w][rb][j]), b,
+                                                                       acc[w][rb][nb], 0, 0, 0);
         }
       }
     }
   }
 
-  // ---- combine the 8 waves (fixed order) and store ----
-  __syncthreads();
+  // ---- combine the 8 waves (fixed order) and store, one row block at a time through the same LDS buffer ----
   f32x4* red = reinterpret_cast<f32x4*>(smem_raw);  // [wave][NW][NB][64 lanes]
 #pragma unroll
-  for (int w = 0; w < NW; ++w)
+  for (int rb = 0; rb < RB; ++rb) {
+    __syncthreads();
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) red[((wave * NW + w) * NB + nb) * 64 + lane] = acc[w][nb];
-  __syncthreads();
-  for (int e = tid; e < NB * 64; e += kSkinnyThreads) {
-    const int nb = e >> 6, ln = e & 63;
-    f32x4 tot[NW];
+    for (int w = 0; w < NW; ++w)
 #pragma unroll
-    for (int w = 0; w < NW; ++w) {
-      f32x4 v = red[((0 * NW + w) * NB + nb) * 64 + ln];
+      for (int nb = 0; nb < NB; ++nb) red[((wave * NW + w) * NB + nb) * 64 + lane] = acc[w][rb][nb];
+    __syncthreads();
+    for (int e = tid; e < NB * 64; e += kSkinnyThreads) {
+      const int nb = e >> 6, ln = e & 63;
+      f32x4 tot[NW];
 #pragma unroll
-      for (int wv = 1; wv < kSkinnyWaves; ++wv) v += red[((wv * NW + w) * NB + nb) * 64 + ln];
-      tot[w] = v;
-    }
-    const int t = nb * 16 + (ln & 15);
-    if (t >= T) continue;
+      for (int w = 0; w < NW; ++w) {
+        f32x4 v = red[((0 * NW + w) * NB + nb) * 64 + ln];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = row0 + (ln >> 4) * 4 + i;
-      if (r >= rows_total) continue;
-      if (EPI == kEpiSilu) {
-        const float gt = bf16_round_f(tot[0][i]), up = bf16_round_f(tot[NW - 1][i]);
-        a.Y[(size_t)t * a.I + r] = f2bf(silu_f(gt) * up);
-      } else {
-        a.Y[(size_t)t * a.M + r] = f2bf(tot[0][i]);
+        for (int wv = 1; wv < kSkinnyWaves; ++wv) v += red[((wv * NW + w) * NB + nb) * 64 + ln];
+        tot[w] = v;
+      }
+      const int t = nb * 16 + (ln & 15);
+      if (t >= T) continue;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = row0 + rb * 16 + (ln >> 4) * 4 + i;
+        if (r >= rows_total) continue;
+        if (EPI == kEpiSilu) {
+          const float gt = bf16_round_f(tot[0][i]), up = bf16_round_f(tot[NW - 1][i]);
+          a.Y[(size_t)t * a.I + r] = f2bf(silu_f(gt) * up);
+        } else {
+          a.Y[(size_t)t * a.M + r] = f2bf(tot[0][i]);
+        }
       }
     }
   }
@@ -353,16 +370,30 @@ inline void skinny_launch_resident(GemvFusedArgs a, hipStream_t s) {
   kern<<<grid, kSkinnyThreads, lds, s>>>(a);
 }
 
-template <int NB, int EPI>
-inline void skinny_launch(GemvFusedArgs a, hipStream_t s) {
-  a.KT = skinny_pick_kt(a.T, a.K);
+template <int NB, int EPI, int RB>
+inline void skinny_launch_rb(const GemvFusedArgs& a, hipStream_t s) {
   const int rows = EPI == kEpiSilu ? a.I : a.M;
   const int lds = skinny_xs_bytes(NB, a.T, a.KT) + (64 + 4) * 4;
-  auto kern = &skinny_mfma_kernel<NB, EPI>;
+  auto kern = &skinny_mfma_kernel<NB, EPI, RB>;
   static const bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
   (void)once;
-  kern<<<ceil_div(rows, 16), kSkinnyThreads, lds, s>>>(a);
+  kern<<<ceil_div(rows, 16 * RB), kSkinnyThreads, lds, s>>>(a);
+}
+template <int NB, int EPI>
+inline void skinny_launch(GemvFusedArgs a, hipStream_t s) {
+  a.KT = skinny_pick_kt(a.T, a.K);
+  // row blocks per workgroup: keep ~8 K steps per wave per tile in flight (PEGAINFER_SKINNY_RB=1 forces 1: A/B)
+  static const bool rb1 = [] { const char* e = getenv("PEGAINFER_SKINNY_RB"); return e && e[0] == '1'; }();
+  const int rows = EPI == kEpiSilu ? a.I : a.M;
+  // largest RB the tile allows (KT <= (8/RB)*256; the SwiGLU form streams two weight sets, so RB <= 2 there keeps
+  // it under 256 VGPRs) that still leaves at least one workgroup per CU
+  int rb = a.KT >= 2048 || rb1 ? 1 : a.KT >= 1024 ? 2 : 4;
+  if (EPI == kEpiSilu && rb > 2) rb = 2;
+  while (rb > 1 && ceil_div(rows, 16 * rb) < 256) rb >>= 1;
+  if (rb == 4) { skinny_launch_rb<NB, EPI, 4>(a, s); }
+  else if (rb == 2) { if (a.KT > 1024) a.KT = 1024; skinny_launch_rb<NB, EPI, 2>(a, s); }
+  else skinny_launch_rb<NB, EPI, 1>(a, s);
 }
 
 // 2 <= T <= 64, K % 32 == 0
