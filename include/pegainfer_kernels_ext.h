@@ -29,8 +29,9 @@ pegainfer_status_t pegainfer_batched_top1(const Half* logits, int32_t vocab_size
  *                                        (fused_add_rms_norm_batched_cuda + gemm; hidden_out != X)
  *   silu_intermediate = I > 0          : W = [gate; up] (M == 2I), Y[T, I] = silu_mul_fused(W.x)
  *                                        (gemm + silu_mul_fused_cuda)
- * Returns hipErrorInvalidValue for shapes it does not take (T > 64, K % 8, misaligned) so the caller can
- * fall back to the unfused sequence. */
+ * The plain form takes T <= 64; the prologue / epilogue forms T <= 16 (larger decode batches run the unfused
+ * sequence, whose big GEMMs use the tiled LDS-DMA kernel).  Returns hipErrorInvalidValue for shapes it does not
+ * take (K % 8, misaligned, ...) so the caller can fall back to the unfused sequence. */
 pegainfer_status_t pegainfer_gemv_fused(const Half* W, const Half* X, Half* Y, int32_t M, int32_t T, int32_t K, const Half* residual, const Half* norm_weight, Half* hidden_out, float eps, int32_t silu_intermediate, pegainfer_stream_t stream);
 
 /* pegainfer_gemv_fused with the Qwen3.5 rounding points (T <= 4): flags bit 0 = the norm weight is (1 + w)

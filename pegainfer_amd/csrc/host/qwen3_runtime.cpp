@@ -341,9 +341,15 @@ struct Model {
   int decode_layer_reference(int li, int bs, bool split, int split_slots) {
     const Layer& ly = layers[li];
     // Q/K/V as three row-sliced GEMMs on purpose (batch_decode.rs:160-186)
-    gemm_graphsafe_cuda(ly.qkv, normed, q, q_dim, bs, H, S());
-    gemm_graphsafe_cuda(ly.qkv + (size_t)q_dim * H, normed, k, kv_dim, bs, H, S());
-    gemm_graphsafe_cuda(ly.qkv + (size_t)(q_dim + kv_dim) * H, normed, v, kv_dim, bs, H, S());
+    if (stacked_qkv(bs)) {
+      if (pegainfer_gemm_split3(ly.qkv, normed, q, q_dim, k, kv_dim, v, kv_dim, bs, H, S())) {
+        set_error("pegainfer_gemm_split3 failed"); return -1;
+      }
+    } else {  // three GEMMs over row slices of the fused matrix, as the reference does (batch_decode.rs:160-163)
+      gemm_graphsafe_cuda(ly.qkv, normed, q, q_dim, bs, H, S());
+      gemm_graphsafe_cuda(ly.qkv + (size_t)q_dim * H, normed, k, kv_dim, bs, H, S());
+      gemm_graphsafe_cuda(ly.qkv + (size_t)(q_dim + kv_dim) * H, normed, v, kv_dim, bs, H, S());
+    }
     qk_norm_rope_batched_decode_cuda(q, k, ly.q_norm, ly.k_norm, cos, sin, md<int32_t>(ml.positions), Hq, Hkv, D, bs,
                                      eps, S());
     int rc = paged_kv_scatter_cuda(kv_buffer, layout.k_offset(li), layout.v_offset(li), md<int32_t>(ml.page_indices),
@@ -425,7 +431,9 @@ struct Model {
     }
     return 0;
   }
-  bool fused_ok(int bs) const { return decode_mode == 1 && bs <= 64 && (H & 31) == 0 && (I & 31) == 0 && D == 128; }
+  // fused kernels up to 16 columns; 17..64 run the unfused sequence with the stacked q|k|v GEMM (mid-batch path)
+  bool fused_ok(int bs) const { return decode_mode == 1 && bs <= 16 && (H & 31) == 0 && (I & 31) == 0 && D == 128; }
+  bool stacked_qkv(int bs) const { return decode_mode == 1 && bs > 16; }
 
   int decode_kernels(int bs, bool split, int split_slots) {
     if (fused_ok(bs)) return decode_kernels_fused(bs, split, split_slots);

@@ -291,19 +291,6 @@ __global__ __launch_bounds__(256) void mfma_gemm_glds_kernel(const Half* __restr
 //   5 <= T <= 64      -> skinny MFMA GEMM (gemm_skinny.h)   when K % 32 == 0
 //   otherwise         -> dot2 GEMV for T <= 16 (K % 8 == 0), else not taken
 // Within each family a column's result does not depend on the batch size (bitwise batch invariance).
-static bool t1_uses_mfma() {
-  static const bool v = [] { const char* e = getenv("PEGAINFER_GEMV_T1"); return e && e[0] == 'm'; }();
-  return v;
-}
-template <int EPI>
-static bool decode_gemm_dispatch(const GemvFusedArgs& a, hipStream_t s) {
-  if ((a.T >= 5 || t1_uses_mfma()) && a.T <= 64 && (a.K & 31) == 0) {
-    if (a.T == 1) { skinny_launch<1, EPI>(a, s); return true; }
-    return skinny_dispatch<EPI>(a, s);
-  }
-  return gemv_dispatch<EPI>(a, s);
-}
-
 static bool glds_gemm_ok(const Half* W, const Half* X, const Half* Y, int M, int K) {
   return (K & 7) == 0 && host_aligned16(W) && host_aligned16(X) && (K % BK) == 0 && (M & 3) == 0 &&
          (reinterpret_cast<uintptr_t>(Y) & 7u) == 0;
@@ -337,6 +324,32 @@ static void glds_gemm_launch(const Half* W, const Half* X, Half* Y, int M, int T
     case 24: glds_gemm_launch_t<64, 4>(W, X, Y, M, T, K, so, s); break;
     default: glds_gemm_launch_t<64, 3>(W, X, Y, M, T, K, so, s); break;
   }
+}
+
+static bool t1_uses_mfma() {
+  static const bool v = [] { const char* e = getenv("PEGAINFER_GEMV_T1"); return e && e[0] == 'm'; }();
+  return v;
+}
+// 17..64 columns with a large weight matrix: the 128-row LDS-DMA tiles beat the 16-row skinny blocks by 2-4x
+// (gate_up at T = 64: 21 vs 64 us; x is staged once per 128 rows and the DMA ring keeps the stream going), small
+// matrices (o_proj / down_proj: 20 tiles) stay on the skinny kernel whose 8 waves split K.
+constexpr int kMidBatchMinRows = 5120;
+template <int EPI>
+static bool decode_gemm_dispatch(const GemvFusedArgs& a, hipStream_t s) {
+  if (a.T > 16 && a.T <= 64) {
+    // the fused prologue / epilogue forms exist for decode batches <= 16 only: above that the host runs the
+    // unfused sequence, whose large GEMMs take the tiled kernel (so fused == unfused stays true by construction)
+    if (a.norm_w || EPI != kEpiStore || a.flags) return false;
+    if (a.M >= kMidBatchMinRows && glds_gemm_ok(a.W, a.X, a.Y, a.M, a.K)) {
+      glds_gemm_launch(a.W, a.X, a.Y, a.M, a.T, a.K, SplitOut{nullptr, nullptr, nullptr, 0, 0, 0}, 23, s);
+      return true;
+    }
+  }
+  if ((a.T >= 5 || t1_uses_mfma()) && a.T <= 64 && (a.K & 31) == 0) {
+    if (a.T == 1) { skinny_launch<1, EPI>(a, s); return true; }
+    return skinny_dispatch<EPI>(a, s);
+  }
+  return gemv_dispatch<EPI>(a, s);
 }
 
 static void gemm_dispatch(const Half* W, const Half* X, Half* Y, int M, int T, int K, hipStream_t s) {
@@ -425,26 +438,27 @@ pegainfer_status_t pegainfer_gemv_fused_ex(const Half* W, const Half* X, Half* Y
 
 // One GEMM over a row-stacked weight writing 2..4 separate outputs Y_i[T][M_i] (extension): what prefill's
 // q_proj / k_proj / v_proj calls (prefill.rs:120-129), Qwen3.5's in_proj_qkv / z / b / a (qwen35 prefill.rs:373-376)
-// and gate_proj / up_proj (:187-188) compute, in one launch that fills the chip.  Each element is bit-identical to
-// the separate gemm_cuda call (same kernel, same K order).
+// and gate_proj / up_proj (:187-188) compute, in one launch that fills the chip.  For T > 64 each element is
+// bit-identical to the separate gemm_cuda call (same kernel, same K order); for 17..64 columns the separate calls
+// on sub-matrices below 5120 rows take the skinny kernel instead, so equality there is within the GEMM tolerance.
 pegainfer_status_t pegainfer_gemm_split(const Half* W, const Half* X, int32_t n_out, Half* const* Y, const int32_t* Ms,
                                         int32_t T, int32_t K, pegainfer_stream_t stream) {
   using namespace pk;
   if (n_out < 2 || n_out > 4 || T <= 0 || K <= 0) return (pegainfer_status_t)hipErrorInvalidValue;
   int M = 0, m[4] = {0, 0, 0, 0};
   Half* y[4] = {nullptr, nullptr, nullptr, nullptr};
-  bool ok = T > 64;
+  bool ok = T > 16;  // 17..64: only worth it (and only taken) when the stacked matrix is mid-batch sized
   for (int i = 0; i < n_out; ++i) {
     if (Ms[i] <= 0 || !Y[i]) return (pegainfer_status_t)hipErrorInvalidValue;
     m[i] = Ms[i]; y[i] = Y[i]; M += Ms[i];
     ok = ok && (Ms[i] & 3) == 0 && (reinterpret_cast<uintptr_t>(Y[i]) & 7u) == 0;
   }
-  ok = ok && glds_gemm_ok(W, X, y[0], M, K);
+  ok = ok && glds_gemm_ok(W, X, y[0], M, K) && (T > 64 || M >= kMidBatchMinRows);
   if (ok) {
     // the last present segment is "the rest"; with fewer than 4 outputs the unused boundaries collapse onto M
     SplitOut so{y[1], y[2] ? y[2] : y[1], y[3] ? y[3] : (y[2] ? y[2] : y[1]), m[0], m[1], n_out > 2 ? m[2] : 0};
     if (n_out == 2) { so.M1 = m[1]; so.M2 = 0; }
-    glds_gemm_launch(W, X, y[0], M, T, K, so, 0, as_stream(stream));
+    glds_gemm_launch(W, X, y[0], M, T, K, so, T <= 64 ? 23 : 0, as_stream(stream));
   } else {  // shapes the tiled kernel does not take: separate reference-ABI calls
     size_t row = 0;
     for (int i = 0; i < n_out; ++i) {

@@ -18,7 +18,7 @@ def rnd(rng, *shape, scale=1.0):
     return bf16_round((rng.standard_normal(shape) * scale).astype(np.float32))
 
 
-@pytest.mark.parametrize("T", [1, 2, 3, 8, 16, 33, 64])
+@pytest.mark.parametrize("T", [1, 2, 3, 8, 11, 16])
 @pytest.mark.parametrize("M,K", [(6144, 2560), (2560, 4096), (512, 256)])
 def test_gemv_fused_prologues_match_unfused(built_libs, T, M, K):
     import torch
@@ -51,7 +51,7 @@ def test_gemv_fused_prologues_match_unfused(built_libs, T, M, K):
     assert np.array_equal(bf16_bits(from_dev(hout)), bf16_bits(from_dev(hid)))
 
 
-@pytest.mark.parametrize("T,I,K", [(1, 9728, 2560), (4, 9728, 2560), (16, 512, 256), (2, 1000, 4096), (40, 9728, 2560)])
+@pytest.mark.parametrize("T,I,K", [(1, 9728, 2560), (4, 9728, 2560), (16, 512, 256), (2, 1000, 4096), (12, 9728, 2560)])
 def test_gemv_fused_silu_epilogue_matches_unfused(built_libs, T, I, K):
     import torch
     import pegainfer_amd.ops as P
@@ -78,6 +78,15 @@ def test_gemv_fused_rejects_unsupported_shapes(built_libs):
     assert L.pegainfer_gemv_fused(x.data_ptr(), x.data_ptr(), x.data_ptr(), 4, 1, 12, None, None, None, 0.0, 0, s) != 0
     assert L.pegainfer_gemv_fused(x.data_ptr(), x.data_ptr(), x.data_ptr(), 4, 1, 8, x.data_ptr(), x.data_ptr(),
                                   x.data_ptr(), 0.0, 0, s) != 0   # hidden_out aliases X
+    # prologue / epilogue forms are for decode batches <= 16; the plain form still takes 17..64 columns
+    big = torch.zeros(64 * 64, dtype=torch.bfloat16, device="cuda")
+    assert L.pegainfer_gemv_fused(big.data_ptr(), big.data_ptr(), big.data_ptr(), 8, 17, 32, None, big.data_ptr(), None,
+                                  1e-6, 0, s) != 0
+    assert L.pegainfer_gemv_fused(big.data_ptr(), big.data_ptr(), big.data_ptr(), 8, 17, 32, None, None, None, 0.0, 4,
+                                  s) != 0
+    y = torch.zeros(17 * 8, dtype=torch.bfloat16, device="cuda")
+    assert L.pegainfer_gemv_fused(big.data_ptr(), big.data_ptr(), y.data_ptr(), 8, 17, 32, None, None, None, 0.0, 0,
+                                  s) == 0
 
 
 @pytest.mark.parametrize("lens,split", [([1], False), ([17, 300], False), ([1024], True), ([2000, 70], True)])

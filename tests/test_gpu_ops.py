@@ -230,7 +230,7 @@ def test_gemm_lm_head_shape(P):
 
 
 @pytest.mark.parametrize("T,K,ms", [(1024, 2560, (4096, 1024, 1024)), (200, 512, (256, 64, 192)),
-                                    (65, 128, (132, 4, 8)), (40, 256, (128, 64, 64))])
+                                    (65, 128, (132, 4, 8)), (40, 256, (128, 64, 64)), (16, 256, (128, 64, 64))])
 def test_gemm_split3_equals_three_gemms(P, T, K, ms):
     """Stacked q/k/v projection in one launch == the three reference-ABI gemm_cuda calls, bit for bit
     (prefill.rs:120-129); also pins the LDS-DMA tiled GEMM against the oracle GEMM."""
@@ -243,9 +243,28 @@ def test_gemm_split3_equals_three_gemms(P, T, K, ms):
     r0 = 0
     for m, o in zip(ms, outs):
         sep = P.gemm(Wd[r0:r0 + m], Xd)
-        assert np.array_equal(bf16_bits(from_dev(o)), bf16_bits(from_dev(sep))), (ms, m)
+        assert np.array_equal(bf16_bits(from_dev(o)), bf16_bits(from_dev(sep))), (ms, m)   # > 64 columns, or fallback
         ref = O.gemm(W[r0:r0 + m], X)
         assert np.abs(from_dev(o) - ref).max() <= 2.0 ** -6 * max(1.0, np.abs(ref).max())
+        r0 += m
+
+
+def test_gemm_split3_mid_batch_matches_oracle_and_full_gemm(P):
+    """17..64 columns, stacked q|k|v of 6144 rows (the mid-batch decode path): the three outputs are the row ranges of
+    ONE tiled GEMM - bit-identical to gemm_cuda over the stacked matrix, within the GEMM tolerance of the oracle."""
+    import torch
+    rng = np.random.default_rng(6)
+    T, K, ms = 48, 2560, (4096, 1024, 1024)
+    W, X = rnd(rng, sum(ms), K, scale=0.05), rnd(rng, T, K)
+    Wd, Xd = to_dev(W), to_dev(X)
+    outs = [torch.empty((T, m), dtype=torch.bfloat16, device=Xd.device) for m in ms]
+    P.gemm_split3_into(Wd, Xd, *outs)
+    full = from_dev(P.gemm(Wd, Xd))
+    ref = O.gemm(W, X)
+    r0 = 0
+    for m, o in zip(ms, outs):
+        assert np.array_equal(bf16_bits(from_dev(o)), bf16_bits(full[:, r0:r0 + m]))
+        assert np.abs(from_dev(o) - ref[:, r0:r0 + m]).max() <= 2.0 ** -6 * max(1.0, np.abs(ref).max())
         r0 += m
 
 
@@ -271,28 +290,35 @@ def test_gemm_split_n_outputs_equals_separate_gemms(P, ms):
 
 
 def test_decode_gemm_batch_invariance_and_row_slices(P):
-    """Decode GEMM: within a kernel family (dot2 GEMV: 1..4 columns, skinny MFMA: 5..64 columns) column t of a
-    batched call == the same column in any other batch size, bit for bit; a row slice of the fused matrix == the
-    fused call's rows (reference relies on this: batch_decode.rs:160-163).  Across families the summation order
+    """Decode GEMM: within a kernel family column t of a batched call == the same column in any other batch size,
+    bit for bit.  Families by token columns: 1..4 (dot2 GEMV), 5..16 (skinny MFMA), 17..64 (tiled LDS-DMA GEMM when
+    the matrix has >= 5120 rows, skinny below).  A row slice of the fused matrix == the fused call's rows in the
+    decode families (reference relies on this: batch_decode.rs:160-163).  Across families the summation order
     differs: equal within the GEMM tolerance (the reference's cuBLAS also switches kernels with N)."""
     rng = np.random.default_rng(11)
     for K in (2560, 9728):
         W, X = rnd(rng, 6144, K, scale=0.05), rnd(rng, 64, K)
         Wd = to_dev(W)
         full = bf16_bits(from_dev(P.gemm(Wd, to_dev(X))))
-        for T in (5, 8, 11, 16, 17, 32, 40):
-            part = bf16_bits(from_dev(P.gemm(Wd, to_dev(X[:T]))))
-            assert np.array_equal(part, full[:T]), (K, T)
+        for T in (17, 32, 40):
+            assert np.array_equal(bf16_bits(from_dev(P.gemm(Wd, to_dev(X[:T])))), full[:T]), (K, T)
+        small = bf16_bits(from_dev(P.gemm(Wd[:2560], to_dev(X))))             # < 5120 rows: skinny at every T >= 5
+        for T in (5, 16, 17, 40):
+            assert np.array_equal(bf16_bits(from_dev(P.gemm(Wd[:2560], to_dev(X[:T])))), small[:T]), (K, T)
+        sixteen = bf16_bits(from_dev(P.gemm(Wd, to_dev(X[:16]))))
+        for T in (5, 8, 11):
+            assert np.array_equal(bf16_bits(from_dev(P.gemm(Wd, to_dev(X[:T])))), sixteen[:T]), (K, T)
         four = bf16_bits(from_dev(P.gemm(Wd, to_dev(X[:4]))))
         for T in (1, 2, 3):
             part = bf16_bits(from_dev(P.gemm(Wd, to_dev(X[:T]))))
             assert np.array_equal(part, four[:T]), (K, T)
-        for T in (1, 8):                                                # row slices, both families
+        for T in (1, 8):                                                # row slices, both decode families
             sl = bf16_bits(from_dev(P.gemm(Wd[4096:5120], to_dev(X[:T]))))
-            ref = four[:1] if T == 1 else full[:8]
+            ref = four[:1] if T == 1 else sixteen[:8]
             assert np.array_equal(sl, ref[:, 4096:5120])
-        a, b = from_dev(P.gemm(Wd, to_dev(X[:4]))), from_dev(P.gemm(Wd, to_dev(X[:8])))[:4]
-        assert np.abs(a - b).max() <= 2.0 ** -6 * max(1.0, np.abs(b).max())
+        for lo, hi in ((4, 8), (16, 32)):                               # family boundaries: tolerance
+            a, b = from_dev(P.gemm(Wd, to_dev(X[:lo]))), from_dev(P.gemm(Wd, to_dev(X[:hi])))[:lo]
+            assert np.abs(a - b).max() <= 2.0 ** -6 * max(1.0, np.abs(b).max())
 
 
 # ------------------------------------------------------------------ paged KV + attention
