@@ -68,6 +68,14 @@ class _Lib:
                 f"{path} is missing - build it with `python -m pegainfer_amd.build` "
                 "(hipcc, gfx950). There is no CPU fallback for the product path.")
         self.path = path
+        # PyTorch-ROCm bundles its own libamdhip64 / librccl.  If ours (linked against /opt/rocm) are mapped first
+        # and torch is imported later, the process ends up with two HIP runtimes and aborts in their exit handlers
+        # ("double free or corruption").  Import torch first when it is installed so both bind to one runtime;
+        # nothing from torch is used here.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         self.cdll = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
         self.protos = {}
         for header in headers:
