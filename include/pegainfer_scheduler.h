@@ -1,0 +1,80 @@
+/*
+ * pegainfer_scheduler.h - C ABI of the continuous-batching scheduler in libpegainfer_qwen3.so (SURVEY.md §8 (f)
+ * rank 2: "the immediate caller of the path").  Mirrors pegainfer-qwen3-4b/src/scheduler.rs:97-327 with
+ * scheduler/{plan,resolve,effects}.rs: admission by KV-page budget (a request is admitted only when its MAXIMUM
+ * context fits next to the future pages of every active request; requests that can never fit are rejected), one
+ * plan per iteration (Prefill / Decode / Unified), stop-token / length resolution, TokenEvent stream, failure of a
+ * step -> Error to every touched request + drop, dropped receiver -> request retired.
+ *
+ * The reference runs the loop on a dedicated thread fed by channels; here ONE call of pegainfer_sched_step() is one
+ * iteration of scheduler_loop, submissions go straight into the deferred queue and events are polled - the host
+ * owns the thread.  echo / logprobs are not carried (they need all-position logits, outside the forward-pass scope).
+ */
+#ifndef PEGAINFER_SCHEDULER_H
+#define PEGAINFER_SCHEDULER_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* pegainfer_sched_t;
+
+/* ModelExecutor (executor.rs:502-512) as a table of callbacks.  execute(): n_prefill prompt requests first, then
+ * n_decode single-token requests; ids / lens (decode lens == 1) / per-request sampling params / random_vals have
+ * n_prefill + n_decode entries, tokens is the concatenation; writes one token per request to out_tokens; returns 0
+ * or an error (last_error() then describes it).  n_prefill == 0 -> execute_decode, n_decode == 0 -> execute_prefill,
+ * both > 0 -> execute_unified. */
+typedef struct {
+  void* user;
+  int32_t (*page_size)(void* user);
+  int32_t (*max_request_pages)(void* user);
+  int32_t (*available_pages)(void* user);
+  int32_t (*is_stop_token)(void* user, uint32_t token);
+  int32_t (*drop_request)(void* user, uint64_t request_id);
+  int32_t (*execute)(void* user, int32_t n_prefill, int32_t n_decode, const uint64_t* request_ids, const int32_t* lens,
+                     const uint32_t* tokens, const float* temperature, const int32_t* top_k, const float* top_p,
+                     const float* random_vals, uint32_t* out_tokens);
+  const char* (*last_error)(void* user);
+} pegainfer_executor_vtbl;
+
+enum { PEGAINFER_EVENT_TOKEN = 1, PEGAINFER_EVENT_FINISHED = 2, PEGAINFER_EVENT_ERROR = 3, PEGAINFER_EVENT_REJECTED = 4 };
+enum { PEGAINFER_FINISH_STOP = 0, PEGAINFER_FINISH_LENGTH = 1 };
+enum { PEGAINFER_PLAN_NONE = 0, PEGAINFER_PLAN_PREFILL = 1, PEGAINFER_PLAN_DECODE = 2, PEGAINFER_PLAN_UNIFIED = 3 };
+
+/* TokenEvent (pegainfer-engine/src/engine.rs:58-87) */
+typedef struct {
+  uint64_t request_id;
+  int32_t kind;
+  uint32_t token;          /* TOKEN */
+  int32_t finish_reason;   /* FINISHED */
+  int32_t prompt_tokens;   /* FINISHED / ERROR / REJECTED */
+  int32_t completion_tokens;
+} pegainfer_token_event;
+
+pegainfer_sched_t pegainfer_sched_create(const pegainfer_executor_vtbl* executor, uint64_t seed);
+/* scheduler over a Qwen3 host model (pegainfer_qwen3.h): prefill -> pegainfer_qwen3_prefill, decode ->
+ * pegainfer_qwen3_decode, unified -> pegainfer_qwen3_unified_step, sampled requests -> pegainfer_qwen3_sample.
+ * `model` is a pegainfer_qwen3_t and must outlive the scheduler. */
+pegainfer_sched_t pegainfer_sched_create_qwen3(void* model, uint64_t seed, const uint32_t* stop_tokens, int32_t n_stop);
+void pegainfer_sched_destroy(pegainfer_sched_t s);
+
+/* EngineHandle::submit: returns the RequestId the events carry (ids count up from 0 in submission order) */
+uint64_t pegainfer_sched_submit(pegainfer_sched_t s, const uint32_t* prompt_tokens, int32_t n_tokens, int32_t max_tokens,
+                                float temperature, int32_t top_k, float top_p, int32_t ignore_eos);
+/* the receiver of this request went away: no further events; the request is retired at its next token */
+int32_t pegainfer_sched_cancel(pegainfer_sched_t s, uint64_t request_id);
+/* one scheduler_loop iteration; returns the plan kind that ran, PLAN_NONE when idle, -1 when the step failed
+ * (every touched request got an ERROR event and was dropped, like scheduler.rs:307-327) */
+int32_t pegainfer_sched_step(pegainfer_sched_t s);
+int32_t pegainfer_sched_poll(pegainfer_sched_t s, pegainfer_token_event* out, int32_t max_events);
+int32_t pegainfer_sched_num_active(pegainfer_sched_t s);
+int32_t pegainfer_sched_num_deferred(pegainfer_sched_t s);
+/* message of the most recent ERROR / REJECTED event */
+const char* pegainfer_sched_last_message(pegainfer_sched_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PEGAINFER_SCHEDULER_H */

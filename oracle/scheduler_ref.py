@@ -1,0 +1,220 @@
+"""CPU restatement of the reference's continuous-batching scheduler (TEST INFRASTRUCTURE ONLY).
+
+Follows pegainfer-qwen3-4b/src/scheduler.rs:97-327 (loop, admission by KV-page budget, failure handling),
+scheduler/plan.rs:31-117 (Prefill / Decode / Unified plan, one random_val per request per step, prompts first),
+scheduler/resolve.rs:9-132 (stop token / length rules) and scheduler/effects.rs:67-217 (event order, swap_remove
+retirement, dropped-receiver cleanup).  One call of ``step()`` = one iteration of ``scheduler_loop``; channels
+become per-scheduler event lists.  echo / logprobs are not modelled (out of scope for the forward-pass path).
+
+Executor protocol (duck-typed, mirrors executor.rs:502-512): page_size(), max_request_pages(), available_pages(),
+is_stop_token(tok), drop_request(id), execute(prefill_items, decode_items) -> (prefill_tokens, decode_tokens) or raises.
+prefill_items: [(id, prompt, params, random_val)], decode_items: [(id, last_token, params, random_val)].
+"""
+
+TOKEN, FINISHED, ERROR, REJECTED = 1, 2, 3, 4
+STOP, LENGTH = 0, 1
+PLAN_NONE, PLAN_PREFILL, PLAN_DECODE, PLAN_UNIFIED, STEP_FAILED = 0, 1, 2, 3, -1
+
+
+def pages_needed(tokens, page_size):
+    return -(-tokens // page_size)
+
+
+class SplitMix:
+    """random_val stream: the reference draws f32 from StdRng(seed) (ChaCha, not reproduced - greedy ignores it);
+    both this oracle and the C++ scheduler use splitmix64 -> 24-bit uniform so their streams agree."""
+
+    def __init__(self, seed):
+        self.s = seed & 0xFFFFFFFFFFFFFFFF
+
+    def next_f32(self):
+        self.s = (self.s + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+        z = self.s
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+        z ^= z >> 31
+        return (z >> 40) / 16777216.0
+
+
+class SchedulerOracle:
+    def __init__(self, executor, seed=42):
+        self.ex = executor
+        self.rng = SplitMix(seed)
+        self.active = []     # dicts: id, closed, last_token, generated, max_tokens, prompt_len, params
+        self.deferred = []   # dicts: id, prompt, params, max_tokens, closed
+        self.next_id = 0
+        self.events = []     # (request_id, kind, token, finish_reason, prompt_tokens, completion_tokens, message)
+        self.closed = set()
+
+    # ---- EngineHandle::submit + receiver drop ----
+    def submit(self, prompt, max_tokens, params=(0.0, -1, 1.0, False)):
+        rid = self.next_id
+        self.next_id += 1
+        self.deferred.append(dict(id=rid, prompt=list(prompt), params=tuple(params), max_tokens=int(max_tokens)))
+        return rid
+
+    def cancel(self, rid):
+        self.closed.add(rid)
+
+    def _send(self, rid, kind, token=0, reason=0, prompt_tokens=0, completion_tokens=0, message=""):
+        if rid in self.closed:
+            return False
+        self.events.append((rid, kind, token, reason, prompt_tokens, completion_tokens, message))
+        return True
+
+    # ---- scheduler.rs:175-261 ----
+    def _admit(self):
+        ps = self.ex.page_size()
+        future = sum(max(0, pages_needed(a["prompt_len"] + max(a["max_tokens"] - 1, 0), ps)
+                         - pages_needed(a["prompt_len"] + max(a["generated"] - 1, 0), ps)) for a in self.active)
+        budget = max(0, self.ex.available_pages() - future)
+        pending, still, rejected = [], [], []
+        for req in self.deferred:
+            need = pages_needed(len(req["prompt"]) + max(req["max_tokens"] - 1, 0), ps)
+            if need > self.ex.max_request_pages():
+                rejected.append(req)
+            elif need <= budget:
+                budget -= need
+                pending.append(req)
+            else:
+                still.append(req)
+        self.deferred = still
+        return pending, rejected
+
+    def step(self):
+        if not self.active and not self.deferred:
+            return PLAN_NONE
+        pending, rejected = self._admit()
+        for req in rejected:
+            mx = len(req["prompt"]) + max(req["max_tokens"] - 1, 0)
+            self._send(req["id"], REJECTED, prompt_tokens=len(req["prompt"]),
+                       message="request requires more KV pages than this model instance can provide: "
+                               f"prompt_tokens={len(req['prompt'])}, max_context_tokens={mx}")
+        have_active = bool(self.active)
+        if pending and have_active:
+            plan = PLAN_UNIFIED
+        elif pending:
+            plan = PLAN_PREFILL
+        elif have_active:
+            plan = PLAN_DECODE
+        else:
+            return PLAN_NONE
+        # failure targets (scheduler.rs:263-284): decode targets first for Unified
+        targets = []
+        if plan in (PLAN_DECODE, PLAN_UNIFIED):
+            targets += [(a["id"], a["prompt_len"], a["generated"]) for a in self.active]
+        if plan in (PLAN_PREFILL, PLAN_UNIFIED):
+            targets += [(p["id"], len(p["prompt"]), 0) for p in pending]
+        pf_items = [(p["id"], p["prompt"], p["params"], self.rng.next_f32()) for p in pending] \
+            if plan != PLAN_DECODE else []
+        dec_items = [(a["id"], a["last_token"], a["params"], self.rng.next_f32()) for a in self.active] \
+            if plan != PLAN_PREFILL else []
+        try:
+            pf_tokens, dec_tokens = self.ex.execute(pf_items, dec_items)
+        except Exception as e:  # scheduler.rs:307-327
+            for rid, pt, ct in targets:
+                self._send(rid, ERROR, prompt_tokens=pt, completion_tokens=ct, message=str(e))
+                self.ex.drop_request(rid)
+            self.active = []
+            return STEP_FAILED
+        # ---- resolve decode (resolve.rs:96-132) + apply (effects.rs:84-159) ----
+        retire = []
+        for (rid, _, _, _), tok in zip(dec_items, dec_tokens):
+            idx = next((i for i, a in enumerate(self.active) if a["id"] == rid), None)
+            if idx is None:
+                continue
+            a = self.active[idx]
+            completion = a["generated"] + 1
+            ignore_eos = a["params"][3]
+            if (not ignore_eos) and self.ex.is_stop_token(tok):
+                self._send(rid, FINISHED, reason=STOP, prompt_tokens=a["prompt_len"], completion_tokens=completion)
+                self.ex.drop_request(rid)
+                retire.append(idx)
+            elif completion >= a["max_tokens"]:
+                if self._send(rid, TOKEN, token=tok):
+                    self._send(rid, FINISHED, reason=LENGTH, prompt_tokens=a["prompt_len"],
+                               completion_tokens=completion)
+                self.ex.drop_request(rid)
+                retire.append(idx)
+            else:
+                if not self._send(rid, TOKEN, token=tok):
+                    self.ex.drop_request(rid)
+                    retire.append(idx)
+                else:
+                    a["last_token"] = tok
+                    a["generated"] = completion
+        for i in reversed(retire):                         # Vec::swap_remove
+            self.active[i] = self.active[-1]
+            self.active.pop()
+        # ---- resolve prefill (resolve.rs:31-94) + apply (effects.rs:164-216) ----
+        for p, tok in zip(pending if plan != PLAN_DECODE else [], pf_tokens):
+            rid, plen, ignore_eos = p["id"], len(p["prompt"]), p["params"][3]
+            if (not ignore_eos) and self.ex.is_stop_token(tok):
+                self._send(rid, FINISHED, reason=STOP, prompt_tokens=plen, completion_tokens=0)
+                self.ex.drop_request(rid)
+            elif p["max_tokens"] <= 1:
+                if self._send(rid, TOKEN, token=tok):
+                    self._send(rid, FINISHED, reason=LENGTH, prompt_tokens=plen, completion_tokens=1)
+                self.ex.drop_request(rid)
+            else:
+                if self._send(rid, TOKEN, token=tok):
+                    self.active.append(dict(id=rid, last_token=tok, generated=1, max_tokens=p["max_tokens"],
+                                            prompt_len=plen, params=p["params"]))
+                else:
+                    self.ex.drop_request(rid)
+        return plan
+
+    def poll(self):
+        ev, self.events = self.events, []
+        return ev
+
+
+class FakeExecutor:
+    """scheduler.rs:343-505: page accounting only; prefill token = 100 + id, decode token = 200 + id."""
+
+    def __init__(self, max_request_pages, page_size=16, fail_decode_once=False, stop_tokens=()):
+        self.ps = page_size
+        self.max_pages = max_request_pages
+        self.avail = max_request_pages
+        self.held = {}
+        self.fail_decode_once = fail_decode_once
+        self.dropped = []
+        self.stop = set(stop_tokens)
+        self.calls = []
+
+    def page_size(self):
+        return self.ps
+
+    def max_request_pages(self):
+        return self.max_pages
+
+    def available_pages(self):
+        return self.avail
+
+    def is_stop_token(self, tok):
+        return tok in self.stop
+
+    def drop_request(self, rid):
+        if rid in self.held:
+            self.avail += pages_needed(self.held.pop(rid), self.ps)
+        self.dropped.append(rid)
+
+    def _ensure(self, rid, tokens):
+        grow = pages_needed(tokens, self.ps) - pages_needed(self.held.get(rid, 0), self.ps)
+        if grow > self.avail:
+            raise RuntimeError("fake KV capacity exhausted")
+        self.avail -= max(grow, 0)
+        self.held[rid] = tokens
+
+    def execute(self, pf_items, dec_items):
+        self.calls.append((len(pf_items), len(dec_items)))
+        if dec_items and not pf_items and self.fail_decode_once:
+            self.fail_decode_once = False
+            raise RuntimeError("fake decode KV capacity exhausted")
+        for rid, prompt, _, _ in pf_items:
+            self._ensure(rid, len(prompt))
+        for rid, _, _, _ in dec_items:
+            if rid not in self.held:
+                raise RuntimeError("missing fake request state")
+            self._ensure(rid, self.held[rid] + 1)
+        return [100 + rid for rid, _, _, _ in pf_items], [200 + rid for rid, _, _, _ in dec_items]

@@ -842,6 +842,7 @@ int32_t pegainfer_qwen3_request_seq_len(pegainfer_qwen3_t m, int32_t id) {
   return r ? r->seq_len : -1;
 }
 int32_t pegainfer_qwen3_available_pages(pegainfer_qwen3_t m) { return M(m)->pool.available(); }
+int32_t pegainfer_qwen3_capacity_pages(pegainfer_qwen3_t m) { return M(m)->pool.capacity(); }
 int32_t pegainfer_qwen3_prefill(pegainfer_qwen3_t m, int32_t n, const int32_t* ids, const int32_t* lens,
                                 const uint32_t* tokens, int32_t* out_tokens, void* out_logits_host) {
   return M(m)->prefill(n, ids, lens, tokens, out_tokens, out_logits_host);

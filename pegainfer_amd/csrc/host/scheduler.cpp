@@ -1,0 +1,300 @@
+// Continuous-batching scheduler (include/pegainfer_scheduler.h): the reference's scheduler_loop, one iteration
+// per step() call, over an executor given as a callback table or bound to the Qwen3 host runtime.
+#include <algorithm>
+#include <cstring>
+#include <deque>
+#include <string>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+#include "pegainfer_qwen3.h"
+#include "pegainfer_scheduler.h"
+
+namespace psched {
+
+struct Sampling { float temperature; int32_t top_k; float top_p; bool ignore_eos; };
+
+struct Active {   // ActiveRequestState (scheduler.rs:31-41)
+  uint64_t id; uint32_t last_token; int generated, max_tokens, prompt_len; Sampling p;
+};
+struct Pending {  // PendingRequest (scheduler.rs:43-51)
+  uint64_t id; std::vector<uint32_t> prompt; Sampling p; int max_tokens;
+};
+
+static inline int pages_needed(long tokens, int page_size) { return (int)((tokens + page_size - 1) / page_size); }
+
+// splitmix64 -> 24-bit uniform (the reference's StdRng stream is not reproduced; greedy ignores random_val)
+struct Rng {
+  uint64_t s;
+  float next_f32() {
+    s += 0x9E3779B97F4A7C15ull;
+    uint64_t z = s;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (float)(z >> 40) * (1.0f / 16777216.0f);
+  }
+};
+
+// executor bound to the Qwen3 host runtime (executor.rs:541-760 for one rank)
+struct Qwen3Exec {
+  pegainfer_qwen3_t model;
+  std::unordered_set<uint32_t> stop;
+  std::unordered_map<uint64_t, int32_t> slot;  // RequestId -> model request id
+  std::string err;
+  static int32_t page_size(void*) { return 16; }
+  static int32_t max_request_pages(void* u) { return pegainfer_qwen3_capacity_pages(((Qwen3Exec*)u)->model) - 1; }
+  static int32_t available_pages(void* u) { return pegainfer_qwen3_available_pages(((Qwen3Exec*)u)->model); }
+  static int32_t is_stop_token(void* u, uint32_t t) { return ((Qwen3Exec*)u)->stop.count(t) ? 1 : 0; }
+  static int32_t drop_request(void* u, uint64_t id) {
+    auto* e = (Qwen3Exec*)u;
+    auto it = e->slot.find(id);
+    if (it == e->slot.end()) return 0;
+    const int32_t rc = pegainfer_qwen3_drop_request(e->model, it->second);
+    e->slot.erase(it);
+    return rc;
+  }
+  static const char* last_error(void* u) { return ((Qwen3Exec*)u)->err.c_str(); }
+  static int32_t execute(void* u, int32_t n_pf, int32_t n_dec, const uint64_t* ids, const int32_t* lens,
+                         const uint32_t* tokens, const float* temp, const int32_t* top_k, const float* top_p,
+                         const float* rv, uint32_t* out) {
+    auto* e = (Qwen3Exec*)u;
+    const int n = n_pf + n_dec;
+    std::vector<int32_t> mids(n), out_i(n);
+    for (int i = 0; i < n; ++i) {
+      if (i < n_pf) {
+        const int32_t r = pegainfer_qwen3_new_request(e->model);
+        if (r < 0) { e->err = "pegainfer_qwen3_new_request failed"; return -1; }
+        e->slot[ids[i]] = r;
+        mids[i] = r;
+      } else {
+        auto it = e->slot.find(ids[i]);
+        if (it == e->slot.end()) { e->err = "decode request without model state"; return -1; }
+        mids[i] = it->second;
+      }
+    }
+    int32_t rc;
+    if (n_dec == 0) rc = pegainfer_qwen3_prefill(e->model, n_pf, mids.data(), lens, tokens, out_i.data(), nullptr);
+    else if (n_pf == 0) rc = pegainfer_qwen3_decode(e->model, n_dec, mids.data(), tokens, out_i.data(), nullptr);
+    else rc = pegainfer_qwen3_unified_step(e->model, n_pf, n_dec, mids.data(), lens, tokens, out_i.data(), nullptr);
+    if (rc) { const char* m = pegainfer_qwen3_last_error(e->model); e->err = m ? m : "model step failed"; return rc; }
+    for (int i = 0; i < n; ++i) {
+      const bool greedy = (temp[i] <= 0.0f || top_k[i] == 1) && top_p[i] >= 1.0f;  // ops/sampling.rs:122
+      if (!greedy) {
+        int32_t t = 0;
+        rc = pegainfer_qwen3_sample(e->model, i, temp[i], top_k[i], top_p[i], rv[i], &t);
+        if (rc) { const char* m = pegainfer_qwen3_last_error(e->model); e->err = m ? m : "sample failed"; return rc; }
+        out_i[i] = t;
+      }
+      out[i] = (uint32_t)out_i[i];
+    }
+    return 0;
+  }
+};
+
+struct Scheduler {
+  pegainfer_executor_vtbl ex;
+  Qwen3Exec* owned = nullptr;
+  Rng rng;
+  std::vector<Active> active;
+  std::vector<Pending> deferred;
+  std::unordered_set<uint64_t> closed;
+  std::deque<pegainfer_token_event> events;
+  uint64_t next_id = 0;
+  std::string last_message;
+
+  bool send(uint64_t id, int kind, uint32_t token, int reason, int prompt_tokens, int completion_tokens) {
+    if (closed.count(id)) return false;
+    events.push_back(pegainfer_token_event{id, kind, token, reason, prompt_tokens, completion_tokens});
+    return true;
+  }
+  static int max_tokens_of(int prompt_len, int max_tokens) { return prompt_len + std::max(max_tokens - 1, 0); }
+
+  int step() {
+    if (active.empty() && deferred.empty()) return PEGAINFER_PLAN_NONE;
+    // ---- admit_deferred_requests (scheduler.rs:222-261) ----
+    const int ps = ex.page_size(ex.user);
+    long future = 0;
+    for (const Active& a : active)
+      future += std::max(0, pages_needed(max_tokens_of(a.prompt_len, a.max_tokens), ps) -
+                                pages_needed(a.prompt_len + std::max(a.generated - 1, 0), ps));
+    long budget = std::max<long>(0, (long)ex.available_pages(ex.user) - future);
+    const int max_req = ex.max_request_pages(ex.user);
+    std::vector<Pending> pending, still;
+    for (Pending& r : deferred) {
+      const int need = pages_needed(max_tokens_of((int)r.prompt.size(), r.max_tokens), ps);
+      if (need > max_req) {
+        last_message = "request requires more KV pages than this model instance can provide: prompt_tokens=" +
+                       std::to_string(r.prompt.size()) + ", max_context_tokens=" +
+                       std::to_string(max_tokens_of((int)r.prompt.size(), r.max_tokens));
+        send(r.id, PEGAINFER_EVENT_REJECTED, 0, 0, (int)r.prompt.size(), 0);
+      } else if (need <= budget) {
+        budget -= need;
+        pending.push_back(std::move(r));
+      } else {
+        still.push_back(std::move(r));
+      }
+    }
+    deferred = std::move(still);
+    // ---- build_next_plan (plan.rs:31-45) ----
+    const bool have_active = !active.empty();
+    int plan;
+    if (!pending.empty() && have_active) plan = PEGAINFER_PLAN_UNIFIED;
+    else if (!pending.empty()) plan = PEGAINFER_PLAN_PREFILL;
+    else if (have_active) plan = PEGAINFER_PLAN_DECODE;
+    else return PEGAINFER_PLAN_NONE;
+    // ---- execute_plan (plan.rs:47-117): prompts first, one random_val per request ----
+    const int n_pf = plan == PEGAINFER_PLAN_DECODE ? 0 : (int)pending.size();
+    const int n_dec = plan == PEGAINFER_PLAN_PREFILL ? 0 : (int)active.size();
+    const int n = n_pf + n_dec;
+    std::vector<uint64_t> ids(n);
+    std::vector<int32_t> lens(n), top_k(n);
+    std::vector<float> temp(n), top_p(n), rv(n);
+    std::vector<uint32_t> tokens, out(n);
+    for (int i = 0; i < n_pf; ++i) {
+      const Pending& r = pending[i];
+      ids[i] = r.id; lens[i] = (int32_t)r.prompt.size();
+      temp[i] = r.p.temperature; top_k[i] = r.p.top_k; top_p[i] = r.p.top_p; rv[i] = rng.next_f32();
+      tokens.insert(tokens.end(), r.prompt.begin(), r.prompt.end());
+    }
+    for (int j = 0; j < n_dec; ++j) {
+      const Active& a = active[j];
+      const int i = n_pf + j;
+      ids[i] = a.id; lens[i] = 1;
+      temp[i] = a.p.temperature; top_k[i] = a.p.top_k; top_p[i] = a.p.top_p; rv[i] = rng.next_f32();
+      tokens.push_back(a.last_token);
+    }
+    const int rc = ex.execute(ex.user, n_pf, n_dec, ids.data(), lens.data(), tokens.data(), temp.data(), top_k.data(),
+                              top_p.data(), rv.data(), out.data());
+    if (rc) {  // fail_touched_requests (scheduler.rs:307-327): active targets first, then the pending ones
+      const char* m = ex.last_error ? ex.last_error(ex.user) : nullptr;
+      last_message = m ? m : "execution step failed";
+      for (int j = 0; j < n_dec; ++j) {
+        send(active[j].id, PEGAINFER_EVENT_ERROR, 0, 0, active[j].prompt_len, active[j].generated);
+        ex.drop_request(ex.user, active[j].id);
+      }
+      for (int i = 0; i < n_pf; ++i) {
+        send(pending[i].id, PEGAINFER_EVENT_ERROR, 0, 0, (int)pending[i].prompt.size(), 0);
+        ex.drop_request(ex.user, pending[i].id);
+      }
+      active.clear();
+      return -1;
+    }
+    // ---- decode results: resolve.rs:96-132 + effects.rs:84-159 ----
+    std::vector<size_t> retire;
+    for (int j = 0; j < n_dec; ++j) {
+      const uint64_t id = ids[n_pf + j];
+      const uint32_t tok = out[n_pf + j];
+      size_t idx = active.size();
+      for (size_t k = 0; k < active.size(); ++k)
+        if (active[k].id == id) { idx = k; break; }
+      if (idx == active.size()) continue;
+      Active& a = active[idx];
+      const int completion = a.generated + 1;
+      if (!a.p.ignore_eos && ex.is_stop_token(ex.user, tok)) {
+        send(id, PEGAINFER_EVENT_FINISHED, 0, PEGAINFER_FINISH_STOP, a.prompt_len, completion);
+        ex.drop_request(ex.user, id);
+        retire.push_back(idx);
+      } else if (completion >= a.max_tokens) {
+        if (send(id, PEGAINFER_EVENT_TOKEN, tok, 0, 0, 0))
+          send(id, PEGAINFER_EVENT_FINISHED, 0, PEGAINFER_FINISH_LENGTH, a.prompt_len, completion);
+        ex.drop_request(ex.user, id);
+        retire.push_back(idx);
+      } else if (!send(id, PEGAINFER_EVENT_TOKEN, tok, 0, 0, 0)) {
+        ex.drop_request(ex.user, id);
+        retire.push_back(idx);
+      } else {
+        a.last_token = tok;
+        a.generated = completion;
+      }
+    }
+    for (size_t r = retire.size(); r-- > 0;) {  // Vec::swap_remove in reverse
+      active[retire[r]] = active.back();
+      active.pop_back();
+    }
+    // ---- prefill results: resolve.rs:31-94 + effects.rs:164-216 ----
+    for (int i = 0; i < n_pf; ++i) {
+      const Pending& r = pending[i];
+      const uint32_t tok = out[i];
+      const int plen = (int)r.prompt.size();
+      if (!r.p.ignore_eos && ex.is_stop_token(ex.user, tok)) {
+        send(r.id, PEGAINFER_EVENT_FINISHED, 0, PEGAINFER_FINISH_STOP, plen, 0);
+        ex.drop_request(ex.user, r.id);
+      } else if (r.max_tokens <= 1) {
+        if (send(r.id, PEGAINFER_EVENT_TOKEN, tok, 0, 0, 0))
+          send(r.id, PEGAINFER_EVENT_FINISHED, 0, PEGAINFER_FINISH_LENGTH, plen, 1);
+        ex.drop_request(ex.user, r.id);
+      } else if (send(r.id, PEGAINFER_EVENT_TOKEN, tok, 0, 0, 0)) {
+        active.push_back(Active{r.id, tok, 1, r.max_tokens, plen, r.p});
+      } else {
+        ex.drop_request(ex.user, r.id);
+      }
+    }
+    return plan;
+  }
+};
+
+}  // namespace psched
+
+using psched::Scheduler;
+static Scheduler* SC(pegainfer_sched_t s) { return static_cast<Scheduler*>(s); }
+
+extern "C" {
+
+pegainfer_sched_t pegainfer_sched_create(const pegainfer_executor_vtbl* executor, uint64_t seed) {
+  if (!executor || !executor->page_size || !executor->max_request_pages || !executor->available_pages ||
+      !executor->is_stop_token || !executor->drop_request || !executor->execute)
+    return nullptr;
+  Scheduler* s = new Scheduler();
+  s->ex = *executor;
+  s->rng.s = seed;
+  return s;
+}
+pegainfer_sched_t pegainfer_sched_create_qwen3(void* model, uint64_t seed, const uint32_t* stop_tokens, int32_t n_stop) {
+  if (!model) return nullptr;
+  auto* e = new psched::Qwen3Exec();
+  e->model = model;
+  for (int i = 0; i < n_stop; ++i) e->stop.insert(stop_tokens[i]);
+  pegainfer_executor_vtbl v{e, &psched::Qwen3Exec::page_size, &psched::Qwen3Exec::max_request_pages,
+                            &psched::Qwen3Exec::available_pages, &psched::Qwen3Exec::is_stop_token,
+                            &psched::Qwen3Exec::drop_request, &psched::Qwen3Exec::execute, &psched::Qwen3Exec::last_error};
+  Scheduler* s = static_cast<Scheduler*>(pegainfer_sched_create(&v, seed));
+  s->owned = e;
+  return s;
+}
+void pegainfer_sched_destroy(pegainfer_sched_t s) {
+  if (!s) return;
+  delete SC(s)->owned;
+  delete SC(s);
+}
+uint64_t pegainfer_sched_submit(pegainfer_sched_t s, const uint32_t* prompt_tokens, int32_t n_tokens, int32_t max_tokens,
+                                float temperature, int32_t top_k, float top_p, int32_t ignore_eos) {
+  Scheduler* sc = SC(s);
+  psched::Pending p;
+  p.id = sc->next_id++;
+  p.prompt.assign(prompt_tokens, prompt_tokens + (n_tokens > 0 ? n_tokens : 0));
+  p.p = psched::Sampling{temperature, top_k, top_p, ignore_eos != 0};
+  p.max_tokens = max_tokens;
+  sc->deferred.push_back(std::move(p));
+  return sc->deferred.back().id;
+}
+int32_t pegainfer_sched_cancel(pegainfer_sched_t s, uint64_t request_id) {
+  SC(s)->closed.insert(request_id);
+  return 0;
+}
+int32_t pegainfer_sched_step(pegainfer_sched_t s) { return SC(s)->step(); }
+int32_t pegainfer_sched_poll(pegainfer_sched_t s, pegainfer_token_event* out, int32_t max_events) {
+  Scheduler* sc = SC(s);
+  int n = 0;
+  while (n < max_events && !sc->events.empty()) {
+    out[n++] = sc->events.front();
+    sc->events.pop_front();
+  }
+  return n;
+}
+int32_t pegainfer_sched_num_active(pegainfer_sched_t s) { return (int32_t)SC(s)->active.size(); }
+int32_t pegainfer_sched_num_deferred(pegainfer_sched_t s) { return (int32_t)SC(s)->deferred.size(); }
+const char* pegainfer_sched_last_message(pegainfer_sched_t s) { return SC(s)->last_message.c_str(); }
+
+}  // extern "C"

@@ -19,6 +19,7 @@ _SCALARS = {
     "uint64_t": ctypes.c_uint64, "float": ctypes.c_float, "int": ctypes.c_int,
     "pegainfer_stream_t": ctypes.c_void_p, "pegainfer_status_t": ctypes.c_int32,
     "pegainfer_qwen3_t": ctypes.c_void_p, "pegainfer_qwen35_t": ctypes.c_void_p, "size_t": ctypes.c_size_t,
+    "pegainfer_sched_t": ctypes.c_void_p,
     "double": ctypes.c_double,
 }
 
@@ -101,5 +102,5 @@ def host_lib():
     """libpegainfer_qwen3.so (include/pegainfer_qwen3.h + pegainfer_qwen35.h)."""
     if "h" not in _cache:
         lib()
-        _cache["h"] = _Lib("libpegainfer_qwen3.so", "pegainfer_qwen3.h", "pegainfer_qwen35.h")
+        _cache["h"] = _Lib("libpegainfer_qwen3.so", "pegainfer_qwen3.h", "pegainfer_qwen35.h", "pegainfer_scheduler.h")
     return _cache["h"]

@@ -1,0 +1,155 @@
+"""Continuous-batching scheduler, CPU only.
+
+The reference pins its scheduler with a FakeExecutor (pegainfer-qwen3-4b/src/scheduler.rs:330-733).  Those six
+scenarios are restated here and run against BOTH the Python restatement (oracle/scheduler_ref.py) and the C++
+scheduler in libpegainfer_qwen3.so driven through its callback executor, plus a randomized trace on which the two
+must emit identical event streams and make identical executor calls.
+"""
+import numpy as np
+import pytest
+
+from oracle.scheduler_ref import (ERROR, FINISHED, LENGTH, REJECTED, STOP, TOKEN, FakeExecutor, SchedulerOracle,
+                                  pages_needed)
+
+
+def make(kind, ex, seed=42):
+    if kind == "oracle":
+        return SchedulerOracle(ex, seed)
+    from pegainfer_amd.scheduler import Scheduler
+    return Scheduler.over_callbacks(ex, seed)
+
+
+def events_of(ev, rid):
+    return [e[:6] for e in ev if e[0] == rid]
+
+
+def run_until_idle(s, limit=1000):
+    ev = []
+    for _ in range(limit):
+        plan = s.step()
+        ev += [tuple(e[:6]) for e in s.poll()]
+        if plan == 0:
+            return ev
+    raise AssertionError("scheduler did not go idle")
+
+
+KINDS = ["oracle", "cxx"]
+
+
+def test_kv_budget_counts_only_tokens_written_to_cache():  # scheduler.rs:507-546
+    assert pages_needed(16 + max(1 - 1, 0), 16) == 1
+    assert 16 + max(3 - 1, 0) == 18 and 16 + max(1 - 1, 0) == 16 and 16 + max(2 - 1, 0) == 17
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_one_token_completion_on_page_boundary_fits_one_page(kind):  # scheduler.rs:548-569
+    ex = FakeExecutor(1)
+    s = make(kind, ex)
+    rid = s.submit([1] * 16, 1)
+    ev = run_until_idle(s)
+    assert events_of(ev, rid) == [(rid, TOKEN, 100, 0, 0, 0), (rid, FINISHED, 0, LENGTH, 16, 1)]
+    assert 0 in ex.dropped
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_request_waits_for_full_kv_budget_before_prefill(kind):  # scheduler.rs:571-604
+    ex = FakeExecutor(4)
+    s = make(kind, ex)
+    long_running = s.submit([1] * 16, 18)
+    assert s.step() == 1 and events_of(s.poll(), long_running)[0][:3] == (long_running, TOKEN, 100)
+    must_wait = s.submit([1] * 17, 1)
+    order = []
+    for _ in range(64):
+        plan = s.step()
+        for e in s.poll():
+            order.append(tuple(e[:3]))
+        if plan == 0:
+            break
+    first_wait = order.index((must_wait, TOKEN, 101))
+    assert 0 in ex.dropped
+    fin_long = next(i for i, e in enumerate(order) if e[0] == long_running and e[1] == FINISHED)
+    assert fin_long < first_wait                      # admitted only after the first request released its KV
+    assert (must_wait, FINISHED, 0) in order
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_impossible_request_is_rejected_without_blocking_later_work(kind):  # scheduler.rs:640-671
+    ex = FakeExecutor(2)
+    s = make(kind, ex)
+    too_large = s.submit([1] * 16, 34)
+    s.step()
+    ev = s.poll()
+    assert [tuple(e[:6]) for e in ev] == [(too_large, REJECTED, 0, 0, 16, 0)]
+    msg = ev[0][6] if kind == "oracle" else s.last_message()
+    assert "requires more KV pages" in msg
+    fits = s.submit([1] * 16, 1)
+    ev = run_until_idle(s)
+    assert events_of(ev, fits) == [(fits, TOKEN, 101, 0, 0, 0), (fits, FINISHED, 0, LENGTH, 16, 1)]
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_decode_error_drops_request_state_and_scheduler_recovers(kind):  # scheduler.rs:673-716
+    ex = FakeExecutor(4, fail_decode_once=True)
+    s = make(kind, ex)
+    will_fail = s.submit([1] * 16, 2)
+    assert s.step() == 1
+    assert [tuple(e[:3]) for e in s.poll()] == [(will_fail, TOKEN, 100)]
+    assert s.step() == -1
+    ev = s.poll()
+    assert [tuple(e[:6]) for e in ev] == [(will_fail, ERROR, 0, 0, 16, 1)]
+    msg = ev[0][6] if kind == "oracle" else s.last_message()
+    assert "fake decode KV capacity exhausted" in msg
+    assert 0 in ex.dropped
+    after = s.submit([1] * 16, 1)
+    ev = run_until_idle(s)
+    assert events_of(ev, after) == [(after, TOKEN, 101, 0, 0, 0), (after, FINISHED, 0, LENGTH, 16, 1)]
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_active_receiver_drop_releases_request_state(kind):  # scheduler.rs:718-733
+    ex = FakeExecutor(4)
+    s = make(kind, ex)
+    rid = s.submit([1] * 16, 3)
+    s.step()
+    assert [tuple(e[:3]) for e in s.poll()] == [(rid, TOKEN, 100)]
+    s.cancel(rid)
+    run_until_idle(s)
+    assert 0 in ex.dropped and ex.available_pages() == 4
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_stop_token_finishes_without_emitting_it(kind):  # resolve.rs:49-58,110-116
+    ex = FakeExecutor(8, stop_tokens=(200,))               # request 0's decode token is 200
+    s = make(kind, ex)
+    a = s.submit([1] * 5, 10)
+    b = s.submit([1] * 5, 3, params=(0.0, -1, 1.0, True))  # ignore_eos: 201 is not a stop token anyway
+    ev = run_until_idle(s)
+    assert events_of(ev, a) == [(a, TOKEN, 100, 0, 0, 0), (a, FINISHED, 0, STOP, 5, 2)]
+    assert events_of(ev, b) == [(b, TOKEN, 101, 0, 0, 0), (b, TOKEN, 201, 0, 0, 0), (b, TOKEN, 201, 0, 0, 0),
+                                (b, FINISHED, 0, LENGTH, 5, 3)]
+
+
+def test_randomized_trace_cxx_equals_oracle():
+    """Random arrivals, prompt lengths, budgets, cancels and stop tokens: identical event streams, identical executor
+    call sequence (plan kinds and batch compositions), identical drop order."""
+    rng = np.random.default_rng(3)
+    for trial in range(6):
+        pages = int(rng.integers(6, 40))
+        stops = (203, 207) if trial % 2 else ()
+        exo, exc = FakeExecutor(pages, stop_tokens=stops), FakeExecutor(pages, stop_tokens=stops)
+        so, sc = make("oracle", exo, 7), make("cxx", exc, 7)
+        evo, evc = [], []
+        for it in range(120):
+            for _ in range(int(rng.integers(0, 3))):
+                plen, mx = int(rng.integers(1, 90)), int(rng.integers(1, 40))
+                params = (0.0, -1, 1.0, bool(rng.integers(0, 2)))
+                assert so.submit([1] * plen, mx, params) == sc.submit([1] * plen, mx, params)
+            if rng.random() < 0.05 and so.next_id:
+                rid = int(rng.integers(0, so.next_id))
+                so.cancel(rid)
+                sc.cancel(rid)
+            assert so.step() == sc.step()
+            evo += [tuple(e[:6]) for e in so.poll()]
+            evc += [tuple(e[:6]) for e in sc.poll()]
+        assert evo == evc and len(evo) > 50
+        assert exo.calls == exc.calls and exo.dropped == exc.dropped and exo.available_pages() == exc.available_pages()
