@@ -194,6 +194,81 @@ def run_qwen35(args, rank, world, local, dist, torch):
     return 0
 
 
+
+def run_serving(args, rank, world, local, dist, torch):
+    """Serving profile: C requests in flight through the C++ scheduler (admission by KV budget, batched prefill /
+    unified / decode steps).  One engine + scheduler per GPU (replicas); value = all output tokens / wall time."""
+    from pegainfer_amd import parallel
+    from pegainfer_amd.qwen3 import QWEN3_4B, QWEN3_8B, Qwen3Engine
+    from pegainfer_amd.scheduler import FINISHED, TOKEN, Scheduler
+    cfg = dict(QWEN3_4B if args.model == "qwen3-4b" else QWEN3_8B)
+    C, out_len = args.concurrency, args.steps
+    per_req_pages = -(-(args.ctx + out_len) // 16) + 1
+    eng = Qwen3Engine(cfg, num_kv_pages=C * per_req_pages + 16, max_batch_size=max(C, 1), enable_graph=not args.no_graph,
+                      decode_mode=args.decode_mode, split_policy=args.split_policy, device=local,
+                      max_positions=max(4096, args.ctx + out_len + 16))
+    eng.fill_synthetic(seed=42 + rank, std=0.02)
+    prompt = synthetic_prompt(args.ctx)
+    warm = Scheduler.over_engine(eng)                       # warm-up: graphs / workspaces for this batch shape
+    for _ in range(C):
+        warm.submit(prompt, min(args.warmup + 1, out_len), (0.0, -1, 1.0, True))
+    while warm.step() != 0:
+        warm.poll()
+    warm.close()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    sched = Scheduler.over_engine(eng)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(C):
+        sched.submit(prompt, out_len, (0.0, -1, 1.0, True))
+    first, done, ntok, plans = {}, 0, 0, {1: 0, 2: 0, 3: 0}
+    while done < C:
+        plan = sched.step()
+        now = time.perf_counter()
+        if plan in plans:
+            plans[plan] += 1
+        for rid, kind, *_ in sched.poll():
+            if kind == TOKEN:
+                ntok += 1
+                first.setdefault(rid, (now - t0) * 1e3)
+            elif kind == FINISHED:
+                done += 1
+            else:
+                raise SystemExit("scheduler reported an error: " + sched.last_message())
+    barrier()
+    elapsed = parallel.max_over_ranks(time.perf_counter() - t0, device="cuda")
+    ttft = sorted(first.values())
+    out = {
+        "metric": "decode tokens/sec + TTFT, Qwen3-4B bf16 greedy, 1xMI355X" if args.model == "qwen3-4b"
+                  else "decode tokens/sec + TTFT, Qwen3-8B bf16 greedy, 1xMI355X",
+        "value": round(ntok * world / elapsed, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / max(sum(plans.values()), 1), 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"{args.model} serving through the continuous-batching scheduler: {C} concurrent "
+                               f"requests/GPU, prompt {args.ctx}, {out_len} output tokens each, greedy, ignore_eos "
+                               "(reference bench_serving decode_heavy with concurrency)",
+                   "concurrency": C, "ctx": args.ctx, "decode_mode": args.decode_mode,
+                   "parallelism": "replicas%d" % world if world > 1 else "single"},
+        "serving": {"wall_s": round(elapsed, 4), "output_tokens": ntok,
+                    "ttft_ms": {"p50": round(float(np.median(ttft)), 2), "p95": round(float(np.percentile(ttft, 95)), 2),
+                                "max": round(ttft[-1], 2)},
+                    "scheduler_steps": {"prefill": plans[1], "decode": plans[2], "unified": plans[3]}},
+        "roofline": None, "cpu_baseline": None,
+    }
+    if rank == 0:
+        print(json.dumps(out))
+    sched.close()
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -208,6 +283,10 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=12, help="decode steps for the CPU baseline (0 = skip)")
     ap.add_argument("--ttft-iters", type=int, default=5)
+    ap.add_argument("--concurrency", type=int, default=0,
+                    help="serving mode (reference bench_serving.rs): this many requests (prompt --ctx, --steps output "
+                         "tokens each, ignore_eos) go through the continuous-batching scheduler; reports aggregate "
+                         "tok/s and the TTFT distribution")
     ap.add_argument("--sampling", default="greedy", choices=["greedy", "topk_topp", "topp"],
                     help="configs[2]: per-request gpu_sample after every step (ops_embedding_sampling_bench.rs:49-90): "
                          "topk_topp = T 0.8, top_k 50, top_p 0.95; topp = T 0.8, top_k -1, top_p 0.9")
@@ -233,6 +312,8 @@ def main():
     from pegainfer_amd import parallel
     if args.model == "qwen3.5-4b":
         return run_qwen35(args, rank, world, local, dist, torch)
+    if args.concurrency > 0:
+        return run_serving(args, rank, world, local, dist, torch)
     cfg = dict(QWEN3_4B if args.model == "qwen3-4b" else QWEN3_8B)
     full_cfg = dict(cfg)
     tp = args.parallelism == "tp" and world > 1
