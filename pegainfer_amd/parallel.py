@@ -149,6 +149,30 @@ class Comm:
                                         group=self.group)
         return out
 
+    # -- expert-parallel token exchange (pegainfer-comm 4-stage dispatch/combine, a2a_*.cu, re-expressed as one
+    #    RCCL all-to-all): `send` holds world equal slabs, slab r goes to rank r; returns what every rank sent us --
+    def all_to_all(self, send):
+        import torch
+        out = torch.empty_like(send)
+        self.dist.all_to_all_single(out.view(-1), send.contiguous().view(-1), group=self.group)
+        return out
+
+    # ragged form (tokens routed per expert rank): send_counts[r] rows go to rank r; returns (rows, recv_counts)
+    def all_to_allv(self, send, send_counts):
+        import torch
+        sc = torch.tensor(list(send_counts), dtype=torch.int64, device=send.device)
+        rc = torch.empty_like(sc)
+        self.dist.all_to_all_single(rc, sc, group=self.group)
+        recv_counts = [int(x) for x in rc.tolist()]
+        width = 1
+        for d in send.shape[1:]:
+            width *= int(d)
+        out = torch.empty((sum(recv_counts),) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+        self.dist.all_to_all_single(out.view(-1), send.contiguous().view(-1),
+                                    output_split_sizes=[c * width for c in recv_counts],
+                                    input_split_sizes=[int(c) * width for c in send_counts], group=self.group)
+        return out, recv_counts
+
     # -- all_gather_logits (core.rs:560-609): vocab/world f32 per rank -> full vocab --
     def all_gather_logits(self, local_logits_f32):
         return self.all_gather(local_logits_f32)
@@ -198,7 +222,7 @@ def bench_mp8_collectives(comm, hidden=4096, token_counts=(1, 8, 32, 256, 4096),
     [T, hidden], bf16 all-gather [T, hidden] -> x world, f32 reduce-scatter of [world*T, hidden]; average us per
     collective over the group (RCCL over xGMI when the group is nccl).  Returns {verb: {T: us}}."""
     import torch
-    out = {"all_reduce_f32": {}, "all_gather_bf16": {}, "reduce_scatter_f32": {}}
+    out = {"all_reduce_f32": {}, "all_gather_bf16": {}, "reduce_scatter_f32": {}, "all_to_all_bf16": {}}
     cuda = str(device).startswith("cuda")
 
     def timed(fn):
@@ -227,4 +251,6 @@ def bench_mp8_collectives(comm, hidden=4096, token_counts=(1, 8, 32, 256, 4096),
         out["all_reduce_f32"][str(T)] = round(timed(lambda: comm.all_reduce_in_place(ar)), 1)
         out["all_gather_bf16"][str(T)] = round(timed(lambda: comm.all_gather(ag)), 1)
         out["reduce_scatter_f32"][str(T)] = round(timed(lambda: comm.reduce_scatter(rs)), 1)
+        a2a = torch.ones((comm.world * T, hidden), dtype=torch.bfloat16, device=device)   # EP dispatch: T rows per peer
+        out["all_to_all_bf16"][str(T)] = round(timed(lambda: comm.all_to_all(a2a)), 1)
     return out

@@ -165,6 +165,33 @@ def test_mp8_collective_bench_runs_on_gloo():
     """The side measurement bench.py adds at N > 1 (BASELINE.json configs[4]): every verb x token count yields a
     positive time on both ranks."""
     for r in run2(_mp8_bench):
-        assert set(r) == {"all_reduce_f32", "all_gather_bf16", "reduce_scatter_f32"}
+        assert set(r) == {"all_reduce_f32", "all_gather_bf16", "reduce_scatter_f32", "all_to_all_bf16"}
         for verb in r.values():
             assert set(verb) == {"1", "8"} and all(v > 0 for v in verb.values())
+
+
+def _a2a(rank):
+    c = P.Comm()
+    send = torch.arange(WORLD * 3 * 4, dtype=torch.float32).reshape(WORLD * 3, 4) + 100 * rank     # 3 rows per peer
+    got = c.all_to_all(send)
+    counts = [1 + rank, 2]                                                                      # ragged: rows per peer
+    rows = torch.arange(sum(counts) * 2, dtype=torch.float32).reshape(sum(counts), 2) + 1000 * rank
+    gv, rc = c.all_to_allv(rows, counts)
+    return {"got": got.numpy(), "gv": gv.numpy(), "rc": rc}
+
+
+def test_expert_all_to_all_matches_dense_routing():
+    """all_to_all: slab r of every rank ends up on rank r, rank-major; all_to_allv: the ragged variant."""
+    r = run2(_a2a)
+    for me in range(WORLD):
+        exp = np.concatenate([(np.arange(WORLD * 3 * 4, dtype=np.float32).reshape(WORLD * 3, 4) + 100 * src)[me * 3:(me + 1) * 3]
+                              for src in range(WORLD)])
+        assert np.array_equal(r[me]["got"], exp)
+        parts = []
+        for src in range(WORLD):
+            counts = [1 + src, 2]
+            rows = np.arange(sum(counts) * 2, dtype=np.float32).reshape(sum(counts), 2) + 1000 * src
+            off = sum(counts[:me])
+            parts.append(rows[off:off + counts[me]])
+        assert r[me]["rc"] == [[1 + src, 2][me] for src in range(WORLD)]
+        assert np.array_equal(r[me]["gv"], np.concatenate(parts))
