@@ -47,6 +47,9 @@ int32_t pegainfer_qwen35_finalize(pegainfer_qwen35_t m);
 int32_t pegainfer_qwen35_new_request(pegainfer_qwen35_t m);
 int32_t pegainfer_qwen35_drop_request(pegainfer_qwen35_t m, int32_t request_id);
 int32_t pegainfer_qwen35_request_seq_len(pegainfer_qwen35_t m, int32_t request_id);
+int32_t pegainfer_qwen35_available_pages(pegainfer_qwen35_t m);
+int32_t pegainfer_qwen35_capacity_pages(pegainfer_qwen35_t m);
+int32_t pegainfer_qwen35_max_batch_size(pegainfer_qwen35_t m);
 
 /* prefill_forward (prefill.rs:21-120): appends n_tokens to the request (recurrent + conv state carried over),
  * returns the greedy token of the last position and optionally its logits (bf16 bits [vocab]). */

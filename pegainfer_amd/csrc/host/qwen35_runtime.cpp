@@ -779,6 +779,9 @@ int32_t pegainfer_qwen35_decode(pegainfer_qwen35_t m, int32_t n_requests, const 
                                 const uint32_t* token_ids, int32_t* out_tokens, void* out_logits_host) {
   return M35(m)->decode(n_requests, request_ids, token_ids, out_tokens, out_logits_host);
 }
+int32_t pegainfer_qwen35_available_pages(pegainfer_qwen35_t m) { return M35(m)->pool.available(); }
+int32_t pegainfer_qwen35_capacity_pages(pegainfer_qwen35_t m) { return M35(m)->pool.capacity(); }
+int32_t pegainfer_qwen35_max_batch_size(pegainfer_qwen35_t m) { return M35(m)->max_bs; }
 float pegainfer_qwen35_last_step_ms(pegainfer_qwen35_t m) { return M35(m)->last_step_ms; }
 int64_t pegainfer_qwen35_weight_bytes(pegainfer_qwen35_t m) { return M35(m)->weight_bytes; }
 

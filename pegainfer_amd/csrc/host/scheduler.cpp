@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "pegainfer_qwen3.h"
+#include "pegainfer_qwen35.h"
 #include "pegainfer_scheduler.h"
 
 namespace psched {
@@ -93,9 +94,67 @@ struct Qwen3Exec {
   }
 };
 
+// executor bound to the Qwen3.5 hybrid runtime: the reference prefills one request per call (prefill.rs:21) and
+// decodes the active set as one batch (batch_decode.rs:113); a Unified plan is its prefills followed by one batched
+// decode (the recurrent state makes a fused mixed step a different kernel set, unified_forward.rs - not built).
+// Greedy only: the hybrid runtime samples on the device inside the step.
+struct Qwen35Exec {
+  pegainfer_qwen35_t model;
+  std::unordered_set<uint32_t> stop;
+  std::unordered_map<uint64_t, int32_t> slot;
+  std::string err;
+  static int32_t page_size(void*) { return 16; }
+  static int32_t max_request_pages(void* u) { return pegainfer_qwen35_capacity_pages(((Qwen35Exec*)u)->model) - 1; }
+  static int32_t available_pages(void* u) { return pegainfer_qwen35_available_pages(((Qwen35Exec*)u)->model); }
+  static int32_t is_stop_token(void* u, uint32_t t) { return ((Qwen35Exec*)u)->stop.count(t) ? 1 : 0; }
+  static int32_t drop_request(void* u, uint64_t id) {
+    auto* e = (Qwen35Exec*)u;
+    auto it = e->slot.find(id);
+    if (it == e->slot.end()) return 0;
+    const int32_t rc = pegainfer_qwen35_drop_request(e->model, it->second);
+    e->slot.erase(it);
+    return rc;
+  }
+  static const char* last_error(void* u) { return ((Qwen35Exec*)u)->err.c_str(); }
+  static int32_t execute(void* u, int32_t n_pf, int32_t n_dec, const uint64_t* ids, const int32_t* lens,
+                         const uint32_t* tokens, const float* temp, const int32_t* top_k, const float* top_p,
+                         const float*, uint32_t* out) {
+    auto* e = (Qwen35Exec*)u;
+    auto fail = [&](const char* what) {
+      const char* m = pegainfer_qwen35_last_error(e->model);
+      e->err = std::string(what) + ": " + (m ? m : "");
+      return -1;
+    };
+    for (int i = 0; i < n_pf + n_dec; ++i)
+      if (!((temp[i] <= 0.0f || top_k[i] == 1) && top_p[i] >= 1.0f)) { e->err = "Qwen3.5 executor is greedy-only"; return -1; }
+    size_t off = 0;
+    for (int i = 0; i < n_pf; ++i) {
+      const int32_t r = pegainfer_qwen35_new_request(e->model);
+      if (r < 0) return fail("new_request");
+      e->slot[ids[i]] = r;
+      int32_t tok = 0;
+      if (pegainfer_qwen35_prefill(e->model, r, lens[i], tokens + off, &tok, nullptr)) return fail("prefill");
+      out[i] = (uint32_t)tok;
+      off += (size_t)lens[i];
+    }
+    if (n_dec > 0) {
+      std::vector<int32_t> mids(n_dec), toks(n_dec);
+      for (int j = 0; j < n_dec; ++j) {
+        auto it = e->slot.find(ids[n_pf + j]);
+        if (it == e->slot.end()) { e->err = "decode request without model state"; return -1; }
+        mids[j] = it->second;
+      }
+      if (pegainfer_qwen35_decode(e->model, n_dec, mids.data(), tokens + off, toks.data(), nullptr)) return fail("decode");
+      for (int j = 0; j < n_dec; ++j) out[n_pf + j] = (uint32_t)toks[j];
+    }
+    return 0;
+  }
+};
+
 struct Scheduler {
   pegainfer_executor_vtbl ex;
   Qwen3Exec* owned = nullptr;
+  Qwen35Exec* owned35 = nullptr;
   Rng rng;
   std::vector<Active> active;
   std::vector<Pending> deferred;
@@ -263,9 +322,22 @@ pegainfer_sched_t pegainfer_sched_create_qwen3(void* model, uint64_t seed, const
   s->owned = e;
   return s;
 }
+pegainfer_sched_t pegainfer_sched_create_qwen35(void* model, uint64_t seed, const uint32_t* stop_tokens, int32_t n_stop) {
+  if (!model) return nullptr;
+  auto* e = new psched::Qwen35Exec();
+  e->model = model;
+  for (int i = 0; i < n_stop; ++i) e->stop.insert(stop_tokens[i]);
+  pegainfer_executor_vtbl v{e, &psched::Qwen35Exec::page_size, &psched::Qwen35Exec::max_request_pages,
+                            &psched::Qwen35Exec::available_pages, &psched::Qwen35Exec::is_stop_token,
+                            &psched::Qwen35Exec::drop_request, &psched::Qwen35Exec::execute, &psched::Qwen35Exec::last_error};
+  Scheduler* s = static_cast<Scheduler*>(pegainfer_sched_create(&v, seed));
+  s->owned35 = e;
+  return s;
+}
 void pegainfer_sched_destroy(pegainfer_sched_t s) {
   if (!s) return;
   delete SC(s)->owned;
+  delete SC(s)->owned35;
   delete SC(s);
 }
 uint64_t pegainfer_sched_submit(pegainfer_sched_t s, const uint32_t* prompt_tokens, int32_t n_tokens, int32_t max_tokens,

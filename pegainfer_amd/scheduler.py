@@ -48,7 +48,9 @@ class Scheduler:
     def over_engine(cls, engine, seed=42, stop_tokens=()):
         lib = ffi.host_lib()
         st = np.ascontiguousarray(list(stop_tokens), dtype=np.uint32)
-        h = lib.pegainfer_sched_create_qwen3(engine.h, seed, st.ctypes.data if st.size else None, int(st.size))
+        create = lib.pegainfer_sched_create_qwen35 if type(engine).__name__ == "Qwen35Engine" \
+            else lib.pegainfer_sched_create_qwen3
+        h = create(engine.h, seed, st.ctypes.data if st.size else None, int(st.size))
         return cls(h, keep=engine)
 
     @classmethod

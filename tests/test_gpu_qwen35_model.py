@@ -152,3 +152,38 @@ def test_qwen35_fused_decode_bitwise_equals_reference_sequence(built_libs, golde
         runs.append(np.stack(rows))
         eng.close()
     assert np.array_equal(runs[0].view(np.uint32), runs[1].view(np.uint32))
+
+
+def test_qwen35_scheduler_streams_equal_per_request_generation(built_libs, golden35):
+    """The continuous-batching scheduler over the hybrid runtime (one prefill per admitted prompt, batched decode with
+    per-slot recurrent state): overlapping requests produce exactly the tokens each prompt gets when generated alone
+    (non-partition attention: batch invariance is bitwise there)."""
+    from pegainfer_amd.scheduler import FINISHED, TOKEN, Scheduler
+    meta, _ = golden35
+    cases = meta["cases"]
+    eng = make_engine(meta, split_policy=0, max_batch_size=4)
+    s = Scheduler.over_engine(eng)
+    arrivals = {0: [(cases[0]["prompt_tokens"], 5)], 1: [(cases[2]["prompt_tokens"], 7), (cases[1]["prompt_tokens"], 1)],
+                3: [(cases[3]["prompt_tokens"], 4)]}
+    streams, fin, it, rid_prompt = {}, 0, 0, {}
+    while fin < 4:
+        for prompt, mx in arrivals.get(it, []):
+            rid_prompt[s.submit(prompt, mx, (0.0, -1, 1.0, True))] = (prompt, mx)
+        assert s.step() >= 0, s.last_message()
+        for rid, kind, tok, *_ in s.poll():
+            if kind == TOKEN:
+                streams.setdefault(rid, []).append(tok)
+            elif kind == FINISHED:
+                fin += 1
+        it += 1
+    s.close()
+    for rid, (prompt, mx) in rid_prompt.items():
+        r = eng.new_request()
+        t = eng.prefill(r, prompt)
+        alone = [t]
+        for _ in range(mx - 1):
+            t = int(eng.decode([r], [t])[0])
+            alone.append(t)
+        eng.drop_request(r)
+        assert streams[rid] == alone, rid
+    eng.close()
