@@ -47,6 +47,15 @@ int32_t pegainfer_qwen3_load_tensor(pegainfer_qwen3_t m, const char* name, const
 /* seeded N(mean, std) bf16 checkpoint generated on the device (BASELINE.md §3 synthetic weights) */
 int32_t pegainfer_qwen3_fill_synthetic(pegainfer_qwen3_t m, uint64_t seed, float std);
 int32_t pegainfer_qwen3_finalize(pegainfer_qwen3_t m);
+/* Native checkpoint load (weight_loader.rs:18-206 + weights.rs:121-291): `path` is a
+ * .safetensors file or an HF model directory (model.safetensors, or model.safetensors.index.json + shards), mmap'ed;
+ * with tp_world > 1 the rank's slices are cut on the fly (q/k/v/gate/up rows, o/down columns) into a model created
+ * with the LOCAL dims.  Finalises the model. */
+int32_t pegainfer_qwen3_load_safetensors(pegainfer_qwen3_t m, const char* path, int32_t tp_rank, int32_t tp_world);
+/* config.json -> create (local dims for the TP rank) -> load_safetensors: a model ready for prefill, no Python */
+pegainfer_qwen3_t pegainfer_qwen3_from_pretrained(const char* model_dir, int32_t device_ordinal, int32_t tp_rank,
+                                                  int32_t tp_world, int32_t num_kv_pages, int32_t max_batch_size,
+                                                  int32_t enable_graph, int32_t decode_mode, int32_t split_policy);
 
 /* Tensor parallel (the reference's Qwen3 TP, weights.rs:121-291,396-405, executor.rs:580-588 - there one
  * thread per rank with cudarc NCCL; here one PROCESS per GPU with RCCL over xGMI).  Create the model with the
@@ -98,6 +107,10 @@ int64_t pegainfer_qwen3_weight_bytes(pegainfer_qwen3_t m);
 void* pegainfer_qwen3_stream(pegainfer_qwen3_t m);
 
 /* ---- pure-host pieces, exported for CPU unit tests (no device needed) ---- */
+/* native safetensors reader: shape (up to 4 dims), dtype string, weighted byte checksum of tensor `name`; path is a
+ * file or an HF directory (index.json + shards supported).  0 ok, -1 unreadable checkpoint, -2 no such tensor */
+int32_t pegainfer_safetensors_probe(const char* path, const char* name, int64_t* shape4, int32_t* ndim, char* dtype8,
+                                    uint64_t* byte_sum, int32_t* num_tensors);
 void* pegainfer_pagepool_create(int32_t capacity_pages);
 void pegainfer_pagepool_destroy(void* pool);
 int32_t pegainfer_pagepool_available(void* pool);

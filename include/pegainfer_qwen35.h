@@ -43,6 +43,8 @@ int32_t pegainfer_qwen35_load_tensor(pegainfer_qwen35_t m, const char* name, con
                                      int32_t is_f32);
 int32_t pegainfer_qwen35_fill_synthetic(pegainfer_qwen35_t m, uint64_t seed, float std);
 int32_t pegainfer_qwen35_finalize(pegainfer_qwen35_t m);
+/* native mmap load of a .safetensors file / HF directory (tensors under model.language_model.); finalises */
+int32_t pegainfer_qwen35_load_safetensors(pegainfer_qwen35_t m, const char* path);
 
 int32_t pegainfer_qwen35_new_request(pegainfer_qwen35_t m);
 int32_t pegainfer_qwen35_drop_request(pegainfer_qwen35_t m, int32_t request_id);

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "kv_pool.h"
+#include "safetensors_loader.h"
 #include "pegainfer_kernels.h"
 #include "pegainfer_kernels_ext.h"
 #include "pegainfer_qwen35.h"
@@ -268,6 +269,21 @@ struct Model35 {
     if (numel != expect || (is_f32 != 0) != f32) { set_error("shape/dtype mismatch for " + std::string(name_c)); return -1; }
     P35_HIP(hipMemcpy(dst, host, (size_t)numel * (f32 ? 4 : 2), hipMemcpyHostToDevice));
     return 0;
+  }
+
+  // native checkpoint load (weights.rs:102-296): every tensor under model.language_model., BF16 or F32
+  int load_safetensors(const char* path) {
+    pst::Checkpoint ck;
+    std::string e;
+    if (!ck.open(path, &e)) { set_error(e); return -1; }
+    for (const auto& kv : ck.tensors()) {
+      if (kv.first.rfind("model.language_model.", 0) != 0) continue;   // vision tower / mtp heads: not this path
+      const pst::TensorView& t = kv.second;
+      const bool f32 = t.dtype == "F32";
+      if (!f32 && t.dtype != "BF16") { set_error("tensor " + kv.first + " has dtype " + t.dtype); return -1; }
+      if (load_tensor(kv.first.c_str(), t.data, t.numel(), f32 ? 1 : 0)) return -1;
+    }
+    return finalize();
   }
 
   void fill(Half* p, size_t n, uint64_t seed, float std, float mean) {
@@ -765,6 +781,7 @@ int32_t pegainfer_qwen35_load_tensor(pegainfer_qwen35_t m, const char* name, con
 }
 int32_t pegainfer_qwen35_fill_synthetic(pegainfer_qwen35_t m, uint64_t seed, float std) { return M35(m)->fill_synthetic(seed, std); }
 int32_t pegainfer_qwen35_finalize(pegainfer_qwen35_t m) { return M35(m)->finalize(); }
+int32_t pegainfer_qwen35_load_safetensors(pegainfer_qwen35_t m, const char* path) { return M35(m)->load_safetensors(path); }
 int32_t pegainfer_qwen35_new_request(pegainfer_qwen35_t m) { return M35(m)->new_request(); }
 int32_t pegainfer_qwen35_drop_request(pegainfer_qwen35_t m, int32_t id) { return M35(m)->drop_request(id); }
 int32_t pegainfer_qwen35_request_seq_len(pegainfer_qwen35_t m, int32_t id) {

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -17,6 +18,7 @@
 #include <vector>
 
 #include "kv_pool.h"
+#include "safetensors_loader.h"
 #include "pegainfer_kernels.h"
 #include "pegainfer_kernels_ext.h"
 #include "pegainfer_qwen3.h"
@@ -267,6 +269,51 @@ struct Model {
     if (numel != expect) { set_error("shape mismatch for " + name); return -1; }
     PQ_HIP(hipMemcpy(dst, host, (size_t)numel * 2, hipMemcpyHostToDevice));
     return 0;
+  }
+
+  // Native checkpoint load with the reference's TP slicing (weights.rs:121-291 over weight_loader.rs:109-206):
+  // q/k/v/gate/up row-sharded, o/down column-sharded, everything else replicated.  The model was created with
+  // the LOCAL head counts / intermediate size; the file holds the full tensors.
+  int load_safetensors(const char* path, int rank, int world) {
+    if (world < 1 || rank < 0 || rank >= world) { set_error("bad TP rank/world"); return -1; }
+    pst::Checkpoint ck;
+    std::string e;
+    if (!ck.open(path, &e)) { set_error(e); return -1; }
+    auto ends_with = [](const std::string& s, const char* suf) {
+      const size_t n = std::strlen(suf);
+      return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
+    };
+    std::vector<uint16_t> staging;
+    for (const auto& kv : ck.tensors()) {
+      const std::string& name = kv.first;
+      const pst::TensorView& t = kv.second;
+      if (name == "lm_head.weight" && tie) continue;
+      if (t.dtype != "BF16") { set_error("tensor " + name + " is " + t.dtype + ", expected BF16"); return -1; }
+      const bool row = ends_with(name, "self_attn.q_proj.weight") || ends_with(name, "self_attn.k_proj.weight") ||
+                       ends_with(name, "self_attn.v_proj.weight") || ends_with(name, "mlp.gate_proj.weight") ||
+                       ends_with(name, "mlp.up_proj.weight");
+      const bool col = ends_with(name, "self_attn.o_proj.weight") || ends_with(name, "mlp.down_proj.weight");
+      const uint16_t* src = reinterpret_cast<const uint16_t*>(t.data);
+      if (world == 1 || (!row && !col)) {
+        if (load_tensor(name.c_str(), src, t.numel())) return -1;
+        continue;
+      }
+      if (t.shape.size() != 2) { set_error("tensor " + name + " expected 2-D"); return -1; }
+      const int64_t rows = t.shape[0], cols = t.shape[1];
+      if (row) {
+        if (rows % world) { set_error("rows of " + name + " not divisible by the TP world"); return -1; }
+        const int64_t lr = rows / world;
+        if (load_tensor(name.c_str(), src + (size_t)rank * lr * cols, lr * cols)) return -1;
+      } else {
+        if (cols % world) { set_error("columns of " + name + " not divisible by the TP world"); return -1; }
+        const int64_t lc = cols / world;
+        staging.resize((size_t)rows * lc);
+        for (int64_t r = 0; r < rows; ++r)
+          std::memcpy(staging.data() + (size_t)r * lc, src + (size_t)r * cols + (size_t)rank * lc, (size_t)lc * 2);
+        if (load_tensor(name.c_str(), staging.data(), rows * lc)) return -1;
+      }
+    }
+    return finalize();
   }
 
   int fill(Half* p, size_t n, uint64_t seed, float std, float mean) {
@@ -840,6 +887,62 @@ int32_t pegainfer_qwen3_drop_request(pegainfer_qwen3_t m, int32_t id) { return M
 int32_t pegainfer_qwen3_request_seq_len(pegainfer_qwen3_t m, int32_t id) {
   auto* r = M(m)->req(id);
   return r ? r->seq_len : -1;
+}
+// host-only probe of the native reader (CPU unit tests): shape / dtype / byte checksum of one tensor
+int32_t pegainfer_safetensors_probe(const char* path, const char* name, int64_t* shape4, int32_t* ndim, char* dtype8,
+                                    uint64_t* byte_sum, int32_t* num_tensors) {
+  pst::Checkpoint ck;
+  std::string e;
+  if (!ck.open(path, &e)) return -1;
+  if (num_tensors) *num_tensors = (int32_t)ck.tensors().size();
+  const pst::TensorView* t = ck.find(name);
+  if (!t) return -2;
+  *ndim = (int32_t)t->shape.size();
+  for (int i = 0; i < 4; ++i) shape4[i] = i < *ndim ? t->shape[i] : 0;
+  std::memset(dtype8, 0, 8);
+  std::strncpy(dtype8, t->dtype.c_str(), 7);
+  uint64_t s = 0;
+  for (size_t i = 0; i < t->nbytes; ++i) s += t->data[i] * (uint64_t)(1 + (i & 0xFF));
+  *byte_sum = s;
+  return 0;
+}
+int32_t pegainfer_qwen3_load_safetensors(pegainfer_qwen3_t m, const char* path, int32_t tp_rank, int32_t tp_world) {
+  return M(m)->load_safetensors(path, tp_rank, tp_world);
+}
+pegainfer_qwen3_t pegainfer_qwen3_from_pretrained(const char* model_dir, int32_t device_ordinal, int32_t tp_rank,
+                                                  int32_t tp_world, int32_t num_kv_pages, int32_t max_batch_size,
+                                                  int32_t enable_graph, int32_t decode_mode, int32_t split_policy) {
+  // Config::from_file (pegainfer-qwen3-4b/src/config.rs): HF config.json
+  std::string err;
+  auto f = pst::MappedFile::open(std::string(model_dir) + "/config.json", &err);
+  pst::Json j;
+  if (!f || !pst::JsonParser(reinterpret_cast<const char*>(f->data), f->size).parse(&j) || j.kind != pst::Json::Obj) {
+    fprintf(stderr, "pegainfer_qwen3_from_pretrained: cannot read %s/config.json\n", model_dir);
+    return nullptr;
+  }
+  const int H = (int)j.number_or("hidden_size", 0), L = (int)j.number_or("num_hidden_layers", 0);
+  const int Hq = (int)j.number_or("num_attention_heads", 0), Hkv = (int)j.number_or("num_key_value_heads", Hq);
+  const int D = (int)j.number_or("head_dim", Hq ? H / Hq : 0), I = (int)j.number_or("intermediate_size", 0);
+  const int V = (int)j.number_or("vocab_size", 0);
+  double theta = j.number_or("rope_theta", 0);
+  if (theta == 0) { const pst::Json* rp = j.get("rope_parameters"); theta = rp ? rp->number_or("rope_theta", 1e6) : 1e6; }
+  const pst::Json* tie = j.get("tie_word_embeddings");
+  const int max_pos = (int)j.number_or("max_position_embeddings", 4096);
+  if (tp_world < 1 || !H || !L || !Hq || !I || !V || Hq % tp_world || Hkv % tp_world || I % tp_world) {
+    fprintf(stderr, "pegainfer_qwen3_from_pretrained: config not usable at TP world %d\n", tp_world);
+    return nullptr;
+  }
+  pegainfer_qwen3_t m = pegainfer_qwen3_create(device_ordinal, H, L, Hq / tp_world, Hkv / tp_world, D, I / tp_world, V,
+                                               (float)j.number_or("rms_norm_eps", 1e-6), (float)theta,
+                                               tie && tie->kind == pst::Json::Bool && tie->b ? 1 : 0, max_pos,
+                                               num_kv_pages, max_batch_size, enable_graph, decode_mode, split_policy);
+  if (!m) return nullptr;
+  if (M(m)->load_safetensors(model_dir, tp_rank, tp_world)) {
+    fprintf(stderr, "pegainfer_qwen3_from_pretrained: %s\n", M(m)->err.c_str());
+    pegainfer_qwen3_destroy(m);
+    return nullptr;
+  }
+  return m;
 }
 int32_t pegainfer_qwen3_available_pages(pegainfer_qwen3_t m) { return M(m)->pool.available(); }
 int32_t pegainfer_qwen3_capacity_pages(pegainfer_qwen3_t m) { return M(m)->pool.capacity(); }

@@ -78,6 +78,12 @@ class Qwen3Engine:
         self._chk(self.lib.pegainfer_qwen3_finalize(self.h), "finalize")
         return self
 
+    def load_safetensors_native(self, path, tp_rank=0, tp_world=1):
+        """C++ mmap loader with on-the-fly TP slicing (pegainfer_qwen3_load_safetensors)."""
+        self._chk(self.lib.pegainfer_qwen3_load_safetensors(self.h, os.fsencode(path), tp_rank, tp_world),
+                  "load_safetensors")
+        return self
+
     def fill_synthetic(self, seed=42, std=0.02):
         self._chk(self.lib.pegainfer_qwen3_fill_synthetic(self.h, seed, std), "fill_synthetic")
         self._chk(self.lib.pegainfer_qwen3_finalize(self.h), "finalize")

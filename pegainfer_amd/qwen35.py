@@ -69,6 +69,11 @@ class Qwen35Engine:
         self._chk(self.lib.pegainfer_qwen35_finalize(self.h), "finalize")
         return self
 
+    def load_safetensors_native(self, path):
+        import os
+        self._chk(self.lib.pegainfer_qwen35_load_safetensors(self.h, os.fsencode(path)), "load_safetensors")
+        return self
+
     def fill_synthetic(self, seed=42, std=0.02):
         self._chk(self.lib.pegainfer_qwen35_fill_synthetic(self.h, seed, std), "fill_synthetic")
         self._chk(self.lib.pegainfer_qwen35_finalize(self.h), "finalize")

@@ -187,3 +187,16 @@ def test_qwen35_scheduler_streams_equal_per_request_generation(built_libs, golde
         eng.drop_request(r)
         assert streams[rid] == alone, rid
     eng.close()
+
+
+def test_qwen35_native_loader_equals_python_loader(built_libs, golden35):
+    from pegainfer_amd.qwen35 import Qwen35Engine
+    meta, _ = golden35
+    prompt = meta["cases"][2]["prompt_tokens"]
+    a = make_engine(meta)
+    b = Qwen35Engine(meta["config"], num_kv_pages=128, max_batch_size=4).load_safetensors_native(CKPT)
+    _, la = a.prefill(a.new_request(), prompt, want_logits=True)
+    _, lb = b.prefill(b.new_request(), prompt, want_logits=True)
+    assert np.array_equal(la.view(np.uint32), lb.view(np.uint32))
+    a.close()
+    b.close()

@@ -1,6 +1,8 @@
 """CPU-only tests of the pure-host pieces of libpegainfer_qwen3.so against the oracle / the
 reference's own unit tests (pegainfer-core/src/page_pool.rs:124-199, kv_pool.rs:290-310,
 batch_decode_buffers.rs)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -81,3 +83,63 @@ def test_mi355x_split_policy_invariants(H, lens, padded):
         assert np.all(ri[oi[r]:oi[r + 1]] == r) and tiles.tolist() == list(range(len(tiles)))
         assert len(tiles) <= 64 and (len(tiles) - 1) * c < n <= len(tiles) * c
     assert va[:oi[len(lens)]].all() and not va[oi[len(lens)]:].any()
+
+
+def test_native_safetensors_reader_matches_python(tmp_path):
+    """The C++ mmap reader (csrc/host/safetensors_loader.h: JSON header parser, single file / HF directory with
+    model.safetensors.index.json shards) sees the same tensors, shapes, dtypes and bytes as a Python parse."""
+    import ctypes
+    import json
+    import struct
+    from pegainfer_amd import ffi
+    lib = ffi.host_lib()
+    golden = os.path.join(os.path.dirname(__file__), "golden")
+
+    def py_parse(fp):
+        with open(fp, "rb") as f:
+            n = struct.unpack("<Q", f.read(8))[0]
+            header = json.loads(f.read(n))
+            blob = np.frombuffer(f.read(), dtype=np.uint8)
+        return {k: (v["dtype"], v["shape"], blob[v["data_offsets"][0]:v["data_offsets"][1]])
+                for k, v in header.items() if k != "__metadata__"}
+
+    def probe(path, name):
+        shape, ndim, dt = (ctypes.c_int64 * 4)(), ctypes.c_int32(), ctypes.create_string_buffer(8)
+        bsum, nt = ctypes.c_uint64(), ctypes.c_int32()
+        rc = lib.pegainfer_safetensors_probe(os.fsencode(path), name.encode(), ctypes.addressof(shape),
+                                             ctypes.addressof(ndim), ctypes.addressof(dt), ctypes.addressof(bsum),
+                                             ctypes.addressof(nt))
+        return rc, list(shape[:ndim.value]), dt.value.decode(), bsum.value, nt.value
+
+    def checksum(b):
+        return int((b.astype(np.uint64) * (1 + (np.arange(b.size, dtype=np.uint64) & 0xFF))).sum(dtype=np.uint64))
+
+    for fn in ("qwen3_tiny.safetensors", "qwen35_tiny.safetensors"):
+        fp = os.path.join(golden, fn)
+        ref = py_parse(fp)
+        for name, (dtype, shape, data) in ref.items():
+            rc, shp, dt, bs, nt = probe(fp, name)
+            assert (rc, shp, dt, nt) == (0, shape, dtype, len(ref)) and bs == checksum(data), name
+    assert probe(os.path.join(golden, "qwen3_tiny.safetensors"), "no.such.tensor")[0] == -2
+    assert probe(str(tmp_path / "missing.safetensors"), "x")[0] == -1
+    # sharded HF directory: two shard files + index
+    ref = py_parse(os.path.join(golden, "qwen3_tiny.safetensors"))
+    names = sorted(ref)
+    d = tmp_path / "model"
+    d.mkdir()
+    weight_map = {}
+    for si, part in enumerate((names[:5], names[5:])):
+        header, blobs, off = {}, [], 0
+        for nme in part:
+            dtype, shape, data = ref[nme]
+            header[nme] = {"dtype": dtype, "shape": shape, "data_offsets": [off, off + data.size]}
+            blobs.append(data.tobytes())
+            off += data.size
+            weight_map[nme] = f"model-{si:05d}-of-00002.safetensors"
+        hj = json.dumps(header, separators=(",", ":")).encode()
+        with open(d / f"model-{si:05d}-of-00002.safetensors", "wb") as f:
+            f.write(struct.pack("<Q", len(hj)) + hj + b"".join(blobs))
+    (d / "model.safetensors.index.json").write_text(json.dumps({"metadata": {"total_size": 1}, "weight_map": weight_map}))
+    for nme in (names[0], names[-1]):
+        rc, shp, dt, bs, nt = probe(str(d), nme)
+        assert (rc, shp, dt, nt) == (0, ref[nme][1], ref[nme][0], len(ref)) and bs == checksum(ref[nme][2])
