@@ -377,7 +377,10 @@ def main():
     # configs[4] side measurement (not part of `value`): the DeepSeek-V4 MP8 collective verbs over the N ranks
     mp8 = None
     if world > 1:
-        mp8 = parallel.bench_mp8_collectives(parallel.Comm(), device=torch.device("cuda", local))
+        try:   # never let the side measurement take the headline line down with it
+            mp8 = parallel.bench_mp8_collectives(parallel.Comm(), device=torch.device("cuda", local))
+        except Exception as e:  # noqa: BLE001
+            mp8 = {"error": f"{type(e).__name__}: {e}"[:300]}
     ctx_mid = args.ctx + args.warmup + args.steps / 2
     step_bytes = algorithmic_bytes_per_token(full_cfg, ctx_mid, args.batch)
 
