@@ -315,7 +315,9 @@ static void glds_gemm_launch(const Half* W, const Half* X, Half* Y, int M, int T
     // than a deeper ring, so the ring only goes to 3 when every 64-token tile is resident at once (<= 2 per CU);
     // 128-token tiles (half the LDS reads per MFMA) once they give each CU >= 1.5 workgroups.
     const long m_tiles = ceil_div(M, BM), wide = m_tiles * ceil_div(T, 128), narrow = m_tiles * ceil_div(T, 64);
-    variant = narrow <= 512 ? 23 : wide >= 384 ? 12 : 22;
+    // With cold (HBM) weights, long-K small matrices (down_proj: 160 wide tiles, K = 9728) do best as one 128-token
+    // tile per CU with the 3-deep ring (102 vs 115 us); measured with tools/bench_prefill_gemm.py 1024 12.
+    variant = narrow <= 512 ? (K >= 8192 && wide <= 256 ? 13 : 23) : wide >= 384 ? 12 : 22;
   }
   switch (variant) {
     case 12: glds_gemm_launch_t<128, 2>(W, X, Y, M, T, K, so, s); break;
