@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <vector>
 
 namespace pq {
@@ -108,7 +109,11 @@ inline SplitPlan make_split_plan(int policy, const std::vector<int>& seq_lens, i
     p.chunk = std::max(256, (max_seq + kSplitMaxChunksPerRequest - 1) / kSplitMaxChunksPerRequest);
     p.use_split = padded_bs <= 2 && max_seq >= 1024;
   } else {
-    int want = (256 + padded_bs * num_kv_heads - 1) / (padded_bs * num_kv_heads);
+    // one workgroup per CU is the measured optimum (device ms/step at ctx 1024 / 4096 / 10000: target 128 ->
+    // 2.46 / 2.84 / 3.42, 256 -> 2.43 / 2.75 / 3.06, 512 -> 2.44 / 2.87 / 3.17: more partials cost more in the merge
+    // than they gain in the scan); PEGAINFER_SPLIT_TARGET_WGS is the probe knob
+    static const int target_wgs = [] { const char* e = getenv("PEGAINFER_SPLIT_TARGET_WGS"); return e ? atoi(e) : 256; }();
+    int want = (target_wgs + padded_bs * num_kv_heads - 1) / (padded_bs * num_kv_heads);
     want = std::min(std::max(want, 1), kSplitMaxChunksPerRequest);
     int chunk = (max_seq + want - 1) / want;
     chunk = std::max(64, (chunk + 15) / 16 * 16);
