@@ -135,8 +135,12 @@ __device__ __forceinline__ void prefill_tile(const Half* __restrict__ q_base, Ha
         lo.y = (w[2][c] & 0xFFFFu) | (w[3][c] << 16);
         hi.x = (w[0][c] >> 16) | (w[1][c] & 0xFFFF0000u);
         hi.y = (w[2][c] >> 16) | (w[3][c] & 0xFFFF0000u);
-        *reinterpret_cast<u32x2*>(vt + (v_dc * 8 + 2 * c) * VT_PITCH + v_tq * 4) = lo;
-        *reinterpret_cast<u32x2*>(vt + (v_dc * 8 + 2 * c + 1) * VT_PITCH + v_tq * 4) = hi;
+        // lanes of a wave write rows 8 apart (v_dc * 8): with any 8-byte-aligned pitch those land on only 4 bank
+        // groups (4-way conflict, 46 % of the LDS cycles of this kernel by SQ_LDS_BANK_CONFLICT).  Rotating the
+        // token columns of each 32-row group by 4 quads spreads the 16 v_dc over all banks (2-way = the b64 floor).
+        const int qcol = ((v_tq + 4 * (v_dc >> 2)) & 15) * 4;
+        *reinterpret_cast<u32x2*>(vt + (v_dc * 8 + 2 * c) * VT_PITCH + qcol) = lo;
+        *reinterpret_cast<u32x2*>(vt + (v_dc * 8 + 2 * c + 1) * VT_PITCH + qcol) = hi;
       }
     }
   };
@@ -215,9 +219,10 @@ __device__ __forceinline__ void prefill_tile(const Half* __restrict__ q_base, Ha
     for (int db = 0; db < DB; ++db) {
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
-        const Half* vrow = vt + (db * 16 + l15) * VT_PITCH + kb * 32 + g * 4;
-        u32x2 a0 = *reinterpret_cast<const u32x2*>(vrow);
-        u32x2 a1 = *reinterpret_cast<const u32x2*>(vrow + 16);
+        const Half* vrow = vt + (db * 16 + l15) * VT_PITCH;
+        const int rot = 4 * (db >> 1);  // column rotation of this 32-row group (see store_tile)
+        u32x2 a0 = *reinterpret_cast<const u32x2*>(vrow + ((kb * 8 + g + rot) & 15) * 4);
+        u32x2 a1 = *reinterpret_cast<const u32x2*>(vrow + ((kb * 8 + g + 4 + rot) & 15) * 4);
         const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, u32x4{a0.x, a0.y, a1.x, a1.y});
 #pragma unroll
         for (int qb = 0; qb < QBLK; ++qb)
