@@ -137,7 +137,9 @@ __device__ __forceinline__ void prefill_tile(const Half* __restrict__ q_base, Ha
         hi.y = (w[2][c] >> 16) | (w[3][c] & 0xFFFF0000u);
         // lanes of a wave write rows 8 apart (v_dc * 8): with any 8-byte-aligned pitch those land on only 4 bank
         // groups (4-way conflict, 46 % of the LDS cycles of this kernel by SQ_LDS_BANK_CONFLICT).  Rotating the
-        // token columns of each 32-row group by 4 quads spreads the 16 v_dc over all banks (2-way = the b64 floor).
+        // token columns of each 32-row group by 4 quads spreads the 16 v_dc over all banks (2-way).  Same-box A/B at
+        // ctx 4096 (us per launch): no rotation 633, this 568; a 2-quad rotation is conflict-free on paper and by
+        // counter (LDS active 5.2M vs 6.3M) yet measured 652 - kept what the clock says.
         const int qcol = ((v_tq + 4 * (v_dc >> 2)) & 15) * 4;
         *reinterpret_cast<u32x2*>(vt + (v_dc * 8 + 2 * c) * VT_PITCH + qcol) = lo;
         *reinterpret_cast<u32x2*>(vt + (v_dc * 8 + 2 * c + 1) * VT_PITCH + qcol) = hi;
