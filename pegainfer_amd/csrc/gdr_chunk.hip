@@ -127,8 +127,12 @@ __global__ __launch_bounds__(64) void gdr_solve_kernel(const float* __restrict__
 // f(value_fp32, token) and one bf16 rounding per application step done by the caller's functor
 template <typename F>
 __device__ __forceinline__ void stage_transposed(Half* dst, const Half* src, size_t rs, int c0, int T, F f) {
+  // token index fastest across lanes: a wave's 2-byte LDS writes of one element slot are then 64 consecutive
+  // tokens of ONE transposed row (conflict-free).  With the 16-byte chunk index fastest instead, lanes wrote rows
+  // 8 apart - 2 bank positions for 16 lanes, and SQ_LDS_BANK_CONFLICT was 90 % of the LDS cycles of the state
+  // kernel.  The price is 64 different source rows per load instruction, served by L1/L2 (the tile is 16 KB).
   for (int idx = threadIdx.x; idx < GC * (GK / 8); idx += 256) {
-    const int s = idx >> 4, n8 = idx & 15, t = c0 + s;
+    const int s = idx & 63, n8 = idx >> 6, t = c0 + s;
     u32x4 v = u32x4{0u, 0u, 0u, 0u};
     if (t < T) v = *reinterpret_cast<const u32x4*>(src + (size_t)t * rs + n8 * 8);
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
@@ -295,7 +299,8 @@ __global__ __launch_bounds__(256) void gdr_o_kernel(const Half* __restrict__ q, 
   // stage bf16(h)^T: h_chunk [k][v] f32, 4 v per 16-byte load
   const float* hc = chunk_state + ((size_t)blockIdx.y * nvh + vh) * GK * GK;
   for (int idx = threadIdx.x; idx < GK * (OBV / 4); idx += 256) {
-    const int kk = idx >> 4, v4 = idx & 15;
+    const int kk = idx >> 4, v4 = idx & 15;  // (k-fastest lanes measured slower here: 25.0 vs 22.4 us - the fp32 source
+                                             //  rows are 512 B apart, the strided loads cost more than the conflicts)
     const f32x4 x = *reinterpret_cast<const f32x4*>(hc + (size_t)kk * GK + v0 + v4 * 4);
 #pragma unroll
     for (int e = 0; e < 4; ++e) hT[(v4 * 4 + e) * KP + kk] = f2bf(x[e]);
