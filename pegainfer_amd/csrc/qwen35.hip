@@ -40,6 +40,51 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const Half* __restrict__ x,
   }
 }
 
+// 8 channels x 1 token per lane (C % 8 == 0, K == 4, 16-byte aligned): 16-byte loads of the K source rows and of the
+// 8 x 4 weights, one 16-byte store.  Per element the taps are summed in the same order as conv1d_kernel.
+__global__ __launch_bounds__(256) void conv1d_vec4_kernel(const Half* __restrict__ x, const Half* __restrict__ w,
+                                                          const Half* __restrict__ state, Half* __restrict__ out,
+                                                          int C, int T) {
+  constexpr int K = 4, sw = 3;
+  const int cvec = C >> 3;
+  const long total = (long)cvec * T;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int c8 = (int)(idx % cvec), t = (int)(idx / cvec), c0 = c8 * 8;
+    float xv[K][8];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int src_t = t - sw + k;
+      if (src_t >= 0) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(x + (size_t)src_t * C + c0);
+        const uint32_t ww[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { xv[k][2 * e] = bf_lo(ww[e]); xv[k][2 * e + 1] = bf_hi(ww[e]); }
+      } else {
+        const int si = sw + src_t;  // >= 0 because K - 1 == sw
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xv[k][e] = bf2f(state[(size_t)(c0 + e) * sw + si]);
+      }
+    }
+    uint32_t o[4];
+#pragma unroll
+    for (int e2 = 0; e2 < 4; ++e2) {
+      float r[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int e = 2 * e2 + h;
+        const u32x2 wv = *reinterpret_cast<const u32x2*>(w + (size_t)(c0 + e) * K);  // 4 taps of this channel
+        float sum = 0.f;
+        sum += xv[0][e] * bf_lo(wv.x);
+        sum += xv[1][e] * bf_hi(wv.x);
+        sum += xv[2][e] * bf_lo(wv.y);
+        sum += xv[3][e] * bf_hi(wv.y);
+        r[h] = silu_f(bf16_round_f(sum));
+      }
+      o[e2] = pack_bf2(r[0], r[1]);
+    }
+    *reinterpret_cast<u32x4*>(out + (size_t)t * C + c0) = u32x4{o[0], o[1], o[2], o[3]};
+  }
+}
 // T == 1 (decode, recurrent.rs:49-79): output and window shift in one pass, same arithmetic as conv1d_kernel
 __global__ __launch_bounds__(256) void conv1d_step_kernel(const Half* __restrict__ x, const Half* __restrict__ w,
                                                           Half* __restrict__ state, Half* __restrict__ out, int C,
@@ -307,8 +352,13 @@ void conv1d_prefill_cuda(const Half* x_seq, const Half* conv_weight, Half* conv_
                                                                    num_channels, kernel_size);
     return;
   }
-  conv1d_kernel<<<grid_cap((long)num_channels * seq_len, 256), 256, 0, s>>>(x_seq, conv_weight, conv_state, out_seq,
-                                                                           num_channels, seq_len, kernel_size);
+  if (kernel_size == 4 && (num_channels & 7) == 0 && host_aligned16(x_seq) && host_aligned16(out_seq) &&
+      (reinterpret_cast<uintptr_t>(conv_weight) & 7u) == 0)
+    conv1d_vec4_kernel<<<grid_cap((long)(num_channels >> 3) * seq_len, 256), 256, 0, s>>>(
+        x_seq, conv_weight, conv_state, out_seq, num_channels, seq_len);
+  else
+    conv1d_kernel<<<grid_cap((long)num_channels * seq_len, 256), 256, 0, s>>>(x_seq, conv_weight, conv_state, out_seq,
+                                                                             num_channels, seq_len, kernel_size);
   if (kernel_size > 1)
     conv1d_state_kernel<<<ceil_div(num_channels, 256), 256, 0, s>>>(x_seq, conv_state, num_channels, seq_len,
                                                                     kernel_size);
