@@ -52,6 +52,11 @@ pegainfer_status_t pegainfer_gemm_split3(const Half* W, const Half* X, Half* Y0,
  * W[sum Ms, K] (Qwen3.5: in_proj_qkv | z | b | a, and gate_proj | up_proj).  Host arrays of n_out entries. */
 pegainfer_status_t pegainfer_gemm_split(const Half* W, const Half* X, int32_t n_out, Half* const* Y, const int32_t* Ms, int32_t T, int32_t K, pegainfer_stream_t stream);
 
+/* gate_up GEMM with SwiGLU in the epilogue: Y[T, I] = silu_mul_fused(W[2I, K] . X) = gemm_cuda + silu_mul_fused_cuda
+ * (prefill.rs:167-175) without the [T, 2I] round trip.  Same bits as that pair.  gate_up_scratch [T, 2I] is used only
+ * when the shape falls back to the pair (T <= 16, small or unaligned matrices); may be NULL otherwise. */
+pegainfer_status_t pegainfer_gemm_silu(const Half* W, const Half* X, Half* Y, Half* gate_up_scratch, int32_t I, int32_t T, int32_t K, pegainfer_stream_t stream);
+
 /* Decode attention with the per-head q/k RMSNorm + RoPE and the KV append folded in (head_dim 128):
  * reads the raw fused-QKV GEMV output qkv[bs, (Hq + 2 Hkv) * 128], writes the new K (normalised, rotated)
  * and V rows into the paged cache and the attention output [bs, Hq*128].  Bit-identical to

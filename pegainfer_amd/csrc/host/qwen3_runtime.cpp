@@ -423,8 +423,12 @@ struct Model {
     gemm_graphsafe_cuda(ly.o, attn_out, attn_proj, H, bs, q_dim, S());
     if (all_reduce_hidden(attn_proj, (size_t)bs * H)) return -1;  // batch_decode.rs:266
     fused_add_rms_norm_batched_cuda(hidden, attn_proj, ly.ln2, normed, H, bs, eps, S());
-    gemm_graphsafe_cuda(ly.gate_up, normed, gate_up_out, 2 * I, bs, H, S());
-    silu_mul_fused_cuda(gate_up_out, mlp_act, I, bs, S());
+    if (stacked_qkv(bs)) {  // mid-batch path: SwiGLU in the tiled GEMM's epilogue (same bits as the pair below)
+      if (pegainfer_gemm_silu(ly.gate_up, normed, mlp_act, gate_up_out, I, bs, H, S())) { set_error("pegainfer_gemm_silu failed"); return -1; }
+    } else {
+      gemm_graphsafe_cuda(ly.gate_up, normed, gate_up_out, 2 * I, bs, H, S());
+      silu_mul_fused_cuda(gate_up_out, mlp_act, I, bs, S());
+    }
     gemm_graphsafe_cuda(ly.down, mlp_act, mlp_out, H, bs, I, S());
     if (all_reduce_hidden(mlp_out, (size_t)bs * H)) return -1;    // batch_decode.rs:292
     return 0;
@@ -748,8 +752,12 @@ struct Model {
       G(ly.o, pf_attn, pf_o, H, q_dim);
       if (all_reduce_hidden(pf_o, (size_t)Ti * H)) return -1;   // prefill.rs:154
       fused_add_rms_norm_batched_cuda(hid, pf_o, ly.ln2, pf_normed, H, Ti, eps, S());
-      G(ly.gate_up, pf_normed, pf_gate_up, 2 * I, H);
-      silu_mul_fused_cuda(pf_gate_up, pf_act, I, Ti, S());
+      if (Ti > 16) {  // SwiGLU in the GEMM epilogue (bit-identical to gemm + silu_mul_fused)
+        if (pegainfer_gemm_silu(ly.gate_up, pf_normed, pf_act, pf_gate_up, I, Ti, H, S())) { set_error("pegainfer_gemm_silu failed"); return -1; }
+      } else {
+        G(ly.gate_up, pf_normed, pf_gate_up, 2 * I, H);
+        silu_mul_fused_cuda(pf_gate_up, pf_act, I, Ti, S());
+      }
       G(ly.down, pf_act, pf_o, H, I);
       if (all_reduce_hidden(pf_o, (size_t)Ti * H)) return -1;   // prefill.rs:180
       if (add_cuda(hid, pf_o, hid_out, Ti * H, S())) { set_error("add_cuda failed"); return -1; }

@@ -152,7 +152,10 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(const Half* __restrict__
 // [M0+M1,M0+M1+M2) -> Y2[T][M2], the rest -> Y3 (one GEMM over a stacked weight writing the separate contiguous
 // buffers the downstream kernels take).  Y1 == nullptr means a plain [T][M] output; unused trailing segments have
 // size 0.  Segment sizes are multiples of 4 (a lane stores 4 consecutive rows).
-struct SplitOut { Half* Y1; Half* Y2; Half* Y3; int M0; int M1; int M2; };
+// silu_I > 0 selects the SwiGLU form instead: W = [gate (I rows); up (I rows)], Y[T][I] = silu_mul_fused(W . x).  A
+// workgroup then owns 64 gate rows AND the 64 up rows below them (each wave 32 + 32, so gate and up of an element
+// meet in one lane's accumulators); per-element K order is unchanged, so the result equals gemm + silu_mul_fused.
+struct SplitOut { Half* Y1; Half* Y2; Half* Y3; int M0; int M1; int M2; int silu_I; };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -186,7 +189,14 @@ __global__ __launch_bounds__(256) void mfma_gemm_glds_kernel(const Half* __restr
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int row = (wave + 4 * j) * 8 + lr;
-    int mr = m0 + row; mr = mr < M ? mr : M - 1;
+    int mr;
+    if (so.silu_I > 0) {  // tile row -> (wave group, 16-row block i, r16): blocks 0,1 = gate rows, 2,3 = up rows
+      int gr = mt * 64 + (row >> 6) * 32 + ((row >> 4) & 1) * 16 + (row & 15);
+      gr = gr < so.silu_I ? gr : so.silu_I - 1;
+      mr = gr + (((row >> 4) & 2) ? so.silu_I : 0);
+    } else {
+      mr = m0 + row; mr = mr < M ? mr : M - 1;
+    }
     wsrc[j] = W + (size_t)mr * K + ((ls ^ (row & 7)) << 3);
   }
 #pragma unroll
@@ -255,6 +265,32 @@ __global__ __launch_bounds__(256) void mfma_gemm_glds_kernel(const Half* __restr
     cur = cur + 1 == ST ? 0 : cur + 1;
     nxt = nxt + 1 == ST ? 0 : nxt + 1;
   }
+  if (so.silu_I > 0) {
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+      const int t = t0 + wt + j * 16 + l15;
+      if (t >= T) continue;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int m = mt * 64 + (wave >> 1) * 32 + i * 16 + g * 4;
+        float r[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)  // the GEMM output is bf16 before SwiGLU (fused_proj.cu:57-62)
+          r[e] = silu_f(bf16_round_f(acc[i][j][e])) * bf16_round_f(acc[i + 2][j][e]);
+        if (m + 3 < so.silu_I) {
+          u32x2 o;
+          o.x = pack_bf2(r[0], r[1]);
+          o.y = pack_bf2(r[2], r[3]);
+          *reinterpret_cast<u32x2*>(Y + (size_t)t * so.silu_I + m) = o;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (m + e < so.silu_I) Y[(size_t)t * so.silu_I + m + e] = f2bf(r[e]);
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < TJ; ++j) {
     const int t = t0 + wt + j * 16 + l15;
@@ -285,12 +321,6 @@ __global__ __launch_bounds__(256) void mfma_gemm_glds_kernel(const Half* __restr
   }
 }
 
-// Decode-shaped GEMM routing (T <= 64 columns, weights streamed once), by shape only (measured on MI355X,
-// Qwen3-4B step: dot2 wins up to 4 columns, the matrix-core kernel from 5):
-//   T <= 4            -> dot2 GEMV (gemv_core.h)            [PEGAINFER_GEMV_T1=mfma routes everything to MFMA]
-//   5 <= T <= 64      -> skinny MFMA GEMM (gemm_skinny.h)   when K % 32 == 0
-//   otherwise         -> dot2 GEMV for T <= 16 (K % 8 == 0), else not taken
-// Within each family a column's result does not depend on the batch size (bitwise batch invariance).
 static bool glds_gemm_ok(const Half* W, const Half* X, const Half* Y, int M, int K) {
   return (K & 7) == 0 && host_aligned16(W) && host_aligned16(X) && (K % BK) == 0 && (M & 3) == 0 &&
          (reinterpret_cast<uintptr_t>(Y) & 7u) == 0;
@@ -304,7 +334,7 @@ static void glds_gemm_launch_t(const Half* W, const Half* X, Half* Y, int M, int
     return true;
   }();
   (void)once;
-  const int m_tiles = ceil_div(M, BM), t_tiles = ceil_div(T, TT);
+  const int m_tiles = so.silu_I > 0 ? ceil_div(so.silu_I, 64) : ceil_div(M, BM), t_tiles = ceil_div(T, TT);
   mfma_gemm_glds_kernel<TT, ST><<<m_tiles * t_tiles, 256, kLds, s>>>(W, X, Y, M, T, K, m_tiles, t_tiles, so);
 }
 // variant: 0 = by shape; else 10*tile + stages with tile 1 = 128-token, 2 = 64-token (A/B probe only)
@@ -328,6 +358,11 @@ static void glds_gemm_launch(const Half* W, const Half* X, Half* Y, int M, int T
   }
 }
 
+// Decode-shaped GEMM routing (T <= 64 columns, weights streamed once), by shape only (measured on MI355X):
+//   T <= 4            -> dot2 GEMV (gemv_core.h)            [PEGAINFER_GEMV_T1=mfma routes everything to MFMA]
+//   5 <= T <= 16      -> skinny MFMA GEMM (gemm_skinny.h)   when K % 32 == 0
+//   17 <= T <= 64     -> tiled LDS-DMA GEMM for >= 5120 rows, skinny below
+// Within each family a column's result does not depend on the batch size (bitwise batch invariance).
 static bool t1_uses_mfma() {
   static const bool v = [] { const char* e = getenv("PEGAINFER_GEMV_T1"); return e && e[0] == 'm'; }();
   return v;
@@ -343,7 +378,7 @@ static bool decode_gemm_dispatch(const GemvFusedArgs& a, hipStream_t s) {
     // unfused sequence, whose large GEMMs take the tiled kernel (so fused == unfused stays true by construction)
     if (a.norm_w || EPI != kEpiStore || a.flags) return false;
     if (a.M >= kMidBatchMinRows && glds_gemm_ok(a.W, a.X, a.Y, a.M, a.K)) {
-      glds_gemm_launch(a.W, a.X, a.Y, a.M, a.T, a.K, SplitOut{nullptr, nullptr, nullptr, 0, 0, 0}, 23, s);
+      glds_gemm_launch(a.W, a.X, a.Y, a.M, a.T, a.K, SplitOut{nullptr, nullptr, nullptr, 0, 0, 0, 0}, 23, s);
       return true;
     }
   }
@@ -375,7 +410,7 @@ static void gemm_dispatch(const Half* W, const Half* X, Half* Y, int M, int T, i
       const int m_tiles = ceil_div(M, BM), t_tiles = ceil_div(T, BT);
       mfma_gemm_kernel<<<m_tiles * t_tiles, 256, 0, s>>>(W, X, Y, M, T, K, m_tiles, t_tiles);
     } else {
-      glds_gemm_launch(W, X, Y, M, T, K, SplitOut{nullptr, nullptr, nullptr, 0, 0, 0}, mode, s);
+      glds_gemm_launch(W, X, Y, M, T, K, SplitOut{nullptr, nullptr, nullptr, 0, 0, 0, 0}, mode, s);
     }
     return;
   }
@@ -458,7 +493,7 @@ pegainfer_status_t pegainfer_gemm_split(const Half* W, const Half* X, int32_t n_
   ok = ok && glds_gemm_ok(W, X, y[0], M, K) && (T > 64 || M >= kMidBatchMinRows);
   if (ok) {
     // the last present segment is "the rest"; with fewer than 4 outputs the unused boundaries collapse onto M
-    SplitOut so{y[1], y[2] ? y[2] : y[1], y[3] ? y[3] : (y[2] ? y[2] : y[1]), m[0], m[1], n_out > 2 ? m[2] : 0};
+    SplitOut so{y[1], y[2] ? y[2] : y[1], y[3] ? y[3] : (y[2] ? y[2] : y[1]), m[0], m[1], n_out > 2 ? m[2] : 0, 0};
     if (n_out == 2) { so.M1 = m[1]; so.M2 = 0; }
     glds_gemm_launch(W, X, y[0], M, T, K, so, T <= 64 ? 23 : 0, as_stream(stream));
   } else {  // shapes the tiled kernel does not take: separate reference-ABI calls
@@ -468,6 +503,26 @@ pegainfer_status_t pegainfer_gemm_split(const Half* W, const Half* X, int32_t n_
       row += m[i];
     }
   }
+  return (pegainfer_status_t)hipGetLastError();
+}
+
+// gate_up GEMM with the SwiGLU activation in its epilogue (extension): Y[T][I] = silu_mul_fused(W[2I][K] . X), what
+// prefill's gemm + silu_mul_fused_cuda pair computes (prefill.rs:167-175) without writing / re-reading [T][2I].
+// Bit-identical to that pair for T > 16 and 2I >= 5120 (same tiled kernel); falls back to the pair otherwise - the
+// caller passes the [T][2I] scratch the pair needs.
+pegainfer_status_t pegainfer_gemm_silu(const Half* W, const Half* X, Half* Y, Half* gate_up_scratch, int32_t I, int32_t T,
+                                       int32_t K, pegainfer_stream_t stream) {
+  using namespace pk;
+  if (I <= 0 || T <= 0 || K <= 0) return (pegainfer_status_t)hipErrorInvalidValue;
+  const int M = 2 * I;
+  if (T > 16 && (I & 3) == 0 && (T > 64 || M >= kMidBatchMinRows) && glds_gemm_ok(W, X, Y, M, K)) {
+    SplitOut so{nullptr, nullptr, nullptr, 0, 0, 0, I};
+    glds_gemm_launch(W, X, Y, M, T, K, so, T <= 64 ? 23 : 0, as_stream(stream));
+    return (pegainfer_status_t)hipGetLastError();
+  }
+  if (!gate_up_scratch) return (pegainfer_status_t)hipErrorInvalidValue;
+  gemm_dispatch(W, X, gate_up_scratch, M, T, K, as_stream(stream));
+  silu_mul_fused_cuda(gate_up_scratch, Y, I, T, stream);
   return (pegainfer_status_t)hipGetLastError();
 }
 

@@ -158,6 +158,17 @@ def gemm_split3_into(weight, x, out0, out1, out2):
                                          weight.shape[1], _stream()), "pegainfer_gemm_split3")
 
 
+def gemm_silu_into(gate_up_weight, x, out, scratch=None):
+    """Y[T, I] = silu_mul_fused(W[2I, K] . X) in one launch (pegainfer_kernels_ext.h: pegainfer_gemm_silu)."""
+    inter = out.shape[1]
+    assert gate_up_weight.shape == (2 * inter, x.shape[1]) and out.shape[0] == x.shape[0]
+    _bf16(gate_up_weight, x, out)
+    if scratch is None:
+        scratch = torch.empty((x.shape[0], 2 * inter), dtype=torch.bfloat16, device=x.device)
+    _chk(ffi.lib().pegainfer_gemm_silu(_p(gate_up_weight), _p(x), _p(out), _p(scratch), inter, x.shape[0],
+                                       gate_up_weight.shape[1], _stream()), "pegainfer_gemm_silu")
+
+
 def gemm(weight, x):
     out = torch.empty((x.shape[0], weight.shape[0]), dtype=torch.bfloat16, device=x.device)
     gemm_into(weight, x, out)

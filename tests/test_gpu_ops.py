@@ -249,6 +249,25 @@ def test_gemm_split3_equals_three_gemms(P, T, K, ms):
         r0 += m
 
 
+@pytest.mark.parametrize("T,I,K", [(1024, 9728, 2560), (130, 512, 256), (40, 9728, 2560), (40, 512, 256), (100, 1000, 128),
+                                   (7, 9728, 2560)])
+def test_gemm_silu_epilogue_equals_gemm_then_silu_mul_fused(P, T, I, K):
+    """SwiGLU in the tiled GEMM's epilogue (64 gate rows + their 64 up rows per workgroup) == gemm_cuda +
+    silu_mul_fused_cuda, bit for bit, incl. partial row tiles, the mid-batch (17..64) family and the small-shape
+    fallback; and within 1 bf16 ulp + GEMM tolerance of the oracle."""
+    import torch
+    rng = np.random.default_rng(T + I)
+    W, X = rnd(rng, 2 * I, K, scale=0.06), rnd(rng, T, K, scale=1.5)
+    Wd, Xd = to_dev(W), to_dev(X)
+    ref = torch.zeros((T, I), dtype=torch.bfloat16, device="cuda")
+    P.silu_mul_fused_batch_into(P.gemm(Wd, Xd), ref)
+    out = torch.zeros_like(ref)
+    P.gemm_silu_into(Wd, Xd, out)
+    assert np.array_equal(bf16_bits(from_dev(out)), bf16_bits(from_dev(ref)))
+    exp = O.silu_mul_fused(O.gemm(W, X), I)
+    assert np.abs(from_dev(out) - exp).max() <= 2.0 ** -6 * max(1.0, np.abs(exp).max())
+
+
 def test_gemm_split3_mid_batch_matches_oracle_and_full_gemm(P):
     """17..64 columns, stacked q|k|v of 6144 rows (the mid-batch decode path): the three outputs are the row ranges of
     ONE tiled GEMM - bit-identical to gemm_cuda over the stacked matrix, within the GEMM tolerance of the oracle."""
