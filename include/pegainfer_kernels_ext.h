@@ -56,6 +56,8 @@ pegainfer_status_t pegainfer_gemm_split(const Half* W, const Half* X, int32_t n_
  * (prefill.rs:167-175) without the [T, 2I] round trip.  Same bits as that pair.  gate_up_scratch [T, 2I] is used only
  * when the shape falls back to the pair (T <= 16, small or unaligned matrices); may be NULL otherwise. */
 pegainfer_status_t pegainfer_gemm_silu(const Half* W, const Half* X, Half* Y, Half* gate_up_scratch, int32_t I, int32_t T, int32_t K, pegainfer_stream_t stream);
+/* same with the Qwen3.5 activation: bf16(bf16(silu(gate)) * up) == gemm_cuda x2 + silu_mul_triton_aot_cuda */
+pegainfer_status_t pegainfer_gemm_silu_rounded(const Half* W, const Half* X, Half* Y, Half* gate_up_scratch, int32_t I, int32_t T, int32_t K, pegainfer_stream_t stream);
 
 /* Decode attention with the per-head q/k RMSNorm + RoPE and the KV append folded in (head_dim 128):
  * reads the raw fused-QKV GEMV output qkv[bs, (Hq + 2 Hkv) * 128], writes the new K (normalised, rotated)

@@ -392,6 +392,12 @@ struct Model35 {
     return 0;
   }
   int mlp(const Layer35& ly, const Half* x, Half* g, Half* up_, Half* act, Half* out, int T) {
+    if (T > 64 && (I & 3) == 0) {  // gate|up stacked: SwiGLU (Qwen3.5 rounding) in the GEMM epilogue, same bits
+      if (pegainfer_gemm_silu_rounded(ly.gate, x, act, nullptr, I, T, H, S()) == 0) {
+        G(ly.down, act, out, H, T, I);
+        return 0;
+      }
+    }
     Half* ys[2] = {g, up_};
     const int32_t ms[2] = {I, I};
     if (GS(ly.gate, x, 2, ys, ms, T, H)) return -1;

@@ -155,7 +155,8 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(const Half* __restrict__
 // silu_I > 0 selects the SwiGLU form instead: W = [gate (I rows); up (I rows)], Y[T][I] = silu_mul_fused(W . x).  A
 // workgroup then owns 64 gate rows AND the 64 up rows below them (each wave 32 + 32, so gate and up of an element
 // meet in one lane's accumulators); per-element K order is unchanged, so the result equals gemm + silu_mul_fused.
-struct SplitOut { Half* Y1; Half* Y2; Half* Y3; int M0; int M1; int M2; int silu_I; };
+// silu_round: the Qwen3.5 activation bf16(bf16(silu(g)) * u) (elementwise.cu:28-42) instead of one rounding.
+struct SplitOut { Half* Y1; Half* Y2; Half* Y3; int M0; int M1; int M2; int silu_I; int silu_round; };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -276,7 +277,10 @@ __global__ __launch_bounds__(256) void mfma_gemm_glds_kernel(const Half* __restr
         float r[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e)  // the GEMM output is bf16 before SwiGLU (fused_proj.cu:57-62)
-          r[e] = silu_f(bf16_round_f(acc[i][j][e])) * bf16_round_f(acc[i + 2][j][e]);
+        {
+          const float sg = silu_f(bf16_round_f(acc[i][j][e]));
+          r[e] = (so.silu_round ? bf16_round_f(sg) : sg) * bf16_round_f(acc[i + 2][j][e]);
+        }
         if (m + 3 < so.silu_I) {
           u32x2 o;
           o.x = pack_bf2(r[0], r[1]);
@@ -378,7 +382,7 @@ static bool decode_gemm_dispatch(const GemvFusedArgs& a, hipStream_t s) {
     // unfused sequence, whose large GEMMs take the tiled kernel (so fused == unfused stays true by construction)
     if (a.norm_w || EPI != kEpiStore || a.flags) return false;
     if (a.M >= kMidBatchMinRows && glds_gemm_ok(a.W, a.X, a.Y, a.M, a.K)) {
-      glds_gemm_launch(a.W, a.X, a.Y, a.M, a.T, a.K, SplitOut{nullptr, nullptr, nullptr, 0, 0, 0, 0}, 23, s);
+      glds_gemm_launch(a.W, a.X, a.Y, a.M, a.T, a.K, SplitOut{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0}, 23, s);
       return true;
     }
   }
@@ -410,7 +414,7 @@ static void gemm_dispatch(const Half* W, const Half* X, Half* Y, int M, int T, i
       const int m_tiles = ceil_div(M, BM), t_tiles = ceil_div(T, BT);
       mfma_gemm_kernel<<<m_tiles * t_tiles, 256, 0, s>>>(W, X, Y, M, T, K, m_tiles, t_tiles);
     } else {
-      glds_gemm_launch(W, X, Y, M, T, K, SplitOut{nullptr, nullptr, nullptr, 0, 0, 0, 0}, mode, s);
+      glds_gemm_launch(W, X, Y, M, T, K, SplitOut{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0}, mode, s);
     }
     return;
   }
@@ -493,7 +497,7 @@ pegainfer_status_t pegainfer_gemm_split(const Half* W, const Half* X, int32_t n_
   ok = ok && glds_gemm_ok(W, X, y[0], M, K) && (T > 64 || M >= kMidBatchMinRows);
   if (ok) {
     // the last present segment is "the rest"; with fewer than 4 outputs the unused boundaries collapse onto M
-    SplitOut so{y[1], y[2] ? y[2] : y[1], y[3] ? y[3] : (y[2] ? y[2] : y[1]), m[0], m[1], n_out > 2 ? m[2] : 0, 0};
+    SplitOut so{y[1], y[2] ? y[2] : y[1], y[3] ? y[3] : (y[2] ? y[2] : y[1]), m[0], m[1], n_out > 2 ? m[2] : 0, 0, 0};
     if (n_out == 2) { so.M1 = m[1]; so.M2 = 0; }
     glds_gemm_launch(W, X, y[0], M, T, K, so, T <= 64 ? 23 : 0, as_stream(stream));
   } else {  // shapes the tiled kernel does not take: separate reference-ABI calls
@@ -510,20 +514,37 @@ pegainfer_status_t pegainfer_gemm_split(const Half* W, const Half* X, int32_t n_
 // prefill's gemm + silu_mul_fused_cuda pair computes (prefill.rs:167-175) without writing / re-reading [T][2I].
 // Bit-identical to that pair for T > 16 and 2I >= 5120 (same tiled kernel); falls back to the pair otherwise - the
 // caller passes the [T][2I] scratch the pair needs.
-pegainfer_status_t pegainfer_gemm_silu(const Half* W, const Half* X, Half* Y, Half* gate_up_scratch, int32_t I, int32_t T,
-                                       int32_t K, pegainfer_stream_t stream) {
+static pegainfer_status_t gemm_silu_impl(const Half* W, const Half* X, Half* Y, Half* gate_up_scratch, int32_t I,
+                                         int32_t T, int32_t K, int double_round, pegainfer_stream_t stream) {
   using namespace pk;
   if (I <= 0 || T <= 0 || K <= 0) return (pegainfer_status_t)hipErrorInvalidValue;
   const int M = 2 * I;
   if (T > 16 && (I & 3) == 0 && (T > 64 || M >= kMidBatchMinRows) && glds_gemm_ok(W, X, Y, M, K)) {
-    SplitOut so{nullptr, nullptr, nullptr, 0, 0, 0, I};
+    SplitOut so{nullptr, nullptr, nullptr, 0, 0, 0, I, double_round};
     glds_gemm_launch(W, X, Y, M, T, K, so, T <= 64 ? 23 : 0, as_stream(stream));
     return (pegainfer_status_t)hipGetLastError();
   }
   if (!gate_up_scratch) return (pegainfer_status_t)hipErrorInvalidValue;
   gemm_dispatch(W, X, gate_up_scratch, M, T, K, as_stream(stream));
-  silu_mul_fused_cuda(gate_up_scratch, Y, I, T, stream);
+  if (double_round) {  // the unfused Qwen3.5 pair works on separate gate / up buffers: run it per token row
+    for (int t = 0; t < T; ++t) {
+      const pegainfer_status_t rc = silu_mul_triton_aot_cuda(gate_up_scratch + (size_t)t * M, gate_up_scratch + (size_t)t * M + I,
+                                                             Y + (size_t)t * I, I, stream);
+      if (rc) return rc;
+    }
+  } else {
+    silu_mul_fused_cuda(gate_up_scratch, Y, I, T, stream);
+  }
   return (pegainfer_status_t)hipGetLastError();
+}
+pegainfer_status_t pegainfer_gemm_silu(const Half* W, const Half* X, Half* Y, Half* gate_up_scratch, int32_t I, int32_t T,
+                                       int32_t K, pegainfer_stream_t stream) {
+  return gemm_silu_impl(W, X, Y, gate_up_scratch, I, T, K, 0, stream);
+}
+// Qwen3.5 form: Y = silu_mul(gate, up) with silu rounded to bf16 first (qwen35 prefill.rs:187-190)
+pegainfer_status_t pegainfer_gemm_silu_rounded(const Half* W, const Half* X, Half* Y, Half* gate_up_scratch, int32_t I,
+                                               int32_t T, int32_t K, pegainfer_stream_t stream) {
+  return gemm_silu_impl(W, X, Y, gate_up_scratch, I, T, K, 1, stream);
 }
 
 pegainfer_status_t pegainfer_gemm_split3(const Half* W, const Half* X, Half* Y0, int32_t M0, Half* Y1, int32_t M1,
