@@ -103,6 +103,21 @@ def cpu_baseline(cfg, steps, threads):
 
 
 
+
+MFMA_PEAK_TFLOPS = 2500.0  # MI355X dense bf16 (MI355X_MICROARCH.md); never the 2:1-sparsity figure
+
+
+def prefill_roofline(c, T, ttft_ms, tp_world=1):
+    """TTFT against the MFMA roofline: layer GEMMs 2*params*T, lm_head on the last token only,
+    causal attention 2*Hq*D*T^2 per layer (QK^T + PV over the causal half)."""
+    H, I, L, V = c["hidden_size"], c["intermediate_size"], c["num_hidden_layers"], c["vocab_size"]
+    qd, kvd = c["num_attention_heads"] * c["head_dim"], c["num_key_value_heads"] * c["head_dim"]
+    layer_params = (qd + 2 * kvd) * H + H * qd + 3 * I * H
+    flops = 2.0 * layer_params * L * T + 2.0 * V * H + 2.0 * qd * T * T * L
+    ach = flops / (ttft_ms * 1e-3) / 1e12
+    return {"bound": "mfma", "flops": flops, "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS * tp_world,
+            "unit": "TFLOP/s", "frac": round(ach / (MFMA_PEAK_TFLOPS * tp_world), 4), "prompt_tokens": T}
+
 def qwen35_bytes_per_token(c, ctx, batch):
     """Algorithmic HBM bytes of one Qwen3.5 decode step: every weight once (bf16; A_log / gated-norm f32), the KV of
     the full-attention layers (2 * Hkv * 256 * 2 B per token per layer), and per request the fp32 delta-rule state
@@ -401,6 +416,7 @@ def main():
         "tpot_ms": {"p50": round(float(np.median(step_ms)), 4), "p95": round(float(np.percentile(step_ms, 95)), 4),
                     "device_p50": round(float(np.median(dev_ms)), 4)},
         "mp8_collectives_us": mp8,
+        "prefill_roofline": prefill_roofline(full_cfg, args.ctx, float(np.median(ttfts)), world if tp else 1),
         "step_roofline": {"algorithmic_bytes_per_step": int(step_bytes),
                           "achieved_GBps": round(step_bytes / (np.median(dev_ms) * 1e-3) / 1e9, 1),
                           "frac_of_8TBps": round(step_bytes / (np.median(dev_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
