@@ -98,17 +98,30 @@ __device__ __forceinline__ void merge_one(const Half* __restrict__ tmp_v, const 
   const float M = wave_max(lse);
   if (M != -INFINITY) {
     const float w_lane = exp2f(lse - M);
-    for (int j = 0; j < n; ++j) {
-      const float w = __shfl(w_lane, j, kWave);
-      const word_t* v = reinterpret_cast<const word_t*>(tmp_v + ((size_t)(s0 + j) * num_qo_heads + head) * D + lane * EPL);
-      const word_t pv = COHERENT ? __hip_atomic_load(v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *v;
-      wsum += w;
-      acc[0] += w * bf_lo((uint32_t)pv);
-      acc[1] += w * bf_hi((uint32_t)pv);
-      if (EPL == 4) {
-        const uint32_t hi = (uint32_t)((uint64_t)pv >> 32);
-        acc[2] += w * bf_lo(hi);
-        acc[3] += w * bf_hi(hi);
+    // 16 partials per batch: all loads of a batch are in flight before the first one is consumed (a plain
+    // load-then-accumulate loop paid one memory round trip per slot); accumulation order is still slot order
+    constexpr int MB = 16;
+    for (int j0 = 0; j0 < n; j0 += MB) {
+      word_t pv[MB];
+#pragma unroll
+      for (int u = 0; u < MB; ++u) {
+        int j = j0 + u;
+        j = j < n ? j : n - 1;  // clamped reload of a valid slot; its weight is dropped below
+        const word_t* v = reinterpret_cast<const word_t*>(tmp_v + ((size_t)(s0 + j) * num_qo_heads + head) * D + lane * EPL);
+        pv[u] = COHERENT ? __hip_atomic_load(v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *v;
+      }
+#pragma unroll
+      for (int u = 0; u < MB; ++u) {
+        if (j0 + u >= n) break;
+        const float w = __shfl(w_lane, j0 + u, kWave);
+        wsum += w;
+        acc[0] += w * bf_lo((uint32_t)pv[u]);
+        acc[1] += w * bf_hi((uint32_t)pv[u]);
+        if (EPL == 4) {
+          const uint32_t hi = (uint32_t)((uint64_t)pv[u] >> 32);
+          acc[2] += w * bf_lo(hi);
+          acc[3] += w * bf_hi(hi);
+        }
       }
     }
   }

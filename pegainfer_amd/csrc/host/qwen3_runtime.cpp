@@ -96,11 +96,12 @@ struct Model {
   float* split_tmp_s = nullptr;
   int32_t* tokens_out_d = nullptr;
   uint8_t* top1_state = nullptr;
-  // PEGAINFER_FUSED_MERGE=1: the split-KV partials are merged by the last workgroup of each (request, kv head)
-  // inside the attention launch instead of by merge_states_kernel.  Same bits; measured a wash on MI355X
-  // (2.418 vs 2.426 ms/step: the write-through publish + ticket + cross-XCD reads cost what the launch did),
-  // so the default keeps the separate launch, which cannot leave a counter armed if a launch is aborted.
-  bool fused_merge = [] { const char* e = getenv("PEGAINFER_FUSED_MERGE"); return e && e[0] == '1'; }();
+  // The split-KV partials are merged by the last workgroup of each (request, kv head) inside the attention launch
+  // (write-through sc1 partials, relaxed agent ticket, batched sc1 loads) instead of by merge_states_kernel: same
+  // bits, 2.47 -> 2.33 ms/step at bs 1 / ctx 1024 once the merge loads were batched.  The counters are re-zeroed at
+  // the head of every captured step, so an aborted launch cannot leave one armed.  PEGAINFER_FUSED_MERGE=0 keeps
+  // the separate merge launch (A/B).
+  bool fused_merge = [] { const char* e = getenv("PEGAINFER_FUSED_MERGE"); return !(e && e[0] == '0'); }();
   int32_t* merge_ctr = nullptr;  // per (request, kv head) arrival counters of the in-kernel split-KV merge
   // sampling scratch (ops/sampling.rs)
   float* probs_scratch = nullptr;
@@ -440,6 +441,7 @@ struct Model {
   // kernel.  Every fused kernel shares its arithmetic core with the reference-named op it replaces, so the
   // logits are bit-identical to decode_mode 0 (tests/test_gpu_fused.py).
   int decode_kernels_fused(int bs, bool split, int split_slots) {
+    if (fused_merge && split) PQ_HIP(hipMemsetAsync(merge_ctr, 0, (size_t)max_bs * Hkv * sizeof(int32_t), stream));
     if (embedding_batched_cuda(embed, md<uint32_t>(ml.token_ids), hidden, H, bs, S())) {
       set_error("embedding_batched_cuda failed");
       return -1;
