@@ -75,8 +75,10 @@ int32_t pegainfer_fused_decode_attention(const Half* qkv, Half* output, const Ha
 
 /* Partition-KV decode attention at head_dim 256 (Qwen3.5 full-attention layers).  No counterpart in ffi.rs (its
  * hd256 decode symbol is non-partition only, ffi.rs:1286-1306); arguments and scratch contract are exactly those of
- * paged_attention_decode_split_kv_cuda.  Equal to the non-partition result within bf16 rounding of the partials. */
-int32_t pegainfer_paged_attention_decode_split_kv_hd256(const Half* q, Half* output, const Half* kv_data, int64_t k_offset_elems, int64_t v_offset_elems, const int32_t* page_indices, const int32_t* page_indptr, const int32_t* last_page_len_d, const int32_t* request_indices, const int32_t* kv_tile_indices, const int32_t* kv_chunk_size_ptr, const int32_t* o_indptr, const uint8_t* block_valid_mask, Half* tmp_v, float* tmp_s, int32_t num_qo_heads, int32_t num_kv_heads, int32_t head_dim, int32_t page_size, int32_t batch_size, int32_t padded_batch_size, int64_t stride_page, float sm_scale, pegainfer_stream_t stream);
+ * paged_attention_decode_split_kv_cuda, plus the optional merge_counters of pegainfer_fused_decode_attention
+ * (batch_size * num_kv_heads zeroed int32: the last workgroup merges in the same launch).  Equal to the non-partition
+ * result within bf16 rounding of the partials. */
+int32_t pegainfer_paged_attention_decode_split_kv_hd256(const Half* q, Half* output, const Half* kv_data, int64_t k_offset_elems, int64_t v_offset_elems, const int32_t* page_indices, const int32_t* page_indptr, const int32_t* last_page_len_d, const int32_t* request_indices, const int32_t* kv_tile_indices, const int32_t* kv_chunk_size_ptr, const int32_t* o_indptr, const uint8_t* block_valid_mask, Half* tmp_v, float* tmp_s, int32_t num_qo_heads, int32_t num_kv_heads, int32_t head_dim, int32_t page_size, int32_t batch_size, int32_t padded_batch_size, int64_t stride_page, float sm_scale, int32_t* merge_counters, pegainfer_stream_t stream);
 
 #ifdef __cplusplus
 }

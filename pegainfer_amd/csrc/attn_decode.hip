@@ -493,12 +493,14 @@ int32_t pegainfer_paged_attention_decode_split_kv_hd256(
     const int32_t* request_indices, const int32_t* kv_tile_indices, const int32_t* kv_chunk_size_ptr,
     const int32_t* o_indptr, const uint8_t* block_valid_mask, Half* tmp_v, float* tmp_s, int32_t num_qo_heads,
     int32_t num_kv_heads, int32_t head_dim, int32_t page_size, int32_t batch_size, int32_t padded_batch_size,
-    int64_t stride_page, float sm_scale, pegainfer_stream_t stream) {
+    int64_t stride_page, float sm_scale, int32_t* merge_counters, pegainfer_stream_t stream) {
   if (head_dim != 256) return static_cast<int32_t>(hipErrorInvalidValue);
   DecodeAttnArgs a;
   fill_args(a, q, output, kv_data, k_offset_elems, v_offset_elems, page_indices, page_indptr, last_page_len_d,
             request_indices, kv_tile_indices, kv_chunk_size_ptr, block_valid_mask, tmp_v, tmp_s, num_qo_heads,
             num_kv_heads, page_size, stride_page, sm_scale);
+  a.merge_counters = merge_counters;  // optional in-launch merge, as in pegainfer_fused_decode_attention
+  a.o_indptr = o_indptr;
   return launch_decode<256, true, false>(a, o_indptr, batch_size, padded_batch_size, as_stream(stream));
 }
 

@@ -106,6 +106,7 @@ struct Model35 {
   // partition-KV decode for the full-attention layers (MI355X policy of kv_pool.h: fill the 256 CUs)
   Half* split_tmp_v = nullptr;
   float* split_tmp_s = nullptr;
+  int32_t* merge_ctr = nullptr;  // in-launch split-KV merge tickets, zeroed at the head of every step
   hipGraphExec_t graph = nullptr;
   std::vector<int> graph_ids;   // request ids of the captured step, then the attention path
   // prefill workspace (grow-only)
@@ -195,7 +196,7 @@ struct Model35 {
         dalloc(&top1_state, bs * 16) || dalloc(&start_pos_d, 1) ||
         dalloc(&wide, (size_t)std::max(C + Z + 2 * vh, 2 * q_dim + 2 * kv_dim)) ||
         dalloc(&split_tmp_v, bs * pq::kSplitMaxChunksPerRequest * q_dim) ||
-        dalloc(&split_tmp_s, bs * pq::kSplitMaxChunksPerRequest * Hq) || dalloc(&pf_last, H) ||
+        dalloc(&split_tmp_s, bs * pq::kSplitMaxChunksPerRequest * Hq) || dalloc(&merge_ctr, bs * (size_t)Hkv) || dalloc(&pf_last, H) ||
         dalloc(&pf_last_normed, H) || dalloc(&pf_logits, V))
       return -1;
     auto al = [](size_t x) { return (x + 63) & ~size_t(63); };
@@ -409,6 +410,7 @@ struct Model35 {
   // ------------------------------------------------------------------ decode (batch_decode.rs:198-365)
   int decode_kernels(int bs, const std::vector<Request35*>& rs, bool split) {
     auto md = [&](size_t off) { return reinterpret_cast<int32_t*>(meta_dev + off); };
+    if (split) P35_HIP(hipMemsetAsync(merge_ctr, 0, (size_t)max_bs * Hkv * sizeof(int32_t), stream));
     if (embedding_batched_cuda(embed, reinterpret_cast<uint32_t*>(meta_dev + m_tok), hidden, H, bs, S())) {
       set_error("embedding failed"); return -1;
     }
@@ -429,7 +431,7 @@ struct Model35 {
           rc = pegainfer_paged_attention_decode_split_kv_hd256(
               q_attn, attn_out, kv_buffer, layout.k_offset(full), layout.v_offset(full), md(m_pages), md(m_indptr),
               md(m_lpl), md(m_sri), md(m_skt), md(m_skc), md(m_soi), meta_dev + m_sva, split_tmp_v, split_tmp_s, Hq, Hkv,
-              D, layout.page_size, bs, bs * pq::kSplitMaxChunksPerRequest, layout.page_stride, sm, S());
+              D, layout.page_size, bs, bs * pq::kSplitMaxChunksPerRequest, layout.page_stride, sm, merge_ctr, S());
         else if (!rc)
           rc = paged_attention_decode_cuda_hd256(q_attn, attn_out, kv_buffer, layout.k_offset(full), layout.v_offset(full),
                                                  md(m_pages), md(m_indptr), md(m_lpl), md(m_ri), md(m_kti), md(m_kcs), Hq,
@@ -472,6 +474,7 @@ struct Model35 {
   // stacked outputs take contiguous [bs, dim] tensors in the reference ABI).
   int decode_kernels_fused1(Request35* r, bool split) {
     auto md = [&](size_t off) { return reinterpret_cast<int32_t*>(meta_dev + off); };
+    if (split) P35_HIP(hipMemsetAsync(merge_ctr, 0, (size_t)max_bs * Hkv * sizeof(int32_t), stream));
     if (embedding_batched_cuda(embed, reinterpret_cast<uint32_t*>(meta_dev + m_tok), hidden, H, 1, S())) {
       set_error("embedding failed"); return -1;
     }
@@ -497,7 +500,7 @@ struct Model35 {
           rc = pegainfer_paged_attention_decode_split_kv_hd256(
               q_attn, attn_out, kv_buffer, layout.k_offset(full), layout.v_offset(full), md(m_pages), md(m_indptr),
               md(m_lpl), md(m_sri), md(m_skt), md(m_skc), md(m_soi), meta_dev + m_sva, split_tmp_v, split_tmp_s, Hq, Hkv,
-              D, layout.page_size, 1, pq::kSplitMaxChunksPerRequest, layout.page_stride, sm, S());
+              D, layout.page_size, 1, pq::kSplitMaxChunksPerRequest, layout.page_stride, sm, merge_ctr, S());
         else if (!rc)
           rc = paged_attention_decode_cuda_hd256(q_attn, attn_out, kv_buffer, layout.k_offset(full), layout.v_offset(full),
                                                  md(m_pages), md(m_indptr), md(m_lpl), md(m_ri), md(m_kti), md(m_kcs), Hq,
