@@ -4,15 +4,27 @@
 //
 // At T >= 4 the dot2 GEMV turns VALU-bound (v_dot2c is a quarter-rate op), so the contraction moves to the
 // matrix cores while the kernel stays HBM-bound: one workgroup = 8 waves = one 16-row block of W; wave w owns
-// the 64-wide K step PAIRS p == w (mod 8) (both 64-byte halves of a row's 128-byte line are fetched by the same
-// wave back to back) - a mapping that does not depend on T or on the tile width, so every column's result is
-// bit-identical for any batch size routed here.  Per K step a wave issues ONE fragment-shaped
-// 16-byte load per lane (16 rows x 64 B, straight HBM -> VGPR, non-temporal; all loads of a tile are in
-// flight before the x tile is even staged), reads the NB x-fragments from LDS (x tile [T][KT] with the
-// 16-byte chunk index XOR-swizzled by token so the 16 token rows hit 16 different slots) and issues NB
-// v_mfma_f32_16x16x32_bf16.  The 8 partial accumulators are combined through LDS in fixed wave order.
-// MFMA utilisation is tiny on purpose - the op is priced against the HBM roofline, not the MFMA one.
+// the 64-wide K "pairs" p == w (mod 8) (128 bytes of every row) - a mapping that does not depend on T or on the
+// tile width, so every column's result is bit-identical for any batch size routed here.
+//
+// Load shape (measured, tools/bench_skinny.py): what the HBM stream cares about is that ONE load instruction
+// covers whole 128-byte lines.  The natural MFMA A-fragment load (lane = row, 16 B per lane: 16 rows x 64 B per
+// instruction, half a line per row) streams at 4.8 TB/s on the 778 MB lm_head and 2-3 TB/s on the layer
+// matrices; 8 rows x 128 B per instruction streams at 6.9 TB/s / 3.5-5.7 TB/s.  So a weight register is loaded as
+//     row-in-8 r = (lane >> 1) & 7,   16-byte chunk of the row's 128-byte segment c = 2 * (lane >> 4) + (lane & 1)
+// and fed to v_mfma_f32_16x16x32_bf16 unpermuted: as an A operand (row index i = lane & 15, k group g = lane >> 4)
+// it is 16 "rows" i = 2 r + h, where h = chunk parity and row i carries the chunks {2 g + h}.  The MFMA against
+// the x fragment of parity h (x chunks 2 g + h) is therefore exact in the rows of that parity and garbage in the
+// others: two MFMAs and two accumulators (even / odd) per register, and the result of real row r is
+// acc_even[i = 2 r] + acc_odd[i = 2 r + 1] - both in the same lane of the D layout, so no cross-lane traffic.
+// Half of the MFMA work is discarded on purpose: the op is priced against the HBM roofline, not the MFMA one.
+//
+// x sits in LDS ([T][KT] tile, or the whole [T][K] block in the resident variant) with the 16-byte chunk index
+// XOR-swizzled by token so the 16 token rows of a fragment read hit 16 different bank groups.  The 8 waves'
+// partial sums meet in LDS and are added in fixed wave order.
 #pragma once
+
+#include <cstdlib>
 
 #include "common.h"
 #include "gemv_core.h"
@@ -21,16 +33,17 @@
 namespace pk {
 
 constexpr int kSkinnyWaves = 8;
+constexpr int kSkinnyThreads = kSkinnyWaves * 64;
+
 // LDS bytes of the x tile region: T staged rows, but never less than the cross-wave reduction buffer
 // ([8 waves][<=2 weight sets][NB][64 lanes] f32x4) that reuses the same memory after the K loop.
 __host__ __device__ inline int skinny_xs_bytes(int NB, int T, int KT) {
   const int x = T * KT * 2, r = 8 * 2 * NB * 64 * 16;
   return ((x > r ? x : r) + 15) & ~15;
 }
-constexpr int kSkinnyThreads = kSkinnyWaves * 64;
 
 // x tile [T][KT]: only the T real token rows are staged; KT = largest multiple of 512 (8 pairs) with
-// T*KT*2 <= 64 KB, capped at 2048 (<= 8 fragment loads per weight set in flight per wave per tile).
+// T*KT*2 <= 64 KB, capped at 2048 (<= 8 weight loads per weight set in flight per wave per tile).
 inline int skinny_pick_kt(int T, int K) {
   int kt = (64 * 1024 / (T * 2)) / 512 * 512;
   kt = kt > 2048 ? 2048 : (kt < 512 ? 512 : kt);
@@ -38,109 +51,224 @@ inline int skinny_pick_kt(int T, int K) {
   return kt > kr ? kr : kt;
 }
 
+// ---- shared pieces ----
+struct SkinnyLane {
+  int wave, lane, l15, g;   // MFMA view: token / row index, k group
+  int prow, pchunk;         // load view: row within the 8-row register, 16-byte chunk of the 128-byte segment
+  __device__ SkinnyLane() {
+    wave = threadIdx.x >> 6; lane = threadIdx.x & 63; l15 = lane & 15; g = lane >> 4;
+    prow = (lane >> 1) & 7; pchunk = 2 * g + (lane & 1);
+  }
+};
+// acc[2 row halves][2 parities] of one 16-row block -> the wave's partial sums in "row slot" order:
+// slot i of lane ln = row (i >> 1) * 8 + 2 * (ln >> 4) + (i & 1) of the block, token ln & 15
+__device__ inline f32x4 skinny_fold(const f32x4 (&acc)[2][2]) {
+  return f32x4{acc[0][0][0] + acc[0][1][1], acc[0][0][2] + acc[0][1][3],
+               acc[1][0][0] + acc[1][1][1], acc[1][0][2] + acc[1][1][3]};
+}
+__device__ inline int skinny_slot_row(int ln, int i) { return (i >> 1) * 8 + 2 * (ln >> 4) + (i & 1); }
+
+// Combine the 8 waves' folded partials of one row block (fixed order) and store.  red: [8][NW][NB][64] f32x4.
+template <int NB, int EPI>
+__device__ inline void skinny_reduce_store(const GemvFusedArgs& a, const f32x4* red, int row0, int rows_total, int tid) {
+  constexpr int NW = EPI == kEpiSilu ? 2 : 1;
+  for (int e = tid; e < NB * 64; e += kSkinnyThreads) {
+    const int nb = e >> 6, ln = e & 63;
+    f32x4 tot[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      f32x4 v = red[((0 * NW + w) * NB + nb) * 64 + ln];
+#pragma unroll
+      for (int wv = 1; wv < kSkinnyWaves; ++wv) v += red[((wv * NW + w) * NB + nb) * 64 + ln];
+      tot[w] = v;
+    }
+    const int t = nb * 16 + (ln & 15);
+    if (t >= a.T) continue;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = row0 + skinny_slot_row(ln, i);
+      if (r >= rows_total) continue;
+      if (EPI == kEpiSilu) {
+        const float gt = bf16_round_f(tot[0][i]), up = bf16_round_f(tot[NW - 1][i]);
+        a.Y[(size_t)t * a.I + r] = f2bf(silu_f(gt) * up);
+      } else {
+        a.Y[(size_t)t * a.M + r] = f2bf(tot[0][i]);
+      }
+    }
+  }
+}
+
+// Stage x[0:T, k0:k0+kt] (optionally normalised on the fly) into the swizzled tile: wave w takes the token rows
+// t == w (mod 8), a lane the 16-byte vectors lane, lane + 64, ... of the row, four at a time so that the global
+// loads of a batch are all in flight before the first LDS write (the one-vector-at-a-time loop cost 2.5-7 us).
+template <int B, bool NORM>
+__device__ inline void skinny_stage_rows(const GemvFusedArgs& a, u32x4* xs, const float* sm_inv, int pitch, int k0,
+                                         int kt, int wave, int lane) {
+  const int nvec = kt >> 3, T = a.T, K = a.K;
+  for (int t = wave; t < T; t += kSkinnyWaves) {
+    const size_t row = (size_t)t * K + k0;
+    const float inv = NORM ? sm_inv[t] : 0.f;
+    for (int c0 = lane; c0 < nvec; c0 += 64 * B) {
+      u32x4 h[B], r[B], gw[B];
+#pragma unroll
+      for (int j = 0; j < B; ++j) {
+        const int c = c0 + 64 * j;
+        if (c < nvec) {
+          h[j] = *reinterpret_cast<const u32x4*>(a.X + row + c * 8);
+          if (NORM) gw[j] = *reinterpret_cast<const u32x4*>(a.norm_w + k0 + c * 8);
+          if (NORM && a.residual) r[j] = *reinterpret_cast<const u32x4*>(a.residual + row + c * 8);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < B; ++j) {
+        const int c = c0 + 64 * j;
+        if (c < nvec) {
+          u32x4 v = h[j];
+          if (NORM) {
+            if (a.residual) {
+              u32x4 nh;
+              v = norm_scale8(h[j], &r[j], gw[j], inv, 0.f, &nh);
+              if (blockIdx.x == 0) *reinterpret_cast<u32x4*>(a.hidden_out + row + c * 8) = nh;
+            } else {
+              v = norm_scale8(h[j], nullptr, gw[j], inv, 0.f, nullptr);
+            }
+          }
+          xs[t * pitch + (c ^ (t & 15))] = v;
+        }
+      }
+    }
+  }
+}
+template <int NB>
+__device__ inline void skinny_stage_x(const GemvFusedArgs& a, u32x4* xs, const float* sm_inv, int pitch, int k0, int kt,
+                                      int wave, int lane) {
+  if (a.norm_w) skinny_stage_rows<2, true>(a, xs, sm_inv, pitch, k0, kt, wave, lane);
+  else skinny_stage_rows<(NB >= 4 ? 2 : 4), false>(a, xs, sm_inv, pitch, k0, kt, wave, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Tiled kernel: x does not fit in LDS as a whole; K is walked in KT-wide tiles (stage, barrier, compute).
 // RB = 16-row blocks of W per workgroup.  The x tile width shrinks as T grows (T*KT*2 <= 64 KB), so at T = 32 / 64 a
-// wave has only 4 / 2 K steps of one row block per tile: too few loads in flight, and x re-staged by every 16 rows.
-// RB = 2 / 4 row blocks per workgroup keep 8 fragment loads per weight set in flight per wave and cut the x
-// staging traffic by RB.  The pair -> wave mapping and the per-wave accumulation order are unchanged, so results
-// are bit-identical to RB = 1.
+// wave has only 2 / 1 pairs of one row block per tile: RB = 2 / 4 row blocks per workgroup keep 8 weight loads
+// per weight set in flight per wave and cut the x staging traffic by RB.  The pair -> wave mapping and the per-wave
+// accumulation order do not depend on RB: bit-identical results.
+// ---------------------------------------------------------------------------------------------------
 template <int NB, int EPI, int RB>
 __global__ __launch_bounds__(kSkinnyThreads) void skinny_mfma_kernel(const GemvFusedArgs a) {
   constexpr int NW = EPI == kEpiSilu ? 2 : 1;
-  constexpr int JM = 8 / RB;  // K steps per wave per tile per row block; host guarantees KT <= JM * 256
+  constexpr int JP = 4 / RB;  // pairs per wave per tile per row block; host guarantees KT <= JP * 512
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   u32x4* xs = reinterpret_cast<u32x4*>(smem_raw);
   const int KT = a.KT, K = a.K, T = a.T;
   const int pitch = KT >> 3;  // 16-byte chunks per token row
   float* sm_inv = reinterpret_cast<float*>(smem_raw + (size_t)skinny_xs_bytes(NB, T, KT));  // [64] inverse RMS per token
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
+  const SkinnyLane L;
+  const int tid = threadIdx.x;
   const int rows_total = EPI == kEpiSilu ? a.I : a.M;
   const int row0 = blockIdx.x * 16 * RB;
-  const Half* wptr[NW][RB];
+  const Half* wptr[NW][RB][2];
 #pragma unroll
-  for (int rb = 0; rb < RB; ++rb) {
-    int row = row0 + rb * 16 + l15;
-    row = row < rows_total ? row : rows_total - 1;
+  for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-    for (int s = 0; s < NW; ++s) wptr[s][rb] = a.W + ((size_t)row + (size_t)s * a.I) * K + g * 8;
-  }
+    for (int rh = 0; rh < 2; ++rh) {
+      int row = row0 + rb * 16 + rh * 8 + L.prow;
+      row = row < rows_total ? row : rows_total - 1;
+#pragma unroll
+      for (int s = 0; s < NW; ++s) wptr[s][rb][rh] = a.W + ((size_t)row + (size_t)s * a.I) * K + L.pchunk * 8;
+    }
 
-  f32x4 acc[NW][RB][NB];
+  f32x4 acc[NW][RB][NB][2][2];
 #pragma unroll
   for (int s = 0; s < NW; ++s)
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) acc[s][rb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[s][rb][nb][q >> 1][q & 1] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // ---- prologue: per-token inverse RMS, canonical one-wave-per-row order, 8 tokens at a time ----
   if (a.norm_w) {
-    for (int t = wave; t < T; t += kSkinnyWaves) {
+    for (int t = L.wave; t < T; t += kSkinnyWaves) {
       const float v = wave_row_inv_rms(a.X + (size_t)t * K, a.residual ? a.residual + (size_t)t * K : nullptr, K, a.eps);
-      if (lane == 0) sm_inv[t] = v;
+      if (L.lane == 0) sm_inv[t] = v;
     }
     __syncthreads();
   }
 
-  for (int k0 = 0; k0 < K; k0 += KT) {
+  // The next tile's weight loads leave BEFORE the current tile is multiplied (second register set), whenever the
+  // accumulators leave room for it: the stream then never drains between tiles.
+  constexpr bool kPipe = NB < 4 && NW * RB * NB * 16 + 2 * NW * 32 <= 128;
+  const int jmax = KT >> 9;  // pairs per wave in a full tile (uniform): no wasted loads on narrow tiles
+  u32x4 avA[NW][RB][JP][2], avB[NW][RB][JP][2];
+  auto issue = [&](int k0, u32x4 (&av)[NW][RB][JP][2]) {
     const int kt = (K - k0) < KT ? (K - k0) : KT;
-    const int nsteps = kt >> 5;  // K % 32 == 0 (dispatch guarantees)
-    // ---- this tile's weight fragments: all loads leave before the x tile is staged ----
-    u32x4 av[NW][RB][JM];
-    const int jmax = KT >> 8;  // steps per wave in a full tile (uniform): no wasted loads on narrow tiles
+    const int npairs = kt >> 6;  // K % 64 == 0 (dispatch guarantees)
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-      for (int j = 0; j < JM; ++j) {
+      for (int j = 0; j < JP; ++j) {
         if (j < jmax) {
-          int s = 2 * (wave + kSkinnyWaves * (j >> 1)) + (j & 1);  // steps of pair wave + 8*(j/2)
-          s = s < nsteps ? s : nsteps - 1;  // clamp on the last, shorter tile (result unused)
+          int p = L.wave + kSkinnyWaves * j;
+          p = p < npairs ? p : npairs - 1;  // clamp on the last, shorter tile (result unused)
 #pragma unroll
           for (int w = 0; w < NW; ++w)
-            av[w][rb][j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wptr[w][rb] + k0 + s * 32));
-        }
-      }
-    // ---- stage x[:, k0:k0+kt] (optionally normalised on the fly) ----
-    __syncthreads();
-    const int nvec = kt >> 3;
-    for (int idx = tid; idx < T * nvec; idx += kSkinnyThreads) {
-      const int t = idx / nvec, c = idx - t * nvec;
-      const size_t off = (size_t)t * K + k0 + c * 8;
-      const u32x4 h = *reinterpret_cast<const u32x4*>(a.X + off);
-      u32x4 v;
-      if (a.norm_w) {
-        const u32x4 gw = *reinterpret_cast<const u32x4*>(a.norm_w + k0 + c * 8);
-        const float inv = sm_inv[t];
-        if (a.residual) {
-          const u32x4 r = *reinterpret_cast<const u32x4*>(a.residual + off);
-          u32x4 nh;
-          v = norm_scale8(h, &r, gw, inv, 0.f, &nh);
-          if (blockIdx.x == 0) *reinterpret_cast<u32x4*>(a.hidden_out + off) = nh;
-        } else {
-          v = norm_scale8(h, nullptr, gw, inv, 0.f, nullptr);
-        }
-      } else {
-        v = h;
-      }
-      xs[t * pitch + (c ^ (t & 15))] = v;
-    }
-    __syncthreads();
 #pragma unroll
-    for (int j = 0; j < JM; ++j) {
-      const int s = 2 * (wave + kSkinnyWaves * (j >> 1)) + (j & 1);
-      if (j < jmax && s < nsteps) {
+            for (int rh = 0; rh < 2; ++rh)
+              av[w][rb][j][rh] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wptr[w][rb][rh] + k0 + p * 64));
+        }
+      }
+  };
+  auto compute = [&](int k0, const u32x4 (&av)[NW][RB][JP][2]) {
+    const int kt = (K - k0) < KT ? (K - k0) : KT;
+    const int npairs = kt >> 6;
+#pragma unroll
+    for (int j = 0; j < JP; ++j) {
+      const int p = L.wave + kSkinnyWaves * j;
+      if (j < jmax && p < npairs) {
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-          int t = nb * 16 + l15;
+          int t = nb * 16 + L.l15;
           t = t < T ? t : T - 1;  // absent token columns re-read a staged row; their results are never stored
-          const bf16x8_t b = __builtin_bit_cast(bf16x8_t, xs[t * pitch + ((s * 4 + g) ^ l15)]);
 #pragma unroll
-          for (int rb = 0; rb < RB; ++rb)
+          for (int h = 0; h < 2; ++h) {
+            const bf16x8_t b = __builtin_bit_cast(bf16x8_t, xs[t * pitch + ((p * 8 + 2 * L.g + h) ^ L.l15)]);
 #pragma unroll
-            for (int w = 0; w < NW; ++w)
-              acc[w][rb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, av[w][rb][j]), b,
-                                                                       acc[w][rb][nb], 0, 0, 0);
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+              for (int w = 0; w < NW; ++w)
+#pragma unroll
+                for (int rh = 0; rh < 2; ++rh)
+                  acc[w][rb][nb][rh][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                      __builtin_bit_cast(bf16x8_t, av[w][rb][j][rh]), b, acc[w][rb][nb][rh][h], 0, 0, 0);
+          }
         }
       }
+    }
+  };
+  auto stage = [&](int k0) {
+    const int kt = (K - k0) < KT ? (K - k0) : KT;
+    __syncthreads();   // the previous tile's fragment reads are done
+    skinny_stage_x<NB>(a, xs, sm_inv, pitch, k0, kt, L.wave, L.lane);
+    __syncthreads();
+  };
+  if constexpr (kPipe) {
+    issue(0, avA);   // the loads of the first TWO tiles leave before the first x tile is staged; after that a
+    if (KT < K) issue(KT, avB);   // register set is refilled (two tiles ahead) as soon as its tile is multiplied
+    for (int k0 = 0; k0 < K; k0 += 2 * KT) {
+      stage(k0);
+      compute(k0, avA);
+      if (k0 + 2 * KT < K) issue(k0 + 2 * KT, avA);
+      if (k0 + KT >= K) break;
+      stage(k0 + KT);
+      compute(k0 + KT, avB);
+      if (k0 + 3 * KT < K) issue(k0 + 3 * KT, avB);
+    }
+  } else {
+    for (int k0 = 0; k0 < K; k0 += KT) {
+      issue(k0, avA);
+      stage(k0);
+      compute(k0, avA);
     }
   }
 
@@ -152,48 +280,25 @@ __global__ __launch_bounds__(kSkinnyThreads) void skinny_mfma_kernel(const GemvF
 #pragma unroll
     for (int w = 0; w < NW; ++w)
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) red[((wave * NW + w) * NB + nb) * 64 + lane] = acc[w][rb][nb];
+      for (int nb = 0; nb < NB; ++nb) red[((L.wave * NW + w) * NB + nb) * 64 + L.lane] = skinny_fold(acc[w][rb][nb]);
     __syncthreads();
-    for (int e = tid; e < NB * 64; e += kSkinnyThreads) {
-      const int nb = e >> 6, ln = e & 63;
-      f32x4 tot[NW];
-#pragma unroll
-      for (int w = 0; w < NW; ++w) {
-        f32x4 v = red[((0 * NW + w) * NB + nb) * 64 + ln];
-#pragma unroll
-        for (int wv = 1; wv < kSkinnyWaves; ++wv) v += red[((wv * NW + w) * NB + nb) * 64 + ln];
-        tot[w] = v;
-      }
-      const int t = nb * 16 + (ln & 15);
-      if (t >= T) continue;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int r = row0 + rb * 16 + (ln >> 4) * 4 + i;
-        if (r >= rows_total) continue;
-        if (EPI == kEpiSilu) {
-          const float gt = bf16_round_f(tot[0][i]), up = bf16_round_f(tot[NW - 1][i]);
-          a.Y[(size_t)t * a.I + r] = f2bf(silu_f(gt) * up);
-        } else {
-          a.Y[(size_t)t * a.M + r] = f2bf(tot[0][i]);
-        }
-      }
-    }
+    skinny_reduce_store<NB, EPI>(a, red, row0 + rb * 16, rows_total, tid);
   }
 }
 
 // ---------------------------------------------------------------------------------------------------
 // Resident-x variant (T*K*2 <= kSkinnyResidentBytes): the whole (normalised) x block is staged ONCE per
 // workgroup; the workgroup then persists over 16-row blocks rb = blockIdx.x, + gridDim.x, ... and every wave
-// walks its K-step pairs of block after block as one flat stream of work items, always keeping the next chunk
-// of fragment loads (CH pairs = 2*CH KB per weight set) in flight - no per-tile barrier, no re-staging.
+// walks its pairs of block after block as one flat stream of work items, always keeping the next chunk of
+// weight loads (CH pairs = 2*CH KB per weight set) in flight - no per-tile barrier, no re-staging.
 // Same pair -> wave mapping and the same per-wave accumulation order as the tiled kernel: bit-identical.
 // ---------------------------------------------------------------------------------------------------
-constexpr int kSkinnyResidentBytes = 100 * 1024;
+constexpr int kSkinnyResidentBytes = 128 * 1024;   // o_proj at 16 columns (16 x 4096 x 2 B) is the largest resident x
 
 template <int NB, int EPI>
 __global__ __launch_bounds__(kSkinnyThreads) void skinny_resident_kernel(const GemvFusedArgs a) {
   constexpr int NW = EPI == kEpiSilu ? 2 : 1;
-  constexpr int CH = NW == 1 ? 4 : 2;  // pairs per chunk: 8 (store) / 2x4 (silu) fragment loads in flight
+  constexpr int CH = NW == 1 ? 4 : 2;  // pairs per chunk: 8 (store) / 2x4 (silu) weight loads in flight
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int K = a.K, T = a.T;
   const int pitch = K >> 3;
@@ -201,113 +306,68 @@ __global__ __launch_bounds__(kSkinnyThreads) void skinny_resident_kernel(const G
   const int xs_bytes = (T * K * 2 + 15) & ~15;
   f32x4* red = reinterpret_cast<f32x4*>(smem_raw + xs_bytes);                          // [8][NW][NB][64]
   float* sm_inv = reinterpret_cast<float*>(smem_raw + xs_bytes + 8 * NW * NB * 64 * 16);  // [64]
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
+  const SkinnyLane L;
+  const int tid = threadIdx.x;
   const int rows_total = EPI == kEpiSilu ? a.I : a.M;
   const int nrb = (rows_total + 15) >> 4;
-  const int np = K >> 6;                       // 64-wide K step pairs (K % 64 == 0)
+  const int np = K >> 6;                       // 64-wide K pairs (K % 64 == 0)
   const int my_np = (np + kSkinnyWaves - 1) / kSkinnyWaves;   // items per row block, same for every wave
   const int my_rb = (nrb - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
   const int total = my_rb * my_np;
 
-  auto item_ptr = [&](int item, int w) -> const Half* {
-    const int rbi = item / my_np, pi = item - rbi * my_np;
-    int row = ((int)blockIdx.x + rbi * (int)gridDim.x) * 16 + l15;
-    row = row < rows_total ? row : rows_total - 1;
-    int pair = wave + kSkinnyWaves * pi;
-    pair = pair < np ? pair : np - 1;          // clamped load of a valid address; skipped in the MFMA loop
-    return a.W + ((size_t)row + (size_t)w * a.I) * K + pair * 64 + g * 8;
-  };
   u32x4 avA[NW][CH][2], avB[NW][CH][2];
   auto issue = [&](int item0, u32x4 (&av)[NW][CH][2]) {
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       const int item = item0 + c < total ? item0 + c : total - 1;
+      const int rbi = item / my_np, pi = item - rbi * my_np;
+      const int row0 = ((int)blockIdx.x + rbi * (int)gridDim.x) * 16 + L.prow;
+      int pair = L.wave + kSkinnyWaves * pi;
+      pair = pair < np ? pair : np - 1;          // clamped load of a valid address; skipped in the MFMA loop
 #pragma unroll
-      for (int w = 0; w < NW; ++w) {
-        const Half* p = item_ptr(item, w);
-        av[w][c][0] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
-        av[w][c][1] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p + 32));
+      for (int rh = 0; rh < 2; ++rh) {
+        int row = row0 + rh * 8;
+        row = row < rows_total ? row : rows_total - 1;
+#pragma unroll
+        for (int w = 0; w < NW; ++w)
+          av[w][c][rh] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(
+              a.W + ((size_t)row + (size_t)w * a.I) * K + pair * 64 + L.pchunk * 8));
       }
     }
   };
-  if (total > 0) issue(0, avA);   // first chunk leaves before the prologue
+  if (total > 0) issue(0, avA);   // the first two chunks leave before the prologue
+  if (total > CH) issue(CH, avB);
 
   // ---- prologue + one-time staging of x ----
   if (a.norm_w) {
-    for (int t = wave; t < T; t += kSkinnyWaves) {
+    for (int t = L.wave; t < T; t += kSkinnyWaves) {
       const float v = wave_row_inv_rms(a.X + (size_t)t * K, a.residual ? a.residual + (size_t)t * K : nullptr, K, a.eps);
-      if (lane == 0) sm_inv[t] = v;
+      if (L.lane == 0) sm_inv[t] = v;
     }
     __syncthreads();
   }
-  {
-    const int nvec = K >> 3;
-    for (int idx = tid; idx < T * nvec; idx += kSkinnyThreads) {
-      const int t = idx / nvec, c = idx - t * nvec;
-      const size_t off = (size_t)t * K + c * 8;
-      const u32x4 h = *reinterpret_cast<const u32x4*>(a.X + off);
-      u32x4 v;
-      if (a.norm_w) {
-        const u32x4 gw = *reinterpret_cast<const u32x4*>(a.norm_w + c * 8);
-        const float inv = sm_inv[t];
-        if (a.residual) {
-          const u32x4 r = *reinterpret_cast<const u32x4*>(a.residual + off);
-          u32x4 nh;
-          v = norm_scale8(h, &r, gw, inv, 0.f, &nh);
-          if (blockIdx.x == 0) *reinterpret_cast<u32x4*>(a.hidden_out + off) = nh;
-        } else {
-          v = norm_scale8(h, nullptr, gw, inv, 0.f, nullptr);
-        }
-      } else {
-        v = h;
-      }
-      xs[t * pitch + (c ^ (t & 15))] = v;
-    }
-  }
+  skinny_stage_x<NB>(a, xs, sm_inv, pitch, 0, K, L.wave, L.lane);
   __syncthreads();
 
-  f32x4 acc[NW][NB];
+  f32x4 acc[NW][NB][2][2];
+  auto zero = [&]() {
 #pragma unroll
-  for (int w = 0; w < NW; ++w)
+    for (int w = 0; w < NW; ++w)
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) acc[w][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[w][nb][q >> 1][q & 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  zero();
 
   auto flush = [&](int rbi) {   // combine the 8 waves (fixed order), store, reset
 #pragma unroll
     for (int w = 0; w < NW; ++w)
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
-        red[((wave * NW + w) * NB + nb) * 64 + lane] = acc[w][nb];
-        acc[w][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
+      for (int nb = 0; nb < NB; ++nb) red[((L.wave * NW + w) * NB + nb) * 64 + L.lane] = skinny_fold(acc[w][nb]);
+    zero();
     __syncthreads();
-    const int row0 = ((int)blockIdx.x + rbi * (int)gridDim.x) * 16;
-    for (int e = tid; e < NB * 64; e += kSkinnyThreads) {
-      const int nb = e >> 6, ln = e & 63;
-      f32x4 tot[NW];
-#pragma unroll
-      for (int w = 0; w < NW; ++w) {
-        f32x4 v = red[((0 * NW + w) * NB + nb) * 64 + ln];
-#pragma unroll
-        for (int wv = 1; wv < kSkinnyWaves; ++wv) v += red[((wv * NW + w) * NB + nb) * 64 + ln];
-        tot[w] = v;
-      }
-      const int t = nb * 16 + (ln & 15);
-      if (t < T) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int r = row0 + (ln >> 4) * 4 + i;
-          if (r < rows_total) {
-            if (EPI == kEpiSilu) {
-              const float gt = bf16_round_f(tot[0][i]), up = bf16_round_f(tot[NW - 1][i]);
-              a.Y[(size_t)t * a.I + r] = f2bf(silu_f(gt) * up);
-            } else {
-              a.Y[(size_t)t * a.M + r] = f2bf(tot[0][i]);
-            }
-          }
-        }
-      }
-    }
+    skinny_reduce_store<NB, EPI>(a, red, ((int)blockIdx.x + rbi * (int)gridDim.x) * 16, rows_total, tid);
     __syncthreads();
   };
   auto compute = [&](int item0, const u32x4 (&av)[NW][CH][2]) {
@@ -316,20 +376,21 @@ __global__ __launch_bounds__(kSkinnyThreads) void skinny_resident_kernel(const G
       const int item = item0 + c;
       if (item < total) {
         const int rbi = item / my_np, pi = item - rbi * my_np;
-        const int pair = wave + kSkinnyWaves * pi;
+        const int pair = L.wave + kSkinnyWaves * pi;
         if (pair < np) {
 #pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const int s = 2 * pair + h;
+          for (int nb = 0; nb < NB; ++nb) {
+            int t = nb * 16 + L.l15;
+            t = t < T ? t : T - 1;
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-              int t = nb * 16 + l15;
-              t = t < T ? t : T - 1;
-              const bf16x8_t b = __builtin_bit_cast(bf16x8_t, xs[t * pitch + ((s * 4 + g) ^ l15)]);
+            for (int h = 0; h < 2; ++h) {
+              const bf16x8_t b = __builtin_bit_cast(bf16x8_t, xs[t * pitch + ((pair * 8 + 2 * L.g + h) ^ L.l15)]);
 #pragma unroll
               for (int w = 0; w < NW; ++w)
-                acc[w][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, av[w][c][h]), b,
-                                                                     acc[w][nb], 0, 0, 0);
+#pragma unroll
+                for (int rh = 0; rh < 2; ++rh)
+                  acc[w][nb][rh][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                      __builtin_bit_cast(bf16x8_t, av[w][c][rh]), b, acc[w][nb][rh][h], 0, 0, 0);
             }
           }
         }
@@ -337,12 +398,12 @@ __global__ __launch_bounds__(kSkinnyThreads) void skinny_resident_kernel(const G
       }
     }
   };
-  for (int item0 = 0; item0 < total; item0 += 2 * CH) {
-    if (item0 + CH < total) issue(item0 + CH, avB);
+  for (int item0 = 0; item0 < total; item0 += 2 * CH) {   // a register set is refilled as soon as it is consumed
     compute(item0, avA);
-    if (item0 + CH >= total) break;
     if (item0 + 2 * CH < total) issue(item0 + 2 * CH, avA);
+    if (item0 + CH >= total) break;
     compute(item0 + CH, avB);
+    if (item0 + 3 * CH < total) issue(item0 + 3 * CH, avB);
   }
 }
 
@@ -382,25 +443,34 @@ inline void skinny_launch_rb(const GemvFusedArgs& a, hipStream_t s) {
 }
 template <int NB, int EPI>
 inline void skinny_launch(GemvFusedArgs a, hipStream_t s) {
+  constexpr int NW = EPI == kEpiSilu ? 2 : 1;
   a.KT = skinny_pick_kt(a.T, a.K);
-  // row blocks per workgroup: keep ~8 K steps per wave per tile in flight (PEGAINFER_SKINNY_RB=1 forces 1: A/B)
+  // row blocks per workgroup: keep ~4 pairs per wave per tile in flight (PEGAINFER_SKINNY_RB=1 forces 1: A/B)
   static const bool rb1 = [] { const char* e = getenv("PEGAINFER_SKINNY_RB"); return e && e[0] == '1'; }();
   const int rows = EPI == kEpiSilu ? a.I : a.M;
-  // largest RB the tile allows (KT <= (8/RB)*256; the SwiGLU form streams two weight sets, so RB <= 2 there keeps
-  // it under 256 VGPRs) that still leaves at least one workgroup per CU
+  // largest RB the tile allows (KT <= (4/RB)*512) whose accumulators (NW*RB*NB*4 f32x4) + weight registers fit
+  // the 256-VGPR budget without spilling, and that still leaves at least one workgroup per CU
+  constexpr int kMaxRb = NW == 1 ? (NB <= 2 ? 4 : 2) : (NB == 1 ? 2 : 1);
   int rb = a.KT >= 2048 || rb1 ? 1 : a.KT >= 1024 ? 2 : 4;
-  if (EPI == kEpiSilu && rb > 2) rb = 2;
+  if (rb > kMaxRb) rb = kMaxRb;
   while (rb > 1 && ceil_div(rows, 16 * rb) < 256) rb >>= 1;
-  if (rb == 4) { skinny_launch_rb<NB, EPI, 4>(a, s); }
-  else if (rb == 2) { if (a.KT > 1024) a.KT = 1024; skinny_launch_rb<NB, EPI, 2>(a, s); }
-  else skinny_launch_rb<NB, EPI, 1>(a, s);
+  if (rb == 4) {
+    if constexpr (kMaxRb >= 4) { if (a.KT > 512) a.KT = 512; skinny_launch_rb<NB, EPI, 4>(a, s); }
+  } else if (rb == 2) {
+    if constexpr (kMaxRb >= 2) { if (a.KT > 1024) a.KT = 1024; skinny_launch_rb<NB, EPI, 2>(a, s); }
+  } else {
+    skinny_launch_rb<NB, EPI, 1>(a, s);
+  }
 }
 
-// 2 <= T <= 64, K % 32 == 0
+// 2 <= T <= 64, K % 64 == 0
 template <int EPI>
 inline bool skinny_dispatch(const GemvFusedArgs& a, hipStream_t s) {
-  if (a.T < 2 || a.T > 64 || (a.K & 31) != 0) return false;
-  const bool resident = (a.K & 63) == 0 && (long)a.T * a.K * 2 <= kSkinnyResidentBytes;
+  if (a.T < 2 || a.T > 64 || (a.K & 63) != 0) return false;
+  constexpr int NW = EPI == kEpiSilu ? 2 : 1;
+  const int nb = a.T <= 16 ? 1 : a.T <= 32 ? 2 : 4;
+  const bool resident = (long)a.T * a.K * 2 <= kSkinnyResidentBytes &&
+                        (long)a.T * a.K * 2 + 8 * NW * nb * 64 * 16 + 256 <= 160 * 1024;
   if (a.T <= 16) { if (resident) skinny_launch_resident<1, EPI>(a, s); else skinny_launch<1, EPI>(a, s); }
   else if (a.T <= 32) { if (resident) skinny_launch_resident<2, EPI>(a, s); else skinny_launch<2, EPI>(a, s); }
   else { if (resident) skinny_launch_resident<4, EPI>(a, s); else skinny_launch<4, EPI>(a, s); }

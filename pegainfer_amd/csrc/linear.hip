@@ -161,10 +161,14 @@ struct SplitOut { Half* Y1; Half* Y2; Half* Y3; int M0; int M1; int M2; int silu
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int TT, int ST>
+// SPLITK: blockIdx.y = K slice z of `ksplit` (each nk_slice K tiles); the workgroup writes its fp32 partial tile to
+// part[z][T][M] and splitk_reduce_kernel adds the slices in z order (decode batches of 17..64 columns on matrices
+// with < 128 row tiles: more workgroups without re-staging x per 16 rows like the skinny kernel has to).
+template <int TT, int ST, bool SPLITK = false>
 __global__ __launch_bounds__(256) void mfma_gemm_glds_kernel(const Half* __restrict__ W, const Half* __restrict__ X,
                                                              Half* __restrict__ Y, int M, int T, int K,
-                                                             int m_tiles, int t_tiles, SplitOut so) {
+                                                             int m_tiles, int t_tiles, SplitOut so,
+                                                             float* __restrict__ part = nullptr, int nk_slice = 0) {
   constexpr int TJ = TT / 32;       // 16-token blocks per wave
   constexpr int XG = TT / 32;       // X row-groups (8 rows) staged per wave
   constexpr int NG = 4 + XG;        // LDS-DMA instructions per wave per K tile
@@ -187,6 +191,8 @@ __global__ __launch_bounds__(256) void mfma_gemm_glds_kernel(const Half* __restr
   const Half* wsrc[4];
   const Half* xsrc[XG];
   const int lr = lane >> 3, ls = lane & 7;
+  const int kt_begin = SPLITK ? (int)blockIdx.y * nk_slice : 0;
+  const size_t kofs = (size_t)kt_begin * BK;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int row = (wave + 4 * j) * 8 + lr;
@@ -198,13 +204,13 @@ __global__ __launch_bounds__(256) void mfma_gemm_glds_kernel(const Half* __restr
     } else {
       mr = m0 + row; mr = mr < M ? mr : M - 1;
     }
-    wsrc[j] = W + (size_t)mr * K + ((ls ^ (row & 7)) << 3);
+    wsrc[j] = W + (size_t)mr * K + kofs + ((ls ^ (row & 7)) << 3);
   }
 #pragma unroll
   for (int j = 0; j < XG; ++j) {
     const int row = (wave + 4 * j) * 8 + lr;
     int tr = t0 + row; tr = tr < T ? tr : T - 1;
-    xsrc[j] = X + (size_t)tr * K + ((ls ^ (row & 7)) << 3);
+    xsrc[j] = X + (size_t)tr * K + kofs + ((ls ^ (row & 7)) << 3);
   }
   f32x4 acc[4][TJ];
 #pragma unroll
@@ -234,7 +240,8 @@ __global__ __launch_bounds__(256) void mfma_gemm_glds_kernel(const Half* __restr
   // ST-deep ring, prefetch distance ST-1.  Tile kt+ST-1 goes into the buffer tile kt-1 was read from (every wave
   // left that compute before the barrier that ended iteration kt-1).  A wave's vmcnt counts its own DMAs in
   // issue order, so "at most (ST-2)*NG outstanding" == tile kt+1 has landed; the barrier extends that to all waves.
-  const int nk = K / BK;
+  const int nk_all = K / BK;
+  const int nk = SPLITK ? (nk_all - kt_begin < nk_slice ? nk_all - kt_begin : nk_slice) : nk_all;
 #pragma unroll
   for (int p = 0; p < ST - 1; ++p)
     if (p < nk) stage(p, p);
@@ -265,6 +272,20 @@ __global__ __launch_bounds__(256) void mfma_gemm_glds_kernel(const Half* __restr
     __syncthreads();
     cur = cur + 1 == ST ? 0 : cur + 1;
     nxt = nxt + 1 == ST ? 0 : nxt + 1;
+  }
+  if constexpr (SPLITK) {   // fp32 partial tile (M % 4 == 0: a lane's 4 rows are all in or all out)
+    float* dst = part + (size_t)blockIdx.y * T * M;
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+      const int t = t0 + wt + j * 16 + l15;
+      if (t >= T) continue;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm + i * 16 + g * 4;
+        if (m < M) *reinterpret_cast<f32x4*>(dst + (size_t)t * M + m) = acc[i][j];
+      }
+    }
+    return;
   }
   if (so.silu_I > 0) {
 #pragma unroll
@@ -325,6 +346,35 @@ __global__ __launch_bounds__(256) void mfma_gemm_glds_kernel(const Half* __restr
   }
 }
 
+// Y[t][m] = bf16(sum over slices z (ascending) of part[z][t][m]); 4 rows per thread, row-segmented like the GEMM
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, Half* __restrict__ Y, int M,
+                                                            int T, int ksplit, SplitOut so) {
+  const int m4 = M >> 2;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)T * m4) return;
+  const int t = (int)(idx / m4), m = (int)(idx - (long)t * m4) * 4;
+  f32x4 v = *reinterpret_cast<const f32x4*>(part + (size_t)t * M + m);
+  for (int z = 1; z < ksplit; ++z) v += *reinterpret_cast<const f32x4*>(part + ((size_t)z * T + t) * M + m);
+  Half* dst = Y;
+  int ld = M, mm = m;
+  if (so.Y1) {
+    const int b1 = so.M0 + so.M1, b2 = b1 + so.M2;
+    if (m < so.M0) { ld = so.M0; }
+    else if (m < b1) { dst = so.Y1; ld = so.M1; mm = m - so.M0; }
+    else if (m < b2) { dst = so.Y2; ld = so.M2; mm = m - b1; }
+    else { dst = so.Y3; ld = M - b2; mm = m - b2; }
+  }
+  u32x2 o;
+  o.x = pack_bf2(v[0], v[1]);
+  o.y = pack_bf2(v[2], v[3]);
+  *reinterpret_cast<u32x2*>(dst + (size_t)t * ld + mm) = o;
+}
+
+// Split-K workspace: created by cublas_init() (the reference's handles own a 32 MB cuBLAS workspace the same way,
+// csrc/linear.cu:14-42), per thread = per GPU rank.  Without it the split-K route is simply not taken.
+constexpr size_t kSplitKWorkspaceBytes = 32u << 20;
+static thread_local float* g_splitk_ws = nullptr;
+
 static bool glds_gemm_ok(const Half* W, const Half* X, const Half* Y, int M, int K) {
   return (K & 7) == 0 && host_aligned16(W) && host_aligned16(X) && (K % BK) == 0 && (M & 3) == 0 &&
          (reinterpret_cast<uintptr_t>(Y) & 7u) == 0;
@@ -341,6 +391,38 @@ static void glds_gemm_launch_t(const Half* W, const Half* X, Half* Y, int M, int
   const int m_tiles = so.silu_I > 0 ? ceil_div(so.silu_I, 64) : ceil_div(M, BM), t_tiles = ceil_div(T, TT);
   mfma_gemm_glds_kernel<TT, ST><<<m_tiles * t_tiles, 256, kLds, s>>>(W, X, Y, M, T, K, m_tiles, t_tiles, so);
 }
+// Decode batches of 17..64 columns on a matrix with too few 128-row tiles to fill the chip: K slices chosen by
+// shape only (M, K), so a column's bits do not depend on the batch size.  nk_slice == 0: not applicable.
+constexpr int kSplitKMaxRows = 16384;   // below this (< 128 row tiles) the 17..64-column GEMM splits K
+struct SplitKPlan { int ksplit, nk_slice; };
+static SplitKPlan splitk_plan(int M, int T, int K) {
+  static const bool enabled = [] { const char* e = getenv("PEGAINFER_SPLITK"); return !(e && e[0] == '0'); }();
+  if (!enabled || !g_splitk_ws || T <= 16 || T > 64 || M >= kSplitKMaxRows) return {0, 0};
+  const int m_tiles = ceil_div(M, BM), nk_all = K / BK;
+  int want = ceil_div(192, m_tiles);
+  want = want > 8 ? 8 : want;
+  if (want < 2 || nk_all < 8) return {0, 0};
+  int nk_slice = ceil_div(nk_all, want);
+  nk_slice = nk_slice < 4 ? 4 : nk_slice;
+  const int ksplit = ceil_div(nk_all, nk_slice);   // no empty slice
+  if (ksplit < 2 || (size_t)ksplit * T * M * 4 > kSplitKWorkspaceBytes) return {0, 0};
+  return {ksplit, nk_slice};
+}
+static void glds_splitk_launch(const Half* W, const Half* X, Half* Y, int M, int T, int K, SplitOut so, SplitKPlan pl,
+                               hipStream_t s) {
+  constexpr int kLds = 3 * (BM + 64) * 8 * 16;
+  static const bool once = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_gemm_glds_kernel<64, 3, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+    return true;
+  }();
+  (void)once;
+  const int m_tiles = ceil_div(M, BM);
+  mfma_gemm_glds_kernel<64, 3, true><<<dim3(m_tiles, pl.ksplit), 256, kLds, s>>>(W, X, Y, M, T, K, m_tiles, 1, so,
+                                                                                 g_splitk_ws, pl.nk_slice);
+  splitk_reduce_kernel<<<ceil_div((long)T * (M >> 2), 256), 256, 0, s>>>(g_splitk_ws, Y, M, T, pl.ksplit, so);
+}
+
 // variant: 0 = by shape; else 10*tile + stages with tile 1 = 128-token, 2 = 64-token (A/B probe only)
 static void glds_gemm_launch(const Half* W, const Half* X, Half* Y, int M, int T, int K, SplitOut so, int variant,
                              hipStream_t s) {
@@ -364,7 +446,7 @@ static void glds_gemm_launch(const Half* W, const Half* X, Half* Y, int M, int T
 
 // Decode-shaped GEMM routing (T <= 64 columns, weights streamed once), by shape only (measured on MI355X):
 //   T <= 4            -> dot2 GEMV (gemv_core.h)            [PEGAINFER_GEMV_T1=mfma routes everything to MFMA]
-//   5 <= T <= 16      -> skinny MFMA GEMM (gemm_skinny.h)   when K % 32 == 0
+//   5 <= T <= 16      -> skinny MFMA GEMM (gemm_skinny.h)   when K % 64 == 0
 //   17 <= T <= 64     -> tiled LDS-DMA GEMM for >= 5120 rows, skinny below
 // Within each family a column's result does not depend on the batch size (bitwise batch invariance).
 static bool t1_uses_mfma() {
@@ -375,18 +457,30 @@ static bool t1_uses_mfma() {
 // (gate_up at T = 64: 21 vs 64 us; x is staged once per 128 rows and the DMA ring keeps the stream going), small
 // matrices (o_proj / down_proj: 20 tiles) stay on the skinny kernel whose 8 waves split K.
 constexpr int kMidBatchMinRows = 5120;
+// 17..64 columns, plain (optionally row-segmented) output: 1 = tiled LDS-DMA GEMM, 2 = its split-K form, 0 = not
+// taken (skinny kernel / separate calls).  One decision for gemm_cuda, pegainfer_gemm_split and pegainfer_gemm_silu,
+// so that a stacked launch and the plain launch over the same matrix always run the same kernel.
+static int mid_batch_route(const Half* W, const Half* X, const Half* Y, int M, int T, int K) {
+  static const int min_rows = [] { const char* e = getenv("PEGAINFER_MID_MIN_ROWS"); return e && *e ? atoi(e) : kMidBatchMinRows; }();
+  if (T <= 16 || T > 64 || !glds_gemm_ok(W, X, Y, M, K)) return 0;
+  if (splitk_plan(M, T, K).nk_slice > 0) return 2;
+  return M >= min_rows ? 1 : 0;
+}
+static bool mid_batch_gemm(const Half* W, const Half* X, Half* Y, int M, int T, int K, const SplitOut& so, hipStream_t s) {
+  const int route = mid_batch_route(W, X, Y, M, T, K);
+  if (route == 2) glds_splitk_launch(W, X, Y, M, T, K, so, splitk_plan(M, T, K), s);
+  else if (route == 1) glds_gemm_launch(W, X, Y, M, T, K, so, 23, s);
+  return route != 0;
+}
 template <int EPI>
 static bool decode_gemm_dispatch(const GemvFusedArgs& a, hipStream_t s) {
   if (a.T > 16 && a.T <= 64) {
     // the fused prologue / epilogue forms exist for decode batches <= 16 only: above that the host runs the
     // unfused sequence, whose large GEMMs take the tiled kernel (so fused == unfused stays true by construction)
     if (a.norm_w || EPI != kEpiStore || a.flags) return false;
-    if (a.M >= kMidBatchMinRows && glds_gemm_ok(a.W, a.X, a.Y, a.M, a.K)) {
-      glds_gemm_launch(a.W, a.X, a.Y, a.M, a.T, a.K, SplitOut{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0}, 23, s);
-      return true;
-    }
+    if (mid_batch_gemm(a.W, a.X, a.Y, a.M, a.T, a.K, SplitOut{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0}, s)) return true;
   }
-  if ((a.T >= 5 || t1_uses_mfma()) && a.T <= 64 && (a.K & 31) == 0) {
+  if ((a.T >= 5 || t1_uses_mfma()) && a.T <= 64 && (a.K & 63) == 0) {
     if (a.T == 1) { skinny_launch<1, EPI>(a, s); return true; }
     return skinny_dispatch<EPI>(a, s);
   }
@@ -428,11 +522,23 @@ extern "C" {
 int32_t cuda_set_device(int32_t device_ordinal) { return static_cast<int32_t>(hipSetDevice(device_ordinal)); }
 
 // The reference creates two thread-local cuBLAS handles + a 32 MB prefill workspace here
-// (csrc/linear.cu:14-42).  The HIP GEMMs are self-contained kernels that need neither, so
-// init/destroy only keep the call contract (idempotent, per-thread, safe to call repeatedly).
+// (csrc/linear.cu:14-42).  The HIP GEMMs need no handles; the one thing kept per thread is a 32 MB fp32
+// workspace for the split-K route of mid-size decode batches.  Same call contract: per-thread, safe to call
+// repeatedly (counted: the workspace goes away with the last destroy).
 static thread_local int g_blas_inits = 0;
-void cublas_init(void) { g_blas_inits = 1; }
-void cublas_destroy(void) { g_blas_inits = 0; }
+void cublas_init(void) {
+  if (g_blas_inits++ == 0 && !pk::g_splitk_ws) {
+    void* p = nullptr;
+    if (hipMalloc(&p, pk::kSplitKWorkspaceBytes) == hipSuccess) pk::g_splitk_ws = static_cast<float*>(p);
+    else (void)hipGetLastError();   // no device / no memory: the split-K route is skipped
+  }
+}
+void cublas_destroy(void) {
+  if (g_blas_inits > 0 && --g_blas_inits == 0 && pk::g_splitk_ws) {
+    (void)hipFree(pk::g_splitk_ws);
+    pk::g_splitk_ws = nullptr;
+  }
+}
 
 void gemm_cuda(const Half* W, const Half* X, Half* Y, int32_t M, int32_t N, int32_t K, pegainfer_stream_t stream) {
   pk::gemm_dispatch(W, X, Y, M, N, K, pk::as_stream(stream));
@@ -494,12 +600,13 @@ pegainfer_status_t pegainfer_gemm_split(const Half* W, const Half* X, int32_t n_
     m[i] = Ms[i]; y[i] = Y[i]; M += Ms[i];
     ok = ok && (Ms[i] & 3) == 0 && (reinterpret_cast<uintptr_t>(Y[i]) & 7u) == 0;
   }
-  ok = ok && glds_gemm_ok(W, X, y[0], M, K) && (T > 64 || M >= kMidBatchMinRows);
+  ok = ok && glds_gemm_ok(W, X, y[0], M, K) && (T > 64 || mid_batch_route(W, X, y[0], M, T, K) != 0);
   if (ok) {
     // the last present segment is "the rest"; with fewer than 4 outputs the unused boundaries collapse onto M
     SplitOut so{y[1], y[2] ? y[2] : y[1], y[3] ? y[3] : (y[2] ? y[2] : y[1]), m[0], m[1], n_out > 2 ? m[2] : 0, 0, 0};
     if (n_out == 2) { so.M1 = m[1]; so.M2 = 0; }
-    glds_gemm_launch(W, X, y[0], M, T, K, so, T <= 64 ? 23 : 0, as_stream(stream));
+    if (T > 64) glds_gemm_launch(W, X, y[0], M, T, K, so, 0, as_stream(stream));
+    else mid_batch_gemm(W, X, y[0], M, T, K, so, as_stream(stream));
   } else {  // shapes the tiled kernel does not take: separate reference-ABI calls
     size_t row = 0;
     for (int i = 0; i < n_out; ++i) {
@@ -519,7 +626,7 @@ static pegainfer_status_t gemm_silu_impl(const Half* W, const Half* X, Half* Y, 
   using namespace pk;
   if (I <= 0 || T <= 0 || K <= 0) return (pegainfer_status_t)hipErrorInvalidValue;
   const int M = 2 * I;
-  if (T > 16 && (I & 3) == 0 && (T > 64 || M >= kMidBatchMinRows) && glds_gemm_ok(W, X, Y, M, K)) {
+  if (T > 16 && (I & 3) == 0 && glds_gemm_ok(W, X, Y, M, K) && (T > 64 || mid_batch_route(W, X, Y, M, T, K) == 1)) {
     SplitOut so{nullptr, nullptr, nullptr, 0, 0, 0, I, double_round};
     glds_gemm_launch(W, X, Y, M, T, K, so, T <= 64 ? 23 : 0, as_stream(stream));
     return (pegainfer_status_t)hipGetLastError();

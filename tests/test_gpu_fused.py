@@ -80,13 +80,15 @@ def test_gemv_fused_rejects_unsupported_shapes(built_libs):
                                   x.data_ptr(), 0.0, 0, s) != 0   # hidden_out aliases X
     # prologue / epilogue forms are for decode batches <= 16; the plain form still takes 17..64 columns
     big = torch.zeros(64 * 64, dtype=torch.bfloat16, device="cuda")
-    assert L.pegainfer_gemv_fused(big.data_ptr(), big.data_ptr(), big.data_ptr(), 8, 17, 32, None, big.data_ptr(), None,
+    assert L.pegainfer_gemv_fused(big.data_ptr(), big.data_ptr(), big.data_ptr(), 8, 17, 64, None, big.data_ptr(), None,
                                   1e-6, 0, s) != 0
-    assert L.pegainfer_gemv_fused(big.data_ptr(), big.data_ptr(), big.data_ptr(), 8, 17, 32, None, None, None, 0.0, 4,
+    assert L.pegainfer_gemv_fused(big.data_ptr(), big.data_ptr(), big.data_ptr(), 8, 17, 64, None, None, None, 0.0, 4,
                                   s) != 0
     y = torch.zeros(17 * 8, dtype=torch.bfloat16, device="cuda")
+    assert L.pegainfer_gemv_fused(big.data_ptr(), big.data_ptr(), y.data_ptr(), 8, 17, 64, None, None, None, 0.0, 0,
+                                  s) == 0      # 17..64 columns: the MFMA kernels take K % 64 == 0
     assert L.pegainfer_gemv_fused(big.data_ptr(), big.data_ptr(), y.data_ptr(), 8, 17, 32, None, None, None, 0.0, 0,
-                                  s) == 0
+                                  s) != 0
 
 
 @pytest.mark.parametrize("lens,split", [([1], False), ([17, 300], False), ([1024], True), ([2000, 70], True)])

@@ -310,10 +310,11 @@ def test_gemm_split_n_outputs_equals_separate_gemms(P, ms):
 
 def test_decode_gemm_batch_invariance_and_row_slices(P):
     """Decode GEMM: within a kernel family column t of a batched call == the same column in any other batch size,
-    bit for bit.  Families by token columns: 1..4 (dot2 GEMV), 5..16 (skinny MFMA), 17..64 (tiled LDS-DMA GEMM when
-    the matrix has >= 5120 rows, skinny below).  A row slice of the fused matrix == the fused call's rows in the
-    decode families (reference relies on this: batch_decode.rs:160-163).  Across families the summation order
-    differs: equal within the GEMM tolerance (the reference's cuBLAS also switches kernels with N)."""
+    bit for bit.  Families by token columns: 1..4 (dot2 GEMV), 5..16 (skinny MFMA), 17..64 (tiled LDS-DMA GEMM, with
+    K split over workgroups - by shape only - when the matrix has < 16384 rows).  A row slice of the fused matrix ==
+    the fused call's rows in the decode families (reference relies on this: batch_decode.rs:160-163).  Across
+    families the summation order differs: equal within the GEMM tolerance (the reference's cuBLAS also switches
+    kernels with N)."""
     rng = np.random.default_rng(11)
     for K in (2560, 9728):
         W, X = rnd(rng, 6144, K, scale=0.05), rnd(rng, 64, K)
@@ -321,9 +322,12 @@ def test_decode_gemm_batch_invariance_and_row_slices(P):
         full = bf16_bits(from_dev(P.gemm(Wd, to_dev(X))))
         for T in (17, 32, 40):
             assert np.array_equal(bf16_bits(from_dev(P.gemm(Wd, to_dev(X[:T])))), full[:T]), (K, T)
-        small = bf16_bits(from_dev(P.gemm(Wd[:2560], to_dev(X))))             # < 5120 rows: skinny at every T >= 5
-        for T in (5, 16, 17, 40):
+        small = bf16_bits(from_dev(P.gemm(Wd[:2560], to_dev(X))))             # 20 row tiles: the split-K form
+        for T in (17, 40):
             assert np.array_equal(bf16_bits(from_dev(P.gemm(Wd[:2560], to_dev(X[:T])))), small[:T]), (K, T)
+        small16 = bf16_bits(from_dev(P.gemm(Wd[:2560], to_dev(X[:16]))))
+        for T in (5, 9):
+            assert np.array_equal(bf16_bits(from_dev(P.gemm(Wd[:2560], to_dev(X[:T])))), small16[:T]), (K, T)
         sixteen = bf16_bits(from_dev(P.gemm(Wd, to_dev(X[:16]))))
         for T in (5, 8, 11):
             assert np.array_equal(bf16_bits(from_dev(P.gemm(Wd, to_dev(X[:T])))), sixteen[:T]), (K, T)
