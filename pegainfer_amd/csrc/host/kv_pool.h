@@ -112,8 +112,12 @@ inline SplitPlan make_split_plan(int policy, const std::vector<int>& seq_lens, i
     // one workgroup per CU is the measured optimum (device ms/step at ctx 1024 / 4096 / 10000: target 128 ->
     // 2.46 / 2.84 / 3.42, 256 -> 2.43 / 2.75 / 3.06, 512 -> 2.44 / 2.87 / 3.17: more partials cost more in the merge
     // than they gain in the scan); PEGAINFER_SPLIT_TARGET_WGS is the probe knob
-    static const int target_wgs = [] { const char* e = getenv("PEGAINFER_SPLIT_TARGET_WGS"); return e ? atoi(e) : 256; }();
-    int want = (target_wgs + padded_bs * num_kv_heads - 1) / (padded_bs * num_kv_heads);
+    // Batches: with 32..255 (request, kv head) pairs two workgroups per CU win (device ms/step at ctx 1024, bs 8 / 16:
+    // 3.26 / 4.16 at 256 vs 3.13 / 3.82 at 512); from 256 pairs on the un-split scan is best (bs 32: 4.85 vs 5.35).
+    static const int target_env = [] { const char* e = getenv("PEGAINFER_SPLIT_TARGET_WGS"); return e ? atoi(e) : 0; }();
+    const int pairs = padded_bs * num_kv_heads;
+    const int target_wgs = target_env > 0 ? target_env : (pairs >= 32 && pairs < 256 ? 512 : 256);
+    int want = pairs >= 256 && target_env <= 0 ? 1 : (target_wgs + pairs - 1) / pairs;
     want = std::min(std::max(want, 1), kSplitMaxChunksPerRequest);
     int chunk = (max_seq + want - 1) / want;
     chunk = std::max(64, (chunk + 15) / 16 * 16);

@@ -445,9 +445,10 @@ static void glds_gemm_launch(const Half* W, const Half* X, Half* Y, int M, int T
 }
 
 // Decode-shaped GEMM routing (T <= 64 columns, weights streamed once), by shape only (measured on MI355X):
-//   T <= 4            -> dot2 GEMV (gemv_core.h)            [PEGAINFER_GEMV_T1=mfma routes everything to MFMA]
-//   5 <= T <= 16      -> skinny MFMA GEMM (gemm_skinny.h)   when K % 64 == 0
-//   17 <= T <= 64     -> tiled LDS-DMA GEMM for >= 5120 rows, skinny below
+//   T <= 2            -> dot2 GEMV (gemv_core.h)            [PEGAINFER_GEMV_T1=mfma routes everything to MFMA]
+//   3 <= T <= 16      -> skinny MFMA GEMM (gemm_skinny.h)   when K % 64 == 0 (layer GEMMs at T = 3 / 4: 52 vs 61 us
+//                        dot2); the Qwen3.5 flag forms (T <= 4 only) stay on the dot2 kernel
+//   17 <= T <= 64     -> tiled LDS-DMA GEMM, K split over workgroups below 16384 rows (skinny if K is too short)
 // Within each family a column's result does not depend on the batch size (bitwise batch invariance).
 static bool t1_uses_mfma() {
   static const bool v = [] { const char* e = getenv("PEGAINFER_GEMV_T1"); return e && e[0] == 'm'; }();
@@ -480,7 +481,8 @@ static bool decode_gemm_dispatch(const GemvFusedArgs& a, hipStream_t s) {
     if (a.norm_w || EPI != kEpiStore || a.flags) return false;
     if (mid_batch_gemm(a.W, a.X, a.Y, a.M, a.T, a.K, SplitOut{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0}, s)) return true;
   }
-  if ((a.T >= 5 || t1_uses_mfma()) && a.T <= 64 && (a.K & 63) == 0) {
+  static const int skinny_min_t = [] { const char* e = getenv("PEGAINFER_SKINNY_MIN_T"); return e && *e ? atoi(e) : 3; }();
+  if ((a.T >= 5 || (a.T >= skinny_min_t && a.flags == 0) || t1_uses_mfma()) && a.T <= 64 && (a.K & 63) == 0) {
     if (a.T == 1) { skinny_launch<1, EPI>(a, s); return true; }
     return skinny_dispatch<EPI>(a, s);
   }
