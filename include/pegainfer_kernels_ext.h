@@ -59,6 +59,13 @@ pegainfer_status_t pegainfer_gemm_silu(const Half* W, const Half* X, Half* Y, Ha
 /* same with the Qwen3.5 activation: bf16(bf16(silu(gate)) * up) == gemm_cuda x2 + silu_mul_triton_aot_cuda */
 pegainfer_status_t pegainfer_gemm_silu_rounded(const Half* W, const Half* X, Half* Y, Half* gate_up_scratch, int32_t I, int32_t T, int32_t K, pegainfer_stream_t stream);
 
+/* o_proj / down_proj + residual add + RMSNorm: exactly gemm_cuda(W, X, y_scratch, M, T, K) followed by
+ * fused_add_rms_norm_batched_cuda(hidden, y_scratch, norm_weight, normed_out, M, T, eps) (batch_decode.rs:262-270,
+ * 288-296).  For decode batches of 17..64 columns on a split-K shape the slice sum, the add and the norm are one
+ * launch over the fp32 partials (y_scratch [T, M] is then left untouched); other shapes run the two calls.  Same
+ * bits either way. */
+pegainfer_status_t pegainfer_gemm_add_rms_norm(const Half* W, const Half* X, Half* y_scratch, Half* hidden, const Half* norm_weight, Half* normed_out, int32_t M, int32_t T, int32_t K, float eps, pegainfer_stream_t stream);
+
 /* Decode attention with the per-head q/k RMSNorm + RoPE and the KV append folded in (head_dim 128):
  * reads the raw fused-QKV GEMV output qkv[bs, (Hq + 2 Hkv) * 128], writes the new K (normalised, rotated)
  * and V rows into the paged cache and the attention output [bs, Hq*128].  Bit-identical to

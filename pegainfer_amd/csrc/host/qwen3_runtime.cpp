@@ -102,6 +102,8 @@ struct Model {
   // the head of every captured step, so an aborted launch cannot leave one armed.  PEGAINFER_FUSED_MERGE=0 keeps
   // the separate merge launch (A/B).
   bool fused_merge = [] { const char* e = getenv("PEGAINFER_FUSED_MERGE"); return !(e && e[0] == '0'); }();
+  // PEGAINFER_MID_BATCH_FUSED=0: decode batches of 17..64 keep the reference op sequence (A/B + bit-equality probe)
+  bool mid_batch_fused = [] { const char* e = getenv("PEGAINFER_MID_BATCH_FUSED"); return !(e && e[0] == '0'); }();
   int32_t* merge_ctr = nullptr;  // per (request, kv head) arrival counters of the in-kernel split-KV merge
   // sampling scratch (ops/sampling.rs)
   float* probs_scratch = nullptr;
@@ -386,6 +388,40 @@ struct Model {
   template <typename T>
   T* md(size_t off) { return reinterpret_cast<T*>(meta_dev + off); }
 
+  // 17..64 requests (decode_mode 1): the same DAG with the launches that have a bit-identical fused form folded:
+  // one GEMM over the stacked q|k|v rows, qk-norm + RoPE + KV append inside the attention launch, SwiGLU in the
+  // gate_up GEMM epilogue, and (single GPU) the split-K slice sum + residual add + RMSNorm of o_proj / down_proj in
+  // one launch.  7 launches per layer instead of 14.  `next_w` = the norm that follows this layer's down_proj.
+  int decode_layer_mid_batch(int li, int bs, bool split, int split_slots, const Half* next_w) {
+    const Layer& ly = layers[li];
+    const float sm = 1.0f / std::sqrt((float)D);
+    gemm_graphsafe_cuda(ly.qkv, normed, qkv_out, q_dim + 2 * kv_dim, bs, H, S());
+    int rc = pegainfer_fused_decode_attention(
+        qkv_out, attn_out, kv_buffer, layout.k_offset(li), layout.v_offset(li), md<int32_t>(ml.page_indices),
+        md<int32_t>(ml.page_indptr), md<int32_t>(ml.last_page_len), md<int32_t>(ml.positions), ly.q_norm, ly.k_norm, cos,
+        sin, eps, split ? 1 : 0, md<int32_t>(ml.split_request_indices), md<int32_t>(ml.split_kv_tile_indices),
+        md<int32_t>(ml.split_kv_chunk_size), md<int32_t>(ml.split_o_indptr), md<uint8_t>(ml.split_valid), split_tmp_v,
+        split_tmp_s, Hq, Hkv, D, layout.page_size, bs, split_slots, layout.page_stride, sm, md<int32_t>(ml.slot_desc),
+        fused_merge ? merge_ctr : nullptr, S());
+    if (rc) { set_error("pegainfer_fused_decode_attention failed"); return -1; }
+    if (tp_comm) {
+      gemm_graphsafe_cuda(ly.o, attn_out, attn_proj, H, bs, q_dim, S());
+      if (all_reduce_hidden(attn_proj, (size_t)bs * H)) return -1;  // batch_decode.rs:266
+      fused_add_rms_norm_batched_cuda(hidden, attn_proj, ly.ln2, normed, H, bs, eps, S());
+    } else if (pegainfer_gemm_add_rms_norm(ly.o, attn_out, attn_proj, hidden, ly.ln2, normed, H, bs, q_dim, eps, S())) {
+      set_error("pegainfer_gemm_add_rms_norm (o_proj) failed"); return -1;
+    }
+    if (pegainfer_gemm_silu(ly.gate_up, normed, mlp_act, gate_up_out, I, bs, H, S())) { set_error("pegainfer_gemm_silu failed"); return -1; }
+    if (tp_comm) {
+      gemm_graphsafe_cuda(ly.down, mlp_act, mlp_out, H, bs, I, S());
+      if (all_reduce_hidden(mlp_out, (size_t)bs * H)) return -1;    // batch_decode.rs:292
+      fused_add_rms_norm_batched_cuda(hidden, mlp_out, next_w, normed, H, bs, eps, S());
+    } else if (pegainfer_gemm_add_rms_norm(ly.down, mlp_act, mlp_out, hidden, next_w, normed, H, bs, I, eps, S())) {
+      set_error("pegainfer_gemm_add_rms_norm (down_proj) failed"); return -1;
+    }
+    return 0;
+  }
+
   int decode_layer_reference(int li, int bs, bool split, int split_slots) {
     const Layer& ly = layers[li];
     // Q/K/V as three row-sliced GEMMs on purpose (batch_decode.rs:160-186)
@@ -495,9 +531,15 @@ struct Model {
       return -1;
     }
     rms_norm_batched_cuda(hidden, layers[0].ln1, normed, H, bs, eps, S());
+    const bool mid = stacked_qkv(bs) && D == 128 && mid_batch_fused;
+    if (mid && fused_merge && split) PQ_HIP(hipMemsetAsync(merge_ctr, 0, (size_t)max_bs * Hkv * sizeof(int32_t), stream));
     for (int li = 0; li < L; ++li) {
-      if (decode_layer_reference(li, bs, split, split_slots)) return -1;
       const Half* next_w = li + 1 < L ? layers[li + 1].ln1 : final_norm;
+      if (mid) {
+        if (decode_layer_mid_batch(li, bs, split, split_slots, next_w)) return -1;
+        continue;
+      }
+      if (decode_layer_reference(li, bs, split, split_slots)) return -1;
       fused_add_rms_norm_batched_cuda(hidden, mlp_out, next_w, normed, H, bs, eps, S());
     }
     gemm_graphsafe_cuda(lm_head, normed, logits, V, bs, H, S());

@@ -370,6 +370,49 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   *reinterpret_cast<u32x2*>(dst + (size_t)t * ld + mm) = o;
 }
 
+// splitk_reduce_kernel + fused_add_rms_norm_batched_cuda in one launch, one workgroup per token row (d = M):
+//   r = bf16(sum_z part[z][t][:])  (what the reduce kernel would have stored),  hidden = bf16(hidden + r),
+//   out = bf16((hidden + r)_fp32 * inv_rms * w).  All 256 threads build r in LDS; wave 0 then takes the row's sum of
+// squares in the canonical one-wave order of norm_core.h, so the result is bit-identical to the two-kernel sequence.
+__global__ __launch_bounds__(256) void splitk_reduce_add_norm_kernel(const float* __restrict__ part,
+                                                                     Half* __restrict__ hidden,
+                                                                     const Half* __restrict__ w, Half* __restrict__ out,
+                                                                     int d, int T, int ksplit, float eps) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char rn_smem[];
+  u32x4* rrow = reinterpret_cast<u32x4*>(rn_smem);              // [d / 8] bf16x8
+  float* sm_inv = reinterpret_cast<float*>(rn_smem + (size_t)d * 2);
+  const int t = blockIdx.x, nvec = d >> 3;
+  for (int i = threadIdx.x; i < nvec; i += 256) {
+    const float* p = part + (size_t)t * d + i * 8;
+    f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+    for (int z = 1; z < ksplit; ++z) {
+      const float* q = p + (size_t)z * T * d;
+      a += *reinterpret_cast<const f32x4*>(q);
+      b += *reinterpret_cast<const f32x4*>(q + 4);
+    }
+    u32x4 r;
+    r.x = pack_bf2(a[0], a[1]); r.y = pack_bf2(a[2], a[3]); r.z = pack_bf2(b[0], b[1]); r.w = pack_bf2(b[2], b[3]);
+    rrow[i] = r;
+  }
+  __syncthreads();
+  Half* hr = hidden + (size_t)t * d;
+  if (threadIdx.x < 64) {
+    const float inv = wave_row_inv_rms(hr, reinterpret_cast<const Half*>(rrow), d, eps);
+    if (threadIdx.x == 0) *sm_inv = inv;
+  }
+  __syncthreads();
+  const float inv = *sm_inv;
+  Half* orow = out + (size_t)t * d;
+  for (int i = threadIdx.x; i < nvec; i += 256) {
+    const u32x4 r = rrow[i];
+    u32x4 nh;
+    const u32x4 o = norm_scale8(reinterpret_cast<const u32x4*>(hr)[i], &r, reinterpret_cast<const u32x4*>(w)[i], inv,
+                                0.f, &nh);
+    reinterpret_cast<u32x4*>(hr)[i] = nh;
+    reinterpret_cast<u32x4*>(orow)[i] = o;
+  }
+}
+
 // Split-K workspace: created by cublas_init() (the reference's handles own a 32 MB cuBLAS workspace the same way,
 // csrc/linear.cu:14-42), per thread = per GPU rank.  Without it the split-K route is simply not taken.
 constexpr size_t kSplitKWorkspaceBytes = 32u << 20;
@@ -409,7 +452,7 @@ static SplitKPlan splitk_plan(int M, int T, int K) {
   return {ksplit, nk_slice};
 }
 static void glds_splitk_launch(const Half* W, const Half* X, Half* Y, int M, int T, int K, SplitOut so, SplitKPlan pl,
-                               hipStream_t s) {
+                               hipStream_t s, bool reduce = true) {
   constexpr int kLds = 3 * (BM + 64) * 8 * 16;
   static const bool once = [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_gemm_glds_kernel<64, 3, true>),
@@ -420,7 +463,7 @@ static void glds_splitk_launch(const Half* W, const Half* X, Half* Y, int M, int
   const int m_tiles = ceil_div(M, BM);
   mfma_gemm_glds_kernel<64, 3, true><<<dim3(m_tiles, pl.ksplit), 256, kLds, s>>>(W, X, Y, M, T, K, m_tiles, 1, so,
                                                                                  g_splitk_ws, pl.nk_slice);
-  splitk_reduce_kernel<<<ceil_div((long)T * (M >> 2), 256), 256, 0, s>>>(g_splitk_ws, Y, M, T, pl.ksplit, so);
+  if (reduce) splitk_reduce_kernel<<<ceil_div((long)T * (M >> 2), 256), 256, 0, s>>>(g_splitk_ws, Y, M, T, pl.ksplit, so);
 }
 
 // variant: 0 = by shape; else 10*tile + stages with tile 1 = 128-token, 2 = 64-token (A/B probe only)
@@ -661,6 +704,31 @@ pegainfer_status_t pegainfer_gemm_split3(const Half* W, const Half* X, Half* Y0,
   Half* ys[3] = {Y0, Y1, Y2};
   const int32_t ms[3] = {M0, M1, M2};
   return pegainfer_gemm_split(W, X, 3, ys, ms, T, K, stream);
+}
+
+// o_proj / down_proj + residual add + RMSNorm (extension): exactly gemm_cuda(W, X, y_scratch) followed by
+// fused_add_rms_norm_batched_cuda(hidden, y_scratch, norm_weight, normed_out) (batch_decode.rs:262-270, 288-296).
+// For 17..64 columns on a split-K shape the slice sum, the add and the norm are ONE launch over the fp32 partials
+// (y_scratch is then left untouched); every other shape runs the two calls.  Same bits either way.
+pegainfer_status_t pegainfer_gemm_add_rms_norm(const Half* W, const Half* X, Half* y_scratch, Half* hidden,
+                                               const Half* norm_weight, Half* normed_out, int32_t M, int32_t T,
+                                               int32_t K, float eps, pegainfer_stream_t stream) {
+  using namespace pk;
+  if (M <= 0 || T <= 0 || K <= 0 || !y_scratch || !hidden || !norm_weight || !normed_out)
+    return (pegainfer_status_t)hipErrorInvalidValue;
+  hipStream_t s = as_stream(stream);
+  const bool vec = (M & 7) == 0 && host_aligned16(hidden) && host_aligned16(norm_weight) && host_aligned16(normed_out) &&
+                   (size_t)M * 2 + 16 <= 64 * 1024;
+  if (vec && (K & 7) == 0 && host_aligned16(W) && host_aligned16(X) && mid_batch_route(W, X, y_scratch, M, T, K) == 2) {
+    const SplitKPlan pl = splitk_plan(M, T, K);
+    glds_splitk_launch(W, X, y_scratch, M, T, K, SplitOut{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0}, pl, s, false);
+    splitk_reduce_add_norm_kernel<<<T, 256, (size_t)M * 2 + 16, s>>>(g_splitk_ws, hidden, norm_weight, normed_out, M, T,
+                                                                    pl.ksplit, eps);
+    return (pegainfer_status_t)hipGetLastError();
+  }
+  gemm_dispatch(W, X, y_scratch, M, T, K, s);
+  fused_add_rms_norm_batched_cuda(hidden, y_scratch, norm_weight, normed_out, M, T, eps, stream);
+  return (pegainfer_status_t)hipGetLastError();
 }
 
 }  // extern "C"

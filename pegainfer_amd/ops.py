@@ -169,6 +169,19 @@ def gemm_silu_into(gate_up_weight, x, out, scratch=None):
                                        gate_up_weight.shape[1], _stream()), "pegainfer_gemm_silu")
 
 
+def gemm_add_rms_norm_into(weight, x, hidden, norm_weight, eps, normed_out, scratch=None):
+    """hidden += W . x; normed_out = rms_norm(hidden) * norm_weight - gemm_cuda + fused_add_rms_norm_batched_cuda in
+    one call (pegainfer_kernels_ext.h: pegainfer_gemm_add_rms_norm)."""
+    T, M = x.shape[0], weight.shape[0]
+    assert weight.shape[1] == x.shape[1] and hidden.shape == normed_out.shape == (T, M) and norm_weight.numel() == M
+    _bf16(weight, x, hidden, norm_weight, normed_out)
+    if scratch is None:
+        scratch = torch.empty((T, M), dtype=torch.bfloat16, device=x.device)
+    _chk(ffi.lib().pegainfer_gemm_add_rms_norm(_p(weight), _p(x), _p(scratch), _p(hidden), _p(norm_weight),
+                                               _p(normed_out), M, T, weight.shape[1], eps, _stream()),
+         "pegainfer_gemm_add_rms_norm")
+
+
 def gemm(weight, x):
     out = torch.empty((x.shape[0], weight.shape[0]), dtype=torch.bfloat16, device=x.device)
     gemm_into(weight, x, out)

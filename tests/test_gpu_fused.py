@@ -207,3 +207,34 @@ def test_model_fused_decode_bitwise_equals_reference_sequence(built_libs, split_
         outs.append(np.stack(rows))
         eng.close()
     assert np.array_equal(outs[0], outs[1])
+
+
+def test_model_mid_batch_fused_layer_bitwise_equals_reference_sequence(built_libs):
+    """Decode batches of 17..64 (bucket 32 here): the 7-launch layer (stacked qkv GEMM, qk-norm + RoPE + KV append in
+    the attention launch, SwiGLU epilogue, split-K slice sum + add + RMSNorm in one launch) == the reference op
+    sequence over the same GEMM kernels (PEGAINFER_MID_BATCH_FUSED=0), logits bit for bit over 5 steps."""
+    from pegainfer_amd.qwen3 import Qwen3Engine
+    meta = json.load(open(os.path.join(G, "qwen3_tiny_golden.json")))
+    ck = os.path.join(G, "qwen3_tiny.safetensors")
+    rng = np.random.default_rng(3)
+    prompts = [rng.integers(0, 1024, int(n)).tolist() for n in rng.integers(3, 90, 20)]
+    outs = []
+    old = os.environ.get("PEGAINFER_MID_BATCH_FUSED")
+    try:
+        for flag in ("0", "1"):
+            os.environ["PEGAINFER_MID_BATCH_FUSED"] = flag
+            eng = Qwen3Engine(meta["config"], num_kv_pages=512, max_batch_size=32, decode_mode=1).load_safetensors(ck)
+            rids = [eng.new_request() for _ in prompts]
+            toks = np.array([int(eng.prefill([r], [p])[0]) for r, p in zip(rids, prompts)], np.int32)
+            rows = []
+            for _ in range(5):
+                toks, lg = eng.decode(rids, toks, return_logits=True)
+                rows.append(lg.copy())
+            outs.append(np.stack(rows))
+            eng.close()
+    finally:
+        if old is None:
+            os.environ.pop("PEGAINFER_MID_BATCH_FUSED", None)
+        else:
+            os.environ["PEGAINFER_MID_BATCH_FUSED"] = old
+    assert np.array_equal(outs[0], outs[1])

@@ -308,6 +308,26 @@ def test_gemm_split_n_outputs_equals_separate_gemms(P, ms):
         r0 += m
 
 
+@pytest.mark.parametrize("T,M,K", [(40, 2560, 4096), (64, 2560, 9728), (17, 1000, 2560), (8, 2560, 4096), (100, 512, 256)])
+def test_gemm_add_rms_norm_equals_gemm_then_fused_add_rms_norm(P, T, M, K):
+    """o_proj / down_proj + residual add + RMSNorm in one call == gemm_cuda + fused_add_rms_norm_batched_cuda, bit
+    for bit (hidden AND normed), on the split-K shapes (one launch over the fp32 partials) and the fallback shapes;
+    and within the GEMM tolerance of the oracle sequence."""
+    import torch
+    rng = np.random.default_rng(T + M)
+    W, X, Hd, G = rnd(rng, M, K, scale=0.05), rnd(rng, T, K), rnd(rng, T, M), rnd(rng, M)
+    Wd, Xd, Gd = to_dev(W), to_dev(X), to_dev(G)
+    h_ref, n_ref = to_dev(Hd), torch.zeros((T, M), dtype=torch.bfloat16, device="cuda")
+    P.fused_add_rms_norm_batch_into(h_ref, P.gemm(Wd, Xd), Gd, 1e-6, n_ref)
+    h, n = to_dev(Hd), torch.zeros_like(n_ref)
+    P.gemm_add_rms_norm_into(Wd, Xd, h, Gd, 1e-6, n)
+    assert np.array_equal(bf16_bits(from_dev(h)), bf16_bits(from_dev(h_ref)))
+    assert np.array_equal(bf16_bits(from_dev(n)), bf16_bits(from_dev(n_ref)))
+    eh, en = O.fused_add_rms_norm(Hd, O.gemm(W, X), G, 1e-6)
+    assert np.abs(from_dev(h) - eh).max() <= 2.0 ** -6 * max(1.0, np.abs(eh).max())
+    assert np.abs(from_dev(n) - en).max() <= 2.0 ** -5 * max(1.0, np.abs(en).max())
+
+
 def test_decode_gemm_batch_invariance_and_row_slices(P):
     """Decode GEMM: within a kernel family column t of a batched call == the same column in any other batch size,
     bit for bit.  Families by token columns: 1..2 (dot2 GEMV), 3..16 (skinny MFMA), 17..64 (tiled LDS-DMA GEMM, with
