@@ -131,14 +131,14 @@ __device__ __forceinline__ void merge_one(const Half* __restrict__ tmp_v, const 
 }
 
 // The KV scan + in-workgroup merge, given the (already normalised / rotated) bf16 q fragments.
-template <int D, int GROUP, bool PARTITION>
+template <int D, int GROUP, bool PARTITION, int NW>
 __device__ __forceinline__ void decode_attn_body(const DecodeAttnArgs& a, const ChunkInfo& ci, const u32x4 (&qv)[GROUP],
                                                  int slot, int kvh) {
   constexpr int LPT = D / 8;     // lanes per token row
   constexpr int TPI = 64 / LPT;  // token rows per load instruction
-  constexpr int U = 4;           // load instructions in flight per operand
+  constexpr int U = 4;           // load instructions in flight per operand (U = 8 measured 25-45 % slower: 256 VGPRs)
   constexpr int TB = TPI * U;    // tokens per wave iteration
-  constexpr int NPART = 4 * TPI; // partial softmax states per workgroup
+  constexpr int NPART = NW * TPI; // partial softmax states per workgroup (NW waves)
   __shared__ float sm_m[NPART][GROUP];
   __shared__ float sm_l[NPART][GROUP];
   __shared__ __attribute__((aligned(16))) float sm_o[NPART][GROUP][D];
@@ -219,12 +219,12 @@ __device__ __forceinline__ void decode_attn_body(const DecodeAttnArgs& a, const 
       bool okA[U], okB[U];
       load_tile(t0, kA, vA, okA);
       for (;;) {
-        int t1 = t0 + 4 * TB;
+        int t1 = t0 + NW * TB;
         bool more = t1 < hi;
         if (more) load_tile(t1, kB, vB, okB);
         compute_tile(kA, vA, okA);
         if (!more) break;
-        t0 = t1 + 4 * TB;
+        t0 = t1 + NW * TB;
         more = t0 < hi;
         if (more) load_tile(t0, kA, vA, okA);
         compute_tile(kB, vB, okB);
@@ -246,7 +246,7 @@ __device__ __forceinline__ void decode_attn_body(const DecodeAttnArgs& a, const 
   // one thread per (head, 8 output dims): 16-byte stores.  With merge_counters the partials are published
   // write-through (sc1): they are read by a workgroup on another XCD later in this same launch.
   const bool publish = PARTITION && a.merge_counters != nullptr;
-  for (int e = threadIdx.x; e < GROUP * (D / 8); e += 256) {
+  for (int e = threadIdx.x; e < GROUP * (D / 8); e += NW * 64) {
     const int h = e / (D / 8), d0 = (e - h * (D / 8)) * 8;
     float M = -INFINITY;
 #pragma unroll
@@ -302,7 +302,7 @@ __device__ __forceinline__ void decode_attn_body(const DecodeAttnArgs& a, const 
     }
     __syncthreads();
     if (sm_last) {
-      for (int h = wave; h < GROUP; h += 4) {
+      for (int h = wave; h < GROUP; h += NW) {
         const int head = kvh * GROUP + h;
         merge_one<D, true>(a.tmp_v, a.tmp_s, s0, s1, head, num_qo_heads,
                            a.o_out + ((size_t)b * num_qo_heads + head) * D);
@@ -312,8 +312,8 @@ __device__ __forceinline__ void decode_attn_body(const DecodeAttnArgs& a, const 
 }
 
 // ---- kernels: reference-ABI form (q already normalised + rotated, K/V already in the cache) ----
-template <int D, int GROUP, bool PARTITION>
-__global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs a) {
+template <int D, int GROUP, bool PARTITION, int NW>
+__global__ __launch_bounds__(NW * 64) void decode_attn_kernel(const DecodeAttnArgs a) {
   const int slot = blockIdx.x, kvh = blockIdx.y;
   if (PARTITION && a.block_valid_mask && !a.block_valid_mask[slot]) return;
   const ChunkInfo ci = decode_chunk<PARTITION>(a, slot);
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs a
 #pragma unroll
   for (int h = 0; h < GROUP; ++h)
     qv[h] = *reinterpret_cast<const u32x4*>(a.q + ((size_t)ci.b * a.num_qo_heads + kvh * GROUP + h) * D + sub * 8);
-  decode_attn_body<D, GROUP, PARTITION>(a, ci, qv, slot, kvh);
+  decode_attn_body<D, GROUP, PARTITION, NW>(a, ci, qv, slot, kvh);
 }
 
 // ---- fused form (head_dim 128): per-head q/k RMSNorm + RoPE and the KV append folded into the prologue.
@@ -330,8 +330,8 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs a
 // the request's chunks); the one workgroup per (request, kv head) whose chunk contains the new position also
 // normalises + rotates the new K row, writes K and V into the page (same bytes paged_kv_scatter_cuda would
 // write) and only then scans.  Replaces qk_norm_rope + paged_kv_scatter + decode attention: 3 launches -> 1.
-template <int GROUP, bool PARTITION>
-__global__ __launch_bounds__(256) void fused_decode_attn_kernel(const DecodeAttnArgs a) {
+template <int GROUP, bool PARTITION, int NW>
+__global__ __launch_bounds__(NW * 64) void fused_decode_attn_kernel(const DecodeAttnArgs a) {
   constexpr int D = 128;
   const int slot = blockIdx.x, kvh = blockIdx.y;
   ChunkInfo ci;
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256) void fused_decode_attn_kernel(const DecodeAttn
     }
     __syncthreads();  // workgroup-scope release/acquire: the new row is visible to the scanning waves
   }
-  decode_attn_body<D, GROUP, PARTITION>(a, ci, qv, slot, kvh);
+  decode_attn_body<D, GROUP, PARTITION, NW>(a, ci, qv, slot, kvh);
 }
 
 // merge of the partition-KV partial states: one wave per (request, q head).  Lanes first fetch all
@@ -411,10 +411,20 @@ static int launch_decode(const DecodeAttnArgs& a, const int* o_indptr, int batch
   if (o_indptr && PARTITION && slots > batch_size * 64) return static_cast<int>(hipErrorInvalidValue);
   const int group = a.num_qo_heads / a.num_kv_heads;
   dim3 grid(slots, a.num_kv_heads);
-#define PK_LAUNCH(G)                                                                    \
-  do {                                                                                  \
-    if constexpr (FUSED) fused_decode_attn_kernel<G, PARTITION><<<grid, 256, 0, s>>>(a);   \
-    else decode_attn_kernel<D, G, PARTITION><<<grid, 256, 0, s>>>(a);                     \
+  // 8 waves per workgroup when the launch has at most one workgroup per CU (bs 32 un-split: 4.60 -> 4.42 ms/step,
+  // bs 1 at ctx 10000: 2.82 -> 2.67): twice the loads in flight per CU.  With two workgroups per CU the 64 KB of
+  // partial states per workgroup cost more than they give (bs 8 / 16: +9 %).  PEGAINFER_ATTN_WAVES = 4 | 8 forces one.
+  static const int nw_env = [] { const char* e = getenv("PEGAINFER_ATTN_WAVES"); return e && *e ? atoi(e) : 0; }();
+  const bool wide = nw_env == 8 || (nw_env == 0 && (long)slots * a.num_kv_heads <= 256);
+#define PK_LAUNCH(G)                                                                                \
+  do {                                                                                              \
+    if (wide) {                                                                                     \
+      if constexpr (FUSED) fused_decode_attn_kernel<G, PARTITION, 8><<<grid, 512, 0, s>>>(a);       \
+      else decode_attn_kernel<D, G, PARTITION, 8><<<grid, 512, 0, s>>>(a);                          \
+    } else {                                                                                        \
+      if constexpr (FUSED) fused_decode_attn_kernel<G, PARTITION, 4><<<grid, 256, 0, s>>>(a);       \
+      else decode_attn_kernel<D, G, PARTITION, 4><<<grid, 256, 0, s>>>(a);                          \
+    }                                                                                               \
   } while (0)
   switch (group) {
     case 1: PK_LAUNCH(1); break;
