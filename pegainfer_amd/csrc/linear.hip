@@ -372,9 +372,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 // splitk_reduce_kernel + fused_add_rms_norm_batched_cuda in one launch, one workgroup per token row (d = M):
 //   r = bf16(sum_z part[z][t][:])  (what the reduce kernel would have stored),  hidden = bf16(hidden + r),
-//   out = bf16((hidden + r)_fp32 * inv_rms * w).  All 256 threads build r in LDS; wave 0 then takes the row's sum of
+//   out = bf16((hidden + r)_fp32 * inv_rms * w).  All 512 threads build r in LDS; wave 0 then takes the row's sum of
 // squares in the canonical one-wave order of norm_core.h, so the result is bit-identical to the two-kernel sequence.
-__global__ __launch_bounds__(256) void splitk_reduce_add_norm_kernel(const float* __restrict__ part,
+__global__ __launch_bounds__(512) void splitk_reduce_add_norm_kernel(const float* __restrict__ part,
                                                                      Half* __restrict__ hidden,
                                                                      const Half* __restrict__ w, Half* __restrict__ out,
                                                                      int d, int T, int ksplit, float eps) {
@@ -382,14 +382,20 @@ __global__ __launch_bounds__(256) void splitk_reduce_add_norm_kernel(const float
   u32x4* rrow = reinterpret_cast<u32x4*>(rn_smem);              // [d / 8] bf16x8
   float* sm_inv = reinterpret_cast<float*>(rn_smem + (size_t)d * 2);
   const int t = blockIdx.x, nvec = d >> 3;
-  for (int i = threadIdx.x; i < nvec; i += 256) {
+  for (int i = threadIdx.x; i < nvec; i += 512) {
     const float* p = part + (size_t)t * d + i * 8;
-    f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
-    for (int z = 1; z < ksplit; ++z) {
-      const float* q = p + (size_t)z * T * d;
-      a += *reinterpret_cast<const f32x4*>(q);
-      b += *reinterpret_cast<const f32x4*>(q + 4);
-    }
+    f32x4 pa[8], pb[8];   // ksplit <= 8: every slice's loads leave before the first add (slice order is kept)
+#pragma unroll
+    for (int z = 0; z < 8; ++z)
+      if (z < ksplit) {
+        const float* q = p + (size_t)z * T * d;
+        pa[z] = *reinterpret_cast<const f32x4*>(q);
+        pb[z] = *reinterpret_cast<const f32x4*>(q + 4);
+      }
+    f32x4 a = pa[0], b = pb[0];
+#pragma unroll
+    for (int z = 1; z < 8; ++z)
+      if (z < ksplit) { a += pa[z]; b += pb[z]; }
     u32x4 r;
     r.x = pack_bf2(a[0], a[1]); r.y = pack_bf2(a[2], a[3]); r.z = pack_bf2(b[0], b[1]); r.w = pack_bf2(b[2], b[3]);
     rrow[i] = r;
@@ -403,7 +409,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_add_norm_kernel(const float
   __syncthreads();
   const float inv = *sm_inv;
   Half* orow = out + (size_t)t * d;
-  for (int i = threadIdx.x; i < nvec; i += 256) {
+  for (int i = threadIdx.x; i < nvec; i += 512) {
     const u32x4 r = rrow[i];
     u32x4 nh;
     const u32x4 o = norm_scale8(reinterpret_cast<const u32x4*>(hr)[i], &r, reinterpret_cast<const u32x4*>(w)[i], inv,
@@ -722,7 +728,7 @@ pegainfer_status_t pegainfer_gemm_add_rms_norm(const Half* W, const Half* X, Hal
   if (vec && (K & 7) == 0 && host_aligned16(W) && host_aligned16(X) && mid_batch_route(W, X, y_scratch, M, T, K) == 2) {
     const SplitKPlan pl = splitk_plan(M, T, K);
     glds_splitk_launch(W, X, y_scratch, M, T, K, SplitOut{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0}, pl, s, false);
-    splitk_reduce_add_norm_kernel<<<T, 256, (size_t)M * 2 + 16, s>>>(g_splitk_ws, hidden, norm_weight, normed_out, M, T,
+    splitk_reduce_add_norm_kernel<<<T, 512, (size_t)M * 2 + 16, s>>>(g_splitk_ws, hidden, norm_weight, normed_out, M, T,
                                                                     pl.ksplit, eps);
     return (pegainfer_status_t)hipGetLastError();
   }

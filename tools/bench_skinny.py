@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""Batched-decode (skinny, 5 <= T <= 16) GEMM probe: per call-site launch time over the 36 layers' weights of a
-synthetic Qwen3-4B (cold weights, like a decode step) and a checksum of a seeded product per shape, so kernel
-variants selected through PEGAINFER_SKINNY_* (csrc/gemm_skinny.h: skinny_opts) can be compared for speed AND
-bit-equality in one GPU call:
+"""Batched-decode GEMM probe (2 <= T <= 64 token columns): per call-site launch time over the 36 layers' weights of a
+synthetic Qwen3-4B (cold weights, like a decode step) and a checksum of a seeded product per shape, so routing /
+kernel variants selected through environment knobs (PEGAINFER_SKINNY_MIN_T, PEGAINFER_SKINNY_RB, PEGAINFER_SPLITK,
+PEGAINFER_MID_MIN_ROWS) can be compared for speed AND bit-equality in one GPU call (tools/gpu_skinny_probe.sh):
 
-    for v in "" "PEGAINFER_SKINNY_DIRECT=1" "PEGAINFER_SKINNY_DBG=0x100"; do env $v python tools/bench_skinny.py 8 16; done
+    SKINNY_TS='8 16 32' SKINNY_VARIANTS='X=0 PEGAINFER_SPLITK=0' bash tools/gpu_skinny_probe.sh
 """
 import hashlib
 import os
@@ -22,13 +22,16 @@ SITES = [(0, "qkv", 6144, 2560), (1, "o", 2560, 4096), (2, "gate_up", 19456, 256
 
 def main():
     Ts = [int(x) for x in sys.argv[1:]] or [8, 16]
-    tag = " ".join(f"{k[17:]}={v}" for k, v in sorted(os.environ.items()) if k.startswith("PEGAINFER_SKINNY_")) or "default"
+    knobs = ("PEGAINFER_SKINNY_", "PEGAINFER_SPLITK", "PEGAINFER_MID_")
+    tag = " ".join(f"{k[10:]}={v}" for k, v in sorted(os.environ.items()) if k.startswith(knobs)) or "default"
     dev = torch.device("cuda:0")
     eng = Qwen3Engine(dict(QWEN3_4B), num_kv_pages=64, max_batch_size=max(Ts), enable_graph=False, device=0)
     eng.fill_synthetic(seed=42, std=0.02)
     for T in Ts:
         cells, total = [], 0.0
         for which, name, M, K in SITES:
+            if which >= 5 and T > 16:      # the fused prologue / epilogue forms exist up to 16 columns
+                continue
             us = eng.bench_gemv(which, 20 if which == 4 else 72, T) * 1e3
             cells.append(f"{name} {us:7.2f}us {M * K * 2 / us * 1e-6:5.2f}TB/s")
             if which in (0, 1, 2, 3):
