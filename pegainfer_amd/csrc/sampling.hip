@@ -80,6 +80,15 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const Half* __restrict__ x
 }
 
 constexpr int kTop1Blocks = 64;
+// Publish a workgroup's best key and draw its ticket.  Only atomics touch the two state words and agent-scope
+// atomics are performed at the device coherence point, so no cache-wide release / acquire is needed (an ACQ_REL
+// ticket cost an L2 write-back + invalidate per workgroup: 114 us for 64 rows x 64 workgroups).  What must hold is
+// that this workgroup's max is performed before its ticket: the RETURNING fetch_max is waited for (vmcnt) first.
+__device__ __forceinline__ unsigned long long top1_publish(unsigned long long* st, unsigned long long best) {
+  const unsigned long long prev = __hip_atomic_fetch_max(&st[0], best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" :: "v"(prev) : "memory");   // uses prev: the returning form, completed
+  return __hip_atomic_fetch_add(&st[1], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __global__ __launch_bounds__(256) void top1_kernel(const Half* __restrict__ logits, Half* __restrict__ top_value,
                                                    unsigned long long* __restrict__ state, int* __restrict__ out,
                                                    int n) {
@@ -87,12 +96,10 @@ __global__ __launch_bounds__(256) void top1_kernel(const Half* __restrict__ logi
   unsigned long long best = scan_best(logits, n, blockIdx.x * 256 + threadIdx.x, kTop1Blocks * 256);
   best = block_max_u64<4>(best, red);
   if (threadIdx.x == 0) {
-    __hip_atomic_fetch_max(&state[0], best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long ticket =
-        __hip_atomic_fetch_add(&state[1], 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long ticket = top1_publish(state, best);
     if (ticket == kTop1Blocks - 1) {
-      const unsigned long long win = __hip_atomic_exchange(&state[0], 0ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&state[1], 0ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long win = __hip_atomic_exchange(&state[0], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&state[1], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const int idx = (int)(0xFFFFFFFFu - (uint32_t)(win & 0xFFFFFFFFu));
       out[0] = idx;
       if (top_value) top_value[0] = logits[idx];
@@ -111,11 +118,10 @@ __global__ __launch_bounds__(256) void batched_top1_kernel(const Half* __restric
   unsigned long long best = scan_best(x, n, blockIdx.x * 256 + threadIdx.x, kTop1Blocks * 256);
   best = block_max_u64<4>(best, red);
   if (threadIdx.x == 0) {
-    __hip_atomic_fetch_max(&st[0], best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long ticket = __hip_atomic_fetch_add(&st[1], 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long ticket = top1_publish(st, best);
     if (ticket == kTop1Blocks - 1) {
-      const unsigned long long win = __hip_atomic_exchange(&st[0], 0ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&st[1], 0ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long win = __hip_atomic_exchange(&st[0], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&st[1], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       out[row] = (int)(0xFFFFFFFFu - (uint32_t)(win & 0xFFFFFFFFu));
     }
   }

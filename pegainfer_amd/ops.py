@@ -320,6 +320,18 @@ def argmax(x):
     return int(out.item())
 
 
+def batched_top1(logits, state, out=None):
+    """Greedy token of every row of logits [rows, V] in one launch (pegainfer_kernels_ext.h: pegainfer_batched_top1);
+    `state` = zero-initialised uint8 scratch of >= 16 * rows bytes, left zero by the kernel."""
+    rows, vocab = logits.shape
+    _bf16(logits)
+    if out is None:
+        out = torch.zeros(rows, dtype=torch.int32, device=logits.device)
+    _chk(ffi.lib().pegainfer_batched_top1(_p(logits), vocab, rows, logits.stride(0), _p(state), _p(out), _stream()),
+         "pegainfer_batched_top1")
+    return out
+
+
 def gpu_sample_into(logits, probs_scratch, top1_value_scratch, row_states_scratch, valid_scratch, out,
                     temperature, top_k, top_p, random_val):
     """ops/sampling.rs:109-170: greedy branch iff (T<=0 or top_k==1) and top_p>=1; syncs and

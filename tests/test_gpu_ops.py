@@ -501,6 +501,27 @@ def test_prefill_invalid_tile_override(P):
 
 
 # ------------------------------------------------------------------ sampling
+@pytest.mark.parametrize("rows,n", [(1, 151936), (64, 151936), (7, 1001)])
+def test_batched_top1_every_row_lowest_index_ties_and_self_resetting_state(P, rows, n):
+    """Greedy token of all batch columns in one launch (64 workgroups per row meet through two atomics per row):
+    == the oracle argmax per row incl. exact ties, over 25 back-to-back launches on the same scratch, which the
+    kernel must leave zero (no ordering fence around the ticket: the atomics alone carry the hand-off)."""
+    import torch
+    rng = np.random.default_rng(rows + n)
+    x = rnd(rng, rows, n, scale=3)
+    for r in range(rows):
+        pos = sorted(rng.choice(n, size=3, replace=False).tolist())
+        x[r, pos] = x[r].max() + 1
+    xd = to_dev(x)
+    want = np.array([O.argmax(x[r]) for r in range(rows)])
+    state = torch.zeros(16 * rows, dtype=torch.uint8, device="cuda")
+    outs = [P.batched_top1(xd, state) for _ in range(25)]
+    torch.cuda.synchronize()
+    for o in outs:
+        assert np.array_equal(o.cpu().numpy(), want)
+    assert int(state.sum().item()) == 0
+
+
 @pytest.mark.parametrize("n", [5, 1000, 151936])
 def test_argmax_and_top1_lowest_index_ties(P, n):
     import torch
