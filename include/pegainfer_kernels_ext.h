@@ -61,10 +61,15 @@ pegainfer_status_t pegainfer_gemm_silu_rounded(const Half* W, const Half* X, Hal
 
 /* o_proj / down_proj + residual add + RMSNorm: exactly gemm_cuda(W, X, y_scratch, M, T, K) followed by
  * fused_add_rms_norm_batched_cuda(hidden, y_scratch, norm_weight, normed_out, M, T, eps) (batch_decode.rs:262-270,
- * 288-296).  For decode batches of 17..64 columns on a split-K shape the slice sum, the add and the norm are one
- * launch over the fp32 partials (y_scratch [T, M] is then left untouched); other shapes run the two calls.  Same
- * bits either way. */
+ * 288-296; prefill.rs:150-160).  On a split-K shape (decode batches of 17..64 columns; prefill when the tiling has
+ * fewer tiles than CUs) the slice sum, the add and the norm are one launch over the fp32 partials (y_scratch [T, M]
+ * is then left untouched); other shapes run the two calls.  Same bits either way. */
 pegainfer_status_t pegainfer_gemm_add_rms_norm(const Half* W, const Half* X, Half* y_scratch, Half* hidden, const Half* norm_weight, Half* normed_out, int32_t M, int32_t T, int32_t K, float eps, pegainfer_stream_t stream);
+
+/* down_proj + residual add: exactly gemm_cuda(W, X, y_scratch, M, T, K) followed by add_cuda(a, y_scratch, out, M*T)
+ * (prefill.rs:176-185).  On a split-K shape the slice sum and the add are one launch over the fp32 partials
+ * (y_scratch [T, M] is then left untouched).  out may alias a.  Same bits either way. */
+pegainfer_status_t pegainfer_gemm_add(const Half* W, const Half* X, Half* y_scratch, const Half* a, Half* out, int32_t M, int32_t T, int32_t K, pegainfer_stream_t stream);
 
 /* Decode attention with the per-head q/k RMSNorm + RoPE and the KV append folded in (head_dim 128):
  * reads the raw fused-QKV GEMV output qkv[bs, (Hq + 2 Hkv) * 128], writes the new K (normalised, rotated)

@@ -793,18 +793,26 @@ struct Model {
                                          layout.page_size, n_decode_tail, layout.page_stride, sm, S());
         if (rc) { set_error("paged_attention_decode_cuda (unified) failed"); return -1; }
       }
-      G(ly.o, pf_attn, pf_o, H, q_dim);
-      if (all_reduce_hidden(pf_o, (size_t)Ti * H)) return -1;   // prefill.rs:154
-      fused_add_rms_norm_batched_cuda(hid, pf_o, ly.ln2, pf_normed, H, Ti, eps, S());
+      if (tp_comm) {
+        G(ly.o, pf_attn, pf_o, H, q_dim);
+        if (all_reduce_hidden(pf_o, (size_t)Ti * H)) return -1;   // prefill.rs:154
+        fused_add_rms_norm_batched_cuda(hid, pf_o, ly.ln2, pf_normed, H, Ti, eps, S());
+      } else if (pegainfer_gemm_add_rms_norm(ly.o, pf_attn, pf_o, hid, ly.ln2, pf_normed, H, Ti, q_dim, eps, S())) {
+        set_error("pegainfer_gemm_add_rms_norm (prefill o_proj) failed"); return -1;   // same two ops, one entry point
+      }
       if (Ti > 16) {  // SwiGLU in the GEMM epilogue (bit-identical to gemm + silu_mul_fused)
         if (pegainfer_gemm_silu(ly.gate_up, pf_normed, pf_act, pf_gate_up, I, Ti, H, S())) { set_error("pegainfer_gemm_silu failed"); return -1; }
       } else {
         G(ly.gate_up, pf_normed, pf_gate_up, 2 * I, H);
         silu_mul_fused_cuda(pf_gate_up, pf_act, I, Ti, S());
       }
-      G(ly.down, pf_act, pf_o, H, I);
-      if (all_reduce_hidden(pf_o, (size_t)Ti * H)) return -1;   // prefill.rs:180
-      if (add_cuda(hid, pf_o, hid_out, Ti * H, S())) { set_error("add_cuda failed"); return -1; }
+      if (tp_comm) {
+        G(ly.down, pf_act, pf_o, H, I);
+        if (all_reduce_hidden(pf_o, (size_t)Ti * H)) return -1;   // prefill.rs:180
+        if (add_cuda(hid, pf_o, hid_out, Ti * H, S())) { set_error("add_cuda failed"); return -1; }
+      } else if (pegainfer_gemm_add(ly.down, pf_act, pf_o, hid, hid_out, H, Ti, I, S())) {
+        set_error("pegainfer_gemm_add (prefill down_proj) failed"); return -1;
+      }
       std::swap(hid, hid_out);  // prefill.rs:183-185
     }
     // per request: last token -> final norm -> lm_head GEMV (prefill.rs:267-282); batched in groups that stay

@@ -419,6 +419,22 @@ __global__ __launch_bounds__(512) void splitk_reduce_add_norm_kernel(const float
   }
 }
 
+// slice sum + residual add: out[t][m] = bf16(a[t][m] + bf16(sum_z part[z][t][m])) = splitk_reduce_kernel + add_cuda
+__global__ __launch_bounds__(256) void splitk_reduce_add_kernel(const float* __restrict__ part, const Half* __restrict__ a,
+                                                                Half* __restrict__ out, int M, int T, int ksplit) {
+  const int m4 = M >> 2;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)T * m4) return;
+  const int t = (int)(idx / m4), m = (int)(idx - (long)t * m4) * 4;
+  f32x4 v = *reinterpret_cast<const f32x4*>(part + (size_t)t * M + m);
+  for (int z = 1; z < ksplit; ++z) v += *reinterpret_cast<const f32x4*>(part + ((size_t)z * T + t) * M + m);
+  const u32x2 av = *reinterpret_cast<const u32x2*>(a + (size_t)t * M + m);
+  u32x2 o;
+  o.x = pack_bf2(bf_lo(av.x) + bf16_round_f(v[0]), bf_hi(av.x) + bf16_round_f(v[1]));
+  o.y = pack_bf2(bf_lo(av.y) + bf16_round_f(v[2]), bf_hi(av.y) + bf16_round_f(v[3]));
+  *reinterpret_cast<u32x2*>(out + (size_t)t * M + m) = o;
+}
+
 // Split-K workspace: created by cublas_init() (the reference's handles own a 32 MB cuBLAS workspace the same way,
 // csrc/linear.cu:14-42), per thread = per GPU rank.  Without it the split-K route is simply not taken.
 constexpr size_t kSplitKWorkspaceBytes = 32u << 20;
@@ -440,14 +456,25 @@ static void glds_gemm_launch_t(const Half* W, const Half* X, Half* Y, int M, int
   const int m_tiles = so.silu_I > 0 ? ceil_div(so.silu_I, 64) : ceil_div(M, BM), t_tiles = ceil_div(T, TT);
   mfma_gemm_glds_kernel<TT, ST><<<m_tiles * t_tiles, 256, kLds, s>>>(W, X, Y, M, T, K, m_tiles, t_tiles, so);
 }
-// Decode batches of 17..64 columns on a matrix with too few 128-row tiles to fill the chip: K slices chosen by
-// shape only (M, K), so a column's bits do not depend on the batch size.  nk_slice == 0: not applicable.
+// Split-K plans (nk_slice == 0: not applicable), both chosen by shape only:
+//  * decode batches of 17..64 columns on a matrix with too few 128-row tiles to fill the chip: 2..8 slices from
+//    (M, K), so a column's bits do not depend on the batch size;
+//  * prefill (T > 64) when the 128x128 tiling has fewer tiles than the 256 CUs (o_proj / down_proj at ~1K tokens:
+//    160 tiles): 3 slices -> 480 workgroups, two per CU (T = 1024: down_proj 100 -> 78 us, o_proj 45 -> 40 us; with 2
+//    slices a quarter of the CUs still carries two workgroups and the makespan does not move).
 constexpr int kSplitKMaxRows = 16384;   // below this (< 128 row tiles) the 17..64-column GEMM splits K
 struct SplitKPlan { int ksplit, nk_slice; };
 static SplitKPlan splitk_plan(int M, int T, int K) {
   static const bool enabled = [] { const char* e = getenv("PEGAINFER_SPLITK"); return !(e && e[0] == '0'); }();
-  if (!enabled || !g_splitk_ws || T <= 16 || T > 64 || M >= kSplitKMaxRows) return {0, 0};
+  if (!enabled || !g_splitk_ws || T <= 16) return {0, 0};
   const int m_tiles = ceil_div(M, BM), nk_all = K / BK;
+  if (T > 64) {
+    if ((long)m_tiles * ceil_div(T, 128) >= 256 || nk_all < 48 || (size_t)3 * T * M * 4 > kSplitKWorkspaceBytes)
+      return {0, 0};
+    const int nk_slice = ceil_div(nk_all, 3);
+    return {ceil_div(nk_all, nk_slice), nk_slice};
+  }
+  if (M >= kSplitKMaxRows) return {0, 0};
   int want = ceil_div(192, m_tiles);
   want = want > 8 ? 8 : want;
   if (want < 2 || nk_all < 8) return {0, 0};
@@ -457,18 +484,33 @@ static SplitKPlan splitk_plan(int M, int T, int K) {
   if (ksplit < 2 || (size_t)ksplit * T * M * 4 > kSplitKWorkspaceBytes) return {0, 0};
   return {ksplit, nk_slice};
 }
+// the split GEMM itself: fp32 partials into the workspace (128x64 tiles, ring 3 up to 64 columns; 128x128 tiles,
+// ring 2 - two workgroups per CU - above), then optionally the plain slice-sum launch
 static void glds_splitk_launch(const Half* W, const Half* X, Half* Y, int M, int T, int K, SplitOut so, SplitKPlan pl,
                                hipStream_t s, bool reduce = true) {
-  constexpr int kLds = 3 * (BM + 64) * 8 * 16;
-  static const bool once = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_gemm_glds_kernel<64, 3, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
-    return true;
-  }();
-  (void)once;
   const int m_tiles = ceil_div(M, BM);
-  mfma_gemm_glds_kernel<64, 3, true><<<dim3(m_tiles, pl.ksplit), 256, kLds, s>>>(W, X, Y, M, T, K, m_tiles, 1, so,
-                                                                                 g_splitk_ws, pl.nk_slice);
+  if (T <= 64) {
+    constexpr int kLds = 3 * (BM + 64) * 8 * 16;
+    static const bool once = [] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_gemm_glds_kernel<64, 3, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+      return true;
+    }();
+    (void)once;
+    mfma_gemm_glds_kernel<64, 3, true><<<dim3(m_tiles, pl.ksplit), 256, kLds, s>>>(W, X, Y, M, T, K, m_tiles, 1, so,
+                                                                                   g_splitk_ws, pl.nk_slice);
+  } else {
+    constexpr int kLds = 2 * (BM + 128) * 8 * 16;
+    static const bool once = [] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_gemm_glds_kernel<128, 2, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+      return true;
+    }();
+    (void)once;
+    const int t_tiles = ceil_div(T, 128);
+    mfma_gemm_glds_kernel<128, 2, true><<<dim3(m_tiles * t_tiles, pl.ksplit), 256, kLds, s>>>(
+        W, X, Y, M, T, K, m_tiles, t_tiles, so, g_splitk_ws, pl.nk_slice);
+  }
   if (reduce) splitk_reduce_kernel<<<ceil_div((long)T * (M >> 2), 256), 256, 0, s>>>(g_splitk_ws, Y, M, T, pl.ksplit, so);
 }
 
@@ -546,6 +588,13 @@ static void gemm_dispatch(const Half* W, const Half* X, Half* Y, int M, int T, i
     if (decode_gemm_dispatch<kEpiStore>(a, s)) return;
   }
   if (glds_gemm_ok(W, X, Y, M, K)) {
+    if (T > 64) {
+      const SplitKPlan pl = splitk_plan(M, T, K);
+      if (pl.nk_slice > 0) {
+        glds_splitk_launch(W, X, Y, M, T, K, SplitOut{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0}, pl, s);
+        return;
+      }
+    }
     // PEGAINFER_GEMM=reg keeps the register-staged kernel; w2 w3 n2 n3 n4 force a 128 / 64-token LDS-DMA tile
     // with that ring depth (A/B probes, tools/bench_prefill_gemm.py); default picks by shape.
     static const int mode = [] {
@@ -656,8 +705,13 @@ pegainfer_status_t pegainfer_gemm_split(const Half* W, const Half* X, int32_t n_
     // the last present segment is "the rest"; with fewer than 4 outputs the unused boundaries collapse onto M
     SplitOut so{y[1], y[2] ? y[2] : y[1], y[3] ? y[3] : (y[2] ? y[2] : y[1]), m[0], m[1], n_out > 2 ? m[2] : 0, 0, 0};
     if (n_out == 2) { so.M1 = m[1]; so.M2 = 0; }
-    if (T > 64) glds_gemm_launch(W, X, y[0], M, T, K, so, 0, as_stream(stream));
-    else mid_batch_gemm(W, X, y[0], M, T, K, so, as_stream(stream));
+    if (T > 64) {   // same decision as gemm_cuda over the stacked matrix
+      const SplitKPlan pl = splitk_plan(M, T, K);
+      if (pl.nk_slice > 0) glds_splitk_launch(W, X, y[0], M, T, K, so, pl, as_stream(stream));
+      else glds_gemm_launch(W, X, y[0], M, T, K, so, 0, as_stream(stream));
+    } else {
+      mid_batch_gemm(W, X, y[0], M, T, K, so, as_stream(stream));
+    }
   } else {  // shapes the tiled kernel does not take: separate reference-ABI calls
     size_t row = 0;
     for (int i = 0; i < n_out; ++i) {
@@ -677,7 +731,8 @@ static pegainfer_status_t gemm_silu_impl(const Half* W, const Half* X, Half* Y, 
   using namespace pk;
   if (I <= 0 || T <= 0 || K <= 0) return (pegainfer_status_t)hipErrorInvalidValue;
   const int M = 2 * I;
-  if (T > 16 && (I & 3) == 0 && glds_gemm_ok(W, X, Y, M, K) && (T > 64 || mid_batch_route(W, X, Y, M, T, K) == 1)) {
+  if (T > 16 && (I & 3) == 0 && glds_gemm_ok(W, X, Y, M, K) &&
+      (T > 64 ? splitk_plan(M, T, K).nk_slice == 0 : mid_batch_route(W, X, Y, M, T, K) == 1)) {
     SplitOut so{nullptr, nullptr, nullptr, 0, 0, 0, I, double_round};
     glds_gemm_launch(W, X, Y, M, T, K, so, T <= 64 ? 23 : 0, as_stream(stream));
     return (pegainfer_status_t)hipGetLastError();
@@ -725,7 +780,9 @@ pegainfer_status_t pegainfer_gemm_add_rms_norm(const Half* W, const Half* X, Hal
   hipStream_t s = as_stream(stream);
   const bool vec = (M & 7) == 0 && host_aligned16(hidden) && host_aligned16(norm_weight) && host_aligned16(normed_out) &&
                    (size_t)M * 2 + 16 <= 64 * 1024;
-  if (vec && (K & 7) == 0 && host_aligned16(W) && host_aligned16(X) && mid_batch_route(W, X, y_scratch, M, T, K) == 2) {
+  const bool split = glds_gemm_ok(W, X, y_scratch, M, K) &&
+                     (T > 64 ? splitk_plan(M, T, K).nk_slice > 0 : mid_batch_route(W, X, y_scratch, M, T, K) == 2);
+  if (vec && split) {
     const SplitKPlan pl = splitk_plan(M, T, K);
     glds_splitk_launch(W, X, y_scratch, M, T, K, SplitOut{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0}, pl, s, false);
     splitk_reduce_add_norm_kernel<<<T, 512, (size_t)M * 2 + 16, s>>>(g_splitk_ws, hidden, norm_weight, normed_out, M, T,
@@ -735,6 +792,27 @@ pegainfer_status_t pegainfer_gemm_add_rms_norm(const Half* W, const Half* X, Hal
   gemm_dispatch(W, X, y_scratch, M, T, K, s);
   fused_add_rms_norm_batched_cuda(hidden, y_scratch, norm_weight, normed_out, M, T, eps, stream);
   return (pegainfer_status_t)hipGetLastError();
+}
+
+// down_proj + residual add (extension): exactly gemm_cuda(W, X, y_scratch) followed by add_cuda(a, y_scratch, out)
+// (prefill.rs:176-185).  On a split-K shape the slice sum and the add are one launch over the fp32 partials
+// (y_scratch is then left untouched).  out may alias a.  Same bits either way.
+pegainfer_status_t pegainfer_gemm_add(const Half* W, const Half* X, Half* y_scratch, const Half* a, Half* out,
+                                      int32_t M, int32_t T, int32_t K, pegainfer_stream_t stream) {
+  using namespace pk;
+  if (M <= 0 || T <= 0 || K <= 0 || !y_scratch || !a || !out) return (pegainfer_status_t)hipErrorInvalidValue;
+  hipStream_t s = as_stream(stream);
+  const bool split = glds_gemm_ok(W, X, y_scratch, M, K) && (reinterpret_cast<uintptr_t>(a) & 7u) == 0 &&
+                     (reinterpret_cast<uintptr_t>(out) & 7u) == 0 &&
+                     (T > 64 ? splitk_plan(M, T, K).nk_slice > 0 : mid_batch_route(W, X, y_scratch, M, T, K) == 2);
+  if (split) {
+    const SplitKPlan pl = splitk_plan(M, T, K);
+    glds_splitk_launch(W, X, y_scratch, M, T, K, SplitOut{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0}, pl, s, false);
+    splitk_reduce_add_kernel<<<ceil_div((long)T * (M >> 2), 256), 256, 0, s>>>(g_splitk_ws, a, out, M, T, pl.ksplit);
+    return (pegainfer_status_t)hipGetLastError();
+  }
+  gemm_dispatch(W, X, y_scratch, M, T, K, s);
+  return add_cuda(a, y_scratch, out, M * T, stream);
 }
 
 }  // extern "C"

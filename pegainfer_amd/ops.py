@@ -182,6 +182,17 @@ def gemm_add_rms_norm_into(weight, x, hidden, norm_weight, eps, normed_out, scra
          "pegainfer_gemm_add_rms_norm")
 
 
+def gemm_add_into(weight, x, a, out, scratch=None):
+    """out = a + W . x - gemm_cuda + add_cuda in one call (pegainfer_kernels_ext.h: pegainfer_gemm_add)."""
+    T, M = x.shape[0], weight.shape[0]
+    assert weight.shape[1] == x.shape[1] and a.shape == out.shape == (T, M)
+    _bf16(weight, x, a, out)
+    if scratch is None:
+        scratch = torch.empty((T, M), dtype=torch.bfloat16, device=x.device)
+    _chk(ffi.lib().pegainfer_gemm_add(_p(weight), _p(x), _p(scratch), _p(a), _p(out), M, T, weight.shape[1], _stream()),
+         "pegainfer_gemm_add")
+
+
 def gemm(weight, x):
     out = torch.empty((x.shape[0], weight.shape[0]), dtype=torch.bfloat16, device=x.device)
     gemm_into(weight, x, out)

@@ -308,7 +308,24 @@ def test_gemm_split_n_outputs_equals_separate_gemms(P, ms):
         r0 += m
 
 
-@pytest.mark.parametrize("T,M,K", [(40, 2560, 4096), (64, 2560, 9728), (17, 1000, 2560), (8, 2560, 4096), (100, 512, 256)])
+@pytest.mark.parametrize("T,M,K", [(1024, 2560, 9728), (300, 2560, 4096), (40, 2560, 4096), (8, 2560, 4096), (100, 512, 256)])
+def test_gemm_add_equals_gemm_then_add(P, T, M, K):
+    """down_proj + residual add in one call == gemm_cuda + add_cuda, bit for bit, on the split-K shapes (prefill with
+    fewer 128x128 tiles than CUs, decode batches of 17..64) and the fallback shapes; out aliasing a is allowed."""
+    rng = np.random.default_rng(T + K)
+    W, X, A = rnd(rng, M, K, scale=0.05), rnd(rng, T, K), rnd(rng, T, M)
+    Wd, Xd = to_dev(W), to_dev(X)
+    ref = empty_like_dev(A)
+    P.add_batch_into(to_dev(A), P.gemm(Wd, Xd), ref)
+    out = to_dev(A)
+    P.gemm_add_into(Wd, Xd, out, out)
+    assert np.array_equal(bf16_bits(from_dev(out)), bf16_bits(from_dev(ref)))
+    exp = O.add(A, O.gemm(W, X))
+    assert np.abs(from_dev(out) - exp).max() <= 2.0 ** -6 * max(1.0, np.abs(exp).max())
+
+
+@pytest.mark.parametrize("T,M,K", [(40, 2560, 4096), (64, 2560, 9728), (17, 1000, 2560), (8, 2560, 4096), (100, 512, 256),
+                                   (1024, 2560, 4096), (200, 2560, 9728)])
 def test_gemm_add_rms_norm_equals_gemm_then_fused_add_rms_norm(P, T, M, K):
     """o_proj / down_proj + residual add + RMSNorm in one call == gemm_cuda + fused_add_rms_norm_batched_cuda, bit
     for bit (hidden AND normed), on the split-K shapes (one launch over the fp32 partials) and the fallback shapes;

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Prefill-shaped GEMM probe: times gemm_cuda on the Qwen3-4B projection shapes at T tokens and prints a
 checksum of each result, so two runs with different PEGAINFER_GEMM modes (reg | default | w | n) can be compared
-for speed AND bit-equality (all variants keep the same per-element K order).
+for speed AND bit-equality (all un-split variants keep the same per-element K order; PEGAINFER_SPLITK=0 turns the
+3-slice split of the < 256-tile shapes off).
 
     PEGAINFER_GEMM=reg python tools/bench_prefill_gemm.py 1024
 """
