@@ -44,8 +44,11 @@ pegainfer_status_t pegainfer_gemv_fused_ex(const Half* W, const Half* X, Half* Y
 /* Prefill q/k/v projection as ONE GEMM over the row-stacked weight W[M0 + M1 + M2, K] (q_proj; k_proj; v_proj
  * rows), writing the three contiguous buffers the reference's prefill kernels take: Y0[T, M0], Y1[T, M1],
  * Y2[T, M2].  Replaces the three gemm_cuda calls of prefill.rs:120-129 (the k/v projections alone cover a
- * quarter of the chip); every element equals the separate call bit for bit.  Falls back to three calls for
- * shapes the tiled kernel does not take. */
+ * quarter of the chip).  The outputs are the row ranges of gemm_cuda over the stacked matrix, bit for bit; against
+ * three separate gemm_cuda calls they are bit-identical whenever the separate calls take the same K-split plan as
+ * the stacked matrix (always up to 64 columns and for un-split shapes; a 1024-row k_proj alone at ~1K tokens is a
+ * split-K shape, the 6144-row stacked matrix is not - there parity is the GEMM tolerance).  Falls back to three
+ * calls for shapes the tiled kernel does not take. */
 pegainfer_status_t pegainfer_gemm_split3(const Half* W, const Half* X, Half* Y0, int32_t M0, Half* Y1, int32_t M1, Half* Y2, int32_t M2, int32_t T, int32_t K, pegainfer_stream_t stream);
 
 /* General form of pegainfer_gemm_split3: n_out in 2..4 outputs Y[i][T, Ms[i]] from the row-stacked weight

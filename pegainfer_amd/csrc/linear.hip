@@ -435,9 +435,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_add_kernel(const float* __r
   *reinterpret_cast<u32x2*>(out + (size_t)t * M + m) = o;
 }
 
-// Split-K workspace: created by cublas_init() (the reference's handles own a 32 MB cuBLAS workspace the same way,
+// Split-K workspace (64 MB): created by cublas_init() (the reference's handles own a 32 MB cuBLAS workspace the same way,
 // csrc/linear.cu:14-42), per thread = per GPU rank.  Without it the split-K route is simply not taken.
-constexpr size_t kSplitKWorkspaceBytes = 32u << 20;
+constexpr size_t kSplitKWorkspaceBytes = 64u << 20;
 static thread_local float* g_splitk_ws = nullptr;
 
 static bool glds_gemm_ok(const Half* W, const Half* X, const Half* Y, int M, int K) {
@@ -459,37 +459,45 @@ static void glds_gemm_launch_t(const Half* W, const Half* X, Half* Y, int M, int
 // Split-K plans (nk_slice == 0: not applicable), both chosen by shape only:
 //  * decode batches of 17..64 columns on a matrix with too few 128-row tiles to fill the chip: 2..8 slices from
 //    (M, K), so a column's bits do not depend on the batch size;
-//  * prefill (T > 64) when the 128x128 tiling has fewer tiles than the 256 CUs (o_proj / down_proj at ~1K tokens:
-//    160 tiles): 3 slices -> 480 workgroups, two per CU (T = 1024: down_proj 100 -> 78 us, o_proj 45 -> 40 us; with 2
-//    slices a quarter of the CUs still carries two workgroups and the makespan does not move).
+//  * prefill (T > 64) when the tiling (128x64 tiles up to 256 tokens, 128x128 above) has at most 170 tiles for the 256
+//    CUs: floor(512 / tiles) slices (at most 8, at least 6 K tiles each), i.e. up to 512 workgroups = two per CU, all
+//    resident.  o_proj / down_proj at 1024 tokens (160 tiles): 3 slices, 45 -> 40 and 100 -> 78 us (2 slices leave a
+//    quarter of the CUs with two workgroups: the makespan does not move); at 128 tokens qkv / o / down have 48 / 20 / 20
+//    tiles of 128x128 and ran at 95-150 TFLOP/s un-split.
 constexpr int kSplitKMaxRows = 16384;   // below this (< 128 row tiles) the 17..64-column GEMM splits K
-struct SplitKPlan { int ksplit, nk_slice; };
+struct SplitKPlan { int ksplit, nk_slice, tt; };
 static SplitKPlan splitk_plan(int M, int T, int K) {
   static const bool enabled = [] { const char* e = getenv("PEGAINFER_SPLITK"); return !(e && e[0] == '0'); }();
-  if (!enabled || !g_splitk_ws || T <= 16) return {0, 0};
+  if (!enabled || !g_splitk_ws || T <= 16) return {0, 0, 0};
   const int m_tiles = ceil_div(M, BM), nk_all = K / BK;
   if (T > 64) {
-    if ((long)m_tiles * ceil_div(T, 128) >= 256 || nk_all < 48 || (size_t)3 * T * M * 4 > kSplitKWorkspaceBytes)
-      return {0, 0};
-    const int nk_slice = ceil_div(nk_all, 3);
-    return {ceil_div(nk_all, nk_slice), nk_slice};
+    const int tt = T <= 256 ? 64 : 128;
+    const long tiles = (long)m_tiles * ceil_div(T, tt);
+    if (tiles > 170) return {0, 0, 0};
+    int want = (int)(512 / tiles);
+    want = want > 8 ? 8 : want;
+    int nk_slice = ceil_div(nk_all, want);
+    nk_slice = nk_slice < 6 ? 6 : nk_slice;
+    const int ksplit = ceil_div(nk_all, nk_slice);
+    if (ksplit < 2 || (size_t)ksplit * T * M * 4 > kSplitKWorkspaceBytes) return {0, 0, 0};
+    return {ksplit, nk_slice, tt};
   }
-  if (M >= kSplitKMaxRows) return {0, 0};
+  if (M >= kSplitKMaxRows) return {0, 0, 0};
   int want = ceil_div(192, m_tiles);
   want = want > 8 ? 8 : want;
-  if (want < 2 || nk_all < 8) return {0, 0};
+  if (want < 2 || nk_all < 8) return {0, 0, 0};
   int nk_slice = ceil_div(nk_all, want);
   nk_slice = nk_slice < 4 ? 4 : nk_slice;
   const int ksplit = ceil_div(nk_all, nk_slice);   // no empty slice
-  if (ksplit < 2 || (size_t)ksplit * T * M * 4 > kSplitKWorkspaceBytes) return {0, 0};
-  return {ksplit, nk_slice};
+  if (ksplit < 2 || (size_t)ksplit * T * M * 4 > kSplitKWorkspaceBytes) return {0, 0, 0};
+  return {ksplit, nk_slice, 64};
 }
 // the split GEMM itself: fp32 partials into the workspace (128x64 tiles, ring 3 up to 64 columns; 128x128 tiles,
 // ring 2 - two workgroups per CU - above), then optionally the plain slice-sum launch
 static void glds_splitk_launch(const Half* W, const Half* X, Half* Y, int M, int T, int K, SplitOut so, SplitKPlan pl,
                                hipStream_t s, bool reduce = true) {
   const int m_tiles = ceil_div(M, BM);
-  if (T <= 64) {
+  if (pl.tt == 64) {
     constexpr int kLds = 3 * (BM + 64) * 8 * 16;
     static const bool once = [] {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_gemm_glds_kernel<64, 3, true>),
@@ -497,8 +505,9 @@ static void glds_splitk_launch(const Half* W, const Half* X, Half* Y, int M, int
       return true;
     }();
     (void)once;
-    mfma_gemm_glds_kernel<64, 3, true><<<dim3(m_tiles, pl.ksplit), 256, kLds, s>>>(W, X, Y, M, T, K, m_tiles, 1, so,
-                                                                                   g_splitk_ws, pl.nk_slice);
+    const int t_tiles = ceil_div(T, 64);
+    mfma_gemm_glds_kernel<64, 3, true><<<dim3(m_tiles * t_tiles, pl.ksplit), 256, kLds, s>>>(
+        W, X, Y, M, T, K, m_tiles, t_tiles, so, g_splitk_ws, pl.nk_slice);
   } else {
     constexpr int kLds = 2 * (BM + 128) * 8 * 16;
     static const bool once = [] {
@@ -622,7 +631,7 @@ extern "C" {
 int32_t cuda_set_device(int32_t device_ordinal) { return static_cast<int32_t>(hipSetDevice(device_ordinal)); }
 
 // The reference creates two thread-local cuBLAS handles + a 32 MB prefill workspace here
-// (csrc/linear.cu:14-42).  The HIP GEMMs need no handles; the one thing kept per thread is a 32 MB fp32
+// (csrc/linear.cu:14-42).  The HIP GEMMs need no handles; the one thing kept per thread is a 64 MB fp32
 // workspace for the split-K route of mid-size decode batches.  Same call contract: per-thread, safe to call
 // repeatedly (counted: the workspace goes away with the last destroy).
 static thread_local int g_blas_inits = 0;
