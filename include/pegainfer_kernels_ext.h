@@ -21,16 +21,17 @@ extern "C" {
 pegainfer_status_t pegainfer_batched_top1(const Half* logits, int32_t vocab_size, int32_t rows, int64_t row_stride, uint8_t* state_scratch, int32_t* out_tokens, pegainfer_stream_t stream);
 
 /* Decode GEMM (T <= 64 token columns, weights streamed once) with optional prologue / epilogue fused in; same
- * accumulation cores as gemm_graphsafe_cuda (dot2 GEMV at T = 1, skinny MFMA GEMM at 2 <= T <= 64), so every
- * form below is bit-identical to the unfused reference-ABI sequence:
+ * accumulation cores as gemm_graphsafe_cuda (dot2 GEMV at T <= 2, skinny MFMA GEMM at 3 <= T <= 16, the tiled
+ * LDS-DMA GEMM - split over K for matrices below 16384 rows - at 17 <= T <= 64), so every form below is
+ * bit-identical to the unfused reference-ABI sequence:
  *   norm_weight == NULL                : Y = W.X                                  (== gemm_graphsafe_cuda)
  *   norm_weight, residual == NULL      : Y = W.rms_norm(X)                        (rms_norm_batched_cuda + gemm)
  *   norm_weight, residual, hidden_out  : hidden_out = bf16(X + residual); Y = W.rms_norm(X + residual)
  *                                        (fused_add_rms_norm_batched_cuda + gemm; hidden_out != X)
  *   silu_intermediate = I > 0          : W = [gate; up] (M == 2I), Y[T, I] = silu_mul_fused(W.x)
  *                                        (gemm + silu_mul_fused_cuda)
- * The plain form takes T <= 64; the prologue / epilogue forms T <= 16 (larger decode batches run the unfused
- * sequence, whose big GEMMs use the tiled LDS-DMA kernel).  Returns hipErrorInvalidValue for shapes it does not
+ * The plain form takes T <= 64; the prologue / epilogue forms T <= 16 (larger decode batches use
+ * pegainfer_gemm_silu / pegainfer_gemm_add_rms_norm around the tiled kernels instead).  Returns hipErrorInvalidValue for shapes it does not
  * take (K % 8, misaligned, ...) so the caller can fall back to the unfused sequence. */
 pegainfer_status_t pegainfer_gemv_fused(const Half* W, const Half* X, Half* Y, int32_t M, int32_t T, int32_t K, const Half* residual, const Half* norm_weight, Half* hidden_out, float eps, int32_t silu_intermediate, pegainfer_stream_t stream);
 
