@@ -353,8 +353,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (long)T * m4) return;
   const int t = (int)(idx / m4), m = (int)(idx - (long)t * m4) * 4;
-  f32x4 v = *reinterpret_cast<const f32x4*>(part + (size_t)t * M + m);
-  for (int z = 1; z < ksplit; ++z) v += *reinterpret_cast<const f32x4*>(part + ((size_t)z * T + t) * M + m);
+  f32x4 pv[8];   // ksplit <= 8: every slice's load leaves before the first add (slice order is kept)
+#pragma unroll
+  for (int z = 0; z < 8; ++z)
+    if (z < ksplit) pv[z] = *reinterpret_cast<const f32x4*>(part + ((size_t)z * T + t) * M + m);
+  f32x4 v = pv[0];
+#pragma unroll
+  for (int z = 1; z < 8; ++z)
+    if (z < ksplit) v += pv[z];
   Half* dst = Y;
   int ld = M, mm = m;
   if (so.Y1) {
@@ -426,8 +432,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_add_kernel(const float* __r
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (long)T * m4) return;
   const int t = (int)(idx / m4), m = (int)(idx - (long)t * m4) * 4;
-  f32x4 v = *reinterpret_cast<const f32x4*>(part + (size_t)t * M + m);
-  for (int z = 1; z < ksplit; ++z) v += *reinterpret_cast<const f32x4*>(part + ((size_t)z * T + t) * M + m);
+  f32x4 pv[8];
+#pragma unroll
+  for (int z = 0; z < 8; ++z)
+    if (z < ksplit) pv[z] = *reinterpret_cast<const f32x4*>(part + ((size_t)z * T + t) * M + m);
+  f32x4 v = pv[0];
+#pragma unroll
+  for (int z = 1; z < 8; ++z)
+    if (z < ksplit) v += pv[z];
   const u32x2 av = *reinterpret_cast<const u32x2*>(a + (size_t)t * M + m);
   u32x2 o;
   o.x = pack_bf2(bf_lo(av.x) + bf16_round_f(v[0]), bf_hi(av.x) + bf16_round_f(v[1]));
