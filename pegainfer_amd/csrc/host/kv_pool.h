@@ -105,6 +105,7 @@ inline SplitPlan make_split_plan(int policy, const std::vector<int>& seq_lens, i
   SplitPlan p;
   int max_seq = 0;
   for (int n : seq_lens) max_seq = std::max(max_seq, n);
+  int slots_per_request = kSplitMaxChunksPerRequest;   // launch-grid slots per (padded) request
   if (policy == 0) {
     p.chunk = std::max(256, (max_seq + kSplitMaxChunksPerRequest - 1) / kSplitMaxChunksPerRequest);
     p.use_split = padded_bs <= 2 && max_seq >= 1024;
@@ -123,8 +124,12 @@ inline SplitPlan make_split_plan(int policy, const std::vector<int>& seq_lens, i
     chunk = std::max(64, (chunk + 15) / 16 * 16);
     p.chunk = chunk;
     p.use_split = want > 1 && max_seq > chunk;
+    // a request never gets more than `want` chunks, and `want` depends on the bucket only: the launch grid (fixed
+    // at graph capture) needs padded_bs * want slots, not the reference's padded_bs * 64 - at bs 16 that is 512
+    // workgroups instead of 8192 of which 7680 exited at once (SQ_WAVES per launch 32768 -> 2048)
+    slots_per_request = want;
   }
-  p.slots = padded_bs * kSplitMaxChunksPerRequest;
+  p.slots = padded_bs * slots_per_request;
   p.o_indptr.push_back(0);
   for (size_t r = 0; r < seq_lens.size(); ++r) {
     const int chunks = std::max(1, (seq_lens[r] + p.chunk - 1) / p.chunk);
