@@ -47,10 +47,10 @@ def algorithmic_bytes_per_token(cfg, ctx, batch=1):
     return weights + batch * (kv_tok * ctx + kv_tok + 2 * H + 2 * V)
 
 
-def cpu_baseline(cfg, steps, threads):
+def cpu_baseline(cfg, steps, threads, ctx=1024):
     """Oracle ("port") decode on the host cores: the numpy restatement of the same DAG on a synthetic
-    checkpoint of the SAME shape, bounded to `steps` decode steps at ctx 16 (weight streaming dominates
-    the CPU cost just as on the GPU).  Reported baseline only."""
+    checkpoint of the SAME shape, bounded to `steps` decode steps at the bench's own context length.
+    Reported baseline only."""
     from oracle import ops as oracle_ops
     from oracle.bf16 import bf16_round
     from oracle.qwen3_ref import KvState, Qwen3Config, Qwen3Oracle
@@ -87,9 +87,16 @@ def cpu_baseline(cfg, steps, threads):
         w[p + "mlp.down_proj.weight"] = t(c.hidden_size, c.intermediate_size)
         w[p + "input_layernorm.weight"] = t(c.hidden_size, mean=1.0)
         w[p + "post_attention_layernorm.weight"] = t(c.hidden_size, mean=1.0)
-    m = Qwen3Oracle(c, w, num_pages=8, rope_positions=64)
+    # the SAME workload as the timed GPU leg: one request at --ctx cached tokens.  The prompt's KV is not computed
+    # (a 36-layer numpy prefill of 1024 tokens would be minutes of untimed CPU work): the request's pages are
+    # filled with seeded bf16 values directly - decode cost depends on the KV bytes scanned, not on their values
+    npages = -(-(ctx + steps + 1) // 16) + 2
+    m = Qwen3Oracle(c, w, num_pages=npages, rope_positions=ctx + steps + 16)
     st = KvState()
-    m.batch_prefill([synthetic_prompt(16)], [st])
+    m._ensure(st, ctx)
+    st.seq_len = ctx
+    kvpool = bf16_round((np.random.default_rng(7).standard_normal(1 << 20) * 0.5).astype(np.float32))
+    m.kv[m.layout.page_stride:] = np.resize(kvpool, m.kv.size - m.layout.page_stride)
     setup_s = time.perf_counter() - t_gen
     t0 = time.perf_counter()
     tok = 100
@@ -97,9 +104,10 @@ def cpu_baseline(cfg, steps, threads):
         tok = int(m.batch_decode([tok], [st])[0].argmax())
     dt = time.perf_counter() - t0
     return {"value": steps / dt, "unit": "tokens/s", "cores": threads, "kind": "port",
-            "sample": f"{steps} greedy decode steps, bs=1, ctx 16->{16 + steps}, oracle/qwen3_ref.py (numpy fp32 "
-                      f"matmul over bf16-valued weights) on a synthetic checkpoint of the same shape; "
-                      f"{dt:.1f} s timed, {setup_s:.0f} s untimed setup"}
+            "sample": f"{steps} greedy decode steps, bs=1, ctx {ctx}->{ctx + steps} (the GPU leg's workload; KV pages "
+                      f"seeded directly, no CPU prefill), oracle/qwen3_ref.py (numpy fp32 matmul over bf16-valued "
+                      f"weights) on a synthetic checkpoint of the same shape; {dt:.1f} s timed, {setup_s:.0f} s "
+                      f"untimed setup"}
 
 
 
@@ -182,7 +190,7 @@ def run_qwen35(args, rank, world, local, dist, torch):
     step_bytes = qwen35_bytes_per_token(cfg, args.ctx + args.warmup + args.steps / 2, args.batch)
     out = {
         "metric": "decode tokens/sec + TTFT, Qwen3.5-4B bf16 greedy, 1xMI355X",
-        "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "rccl_ranks": (dist.get_world_size() if world > 1 else 1), "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"qwen3.5-4b hybrid (24 linear + 8 full-attention layers) greedy decode, hipGraph "
@@ -261,7 +269,7 @@ def run_serving(args, rank, world, local, dist, torch):
     out = {
         "metric": "decode tokens/sec + TTFT, Qwen3-4B bf16 greedy, 1xMI355X" if args.model == "qwen3-4b"
                   else "decode tokens/sec + TTFT, Qwen3-8B bf16 greedy, 1xMI355X",
-        "value": round(ntok * world / elapsed, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
+        "value": round(ntok * world / elapsed, 2), "unit": "tokens/s", "n_gpus": world, "rccl_ranks": (dist.get_world_size() if world > 1 else 1), "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / max(sum(plans.values()), 1), 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"{args.model} serving through the continuous-batching scheduler: {C} concurrent "
@@ -311,6 +319,19 @@ def main():
                          "(strong scaling, 72 all-reduces per step)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher - one process per GPU over RCCL, exactly what the
+        # driver's `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` does
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        return subprocess.call(cmd, env=env)
+
     import torch
     import torch.distributed as dist
     from pegainfer_amd.qwen3 import QWEN3_4B, QWEN3_8B, Qwen3Engine
@@ -318,11 +339,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    if world > 1:
+        if torch.cuda.device_count() < world:
+            raise SystemExit(f"--gpus {world} but only {torch.cuda.device_count()} device(s) are visible")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if world != args.gpus or (world > 1 and dist.get_world_size() != args.gpus):
+        raise SystemExit(f"--gpus {args.gpus} does not match the launched world size {world}: the line would "
+                         "mis-report n_gpus")
 
     from pegainfer_amd import parallel
     if args.model == "qwen3.5-4b":
@@ -402,7 +428,7 @@ def main():
     out = {
         "metric": "decode tokens/sec + TTFT, Qwen3-4B bf16 greedy, 1xMI355X" if args.model == "qwen3-4b"
                   else "decode tokens/sec + TTFT, Qwen3-8B bf16 greedy, 1xMI355X",
-        "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "rccl_ranks": (dist.get_world_size() if world > 1 else 1), "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
         "scaling": "strong" if tp else "weak",
         "vs_baseline": None, "dtype": "bf16", "data": data,
@@ -460,7 +486,7 @@ def main():
         if args.cpu_steps > 0 and world == 1:
             threads = os.cpu_count() or 1
             try:
-                out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_steps, threads)
+                out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_steps, threads, args.ctx)
             except MemoryError:
                 out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": threads, "kind": "port",
                                        "sample": "skipped: host RAM too small for the fp32 oracle weights"}
@@ -472,4 +498,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

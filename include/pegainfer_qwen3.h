@@ -72,6 +72,8 @@ int32_t pegainfer_qwen3_request_seq_len(pegainfer_qwen3_t m, int32_t request_id)
 int32_t pegainfer_qwen3_available_pages(pegainfer_qwen3_t m);
 /* KvPool::capacity_pages (kv_pool.rs): pages in the pool including the reserved padding page */
 int32_t pegainfer_qwen3_capacity_pages(pegainfer_qwen3_t m);
+/* the max_batch_size the model was created with (rows of the decode buffers) */
+int32_t pegainfer_qwen3_max_batch_size(pegainfer_qwen3_t m);
 
 /* batch_prefill (prefill.rs:220-285): greedy first token per request; optional last-position
  * logits copied to host as bf16 bits [n_requests, vocab]. */

@@ -51,6 +51,7 @@ int32_t pegainfer_qwen35_drop_request(pegainfer_qwen35_t m, int32_t request_id);
 int32_t pegainfer_qwen35_request_seq_len(pegainfer_qwen35_t m, int32_t request_id);
 int32_t pegainfer_qwen35_available_pages(pegainfer_qwen35_t m);
 int32_t pegainfer_qwen35_capacity_pages(pegainfer_qwen35_t m);
+/* the max_batch_size the model was created with (rows of the decode buffers) */
 int32_t pegainfer_qwen35_max_batch_size(pegainfer_qwen35_t m);
 
 /* prefill_forward (prefill.rs:21-120): appends n_tokens to the request (recurrent + conv state carried over),

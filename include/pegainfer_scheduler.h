@@ -37,6 +37,10 @@ typedef struct {
                      const uint32_t* tokens, const float* temperature, const int32_t* top_k, const float* top_p,
                      const float* random_vals, uint32_t* out_tokens);
   const char* (*last_error)(void* user);
+  /* optional (may be NULL = unlimited): the largest n_prefill + n_decode one execute() call accepts - the model's
+   * decode-buffer batch (the reference lane always allocates its 64 bucket, batch_decode_buffers.rs:12-46; here it is
+   * a constructor argument).  Admission leaves requests beyond it in the deferred queue instead of failing the step. */
+  int32_t (*max_batch_size)(void* user);
 } pegainfer_executor_vtbl;
 
 enum { PEGAINFER_EVENT_TOKEN = 1, PEGAINFER_EVENT_FINISHED = 2, PEGAINFER_EVENT_ERROR = 3, PEGAINFER_EVENT_REJECTED = 4 };

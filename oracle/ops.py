@@ -320,11 +320,54 @@ def paged_attention_decode_split_kv(q, kv_data, layout, layer, page_indices, pag
 
 
 def batch_prefill_paged(q, kv_data, layout, layer, page_indices, page_indptr, last_page_len,
-                        q_indptr, num_q_heads, sm_scale):
+                        q_indptr, num_q_heads, sm_scale, row_block=1024):
     """Causal varlen GQA prefill over the paged cache (wrapper
     csrc/paged_attention.cu:399-535 -> FlashInfer BatchPrefillWithPagedKVCacheDispatched,
     MaskMode::kCausal): query row i of a request with qo_len rows and kv_len cached
-    tokens attends kv positions <= i + kv_len - qo_len.  q: [T, Hq*D] -> o: [T, Hq*D]."""
+    tokens attends kv positions <= i + kv_len - qo_len.  q: [T, Hq*D] -> o: [T, Hq*D].
+
+    Same float64 arithmetic as ``batch_prefill_paged_rowwise`` (scores, max-subtracted exp,
+    normalised PV, one bf16 rounding), evaluated one (request, kv head, row block) at a time as two
+    matrix products so that 2-4k-token cases finish in seconds; tests/test_oracle_kats.py pins the
+    two forms against each other."""
+    D = layout.head_dim
+    out = np.zeros_like(q, dtype=F32)
+    nreq = len(q_indptr) - 1
+    for b in range(nreq):
+        q0, q1 = int(q_indptr[b]), int(q_indptr[b + 1])
+        qo_len = q1 - q0
+        if qo_len <= 0:
+            continue
+        kv_len = paged_kv_len(page_indptr, last_page_len, b, layout.page_size)
+        pages = page_indices[int(page_indptr[b]): int(page_indptr[b + 1])]
+        K, V = _gather_kv(kv_data, layout, layer, pages, kv_len)
+        Hkv = K.shape[1]
+        g = num_q_heads // Hkv
+        Qb = q[q0:q1].reshape(qo_len, num_q_heads, D)
+        ob = out[q0:q1].reshape(qo_len, num_q_heads, D)
+        for kh in range(Hkv):
+            Kh = K[:, kh, :].astype(np.float64)
+            Vh = V[:, kh, :].astype(np.float64)
+            for r0 in range(0, qo_len, row_block):
+                r1 = min(qo_len, r0 + row_block)
+                hi = np.arange(r0, r1) + (kv_len - qo_len) + 1            # kv positions < hi are visible
+                top = int(hi[-1])
+                Qg = Qb[r0:r1, kh * g:(kh + 1) * g, :].astype(np.float64)  # [rows, g, D]
+                S = (Qg.reshape(-1, D) @ Kh[:top].T) * np.float64(sm_scale)
+                S = S.reshape(r1 - r0, g, top)
+                masked = np.arange(top)[None, :] >= hi[:, None]          # [rows, top], shared by the g heads
+                S = np.where(masked[:, None, :], -np.inf, S)
+                m = S.max(axis=-1, keepdims=True)
+                P = np.exp(S - m)
+                d = P.sum(axis=-1, keepdims=True)
+                O = (P.reshape(-1, top) @ Vh[:top]).reshape(r1 - r0, g, D) / d
+                ob[r0:r1, kh * g:(kh + 1) * g, :] = bf16_round(O.astype(F32))
+    return out
+
+
+def batch_prefill_paged_rowwise(q, kv_data, layout, layer, page_indices, page_indptr, last_page_len,
+                                q_indptr, num_q_heads, sm_scale):
+    """Row-at-a-time form of batch_prefill_paged (the literal restatement: one _attend per query row)."""
     D = layout.head_dim
     out = np.zeros_like(q, dtype=F32)
     nreq = len(q_indptr) - 1

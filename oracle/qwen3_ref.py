@@ -202,12 +202,28 @@ class Qwen3Oracle:
 
 def synthetic_weights(cfg, seed=42, std=0.02, dtype_round=True):
     """Seeded N(0, std) bf16 checkpoint of the given shape (used when no
-    real weights are on disk; throughput is data-independent)."""
-    rng = np.random.default_rng(seed)
+    real weights are on disk; throughput is data-independent).  Every tensor is drawn in fixed
+    4 Mi-element chunks, chunk j of tensor i from default_rng([seed, i, j]), so the values do not
+    depend on how many host threads fill them (a Qwen3-4B-width embedding table is 389 M draws)."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    CH = 1 << 22
+    pool = ThreadPoolExecutor(max_workers=max(1, min(32, os.cpu_count() or 1)))
+    counter = [0]
 
     def t(*shape, scale=std, mean=0.0):
-        a = (rng.standard_normal(shape, dtype=F32) * F32(scale) + F32(mean)).astype(F32)
-        return bf16_round(a) if dtype_round else a
+        idx = counter[0]
+        counter[0] += 1
+        n = int(np.prod(shape))
+        out = np.empty(n, dtype=F32)
+
+        def fill(j):
+            lo, hi = j * CH, min(n, (j + 1) * CH)
+            a = np.random.default_rng([seed, idx, j]).standard_normal(hi - lo, dtype=F32)
+            a = a * F32(scale) + F32(mean)
+            out[lo:hi] = bf16_round(a) if dtype_round else a
+        list(pool.map(fill, range(-(-n // CH))))
+        return out.reshape(shape)
 
     c = cfg
     w = {"model.embed_tokens.weight": t(c.vocab_size, c.hidden_size),
@@ -227,4 +243,5 @@ def synthetic_weights(cfg, seed=42, std=0.02, dtype_round=True):
         w[p + "mlp.down_proj.weight"] = t(c.hidden_size, c.intermediate_size)
         w[p + "input_layernorm.weight"] = t(c.hidden_size, scale=0.1, mean=1.0)
         w[p + "post_attention_layernorm.weight"] = t(c.hidden_size, scale=0.1, mean=1.0)
+    pool.shutdown()
     return w

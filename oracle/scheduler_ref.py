@@ -69,12 +69,16 @@ class SchedulerOracle:
                          - pages_needed(a["prompt_len"] + max(a["generated"] - 1, 0), ps)) for a in self.active)
         budget = max(0, self.ex.available_pages() - future)
         pending, still, rejected = [], [], []
+        # optional executor.max_batch_size(): rows one execute() call may carry (active requests always decode)
+        cap = getattr(self.ex, "max_batch_size", None)
+        rows_left = max(0, cap() - len(self.active)) if cap else -1
         for req in self.deferred:
             need = pages_needed(len(req["prompt"]) + max(req["max_tokens"] - 1, 0), ps)
             if need > self.ex.max_request_pages():
                 rejected.append(req)
-            elif need <= budget:
+            elif need <= budget and rows_left != 0:
                 budget -= need
+                rows_left -= 1 if rows_left > 0 else 0
                 pending.append(req)
             else:
                 still.append(req)

@@ -62,6 +62,11 @@ struct KvState {
     const int rem = seq_len % page_size;
     return rem == 0 ? page_size : rem;
   }
+  // pages a later ensure_capacity(tokens) would have to acquire (callers validate a whole batch before mutating)
+  int pages_short(int tokens, int page_size) const {
+    const int needed = (tokens + page_size - 1) / page_size;
+    return std::max(0, needed - static_cast<int>(pages.size()));
+  }
   bool ensure_capacity(PagePool* pool, int tokens, int page_size) {
     const int needed = (tokens + page_size - 1) / page_size;
     const int held = static_cast<int>(pages.size());

@@ -79,6 +79,7 @@ struct Request35 {
 struct Model35 {
   int device, H, I, L, V, Hq, Hkv, D, kh, vh, convK, rotary, max_pos, num_pages, max_bs, enable_graph, split_policy;
   int decode_mode = [] { const char* e = getenv("PEGAINFER_Q35_DECODE_MODE"); return e ? atoi(e) : 1; }();
+  int split_slots = 0;  // slots launched by the partition-KV attention of the current step (= SplitPlan::slots)
   float eps, theta;
   int q_dim, kv_dim, C, Z, n_full = 0, n_lin = 0;
   std::string err;
@@ -431,7 +432,7 @@ struct Model35 {
           rc = pegainfer_paged_attention_decode_split_kv_hd256(
               q_attn, attn_out, kv_buffer, layout.k_offset(full), layout.v_offset(full), md(m_pages), md(m_indptr),
               md(m_lpl), md(m_sri), md(m_skt), md(m_skc), md(m_soi), meta_dev + m_sva, split_tmp_v, split_tmp_s, Hq, Hkv,
-              D, layout.page_size, bs, bs * pq::kSplitMaxChunksPerRequest, layout.page_stride, sm, merge_ctr, S());
+              D, layout.page_size, bs, split_slots, layout.page_stride, sm, merge_ctr, S());
         else if (!rc)
           rc = paged_attention_decode_cuda_hd256(q_attn, attn_out, kv_buffer, layout.k_offset(full), layout.v_offset(full),
                                                  md(m_pages), md(m_indptr), md(m_lpl), md(m_ri), md(m_kti), md(m_kcs), Hq,
@@ -500,7 +501,7 @@ struct Model35 {
           rc = pegainfer_paged_attention_decode_split_kv_hd256(
               q_attn, attn_out, kv_buffer, layout.k_offset(full), layout.v_offset(full), md(m_pages), md(m_indptr),
               md(m_lpl), md(m_sri), md(m_skt), md(m_skc), md(m_soi), meta_dev + m_sva, split_tmp_v, split_tmp_s, Hq, Hkv,
-              D, layout.page_size, 1, pq::kSplitMaxChunksPerRequest, layout.page_stride, sm, merge_ctr, S());
+              D, layout.page_size, 1, split_slots, layout.page_stride, sm, merge_ctr, S());
         else if (!rc)
           rc = paged_attention_decode_cuda_hd256(q_attn, attn_out, kv_buffer, layout.k_offset(full), layout.v_offset(full),
                                                  md(m_pages), md(m_indptr), md(m_lpl), md(m_ri), md(m_kti), md(m_kcs), Hq,
@@ -548,12 +549,18 @@ struct Model35 {
         if (ids[j] == ids[i]) { set_error("duplicate request id in decode batch"); return -1; }
     }
     auto mh = [&](size_t off) { return reinterpret_cast<int32_t*>(meta_host + off); };
+    // validate the whole batch before any KvState is advanced: a failed call leaves every request untouched
+    int pages_short = 0;
+    for (int i = 0; i < n; ++i) {
+      if (rs[i]->kv.seq_len + 1 > max_pos) { set_error("position beyond the RoPE table"); return -1; }
+      pages_short += rs[i]->kv.pages_short(rs[i]->kv.seq_len + 1, layout.page_size);
+    }
+    if (pages_short > pool.available()) { set_error("KV pool exhausted"); return -1; }
     int np = 0;
     mh(m_indptr)[0] = 0;
     for (int i = 0; i < n; ++i) {
       KvState& kv = rs[i]->kv;
       const int pos = kv.seq_len;
-      if (pos + 1 > max_pos) { set_error("position beyond the RoPE table"); return -1; }
       if (!kv.ensure_capacity(&pool, pos + 1, layout.page_size)) { set_error("KV pool exhausted"); return -1; }
       kv.seq_len += 1;
       mh(m_tok)[i] = (int32_t)toks[i];
@@ -571,6 +578,11 @@ struct Model35 {
     for (int i = 0; i < n; ++i) seq_lens[i] = rs[i]->kv.seq_len;
     const pq::SplitPlan plan = pq::make_split_plan(1, seq_lens, n, Hkv);
     const bool split = allow_split && plan.use_split;
+    // the launch covers exactly the slots refreshed below: plan.slots = n * (chunks per request), a function of n and
+    // Hkv only, so it is constant for a captured graph (the key holds the request ids).  Launching n * 64 slots would
+    // run slots whose request / tile / valid entries are left over from a step with a different batch size; such a
+    // stale slot naming a live request bumps its merge counter and can fire the in-launch merge early.
+    split_slots = plan.slots;
     std::memcpy(mh(m_sri), plan.request_indices.data(), (size_t)plan.slots * 4);
     std::memcpy(mh(m_skt), plan.kv_tile_indices.data(), (size_t)plan.slots * 4);
     mh(m_skc)[0] = plan.chunk;

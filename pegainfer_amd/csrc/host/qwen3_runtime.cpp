@@ -242,35 +242,69 @@ struct Model {
   }
 
   // ------------------------------------------------------------------ weights
-  int load_tensor(const char* name_c, const void* host, int64_t numel) {
+  // expected tensors: 3 globals (embed, lm_head unless tied, final norm) + 11 per layer; `loaded` is checked by finalize()
+  enum { kSlotEmbed = 0, kSlotLmHead = 1, kSlotNorm = 2, kSlotLayer0 = 3, kSlotsPerLayer = 11 };
+  std::vector<uint8_t> loaded;
+  int load_tensor(const char* name_c, const void* host, int64_t numel, const int64_t* shape = nullptr, int ndim = 0) {
     const std::string name(name_c);
     Half* dst = nullptr;
-    int64_t expect = 0;
-    auto set = [&](Half* p, int64_t n) { dst = p; expect = n; };
-    if (name == "model.embed_tokens.weight") set(embed, (int64_t)V * H);
-    else if (name == "lm_head.weight") { if (tie) return 0; set(lm_head, (int64_t)V * H); }
-    else if (name == "model.norm.weight") set(final_norm, H);
+    int64_t rows = 0, cols = 0;
+    int slot = -1;
+    auto set = [&](Half* p, int64_t r, int64_t c, int sl) { dst = p; rows = r; cols = c; slot = sl; };
+    if (name == "model.embed_tokens.weight") set(embed, V, H, kSlotEmbed);
+    else if (name == "lm_head.weight") { if (tie) return 0; set(lm_head, V, H, kSlotLmHead); }
+    else if (name == "model.norm.weight") set(final_norm, H, 1, kSlotNorm);
     else if (name.rfind("model.layers.", 0) == 0) {
       const size_t p0 = 13, p1 = name.find('.', p0);
-      const int li = std::stoi(name.substr(p0, p1 - p0));
+      if (p1 == std::string::npos || p1 == p0 || p1 - p0 > 6) { set_error("bad layer index in tensor name: " + name); return -1; }
+      int li = 0;
+      for (size_t i = p0; i < p1; ++i) {
+        if (name[i] < '0' || name[i] > '9') { set_error("bad layer index in tensor name: " + name); return -1; }
+        li = li * 10 + (name[i] - '0');
+      }
       if (li < 0 || li >= L) { set_error("layer index out of range: " + name); return -1; }
       const std::string rest = name.substr(p1 + 1);
       Layer& ly = layers[li];
-      if (rest == "self_attn.q_proj.weight") set(ly.qkv, (int64_t)q_dim * H);
-      else if (rest == "self_attn.k_proj.weight") set(ly.qkv + (size_t)q_dim * H, (int64_t)kv_dim * H);
-      else if (rest == "self_attn.v_proj.weight") set(ly.qkv + (size_t)(q_dim + kv_dim) * H, (int64_t)kv_dim * H);
-      else if (rest == "self_attn.o_proj.weight") set(ly.o, (int64_t)H * q_dim);
-      else if (rest == "self_attn.q_norm.weight") set(ly.q_norm, D);
-      else if (rest == "self_attn.k_norm.weight") set(ly.k_norm, D);
-      else if (rest == "mlp.gate_proj.weight") set(ly.gate_up, (int64_t)I * H);
-      else if (rest == "mlp.up_proj.weight") set(ly.gate_up + (size_t)I * H, (int64_t)I * H);
-      else if (rest == "mlp.down_proj.weight") set(ly.down, (int64_t)H * I);
-      else if (rest == "input_layernorm.weight") set(ly.ln1, H);
-      else if (rest == "post_attention_layernorm.weight") set(ly.ln2, H);
+      const int base = kSlotLayer0 + li * kSlotsPerLayer;
+      if (rest == "self_attn.q_proj.weight") set(ly.qkv, q_dim, H, base + 0);
+      else if (rest == "self_attn.k_proj.weight") set(ly.qkv + (size_t)q_dim * H, kv_dim, H, base + 1);
+      else if (rest == "self_attn.v_proj.weight") set(ly.qkv + (size_t)(q_dim + kv_dim) * H, kv_dim, H, base + 2);
+      else if (rest == "self_attn.o_proj.weight") set(ly.o, H, q_dim, base + 3);
+      else if (rest == "self_attn.q_norm.weight") set(ly.q_norm, D, 1, base + 4);
+      else if (rest == "self_attn.k_norm.weight") set(ly.k_norm, D, 1, base + 5);
+      else if (rest == "mlp.gate_proj.weight") set(ly.gate_up, I, H, base + 6);
+      else if (rest == "mlp.up_proj.weight") set(ly.gate_up + (size_t)I * H, I, H, base + 7);
+      else if (rest == "mlp.down_proj.weight") set(ly.down, H, I, base + 8);
+      else if (rest == "input_layernorm.weight") set(ly.ln1, H, 1, base + 9);
+      else if (rest == "post_attention_layernorm.weight") set(ly.ln2, H, 1, base + 10);
     }
     if (!dst) { set_error("unknown tensor name: " + name); return -1; }
-    if (numel != expect) { set_error("shape mismatch for " + name); return -1; }
+    if (numel != rows * cols) { set_error("shape mismatch for " + name); return -1; }
+    if (shape) {  // a transposed or re-shaped tensor with the right element count is still wrong
+      const bool ok = cols == 1 ? (ndim == 1 && shape[0] == rows) : (ndim == 2 && shape[0] == rows && shape[1] == cols);
+      if (!ok) { set_error("tensor " + name + " has the wrong shape (expected [" + std::to_string(rows) +
+                           (cols == 1 ? "]" : ", " + std::to_string(cols) + "]") + ")"); return -1; }
+    }
     PQ_HIP(hipMemcpy(dst, host, (size_t)numel * 2, hipMemcpyHostToDevice));
+    if (loaded.empty()) loaded.assign(kSlotLayer0 + (size_t)L * kSlotsPerLayer, 0);
+    loaded[slot] = 1;
+    return 0;
+  }
+  // every weight the forward pass reads must have been uploaded (weights are hipMalloc'ed uninitialised)
+  int check_all_loaded() {
+    if (loaded.empty()) loaded.assign(kSlotLayer0 + (size_t)L * kSlotsPerLayer, 0);
+    static const char* per_layer[] = {"self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "self_attn.o_proj",
+                                      "self_attn.q_norm", "self_attn.k_norm", "mlp.gate_proj", "mlp.up_proj",
+                                      "mlp.down_proj", "input_layernorm", "post_attention_layernorm"};
+    for (size_t sl = 0; sl < loaded.size(); ++sl) {
+      if (loaded[sl] || (sl == kSlotLmHead && tie)) continue;
+      std::string what = sl == kSlotEmbed ? "model.embed_tokens.weight" : sl == kSlotLmHead ? "lm_head.weight"
+                         : sl == kSlotNorm ? "model.norm.weight"
+                         : "model.layers." + std::to_string((sl - kSlotLayer0) / kSlotsPerLayer) + "." +
+                               per_layer[(sl - kSlotLayer0) % kSlotsPerLayer] + ".weight";
+      set_error("checkpoint is missing tensor " + what);
+      return -1;
+    }
     return 0;
   }
 
@@ -297,8 +331,9 @@ struct Model {
                        ends_with(name, "mlp.up_proj.weight");
       const bool col = ends_with(name, "self_attn.o_proj.weight") || ends_with(name, "mlp.down_proj.weight");
       const uint16_t* src = reinterpret_cast<const uint16_t*>(t.data);
+      if ((int64_t)t.nbytes != t.numel() * 2) { set_error("tensor " + name + ": data_offsets do not match its shape"); return -1; }
       if (world == 1 || (!row && !col)) {
-        if (load_tensor(name.c_str(), src, t.numel())) return -1;
+        if (load_tensor(name.c_str(), src, t.numel(), t.shape.data(), (int)t.shape.size())) return -1;
         continue;
       }
       if (t.shape.size() != 2) { set_error("tensor " + name + " expected 2-D"); return -1; }
@@ -306,14 +341,16 @@ struct Model {
       if (row) {
         if (rows % world) { set_error("rows of " + name + " not divisible by the TP world"); return -1; }
         const int64_t lr = rows / world;
-        if (load_tensor(name.c_str(), src + (size_t)rank * lr * cols, lr * cols)) return -1;
+        const int64_t shp[2] = {lr, cols};
+        if (load_tensor(name.c_str(), src + (size_t)rank * lr * cols, lr * cols, shp, 2)) return -1;
       } else {
         if (cols % world) { set_error("columns of " + name + " not divisible by the TP world"); return -1; }
         const int64_t lc = cols / world;
         staging.resize((size_t)rows * lc);
         for (int64_t r = 0; r < rows; ++r)
           std::memcpy(staging.data() + (size_t)r * lc, src + (size_t)r * cols + (size_t)rank * lc, (size_t)lc * 2);
-        if (load_tensor(name.c_str(), staging.data(), rows * lc)) return -1;
+        const int64_t shp[2] = {rows, lc};
+        if (load_tensor(name.c_str(), staging.data(), rows * lc, shp, 2)) return -1;
       }
     }
     return finalize();
@@ -324,6 +361,7 @@ struct Model {
     return 0;
   }
   int fill_synthetic(uint64_t seed, float std) {
+    loaded.assign(kSlotLayer0 + (size_t)L * kSlotsPerLayer, 1);
     uint64_t s = seed * 1000003ull;
     fill(embed, (size_t)V * H, ++s, std, 0.f);
     if (!tie) fill(lm_head, (size_t)V * H, ++s, std, 0.f);
@@ -345,6 +383,7 @@ struct Model {
   // RoPE tables: fp32 pos * theta^(-2i/D) -> cos/sin -> bf16, duplicated halves (weight_loader.rs:210-244),
   // sized to max_position_embeddings (the reference's 4096-row table is a latent OOB).
   int finalize() {
+    if (check_all_loaded()) return -1;
     const int half = D / 2;
     std::vector<float> inv(half);
     for (int i = 0; i < half; ++i) inv[i] = 1.0f / std::pow(theta, (float)i * 2.0f / (float)D);
@@ -556,11 +595,22 @@ struct Model {
     if (n <= 0 || n > max_bs) { set_error("bad batch size"); return -1; }
     std::vector<KvState*> st(n);
     std::vector<int> positions(n), seq_lens(n);
+    // validate the whole batch first (ids, RoPE range, bucket, total pages): a failed call must leave every
+    // request exactly as it was - no seq_len advanced, no page acquired
+    const int padded = enable_graph ? bucket_for(n) : n;
+    if (padded < 0 || padded > max_bs) { set_error("batch exceeds largest bucket"); return -1; }
+    int pages_short = 0;
     for (int i = 0; i < n; ++i) {
       st[i] = req(ids[i]);
       if (!st[i]) return -1;
+      for (int j = 0; j < i; ++j)
+        if (ids[j] == ids[i]) { set_error("duplicate request id in decode batch"); return -1; }
+      if (st[i]->seq_len + 1 > max_pos) { set_error("position exceeds RoPE table"); return -1; }
+      pages_short += st[i]->pages_short(st[i]->seq_len + 1, layout.page_size);
+    }
+    if (pages_short > pool.available()) { set_error("KvState: out of pages"); return -2; }
+    for (int i = 0; i < n; ++i) {
       positions[i] = st[i]->seq_len;
-      if (positions[i] + 1 > max_pos) { set_error("position exceeds RoPE table"); return -1; }
       if (!st[i]->ensure_capacity(&pool, positions[i] + 1, layout.page_size)) {
         set_error("KvState: out of pages");
         return -2;
@@ -568,8 +618,6 @@ struct Model {
       st[i]->seq_len += 1;
       seq_lens[i] = st[i]->seq_len;
     }
-    const int padded = enable_graph ? bucket_for(n) : n;
-    if (padded < 0 || padded > max_bs) { set_error("batch exceeds largest bucket"); return -1; }
     // ---- pack metadata (batch_decode.rs:45-59, batch_decode_buffers.rs:178-279) ----
     auto* tok = mh<uint32_t>(ml.token_ids);
     auto* pos = mh<int32_t>(ml.positions);
@@ -691,26 +739,31 @@ struct Model {
               void* out_logits_host, int n_decode_tail = 0) {
     if (!finalized) { set_error("model not finalized"); return -1; }
     if (n <= 0) { set_error("empty prefill"); return -1; }
+    if (n > max_bs) { set_error("prefill batch larger than max_batch_size"); return -1; }
+    const int n_pf = n - n_decode_tail;
+    if (n_decode_tail < 0 || n_pf < 1) { set_error("unified step needs >= 1 prefill request"); return -1; }
     std::vector<KvState*> st(n);
     std::vector<int> starts(n);
     size_t T = 0;
-    for (int i = 0; i < n; ++i) {
+    int pages_short = 0;
+    for (int i = 0; i < n; ++i) {   // every check before any KvState is advanced
       st[i] = req(ids[i]);
       if (!st[i]) return -1;
+      for (int j = 0; j < i; ++j)
+        if (ids[j] == ids[i]) { set_error("duplicate request id in prefill batch"); return -1; }
       if (lens[i] <= 0) { set_error("empty prompt"); return -1; }
+      if (i >= n_pf && lens[i] != 1) { set_error("decode-tail requests must contribute exactly one token"); return -1; }
       starts[i] = st[i]->seq_len;
       if (starts[i] + lens[i] > max_pos) { set_error("position exceeds RoPE table"); return -1; }
+      pages_short += st[i]->pages_short(starts[i] + lens[i], layout.page_size);
       T += lens[i];
     }
+    if (pages_short > pool.available()) { set_error("KvState: out of pages"); return -2; }
+    if (ensure_prefill_ws(T, n)) return -1;
     for (int i = 0; i < n; ++i) {  // ensure_capacity + advance (prefill.rs:236-240)
       if (!st[i]->ensure_capacity(&pool, starts[i] + lens[i], layout.page_size)) { set_error("KvState: out of pages"); return -2; }
       st[i]->seq_len += lens[i];
     }
-    const int n_pf = n - n_decode_tail;
-    if (n_decode_tail < 0 || n_pf < 1) { set_error("unified step needs >= 1 prefill request"); return -1; }
-    for (int i = n_pf; i < n; ++i)
-      if (lens[i] != 1) { set_error("decode-tail requests must contribute exactly one token"); return -1; }
-    if (ensure_prefill_ws(T, n)) return -1;
     // ---- plan (PrefillPagedPlan::new_batch_with_cta_tile_q, ops/attention.rs:208-302; tile 64 = config.rs:5) ----
     const int group = Hq / Hkv;
     const int P = (int)T - n_decode_tail;  // prefill token columns
@@ -825,7 +878,6 @@ struct Model {
       const int nb = std::min(16, n - i0);
       gemm_graphsafe_cuda(lm_head, pf_last_normed + (size_t)i0 * H, pf_logits + (size_t)i0 * V, V, nb, H, S());
     }
-    if (n > max_bs) { set_error("prefill batch larger than max_batch_size"); return -1; }
     if (pegainfer_batched_top1(pf_logits, V, n, V, top1_state, tokens_out_d, S())) { set_error("top1 failed"); return -1; }
     PQ_HIP(hipMemcpyAsync(tokens_out_host, tokens_out_d, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
     PQ_HIP(hipStreamSynchronize(stream));
@@ -1006,6 +1058,7 @@ pegainfer_qwen3_t pegainfer_qwen3_from_pretrained(const char* model_dir, int32_t
 }
 int32_t pegainfer_qwen3_available_pages(pegainfer_qwen3_t m) { return M(m)->pool.available(); }
 int32_t pegainfer_qwen3_capacity_pages(pegainfer_qwen3_t m) { return M(m)->pool.capacity(); }
+int32_t pegainfer_qwen3_max_batch_size(pegainfer_qwen3_t m) { return M(m)->max_bs; }
 int32_t pegainfer_qwen3_prefill(pegainfer_qwen3_t m, int32_t n, const int32_t* ids, const int32_t* lens,
                                 const uint32_t* tokens, int32_t* out_tokens, void* out_logits_host) {
   return M(m)->prefill(n, ids, lens, tokens, out_tokens, out_logits_host);

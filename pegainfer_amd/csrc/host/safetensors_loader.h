@@ -11,7 +11,9 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -130,11 +132,22 @@ class JsonParser {
     if (lit("true")) { out->kind = Json::Bool; out->b = true; return true; }
     if (lit("false")) { out->kind = Json::Bool; out->b = false; return true; }
     if (lit("null")) { out->kind = Json::Null; return true; }
+    // number: copy the token into a NUL-terminated buffer first - the input is an mmap with no terminator, and
+    // strtod on a file that ends in a digit would read past the mapping
+    char buf[64];
+    size_t len = 0;
+    while (p_ + len < e_ && len + 1 < sizeof(buf)) {
+      const char c = p_[len];
+      if (!((c >= '0' && c <= '9') || c == '-' || c == '+' || c == '.' || c == 'e' || c == 'E')) break;
+      buf[len++] = c;
+    }
+    if (len == 0) return false;
+    buf[len] = 0;
     char* end = nullptr;
-    out->num = std::strtod(p_, &end);
-    if (end == p_ || end > e_) return false;
+    out->num = std::strtod(buf, &end);
+    if (end != buf + len) return false;
     out->kind = Json::Num;
-    p_ = end;
+    p_ += len;
     return true;
   }
 };
@@ -186,8 +199,14 @@ class Checkpoint {
       for (auto& kv : wm->obj)
         if (kv.second.kind == Json::Str && std::find(files.begin(), files.end(), kv.second.str) == files.end())
           files.push_back(kv.second.str);
-      for (auto& fn : files)
+      for (auto& fn : files) {
+        // shard names come from an untrusted index: plain file names only, inside the model directory
+        if (fn.empty() || fn.find('/') != std::string::npos || fn.find('\\') != std::string::npos || fn == "." || fn == "..") {
+          *err = "index names a shard outside the model directory: " + fn;
+          return false;
+        }
         if (!add_file(path + "/" + fn, err)) return false;
+      }
       return true;
     }
     return add_file(path + "/model.safetensors", err);
@@ -222,11 +241,24 @@ class Checkpoint {
       if (!dt || !sh || !off || off->arr.size() != 2) { *err = "bad tensor entry " + kv.first; return false; }
       TensorView t;
       t.dtype = dt->str;
-      for (auto& d : sh->arr) t.shape.push_back((int64_t)d.num);
+      for (auto& d : sh->arr) {
+        if (d.kind != Json::Num || d.num < 0 || d.num > 4e12) { *err = "bad shape in tensor entry " + kv.first; return false; }
+        t.shape.push_back((int64_t)d.num);
+      }
       const size_t a = (size_t)off->arr[0].num, b = (size_t)off->arr[1].num;
       if (a > b || b > avail) { *err = "tensor out of file bounds: " + kv.first; return false; }
       t.data = base + a;
       t.nbytes = b - a;
+      {  // the byte range must be exactly numel x element size: consumers slice and upload by shape
+        static const std::pair<const char*, int> kSizes[] = {{"BF16", 2}, {"F16", 2}, {"F32", 4}, {"F64", 8}, {"I64", 8},
+                                                             {"I32", 4}, {"I16", 2}, {"I8", 1}, {"U8", 1}, {"BOOL", 1},
+                                                             {"F8_E4M3", 1}, {"F8_E5M2", 1}};
+        for (auto& ds : kSizes)
+          if (t.dtype == ds.first && (uint64_t)t.numel() * (uint64_t)ds.second != (uint64_t)t.nbytes) {
+            *err = "tensor " + kv.first + ": data_offsets do not match its shape";
+            return false;
+          }
+      }
       tensors_[kv.first] = std::move(t);
     }
     files_.push_back(std::move(f));

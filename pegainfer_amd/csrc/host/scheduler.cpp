@@ -47,6 +47,7 @@ struct Qwen3Exec {
   static int32_t page_size(void*) { return 16; }
   static int32_t max_request_pages(void* u) { return pegainfer_qwen3_capacity_pages(((Qwen3Exec*)u)->model) - 1; }
   static int32_t available_pages(void* u) { return pegainfer_qwen3_available_pages(((Qwen3Exec*)u)->model); }
+  static int32_t max_batch_size(void* u) { return pegainfer_qwen3_max_batch_size(((Qwen3Exec*)u)->model); }
   static int32_t is_stop_token(void* u, uint32_t t) { return ((Qwen3Exec*)u)->stop.count(t) ? 1 : 0; }
   static int32_t drop_request(void* u, uint64_t id) {
     auto* e = (Qwen3Exec*)u;
@@ -106,6 +107,7 @@ struct Qwen35Exec {
   static int32_t page_size(void*) { return 16; }
   static int32_t max_request_pages(void* u) { return pegainfer_qwen35_capacity_pages(((Qwen35Exec*)u)->model) - 1; }
   static int32_t available_pages(void* u) { return pegainfer_qwen35_available_pages(((Qwen35Exec*)u)->model); }
+  static int32_t max_batch_size(void* u) { return pegainfer_qwen35_max_batch_size(((Qwen35Exec*)u)->model); }
   static int32_t is_stop_token(void* u, uint32_t t) { return ((Qwen35Exec*)u)->stop.count(t) ? 1 : 0; }
   static int32_t drop_request(void* u, uint64_t id) {
     auto* e = (Qwen35Exec*)u;
@@ -180,6 +182,8 @@ struct Scheduler {
                                 pages_needed(a.prompt_len + std::max(a.generated - 1, 0), ps));
     long budget = std::max<long>(0, (long)ex.available_pages(ex.user) - future);
     const int max_req = ex.max_request_pages(ex.user);
+    // rows one execute() call may carry: active requests always decode, so only the remainder can be admitted
+    long rows_left = ex.max_batch_size ? std::max<long>(0, (long)ex.max_batch_size(ex.user) - (long)active.size()) : -1;
     std::vector<Pending> pending, still;
     for (Pending& r : deferred) {
       const int need = pages_needed(max_tokens_of((int)r.prompt.size(), r.max_tokens), ps);
@@ -188,8 +192,9 @@ struct Scheduler {
                        std::to_string(r.prompt.size()) + ", max_context_tokens=" +
                        std::to_string(max_tokens_of((int)r.prompt.size(), r.max_tokens));
         send(r.id, PEGAINFER_EVENT_REJECTED, 0, 0, (int)r.prompt.size(), 0);
-      } else if (need <= budget) {
+      } else if (need <= budget && rows_left != 0) {
         budget -= need;
+        if (rows_left > 0) --rows_left;
         pending.push_back(std::move(r));
       } else {
         still.push_back(std::move(r));
@@ -317,7 +322,8 @@ pegainfer_sched_t pegainfer_sched_create_qwen3(void* model, uint64_t seed, const
   for (int i = 0; i < n_stop; ++i) e->stop.insert(stop_tokens[i]);
   pegainfer_executor_vtbl v{e, &psched::Qwen3Exec::page_size, &psched::Qwen3Exec::max_request_pages,
                             &psched::Qwen3Exec::available_pages, &psched::Qwen3Exec::is_stop_token,
-                            &psched::Qwen3Exec::drop_request, &psched::Qwen3Exec::execute, &psched::Qwen3Exec::last_error};
+                            &psched::Qwen3Exec::drop_request, &psched::Qwen3Exec::execute, &psched::Qwen3Exec::last_error,
+                            &psched::Qwen3Exec::max_batch_size};
   Scheduler* s = static_cast<Scheduler*>(pegainfer_sched_create(&v, seed));
   s->owned = e;
   return s;
@@ -329,7 +335,8 @@ pegainfer_sched_t pegainfer_sched_create_qwen35(void* model, uint64_t seed, cons
   for (int i = 0; i < n_stop; ++i) e->stop.insert(stop_tokens[i]);
   pegainfer_executor_vtbl v{e, &psched::Qwen35Exec::page_size, &psched::Qwen35Exec::max_request_pages,
                             &psched::Qwen35Exec::available_pages, &psched::Qwen35Exec::is_stop_token,
-                            &psched::Qwen35Exec::drop_request, &psched::Qwen35Exec::execute, &psched::Qwen35Exec::last_error};
+                            &psched::Qwen35Exec::drop_request, &psched::Qwen35Exec::execute, &psched::Qwen35Exec::last_error,
+                            &psched::Qwen35Exec::max_batch_size};
   Scheduler* s = static_cast<Scheduler*>(pegainfer_sched_create(&v, seed));
   s->owned35 = e;
   return s;

@@ -33,7 +33,7 @@ _ERR = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_void_p)   # const char*: a poi
 class ExecutorVtbl(ctypes.Structure):
     _fields_ = [("user", ctypes.c_void_p), ("page_size", _I32_V), ("max_request_pages", _I32_V),
                 ("available_pages", _I32_V), ("is_stop_token", _STOP), ("drop_request", _DROP), ("execute", _EXEC),
-                ("last_error", _ERR)]
+                ("last_error", _ERR), ("max_batch_size", _I32_V)]
 
 
 class Scheduler:
@@ -81,8 +81,12 @@ class Scheduler:
                    is_stop_token=_STOP(lambda _u, t: 1 if ex.is_stop_token(t) else 0),
                    drop_request=_DROP(lambda _u, rid: (ex.drop_request(rid), 0)[1]), execute=_EXEC(execute),
                    last_error=_ERR(lambda _u: ctypes.addressof(state["buf"])))
-        vt = ExecutorVtbl(None, *[cbs[k] for k in ("page_size", "max_request_pages", "available_pages",
-                                                   "is_stop_token", "drop_request", "execute", "last_error")])
+        keys = ["page_size", "max_request_pages", "available_pages", "is_stop_token", "drop_request", "execute",
+                "last_error"]
+        if hasattr(ex, "max_batch_size"):   # optional callback: NULL = unlimited
+            cbs["max_batch_size"] = _I32_V(lambda _u: ex.max_batch_size())
+            keys.append("max_batch_size")
+        vt = ExecutorVtbl(None, *[cbs[k] for k in keys])
         h = lib.pegainfer_sched_create(ctypes.addressof(vt), seed)
         return cls(h, keep=(vt, cbs, state, ex))
 

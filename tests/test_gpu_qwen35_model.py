@@ -214,3 +214,38 @@ def test_qwen35_native_loader_equals_python_loader(built_libs, golden35):
     assert np.array_equal(la.view(np.uint32), lb.view(np.uint32))
     a.close()
     b.close()
+
+
+def test_qwen35_split_kv_after_batch_shrink_equals_unsplit(built_libs, golden35):
+    """the partition-KV launch covered bs * 64 slots while only the first plan.slots entries of the
+    slot arrays are refreshed per step, so after a batch shrink stale `valid` slots of the larger batch (naming
+    requests that are still live) ran again, bumped merge counters and could fire the in-launch merge early.  The launch
+    now covers exactly plan.slots.  Scenario sized for this checkpoint (1 kv head): 32 long requests -> 16 chunks per
+    request, entries 14 b + c; then the first 20 of them -> 260 refreshed slots, old launch 1280 of which 260..447
+    were stale and named requests 18..31.  Every logit of the shrunk batch must match the un-split engine within the
+    split-vs-non-partition bar (partials are bf16-rounded before the merge)."""
+    meta, _ = golden35
+    rng = np.random.default_rng(35)
+    V = meta["config"]["vocab_size"]
+    prompts = [rng.integers(0, V, 1090 + 3 * i).tolist() for i in range(32)]
+    outs = {}
+    for split in (1, 0):
+        eng = make_engine(meta, split_policy=split, num_kv_pages=32 * 72 + 8, max_batch_size=32, max_positions=2048)
+        rids = [eng.new_request() for _ in prompts]
+        toks = [eng.prefill(r, p) for r, p in zip(rids, prompts)]
+        rows = []
+        for step in range(3):                                   # 32 requests, long context
+            t, lg = eng.decode(rids, toks, want_logits=True)
+            toks = [int(x) for x in lg.argmax(-1)] if split == 1 else outs[1]["toks"][step]
+            rows.append(lg)
+            outs.setdefault(split, {}).setdefault("toks", []).append(toks)
+        keep, ktoks = rids[:20], toks[:20]
+        for step in range(4):                                   # shrink to 20: stale slots would name requests 18, 19
+            t, lg = eng.decode(keep, ktoks, want_logits=True)
+            ktoks = [int(x) for x in lg.argmax(-1)] if split == 1 else outs[1]["ktoks"][step]
+            rows.append(lg)
+            outs[split].setdefault("ktoks", []).append(ktoks)
+        outs[split]["rows"] = rows
+        eng.close()
+    for a, b in zip(outs[1]["rows"], outs[0]["rows"]):
+        assert np.abs(a - b).max() <= 0.25, np.abs(a - b).max()

@@ -153,3 +153,55 @@ def test_randomized_trace_cxx_equals_oracle():
             evc += [tuple(e[:6]) for e in sc.poll()]
         assert evo == evc and len(evo) > 50
         assert exo.calls == exc.calls and exo.dropped == exc.dropped and exo.available_pages() == exc.available_pages()
+
+
+class CappedExecutor(FakeExecutor):
+    """FakeExecutor + the optional max_batch_size() callback; execute() fails like the model does when a call
+    carries more rows than its decode buffers hold (qwen3_runtime.cpp decode()/prefill(): 'bad batch size')."""
+
+    def __init__(self, pages, cap, **kw):
+        super().__init__(pages, **kw)
+        self.cap = cap
+
+    def max_batch_size(self):
+        return self.cap
+
+    def execute(self, pf_items, dec_items):
+        if len(pf_items) + len(dec_items) > self.cap:
+            raise RuntimeError("bad batch size")
+        return super().execute(pf_items, dec_items)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_admission_is_capped_by_the_executors_max_batch_size(kind):
+    """admission went by KV pages only, so one request too many made execute() fail and
+    fail_touched_requests dropped EVERY in-flight request.  With executor.max_batch_size() the scheduler never builds a
+    call with more rows than the model takes: excess requests wait in `deferred` and are admitted as rows free up;
+    nobody gets an ERROR."""
+    ex = CappedExecutor(64, 3)
+    s = make(kind, ex)
+    rids = [s.submit([1] * 4, 3 + i) for i in range(7)]
+    ev = run_until_idle(s)
+    assert all(n_pf + n_dec <= 3 for n_pf, n_dec in ex.calls), ex.calls
+    assert not [e for e in ev if e[1] == ERROR]
+    for i, rid in enumerate(rids):
+        mine = events_of(ev, rid)
+        assert [e[1] for e in mine] == [TOKEN] * (3 + i) + [FINISHED] and mine[-1][3] == LENGTH
+    assert ex.calls[0] == (3, 0)                                   # first iteration admits exactly the cap
+    assert ex.available_pages() == 64 and sorted(ex.dropped) == rids
+
+
+def test_capped_trace_cxx_equals_oracle():
+    rng = np.random.default_rng(5)
+    exo, exc = CappedExecutor(40, 4), CappedExecutor(40, 4)
+    so, sc = make("oracle", exo, 9), make("cxx", exc, 9)
+    evo, evc = [], []
+    for it in range(150):
+        for _ in range(int(rng.integers(0, 3))):
+            plen, mx = int(rng.integers(1, 60)), int(rng.integers(1, 30))
+            assert so.submit([1] * plen, mx) == sc.submit([1] * plen, mx)
+        assert so.step() == sc.step()
+        evo += [tuple(e[:6]) for e in so.poll()]
+        evc += [tuple(e[:6]) for e in sc.poll()]
+    assert evo == evc and exo.calls == exc.calls and max(a + b for a, b in exo.calls) <= 4
+    assert not [e for e in evo if e[1] == ERROR]
