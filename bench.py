@@ -301,7 +301,8 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="requests decoded together per rank")
     ap.add_argument("--model", default="qwen3-4b", choices=["qwen3-4b", "qwen3-8b", "qwen3.5-4b"])
     ap.add_argument("--decode-mode", type=int, default=int(os.environ.get("PEGAINFER_DECODE_MODE", "1")),
-                    help="0 = reference op sequence 1:1, 1 = fused MI355X decode kernels (bit-identical)")
+                    help="0 = reference op sequence 1:1, 1 = fused MI355X decode kernels, 2 = persistent decode-step engine "
+                         "for bs 1 (all bit-identical)")
     ap.add_argument("--split-policy", type=int, default=1)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=12, help="decode steps for the CPU baseline (0 = skip)")
@@ -452,7 +453,7 @@ def main():
         # decode_mode 1 launches it with the add+RMSNorm prologue and SwiGLU epilogue fused in; the timing loop
         # launches exactly that kernel over the 36 layers' weights, hipEvents on the model stream. ----
         H, I = cfg["hidden_size"], cfg["intermediate_size"]
-        fused = args.decode_mode == 1 and args.batch <= 16
+        fused = args.decode_mode >= 1 and args.batch <= 16
         # weights once + (hidden, residual, norm weight in; hidden out by one workgroup; act out)
         gate_up_bytes = 2 * I * H * 2 + args.batch * (2 * H * 2 + H * 2 + I * 2) + H * 2
         ms = eng.bench_gemv(5 if fused else 2, 360, args.batch)

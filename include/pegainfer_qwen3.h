@@ -30,6 +30,9 @@ typedef void* pegainfer_qwen3_t;
 
 /* decode_mode: 0 = replay the reference's op sequence 1:1 through the reference-named symbols
  *              1 = MI355X fused decode kernels (bit-identical results, fewer launches)
+ *              2 = persistent decode-step engine for single-request steps (one launch for all layers, weights
+ *                  streamed through an LDS-DMA ring across op boundaries; bit-identical results); batches > 1,
+ *                  tensor parallel and shapes the engine does not take run the decode_mode 1 kernels
  * split_policy: 0 = reference gate (bs<=2 && L>=1024, chunk max(256, ceil(L/64)))
  *               1 = MI355X policy (fill >=256 workgroups) */
 pegainfer_qwen3_t pegainfer_qwen3_create(int32_t device_ordinal, int32_t hidden_size, int32_t num_layers,
@@ -98,7 +101,13 @@ int32_t pegainfer_qwen3_sample(pegainfer_qwen3_t m, int32_t column, float temper
 
 /* device-side timing of the last decode step's graph (hipEvent pair on the model stream), ms */
 float pegainfer_qwen3_last_step_ms(pegainfer_qwen3_t m);
-int32_t pegainfer_qwen3_last_attention_path(pegainfer_qwen3_t m); /* 0 non-partition, 1 split-KV */
+int32_t pegainfer_qwen3_last_attention_path(pegainfer_qwen3_t m);
+/* decode_mode 2 diagnostics: 1 when the last decode step ran on the persistent engine; with PEGAINFER_ENGINE_TRACE=1 in
+ * the environment at creation, engine_trace copies 32 uint64 per workgroup (phase cycle sums of the last engine step:
+ * [0..17] consumer wave 0 {wait, stage, gemv, store} x {qkv, attention, o, gate|up, down}, [18] its wait for landed
+ * fills, [20] loader wait for free slots, [21] loader total, [22] consumer total) and returns the word count */
+int32_t pegainfer_qwen3_engine_active(pegainfer_qwen3_t m);
+int32_t pegainfer_qwen3_engine_trace(pegainfer_qwen3_t m, uint64_t* out, int32_t max_words); /* 0 non-partition, 1 split-KV */
 /* average ms per launch of one GEMM call site over the layers' real weights, hipEvents on the model
  * stream (bench.py roofline).  which: 0 fused qkv, 1 o, 2 gate_up, 3 down, 4 lm_head (plain GEMM call sites);
  * 5 gate_up with add+RMSNorm prologue and SwiGLU epilogue, 6 qkv with add+RMSNorm prologue, 7 lm_head with

@@ -17,39 +17,10 @@
 // caller's tmp_v / tmp_s exactly like FlashInfer, and merge_states_kernel combines slots
 // o_indptr[b]..o_indptr[b+1].  kv_len always comes from the page table
 // ((pages-1)*page_size + last_page_len), kv_chunk_size_ptr[0] is read only when partitioning.
-#include <type_traits>
-
-#include "common.h"
+#include "attn_decode_core.h"
 #include "pegainfer_kernels_ext.h"
-#include "rope_core.h"
 
 namespace pk {
-
-template <int LPT>
-__device__ __forceinline__ float token_sum(float v) {
-  v = row16_sum(v);
-  if (LPT == 32) v += __shfl_xor(v, 16, kWave);
-  return v;
-}
-
-struct DecodeAttnArgs {
-  const Half* q; Half* o_out; const Half* kv; long k_off, v_off;
-  const int* page_indices; const int* page_indptr; const int* last_page_len; const int* request_indices;
-  const int* kv_tile_indices; const int* kv_chunk_size_ptr; const uint8_t* block_valid_mask;
-  Half* tmp_v; float* tmp_s; int num_qo_heads, num_kv_heads, page_size; long stride_page; float scale_log2;
-  // fused form only: raw qkv rows [bs, (Hq + 2 Hkv) * 128], per-head norm weights, RoPE tables, positions
-  const Half* qkv; const Half* q_norm_w; const Half* k_norm_w; const Half* cos_cache; const Half* sin_cache;
-  const int* positions; float eps;
-  // fused form, optional: one 32-byte record per slot {b, lo, hi, pbase, pos, kv_len, 0, 0} built by the host
-  // (lo < 0 = padding slot) - replaces a 4-deep chain of dependent metadata loads by one load
-  const int* slot_desc;
-  // partition form, optional: when merge_counters is non-null the LAST workgroup of a (request, kv head) to
-  // finish merges that head group's partials itself (no merge_states_kernel launch).  One int per
-  // (request, kv head), zero before the first launch; the merging workgroup leaves it zero again.
-  int* merge_counters; const int* o_indptr;
-};
-
-struct ChunkInfo { int b, pbase, kv_len, lo, hi; };
 
 template <bool PARTITION>
 __device__ __forceinline__ ChunkInfo decode_chunk(const DecodeAttnArgs& a, int slot) {
@@ -69,223 +40,28 @@ __device__ __forceinline__ ChunkInfo decode_chunk(const DecodeAttnArgs& a, int s
   return c;
 }
 
-// One wave merges the partition-KV partials of one (request, q head): lanes first fetch all log2-sum-exps of
-// the request's slots in parallel (<= 64 slots), then every lane accumulates its D/64 output dims over the
-// slots with the weights broadcast from registers:  out = sum_s 2^(lse_s - M) v_s / sum_s 2^(lse_s - M).
-// Shared by merge_states_kernel and the in-kernel merge so both round identically.
-template <int D, bool COHERENT>
-__device__ __forceinline__ void merge_one(const Half* __restrict__ tmp_v, const float* __restrict__ tmp_s, int s0,
-                                          int s1, int head, int num_qo_heads, Half* __restrict__ dst_row) {
-  // COHERENT: the partials were published write-through by other workgroups of this launch -> agent-scope
-  // relaxed atomic loads (global_load ... sc1), which are served past this CU's L1.
-  const int lane = threadIdx.x & 63;
-  constexpr int EPL = D / 64;  // elements per lane (2 or 4)
-  typedef typename std::conditional<EPL == 2, uint32_t, uint64_t>::type word_t;
-  float acc[EPL], wsum = 0.f;
-#pragma unroll
-  for (int i = 0; i < EPL; ++i) acc[i] = 0.f;
-  // both split plans cap a request at 64 chunks (batch_decode_buffers.rs:15); launch_decode rejects more
-  const int n = s1 - s0 < 64 ? s1 - s0 : 64;
-  float lse = -INFINITY;
-  if (lane < n) {
-    const float* ps = tmp_s + (size_t)(s0 + lane) * num_qo_heads + head;
-    if (COHERENT)
-      lse = __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<const uint32_t*>(ps), __ATOMIC_RELAXED,
-                                                        __HIP_MEMORY_SCOPE_AGENT));
-    else
-      lse = *ps;
-  }
-  const float M = wave_max(lse);
-  if (M != -INFINITY) {
-    const float w_lane = exp2f(lse - M);
-    // 16 partials per batch: all loads of a batch are in flight before the first one is consumed (a plain
-    // load-then-accumulate loop paid one memory round trip per slot); accumulation order is still slot order
-    constexpr int MB = 16;
-    for (int j0 = 0; j0 < n; j0 += MB) {
-      word_t pv[MB];
-#pragma unroll
-      for (int u = 0; u < MB; ++u) {
-        int j = j0 + u;
-        j = j < n ? j : n - 1;  // clamped reload of a valid slot; its weight is dropped below
-        const word_t* v = reinterpret_cast<const word_t*>(tmp_v + ((size_t)(s0 + j) * num_qo_heads + head) * D + lane * EPL);
-        pv[u] = COHERENT ? __hip_atomic_load(v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *v;
-      }
-#pragma unroll
-      for (int u = 0; u < MB; ++u) {
-        if (j0 + u >= n) break;
-        const float w = __shfl(w_lane, j0 + u, kWave);
-        wsum += w;
-        acc[0] += w * bf_lo((uint32_t)pv[u]);
-        acc[1] += w * bf_hi((uint32_t)pv[u]);
-        if (EPL == 4) {
-          const uint32_t hi = (uint32_t)((uint64_t)pv[u] >> 32);
-          acc[2] += w * bf_lo(hi);
-          acc[3] += w * bf_hi(hi);
-        }
-      }
-    }
-  }
-  Half* dst = dst_row + lane * EPL;
-#pragma unroll
-  for (int i = 0; i < EPL; ++i) dst[i] = f2bf(wsum > 0.f ? acc[i] / wsum : 0.f);
-}
-
-// The KV scan + in-workgroup merge, given the (already normalised / rotated) bf16 q fragments.
+// The KV scan + in-workgroup merge, given the (already normalised / rotated) bf16 q fragments (attn_decode_core.h
+// holds the arithmetic; this is the real-workgroup driver: NW waves, __syncthreads, static LDS).
 template <int D, int GROUP, bool PARTITION, int NW>
 __device__ __forceinline__ void decode_attn_body(const DecodeAttnArgs& a, const ChunkInfo& ci, const u32x4 (&qv)[GROUP],
                                                  int slot, int kvh) {
-  constexpr int LPT = D / 8;     // lanes per token row
-  constexpr int TPI = 64 / LPT;  // token rows per load instruction
-  constexpr int U = 4;           // load instructions in flight per operand (U = 8 measured 25-45 % slower: 256 VGPRs)
-  constexpr int TB = TPI * U;    // tokens per wave iteration
-  constexpr int NPART = NW * TPI; // partial softmax states per workgroup (NW waves)
-  __shared__ float sm_m[NPART][GROUP];
-  __shared__ float sm_l[NPART][GROUP];
-  __shared__ __attribute__((aligned(16))) float sm_o[NPART][GROUP][D];
-  const Half* __restrict__ kv = a.kv;
-  const int* __restrict__ page_indices = a.page_indices;
-  const long k_off = a.k_off, v_off = a.v_off, stride_page = a.stride_page;
-  const int page_size = a.page_size, num_qo_heads = a.num_qo_heads, num_kv_heads = a.num_kv_heads;
-  const float scale_log2 = a.scale_log2;
-  const int b = ci.b, pbase = ci.pbase, lo = ci.lo, hi = ci.hi;
+  typedef AttnScan<D, GROUP> Scan;
+  constexpr int NPART = NW * Scan::TPI;  // partial softmax states per workgroup (NW waves)
+  __shared__ float sm_m[NPART * GROUP];
+  __shared__ float sm_l[NPART * GROUP];
+  __shared__ __attribute__((aligned(16))) float sm_o[NPART * GROUP * D];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int sub = lane % LPT, grp = lane / LPT;
-
-  float m[GROUP], l[GROUP], o[GROUP][8];
-#pragma unroll
-  for (int h = 0; h < GROUP; ++h) {
-    m[h] = -INFINITY;
-    l[h] = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) o[h][i] = 0.f;
-  }
-  const long head_off = (long)kvh * D + sub * 8;
-  const long row_stride = (long)num_kv_heads * D;
-
-  auto load_tile = [&](int t0, u32x4 (&kx)[U], u32x4 (&vx)[U], bool (&ok)[U]) {
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int t = t0 + u * TPI + grp;
-      ok[u] = t >= lo && t < hi;
-      const int tc = ok[u] ? t : lo;  // clamp to a valid token of this chunk (hi > lo here)
-      const int page = page_indices[pbase + tc / page_size];
-      const long base = (long)page * stride_page + (long)(tc % page_size) * row_stride + head_off;
-      kx[u] = *reinterpret_cast<const u32x4*>(kv + base + k_off);
-      vx[u] = *reinterpret_cast<const u32x4*>(kv + base + v_off);
-    }
-  };
-  auto compute_tile = [&](const u32x4 (&kx)[U], const u32x4 (&vx)[U], const bool (&ok)[U]) {
-    float s[GROUP][U];
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-#pragma unroll
-      for (int h = 0; h < GROUP; ++h) {
-        const float d = token_sum<LPT>(dot8(qv[h], kx[u], 0.f)) * scale_log2;
-        s[h][u] = ok[u] ? d : -INFINITY;
-      }
-#pragma unroll
-    for (int h = 0; h < GROUP; ++h) {
-      float mn = m[h];
-#pragma unroll
-      for (int u = 0; u < U; ++u) mn = fmaxf(mn, s[h][u]);
-      if (mn == -INFINITY) continue;  // nothing seen yet by this lane row (uniform per row)
-      const float sc = exp2f(m[h] - mn);  // m = -inf -> 0
-      float p[U], ps = 0.f;
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        p[u] = exp2f(s[h][u] - mn);  // masked -> 0
-        ps += p[u];
-      }
-      m[h] = mn;
-      l[h] = l[h] * sc + ps;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) o[h][i] *= sc;
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const uint32_t w[4] = {vx[u].x, vx[u].y, vx[u].z, vx[u].w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          o[h][2 * j] += p[u] * bf_lo(w[j]);
-          o[h][2 * j + 1] += p[u] * bf_hi(w[j]);
-        }
-      }
-    }
-  };
-  // software-pipelined scan: the next tile's 2*U loads are in flight while the current one is reduced
-  {
-    int t0 = (lo / TB) * TB + wave * TB;
-    if (lo < hi && t0 < hi) {
-      u32x4 kA[U], vA[U], kB[U], vB[U];
-      bool okA[U], okB[U];
-      load_tile(t0, kA, vA, okA);
-      for (;;) {
-        int t1 = t0 + NW * TB;
-        bool more = t1 < hi;
-        if (more) load_tile(t1, kB, vB, okB);
-        compute_tile(kA, vA, okA);
-        if (!more) break;
-        t0 = t1 + NW * TB;
-        more = t0 < hi;
-        if (more) load_tile(t0, kA, vA, okA);
-        compute_tile(kB, vB, okB);
-        if (!more) break;
-      }
-    }
-  }
-
+  Scan st;
+  st.init();
+  st.scan(a, ci, qv, kvh, lane, wave, NW);
   // merge the workgroup's NPART partial states
-  const int part = wave * TPI + grp;
-#pragma unroll
-  for (int h = 0; h < GROUP; ++h) {
-    if (sub == 0) { sm_m[part][h] = m[h]; sm_l[part][h] = l[h]; }
-    f32x4 a = {o[h][0], o[h][1], o[h][2], o[h][3]}, c = {o[h][4], o[h][5], o[h][6], o[h][7]};
-    *reinterpret_cast<f32x4*>(&sm_o[part][h][sub * 8]) = a;
-    *reinterpret_cast<f32x4*>(&sm_o[part][h][sub * 8 + 4]) = c;
-  }
+  st.store_state(sm_m, sm_l, sm_o, wave * Scan::TPI + lane / Scan::LPT, lane);
   __syncthreads();
   // one thread per (head, 8 output dims): 16-byte stores.  With merge_counters the partials are published
   // write-through (sc1): they are read by a workgroup on another XCD later in this same launch.
   const bool publish = PARTITION && a.merge_counters != nullptr;
-  for (int e = threadIdx.x; e < GROUP * (D / 8); e += NW * 64) {
-    const int h = e / (D / 8), d0 = (e - h * (D / 8)) * 8;
-    float M = -INFINITY;
-#pragma unroll
-    for (int p = 0; p < NPART; ++p) M = fmaxf(M, sm_m[p][h]);
-    float L = 0.f, O[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) O[i] = 0.f;
-    if (M != -INFINITY) {
-#pragma unroll
-      for (int p = 0; p < NPART; ++p) {
-        const float w = exp2f(sm_m[p][h] - M);
-        L += sm_l[p][h] * w;
-        const f32x4 x0 = *reinterpret_cast<const f32x4*>(&sm_o[p][h][d0]);
-        const f32x4 x1 = *reinterpret_cast<const f32x4*>(&sm_o[p][h][d0 + 4]);
-        O[0] += x0[0] * w; O[1] += x0[1] * w; O[2] += x0[2] * w; O[3] += x0[3] * w;
-        O[4] += x1[0] * w; O[5] += x1[1] * w; O[6] += x1[2] * w; O[7] += x1[3] * w;
-      }
-    }
-    u32x4 pk;
-    pk.x = pack_bf2(L > 0.f ? O[0] / L : 0.f, L > 0.f ? O[1] / L : 0.f);
-    pk.y = pack_bf2(L > 0.f ? O[2] / L : 0.f, L > 0.f ? O[3] / L : 0.f);
-    pk.z = pack_bf2(L > 0.f ? O[4] / L : 0.f, L > 0.f ? O[5] / L : 0.f);
-    pk.w = pack_bf2(L > 0.f ? O[6] / L : 0.f, L > 0.f ? O[7] / L : 0.f);
-    const int head = kvh * GROUP + h;
-    if (PARTITION) {
-      Half* pv = a.tmp_v + ((size_t)slot * num_qo_heads + head) * D + d0;
-      float* ps = a.tmp_s + (size_t)slot * num_qo_heads + head;
-      const float lse = L > 0.f ? M + log2f(L) : -INFINITY;
-      if (publish) {
-        asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(pv), "v"(pk) : "memory");
-        if (d0 == 0) asm volatile("global_store_dword %0, %1, off sc1" :: "v"(ps), "v"(lse) : "memory");
-      } else {
-        *reinterpret_cast<u32x4*>(pv) = pk;
-        if (d0 == 0) *ps = lse;
-      }
-    } else {
-      *reinterpret_cast<u32x4*>(a.o_out + ((size_t)b * num_qo_heads + head) * D + d0) = pk;
-    }
-  }
+  for (int e = threadIdx.x; e < GROUP * (D / 8); e += NW * 64)
+    attn_finish_part<D, GROUP, PARTITION>(a, ci.b, slot, kvh, e, NPART, sm_m, sm_l, sm_o, publish);
   if (publish) {
     // "last workgroup done" merge without cache-wide fences (guide: sc1 payload -> vmcnt(0) -> counter; the
     // reader uses sc1 loads): every chunk's partials are write-through, the ticket is a relaxed agent atomic,
@@ -293,6 +69,7 @@ __device__ __forceinline__ void decode_attn_body(const DecodeAttnArgs& a, const 
     __shared__ int sm_last;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    const int b = ci.b, num_kv_heads = a.num_kv_heads, num_qo_heads = a.num_qo_heads;
     const int s0 = a.o_indptr[b], s1 = a.o_indptr[b + 1];
     if (threadIdx.x == 0) {
       int* ctr = a.merge_counters + b * num_kv_heads + kvh;

@@ -105,6 +105,14 @@ struct Model {
   // PEGAINFER_MID_BATCH_FUSED=0: decode batches of 17..64 keep the reference op sequence (A/B + bit-equality probe)
   bool mid_batch_fused = [] { const char* e = getenv("PEGAINFER_MID_BATCH_FUSED"); return !(e && e[0] == '0'); }();
   int32_t* merge_ctr = nullptr;  // per (request, kv head) arrival counters of the in-kernel split-KV merge
+  // decode_mode 2: the persistent decode-step engine (csrc/decode_engine.hip) for a single request; larger batches and
+  // unsupported shapes run the decode_mode 1 kernels.  PEGAINFER_ENGINE_WGS overrides the workgroup count (probe knob).
+  pegainfer_engine_layer_t* eng_layers_d = nullptr;
+  uint32_t *eng_sync = nullptr, *eng_status = nullptr, *eng_status_host = nullptr;
+  Half *eng_act = nullptr;
+  uint64_t* eng_trace = nullptr;   // PEGAINFER_ENGINE_TRACE=1: per-workgroup phase cycle sums of the last engine step
+  int eng_wgs = 0;
+  bool eng_disabled = false, eng_used = false;
   // sampling scratch (ops/sampling.rs)
   float* probs_scratch = nullptr;
   Half* top1_value = nullptr;
@@ -218,7 +226,64 @@ struct Model {
     std::memset(meta_host, 0, ml.total);
     if (dalloc(&meta_dev, ml.total)) return -1;
     PQ_HIP(hipHostMalloc(reinterpret_cast<void**>(&tokens_out_host), bs * 4, hipHostMallocDefault));
+    if (decode_mode == 2) {
+      int cus = 0;
+      PQ_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+      const char* e = getenv("PEGAINFER_ENGINE_WGS");
+      eng_wgs = e && *e ? atoi(e) : cus;
+      if (eng_wgs > cus) eng_wgs = cus;   // one workgroup per CU, all co-resident: the engine's hand-offs spin
+      if (dalloc(&eng_layers_d, (size_t)L) || dalloc(&eng_sync, (size_t)L * 5 * 8) || dalloc(&eng_status, 4) ||
+          dalloc(&eng_act, (size_t)I))
+        return -1;
+      PQ_HIP(hipHostMalloc(reinterpret_cast<void**>(&eng_status_host), 16, hipHostMallocDefault));
+      if (const char* t = getenv("PEGAINFER_ENGINE_TRACE"); t && t[0] == '1')
+        if (dalloc(&eng_trace, (size_t)eng_wgs * 32)) return -1;
+      std::vector<pegainfer_engine_layer_t> tab(L);
+      for (int i = 0; i < L; ++i)
+        tab[i] = pegainfer_engine_layer_t{layers[i].qkv, layers[i].o, layers[i].gate_up, layers[i].down,
+                                          layers[i].ln1, layers[i].ln2, layers[i].q_norm, layers[i].k_norm};
+      PQ_HIP(hipMemcpy(eng_layers_d, tab.data(), tab.size() * sizeof(tab[0]), hipMemcpyHostToDevice));
+    }
     PQ_HIP(hipStreamSynchronize(stream));
+    return 0;
+  }
+
+  // ---- decode_mode 2: one persistent launch for all layers (bs = 1), then lm_head + top-1 as in the fused path ----
+  void engine_args(pegainfer_engine_args_t* a, bool split, int split_slots) {
+    *a = pegainfer_engine_args_t{};
+    a->hidden = H; a->layers = L; a->num_qo_heads = Hq; a->num_kv_heads = Hkv; a->head_dim = D; a->intermediate = I;
+    a->rms_eps = eps; a->sm_scale = 1.0f / std::sqrt((float)D);
+    a->layer_table = eng_layers_d; a->embed = embed; a->cos_cache = cos; a->sin_cache = sin;
+    a->hidden_a = hidden; a->hidden_b = hidden2; a->qkv_out = qkv_out; a->attn_out = attn_out; a->attn_proj = attn_proj;
+    a->act = eng_act; a->mlp_out = mlp_out;
+    a->kv_data = kv_buffer; a->page_stride = layout.page_stride; a->layer_stride = layout.layer_stride;
+    a->kv_block_len = layout.kv_block_len; a->page_size = layout.page_size;
+    a->token_id = md<uint32_t>(ml.token_ids); a->page_indices = md<int32_t>(ml.page_indices);
+    a->slot_desc = md<int32_t>(ml.slot_desc); a->num_slots = split ? split_slots : 1; a->use_split = split ? 1 : 0;
+    a->tmp_v = split_tmp_v; a->tmp_s = split_tmp_s; a->merge_counters = merge_ctr;
+    a->sync = eng_sync; a->status = eng_status; a->trace = eng_trace;
+  }
+  bool engine_ok(int bs) {
+    if (decode_mode != 2 || eng_disabled || bs != 1 || tp_comm || !eng_layers_d) return false;
+    pegainfer_engine_args_t a;
+    engine_args(&a, false, 1);
+    return pegainfer_decode_engine_supported(&a, eng_wgs) == 0;
+  }
+  int decode_kernels_engine(bool split, int split_slots) {
+    PQ_HIP(hipMemsetAsync(eng_sync, 0, (size_t)L * 5 * 8 * sizeof(uint32_t), stream));
+    PQ_HIP(hipMemsetAsync(eng_status, 0, 16, stream));
+    if (split) PQ_HIP(hipMemsetAsync(merge_ctr, 0, (size_t)max_bs * Hkv * sizeof(int32_t), stream));
+    pegainfer_engine_args_t a;
+    engine_args(&a, split, split_slots);
+    if (pegainfer_decode_engine_step(&a, eng_wgs, S())) { set_error("pegainfer_decode_engine_step failed"); return -1; }
+    if (pegainfer_gemv_fused(lm_head, hidden, logits, V, 1, H, mlp_out, final_norm, hidden2, eps, 0, S())) {
+      set_error("fused lm_head failed");
+      return -1;
+    }
+    if (pegainfer_batched_top1(logits, V, 1, V, top1_state, tokens_out_d, S())) {
+      set_error("pegainfer_batched_top1 failed");
+      return -1;
+    }
     return 0;
   }
 
@@ -560,10 +625,12 @@ struct Model {
     return 0;
   }
   // fused kernels up to 16 columns; 17..64 run the unfused sequence with the stacked q|k|v GEMM (mid-batch path)
-  bool fused_ok(int bs) const { return decode_mode == 1 && bs <= 16 && (H & 31) == 0 && (I & 31) == 0 && D == 128; }
-  bool stacked_qkv(int bs) const { return decode_mode == 1 && bs > 16; }
+  bool fused_ok(int bs) const { return decode_mode >= 1 && bs <= 16 && (H & 31) == 0 && (I & 31) == 0 && D == 128; }
+  bool stacked_qkv(int bs) const { return decode_mode >= 1 && bs > 16; }
 
   int decode_kernels(int bs, bool split, int split_slots) {
+    eng_used = engine_ok(bs);
+    if (eng_used) return decode_kernels_engine(split, split_slots);
     if (fused_ok(bs)) return decode_kernels_fused(bs, split, split_slots);
     if (embedding_batched_cuda(embed, md<uint32_t>(ml.token_ids), hidden, H, bs, S())) {
       set_error("embedding_batched_cuda failed");
@@ -670,7 +737,8 @@ struct Model {
         } else {
           b = sl; lo = 0; hi = kcs[b];
         }
-        r[0] = b; r[1] = lo; r[2] = hi; r[3] = indptr[b]; r[4] = pos[b]; r[5] = kcs[b]; r[6] = r[7] = 0;
+        r[0] = b; r[1] = lo; r[2] = hi; r[3] = indptr[b]; r[4] = pos[b]; r[5] = kcs[b];
+        r[6] = plan.o_indptr[b]; r[7] = plan.o_indptr[b + 1];   // partial slots of this request (engine merge)
       }
     }
     const size_t upload = ml.page_indices + (size_t)np * 4;
@@ -697,8 +765,21 @@ struct Model {
     }
     PQ_HIP(hipEventRecord(ev1, stream));
     PQ_HIP(hipMemcpyAsync(tokens_out_host, tokens_out_d, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
+    const bool engine_step = decode_mode == 2 && !eng_disabled && padded == 1 && engine_ok(padded);
+    if (engine_step) PQ_HIP(hipMemcpyAsync(eng_status_host, eng_status, 16, hipMemcpyDeviceToHost, stream));
     PQ_HIP(hipStreamSynchronize(stream));
     hipEventElapsedTime(&last_step_ms, ev0, ev1);
+    if (engine_step && eng_status_host[0] != 0) {
+      // a bounded spin expired (the grid was not co-resident, or a hand-off never completed): the step's outputs are
+      // invalid.  Report it and run every later step on the decode_mode 1 kernels.
+      eng_disabled = true;
+      for (auto& bkt : graphs)
+        for (auto& g : bkt)
+          if (g) { hipGraphExecDestroy(g); g = nullptr; }
+      set_error("decode engine gave up: code " + std::to_string(eng_status_host[0] & 0xff) + " at " +
+                std::to_string(eng_status_host[1]) + " (falling back to decode_mode 1 for later steps)");
+      return -3;
+    }
     for (int i = 0; i < n; ++i) out_tokens[i] = tokens_out_host[i];
     last_logits = logits;
     last_rows = n;
@@ -949,6 +1030,7 @@ struct Model {
     if (pf_meta_host) hipHostFree(pf_meta_host);
     if (meta_host) hipHostFree(meta_host);
     if (tokens_out_host) hipHostFree(tokens_out_host);
+    if (eng_status_host) hipHostFree(eng_status_host);
     if (ev0) hipEventDestroy(ev0);
     if (ev1) hipEventDestroy(ev1);
     if (stream) hipStreamDestroy(stream);
@@ -1090,6 +1172,14 @@ float pegainfer_qwen3_bench_gemv(pegainfer_qwen3_t m, int32_t which, int32_t ite
   return M(m)->bench_gemv(which, iters, bs);
 }
 int32_t pegainfer_qwen3_last_attention_path(pegainfer_qwen3_t m) { return M(m)->last_path; }
+int32_t pegainfer_qwen3_engine_trace(pegainfer_qwen3_t m, uint64_t* out, int32_t max_words) {
+  pq::Model* md = M(m);
+  if (!md->eng_trace) return 0;
+  const int n = std::min(max_words, md->eng_wgs * 32);
+  if (hipMemcpy(out, md->eng_trace, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return n;
+}
+int32_t pegainfer_qwen3_engine_active(pegainfer_qwen3_t m) { return M(m)->eng_used ? 1 : 0; }
 int64_t pegainfer_qwen3_weight_bytes(pegainfer_qwen3_t m) { return M(m)->weight_bytes; }
 void* pegainfer_qwen3_stream(pegainfer_qwen3_t m) { return M(m)->S(); }
 

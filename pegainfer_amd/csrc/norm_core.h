@@ -15,26 +15,26 @@ constexpr int kNormWaves = kNormBlock / 64;
 
 __device__ __forceinline__ void sq8(const u32x4& v, float& ss) {
   float a;
-  a = bf_lo(v.x); ss += a * a; a = bf_hi(v.x); ss += a * a;
-  a = bf_lo(v.y); ss += a * a; a = bf_hi(v.y); ss += a * a;
-  a = bf_lo(v.z); ss += a * a; a = bf_hi(v.z); ss += a * a;
-  a = bf_lo(v.w); ss += a * a; a = bf_hi(v.w); ss += a * a;
+  a = bf_lo(v.x); ss = fmaf(a, a, ss); a = bf_hi(v.x); ss = fmaf(a, a, ss);
+  a = bf_lo(v.y); ss = fmaf(a, a, ss); a = bf_hi(v.y); ss = fmaf(a, a, ss);
+  a = bf_lo(v.z); ss = fmaf(a, a, ss); a = bf_hi(v.z); ss = fmaf(a, a, ss);
+  a = bf_lo(v.w); ss = fmaf(a, a, ss); a = bf_hi(v.w); ss = fmaf(a, a, ss);
 }
 __device__ __forceinline__ void add_sq8(const u32x4& h, const u32x4& r, float& ss) {
   float a;
-  a = bf_lo(h.x) + bf_lo(r.x); ss += a * a; a = bf_hi(h.x) + bf_hi(r.x); ss += a * a;
-  a = bf_lo(h.y) + bf_lo(r.y); ss += a * a; a = bf_hi(h.y) + bf_hi(r.y); ss += a * a;
-  a = bf_lo(h.z) + bf_lo(r.z); ss += a * a; a = bf_hi(h.z) + bf_hi(r.z); ss += a * a;
-  a = bf_lo(h.w) + bf_lo(r.w); ss += a * a; a = bf_hi(h.w) + bf_hi(r.w); ss += a * a;
+  a = bf_lo(h.x) + bf_lo(r.x); ss = fmaf(a, a, ss); a = bf_hi(h.x) + bf_hi(r.x); ss = fmaf(a, a, ss);
+  a = bf_lo(h.y) + bf_lo(r.y); ss = fmaf(a, a, ss); a = bf_hi(h.y) + bf_hi(r.y); ss = fmaf(a, a, ss);
+  a = bf_lo(h.z) + bf_lo(r.z); ss = fmaf(a, a, ss); a = bf_hi(h.z) + bf_hi(r.z); ss = fmaf(a, a, ss);
+  a = bf_lo(h.w) + bf_lo(r.w); ss = fmaf(a, a, ss); a = bf_hi(h.w) + bf_hi(r.w); ss = fmaf(a, a, ss);
 }
 // same with the sum rounded to bf16 first: "add_cuda, then rms_norm on its bf16 output" (the Qwen3.5 residual
 // chain, batch_decode.rs:246-262) as opposed to FlashInfer's fused add+norm over the un-rounded sum
 __device__ __forceinline__ void add_round_sq8(const u32x4& h, const u32x4& r, float& ss) {
   float a;
-  a = bf16_round_f(bf_lo(h.x) + bf_lo(r.x)); ss += a * a; a = bf16_round_f(bf_hi(h.x) + bf_hi(r.x)); ss += a * a;
-  a = bf16_round_f(bf_lo(h.y) + bf_lo(r.y)); ss += a * a; a = bf16_round_f(bf_hi(h.y) + bf_hi(r.y)); ss += a * a;
-  a = bf16_round_f(bf_lo(h.z) + bf_lo(r.z)); ss += a * a; a = bf16_round_f(bf_hi(h.z) + bf_hi(r.z)); ss += a * a;
-  a = bf16_round_f(bf_lo(h.w) + bf_lo(r.w)); ss += a * a; a = bf16_round_f(bf_hi(h.w) + bf_hi(r.w)); ss += a * a;
+  a = bf16_round_f(bf_lo(h.x) + bf_lo(r.x)); ss = fmaf(a, a, ss); a = bf16_round_f(bf_hi(h.x) + bf_hi(r.x)); ss = fmaf(a, a, ss);
+  a = bf16_round_f(bf_lo(h.y) + bf_lo(r.y)); ss = fmaf(a, a, ss); a = bf16_round_f(bf_hi(h.y) + bf_hi(r.y)); ss = fmaf(a, a, ss);
+  a = bf16_round_f(bf_lo(h.z) + bf_lo(r.z)); ss = fmaf(a, a, ss); a = bf16_round_f(bf_hi(h.z) + bf_hi(r.z)); ss = fmaf(a, a, ss);
+  a = bf16_round_f(bf_lo(h.w) + bf_lo(r.w)); ss = fmaf(a, a, ss); a = bf16_round_f(bf_hi(h.w) + bf_hi(r.w)); ss = fmaf(a, a, ss);
 }
 
 // inv_rms of row `hr` (+ `rr` when non-null), d % 8 == 0; call from ALL 64 lanes of one wave.
@@ -53,7 +53,7 @@ __device__ __forceinline__ float wave_row_inv_rms(const Half* __restrict__ hr, c
     for (int i = lane; i < nvec; i += 64) sq8(reinterpret_cast<const u32x4*>(hr)[i], ss);
   }
   ss = wave_sum(ss);
-  return rsqrtf(ss / (float)d + eps);
+  return rsqrtf(__fadd_rn(ss / (float)d, eps));
 }
 
 // out = bf16(s * inv * (bias + w)) on 8 packed elements; s = h (+ r).  Also returns bf16(s) in `nh`.
@@ -70,7 +70,8 @@ __device__ __forceinline__ u32x4 norm_scale8(const u32x4& h, const u32x4* r, con
     if (r) { s0 += bf_lo(rw[j]); s1 += bf_hi(rw[j]); }
     if (round_sum) { s0 = bf16_round_f(s0); s1 = bf16_round_f(s1); }
     nw[j] = pack_bf2(s0, s1);
-    ow[j] = pack_bf2(s0 * inv * (bias + bf_lo(gw[j])), s1 * inv * (bias + bf_hi(gw[j])));
+    ow[j] = pack_bf2(__fmul_rn(__fmul_rn(s0, inv), __fadd_rn(bias, bf_lo(gw[j]))),
+                     __fmul_rn(__fmul_rn(s1, inv), __fadd_rn(bias, bf_hi(gw[j]))));
   }
   o.x = ow[0]; o.y = ow[1]; o.z = ow[2]; o.w = ow[3];
   n.x = nw[0]; n.y = nw[1]; n.z = nw[2]; n.w = nw[3];

@@ -21,9 +21,9 @@ __device__ __forceinline__ u32x4 head_norm_rope16(const u32x4& x, const Half* __
   for (int j = 0; j < 4; ++j) { v[2 * j] = bf_lo(xw[j]); v[2 * j + 1] = bf_hi(xw[j]); }
   float ss = 0.f;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) ss += v[j] * v[j];
+  for (int j = 0; j < 8; ++j) ss = fmaf(v[j], v[j], ss);
   ss = row16_sum(ss);
-  const float inv = rsqrtf(ss / 128.0f + eps);
+  const float inv = rsqrtf(__fadd_rn(ss / 128.0f, eps));
   const u32x4 wv = *reinterpret_cast<const u32x4*>(w + sub * 8);
   const u32x4 cv = *reinterpret_cast<const u32x4*>(cos_row + (sub & 7) * 8);
   const u32x4 sv = *reinterpret_cast<const u32x4*>(sin_row + (sub & 7) * 8);
@@ -35,9 +35,11 @@ __device__ __forceinline__ u32x4 head_norm_rope16(const u32x4& x, const Half* __
     const float wj = (j & 1) ? bf_hi(ww[j >> 1]) : bf_lo(ww[j >> 1]);
     const float c = (j & 1) ? bf_hi(cw[j >> 1]) : bf_lo(cw[j >> 1]);
     const float s = (j & 1) ? bf_hi(sw[j >> 1]) : bf_lo(sw[j >> 1]);
-    const float m = bf16_round_f(bf16_round_f(v[j] * inv) * wj);
+    const float m = bf16_round_f(__fmul_rn(bf16_round_f(__fmul_rn(v[j], inv)), wj));
     const float pm = dpp_mov<kDppRowRor8>(m);  // partner lane sub^8
-    o[j] = first_half ? (m * c - pm * s) : (pm * s + m * c);
+    // named fused forms: a difference / sum of two products can be contracted either way, and every caller of this
+    // core must round identically
+    o[j] = first_half ? fmaf(m, c, -__fmul_rn(pm, s)) : fmaf(pm, s, __fmul_rn(m, c));
   }
   u32x4 r;
   r.x = pack_bf2(o[0], o[1]); r.y = pack_bf2(o[2], o[3]); r.z = pack_bf2(o[4], o[5]); r.w = pack_bf2(o[6], o[7]);

@@ -290,3 +290,67 @@ def test_real_dims_fused_path_bit_identical_to_reference_sequence(built_libs, re
             eng.close()
             outs.append(bf16_bits(dec))
         assert np.array_equal(outs[0], outs[1]), name
+
+
+# ------------------------------------------------------------------ decode_mode 2: the persistent decode-step engine
+def _decode_bits(eng, prompt, n_steps, feed=None):
+    """prefill + n greedy decode steps; returns (tokens fed, logits bits per step)."""
+    rid = eng.new_request()
+    tok, _ = eng.prefill([rid], [prompt], return_logits=True)
+    toks, rows = [int(tok[0])], []
+    for step in range(n_steps):
+        t = toks[-1] if feed is None else feed[step]
+        out, lg = eng.decode([rid], [t], return_logits=True)
+        rows.append(lg[0].copy())
+        toks.append(int(out[0]))
+    eng.drop_request(rid)
+    return toks, np.stack(rows)
+
+
+@pytest.mark.parametrize("ctx,policy,graph", [(1024, 1, True), (1024, 0, True), (1024, 1, False), (20, 1, True), (3000, 1, True)])
+def test_engine_bit_identical_to_fused_decode_path(built_libs, real2, ctx, policy, graph):
+    """decode_mode 2 (ONE persistent launch for all layers: LDS-DMA weight ring, in-launch hand-offs) == decode_mode 1
+    (five launches per layer) in every logit bit and every greedy token, at Qwen3-4B widths: ctx 1024 (partition-KV,
+    64-token chunks), ctx 20 (non-partition attention), ctx 3000 (longer chunks: more than four scan waves per chunk),
+    both split policies, captured graph and eager.  decode_mode 1 is itself pinned to the oracle above."""
+    _, state, _ = real2
+    rng = np.random.default_rng(ctx)
+    prompt = rng.integers(0, CFG2["vocab_size"], ctx).tolist()
+    e1 = _engine(state, decode_mode=1, split_policy=policy, enable_graph=graph, max_batch_size=4)
+    toks1, bits1 = _decode_bits(e1, prompt, 12)
+    e1.close()
+    e2 = _engine(state, decode_mode=2, split_policy=policy, enable_graph=graph, max_batch_size=4)
+    toks2, bits2 = _decode_bits(e2, prompt, 12, feed=toks1[:-1])
+    e2.close()
+    assert np.array_equal(bits1, bits2), int((bits1 != bits2).sum())
+    assert toks1 == toks2
+
+
+def test_engine_many_steps_and_interleaved_requests(built_libs, real2):
+    """200 engine steps over two alternating requests (hand-off counters, ring epochs and KV appends are re-armed
+    every launch) == the fused path, token for token and bit for bit on every 10th step; then a batch of two falls
+    back to the decode_mode 1 kernels on the same engine object and still matches."""
+    _, state, _ = real2
+    rng = np.random.default_rng(5)
+    prompts = [rng.integers(0, CFG2["vocab_size"], n).tolist() for n in (700, 90)]
+    outs = {}
+    for mode in (1, 2):
+        eng = _engine(state, decode_mode=mode, max_batch_size=4)
+        rids = [eng.new_request() for _ in prompts]
+        last = [int(eng.prefill([r], [p])[0]) for r, p in zip(rids, prompts)]
+        toks, bits = [], []
+        for step in range(200):
+            i = step & 1
+            feed = last[i] if mode == 1 else outs[1]["feed"][step]
+            o, lg = eng.decode([rids[i]], [feed], return_logits=True)
+            toks.append(int(o[0]))
+            outs.setdefault(mode, {}).setdefault("feed", []).append(feed)
+            last[i] = int(o[0])
+            if step % 10 == 0:
+                bits.append(lg[0].copy())
+        o, lg = eng.decode(rids, last, return_logits=True)        # bs 2: not an engine step
+        outs[mode].update(toks=toks, bits=np.stack(bits), pair=lg.copy())
+        eng.close()
+    assert outs[1]["toks"] == outs[2]["toks"]
+    assert np.array_equal(outs[1]["bits"], outs[2]["bits"])
+    assert np.array_equal(outs[1]["pair"], outs[2]["pair"])
