@@ -1,0 +1,266 @@
+// Prefill GEMM, long prompts: 256 x 256 x 64 tiles, 8 waves (2 x 4), v_mfma_f32_16x16x32_bf16, 128 KiB of LDS.
+//
+//   Y[T, M] = X[T, K] . W[M, K]^T,  a workgroup owns 256 W rows x 256 token rows, wave (wr, wc) a 128 x 64 block of it
+//   as 8 x 4 MFMA tiles (128 accumulator VGPRs).
+//
+// The 128 x {128,64} kernel of linear.hip is LDS-read bound (two barriers per K tile, every fragment read serialised
+// behind the stage) and reaches 23-28 % of the dense bf16 peak.  This one follows the CDNA4 "8-phase" schedule:
+//   * a K tile is FOUR 16 KiB half-tiles - A_lo / A_hi = the rows of the wave's m-tiles 0-3 / 4-7 (both wave rows),
+//     B_lo / B_hi = the token rows of n-tiles 0-1 / 2-3 (all four wave columns) - and one phase computes one quadrant
+//     (4 m-tiles x 2 n-tiles x K 64 = 16 MFMAs) from one A half and one B half:
+//       phase 1: read A_lo + B_lo, quadrant (lo, lo)     phase 2: read B_hi, quadrant (lo, hi)
+//       phase 3: read A_hi,        quadrant (hi, hi)     phase 4: read B_lo, quadrant (hi, lo)
+//     so a K tile costs 24 ds_read_b128 per wave for 64 MFMAs (the 128-tile kernel: 16 for 32);
+//   * half-tiles travel global -> LDS by LDS-DMA (global_load_lds_dwordx4, XOR-swizzled through the SOURCE address),
+//     two instructions per thread per half-tile, ONE half-tile staged per phase into the slot whose last reader is two
+//     phases back: A_hi / B_lo of the next K tile in phases 1 / 2, A_lo / B_hi of the tile after that in phases 3 / 4.
+//     The only wait is a counted `s_waitcnt vmcnt(4)` at phases 4 and 8 (the two youngest half-tiles stay in flight
+//     across the barrier); a staged slot is first read one phase after the wait that retires it;
+//   * two raw s_barrier per phase, and the wave row wr = 1 runs one barrier behind wr = 0: while one half of the
+//     workgroup (one wave per SIMD) issues its 16 MFMAs, the other half does its fragment reads and its share of the
+//     DMA - the matrix pipe of every SIMD always has a wave in its MFMA segment.
+// Per-element K order (K tile by K tile, k-step 0 then 1) is that of the other tiled kernels: same bits.
+#pragma once
+
+#include "common.h"
+
+namespace pk {
+
+constexpr int G256_BM = 256, G256_BT = 256, G256_BK = 64;
+constexpr int kG256HalfBytes = 128 * 128;            // 128 rows x 128 B
+constexpr int kG256LdsBytes = 8 * kG256HalfBytes;    // 2 parities x {A_lo, A_hi, B_lo, B_hi}
+enum { kHalfAlo = 0, kHalfAhi = 1, kHalfBlo = 2, kHalfBhi = 3 };
+
+struct G256Out { Half* Y; int ld; };
+
+template <bool SILU>
+__global__ __launch_bounds__(512) void mfma_gemm256_kernel(const Half* __restrict__ W, const Half* __restrict__ X,
+                                                           Half* __restrict__ Y, int M, int T, int K, int m_tiles,
+                                                           int t_tiles, SplitOut so) {
+  extern __shared__ __attribute__((aligned(16))) u32x4 g256_smem[];
+  const int ntiles = m_tiles * t_tiles;
+  int tile = blockIdx.x;
+  {  // XCD-aware order (block b runs on XCD b % 8): every XCD walks a contiguous run of tiles, token tile fastest
+    const int q = ntiles / 8, r = ntiles % 8, xcd = tile % 8, idx = tile / 8;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int mt = tile / t_tiles, tt = tile - mt * t_tiles;
+  const int m0 = mt * G256_BM, t0 = tt * G256_BT;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int l15 = lane & 15, g = lane >> 4;
+
+  // ---- DMA sources: piece j of a half-tile = LDS positions (j*8 + wave)*64 + lane: half-row hrow, 16-byte slot cpos;
+  //      the lane fetches global slot cpos ^ (hrow & 7) so that readers use lds_slot() ----
+  const Half* src[4][2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int p = (j * 8 + wave) * 64 + lane, hrow = p >> 3, cs = (p & 7) ^ (hrow & 7);
+    // A halves: hrow = wr' * 64 + r  ->  tile row wr' * 128 (+ 64 for hi) + r
+    {
+      const int wr_ = hrow >> 6, r = hrow & 63;
+#pragma unroll
+      for (int hi = 0; hi < 2; ++hi) {
+        int row;
+        if (SILU) {  // tile = 128 gate rows + their 128 up rows: the wave's m-tiles 0-3 are gate rows, 4-7 the up rows
+          int gr = mt * 128 + wr_ * 64 + r;
+          gr = gr < so.silu_I ? gr : so.silu_I - 1;
+          row = gr + (hi ? so.silu_I : 0);
+        } else {
+          row = m0 + wr_ * 128 + hi * 64 + r;
+          row = row < M ? row : M - 1;
+        }
+        src[hi ? kHalfAhi : kHalfAlo][j] = W + (size_t)row * K + cs * 8;
+      }
+    }
+    // B halves: hrow = wc' * 32 + r  ->  tile token wc' * 64 (+ 32 for hi) + r
+    {
+      const int wc_ = hrow >> 5, r = hrow & 31;
+#pragma unroll
+      for (int hi = 0; hi < 2; ++hi) {
+        int tr = t0 + wc_ * 64 + hi * 32 + r;
+        tr = tr < T ? tr : T - 1;
+        src[hi ? kHalfBhi : kHalfBlo][j] = X + (size_t)tr * K + cs * 8;
+      }
+    }
+  }
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)&g256_smem[0];
+  const int nk = K / G256_BK;
+  // stage half-tile `which` of K tile kt (clamped: past the end the slot is dead, the load only keeps vmcnt uniform)
+  auto stage = [&](int which, int kt) {
+    const int ktc = kt < nk ? kt : nk - 1;
+    const uint32_t slot = lds0 + (uint32_t)(((kt & 1) * 4 + which) * kG256HalfBytes);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const uint32_t dst = __builtin_amdgcn_readfirstlane(slot + (uint32_t)(j * 8 + wave) * 1024u);
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                   :: "v"(src[which][j] + (size_t)ktc * G256_BK), "s"(dst) : "memory", "m0");
+    }
+  };
+  auto half_ptr = [&](int par, int which) { return g256_smem + (size_t)(par * 4 + which) * (kG256HalfBytes / 16); };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8_t a[4][2], b[2][2];
+  auto read_a = [&](int par, int which) {
+    const u32x4* h = half_ptr(par, which);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        a[i][ks] = __builtin_bit_cast(bf16x8_t, h[lds_slot(wr * 64 + i * 16 + l15, ks * 4 + g)]);
+  };
+  auto read_b = [&](int par, int which) {
+    const u32x4* h = half_ptr(par, which);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        b[j][ks] = __builtin_bit_cast(bf16x8_t, h[lds_slot(wc * 32 + j * 16 + l15, ks * 4 + g)]);
+  };
+  auto quad = [&](int ih, int jh) {   // 16 MFMAs: m-tiles ih*4.., n-tiles jh*2..
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[ih * 4 + i][jh * 2 + j] =
+              __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][ks], b[j][ks], acc[ih * 4 + i][jh * 2 + j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // ---- prologue: K tile 0 complete, A_lo / B_hi of K tile 1 in flight ----
+  stage(kHalfAlo, 0); stage(kHalfBlo, 0); stage(kHalfBhi, 0); stage(kHalfAhi, 0);
+  stage(kHalfAlo, 1); stage(kHalfBhi, 1);
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();   // the second wave row runs one barrier behind the first
+
+  // one K tile = four phases; `kt` has parity `par`, the other slots belong to kt + 1
+  auto ktile = [&](int kt, int par) {
+    // phase 1: A_lo + B_lo -> (lo, lo); stage A_hi of kt + 1
+    read_b(par, kHalfBlo);
+    __builtin_amdgcn_sched_barrier(0);
+    read_a(par, kHalfAlo);
+    stage(kHalfAhi, kt + 1);
+    __builtin_amdgcn_s_barrier();
+    quad(0, 0);
+    __builtin_amdgcn_s_barrier();
+    // phase 2: B_hi -> (lo, hi); stage B_lo of kt + 1
+    read_b(par, kHalfBhi);
+    stage(kHalfBlo, kt + 1);
+    __builtin_amdgcn_s_barrier();
+    quad(0, 1);
+    __builtin_amdgcn_s_barrier();
+    // phase 3: A_hi -> (hi, hi); stage A_lo of kt + 2
+    read_a(par, kHalfAhi);
+    stage(kHalfAlo, kt + 2);
+    __builtin_amdgcn_s_barrier();
+    quad(1, 1);
+    __builtin_amdgcn_s_barrier();
+    // phase 4: B_lo -> (hi, lo); stage B_hi of kt + 2; everything but the two youngest half-tiles has landed
+    read_b(par, kHalfBlo);
+    stage(kHalfBhi, kt + 2);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    quad(1, 0);
+    __builtin_amdgcn_s_barrier();
+  };
+  for (int kt = 0; kt < nk; kt += 2) {
+    ktile(kt, 0);
+    ktile(kt + 1, 1);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail loads must not outlive the workgroup's LDS
+  if (wr == 0) __builtin_amdgcn_s_barrier();
+
+  // ---- epilogue: lane holds rows m = .. + g*4 + e (4 consecutive) of token t = .. + l15 ----
+  if (SILU) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int t = t0 + wc * 64 + j * 16 + l15;
+      if (t >= T) continue;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = mt * 128 + wr * 64 + i * 16 + g * 4;
+        float r[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {  // the GEMM output is bf16 before SwiGLU (fused_proj.cu:57-62)
+          const float sg = silu_f(bf16_round_f(acc[i][j][e]));
+          r[e] = (so.silu_round ? bf16_round_f(sg) : sg) * bf16_round_f(acc[i + 4][j][e]);
+        }
+        if (m + 3 < so.silu_I) {
+          u32x2 o;
+          o.x = pack_bf2(r[0], r[1]);
+          o.y = pack_bf2(r[2], r[3]);
+          *reinterpret_cast<u32x2*>(Y + (size_t)t * so.silu_I + m) = o;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (m + e < so.silu_I) Y[(size_t)t * so.silu_I + m + e] = f2bf(r[e]);
+        }
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int t = t0 + wc * 64 + j * 16 + l15;
+    if (t >= T) continue;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int m = m0 + wr * 128 + i * 16 + g * 4;
+      Half* dst = Y;
+      int ld = M, mm = m, mlim = M;
+      if (so.Y1) {
+        const int b1 = so.M0 + so.M1, b2 = b1 + so.M2;
+        if (m < so.M0) { ld = mlim = so.M0; }
+        else if (m < b1) { dst = so.Y1; ld = mlim = so.M1; mm = m - so.M0; }
+        else if (m < b2) { dst = so.Y2; ld = mlim = so.M2; mm = m - b1; }
+        else { dst = so.Y3; ld = mlim = M - b2; mm = m - b2; }
+      }
+      if (mm + 3 < mlim) {
+        u32x2 o;
+        o.x = pack_bf2(acc[i][j][0], acc[i][j][1]);
+        o.y = pack_bf2(acc[i][j][2], acc[i][j][3]);
+        *reinterpret_cast<u32x2*>(dst + (size_t)t * ld + mm) = o;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (mm + e < mlim) dst[(size_t)t * ld + mm + e] = f2bf(acc[i][j][e]);
+      }
+    }
+  }
+}
+
+// K must be a multiple of 128 (K tiles are processed in pairs); same alignment rules as the other LDS-DMA kernels
+inline bool gemm256_ok(int M, int T, int K) { return (K % 128) == 0 && K >= 256 && M >= 256 && T >= 256; }
+
+inline void gemm256_launch(const Half* W, const Half* X, Half* Y, int M, int T, int K, SplitOut so, hipStream_t s) {
+  const bool silu = so.silu_I > 0;
+  const int m_tiles = silu ? ceil_div(so.silu_I, 128) : ceil_div(M, G256_BM), t_tiles = ceil_div(T, G256_BT);
+  if (silu) {
+    static const bool once = [] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_gemm256_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kG256LdsBytes);
+      return true;
+    }();
+    (void)once;
+    mfma_gemm256_kernel<true><<<m_tiles * t_tiles, 512, kG256LdsBytes, s>>>(W, X, Y, M, T, K, m_tiles, t_tiles, so);
+  } else {
+    static const bool once = [] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_gemm256_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kG256LdsBytes);
+      return true;
+    }();
+    (void)once;
+    mfma_gemm256_kernel<false><<<m_tiles * t_tiles, 512, kG256LdsBytes, s>>>(W, X, Y, M, T, K, m_tiles, t_tiles, so);
+  }
+}
+
+}  // namespace pk

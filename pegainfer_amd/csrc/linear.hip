@@ -161,6 +161,10 @@ struct SplitOut { Half* Y1; Half* Y2; Half* Y3; int M0; int M1; int M2; int silu
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+}  // namespace pk
+#include "gemm256.h"   // 256 x 256 tiles, 8 waves, 8-phase schedule (long prompts); uses SplitOut / lds_slot
+namespace pk {
+
 // SPLITK: blockIdx.y = K slice z of `ksplit` (each nk_slice K tiles); the workgroup writes its fp32 partial tile to
 // part[z][T][M] and splitk_reduce_kernel adds the slices in z order (decode batches of 17..64 columns on matrices
 // with < 128 row tiles: more workgroups without re-staging x per 16 rows like the skinny kernel has to).
@@ -539,6 +543,13 @@ static void glds_splitk_launch(const Half* W, const Half* X, Half* Y, int M, int
 static void glds_gemm_launch(const Half* W, const Half* X, Half* Y, int M, int T, int K, SplitOut so, int variant,
                              hipStream_t s) {
   if (variant == 0) {
+    // long prompts: 256 x 256 tiles on the 8-phase schedule once they give every CU work (PEGAINFER_GEMM256 = 0 never,
+    // 1 whenever the shape allows, N = from N tiles on; A/B probe knob)
+    static const int g256_min = [] { const char* e = getenv("PEGAINFER_GEMM256"); return e && *e ? atoi(e) : 224; }();
+    if (g256_min > 0 && gemm256_ok(M, T, K)) {
+      const long tiles256 = (long)(so.silu_I > 0 ? ceil_div(so.silu_I, 128) : ceil_div(M, G256_BM)) * ceil_div(T, G256_BT);
+      if (tiles256 >= g256_min) { gemm256_launch(W, X, Y, M, T, K, so, s); return; }
+    }
     // Measured on MI355X (tools/bench_prefill_gemm.py, T = 1024): co-resident workgroups hide DMA latency better
     // than a deeper ring, so the ring only goes to 3 when every 64-token tile is resident at once (<= 2 per CU);
     // 128-token tiles (half the LDS reads per MFMA) once they give each CU >= 1.5 workgroups.
