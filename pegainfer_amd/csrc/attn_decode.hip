@@ -25,6 +25,8 @@ namespace pk {
 template <bool PARTITION>
 __device__ __forceinline__ ChunkInfo decode_chunk(const DecodeAttnArgs& a, int slot) {
   ChunkInfo c;
+  c.rec = 0;
+  c.inline_pages = false;
   c.b = a.request_indices ? a.request_indices[slot] : slot;
   c.pbase = a.page_indptr[c.b];
   const int npages = a.page_indptr[c.b + 1] - c.pbase;
@@ -41,19 +43,19 @@ __device__ __forceinline__ ChunkInfo decode_chunk(const DecodeAttnArgs& a, int s
 }
 
 // The KV scan + in-workgroup merge, given the (already normalised / rotated) bf16 q fragments (attn_decode_core.h
-// holds the arithmetic; this is the real-workgroup driver: NW waves, __syncthreads, static LDS).
-template <int D, int GROUP, bool PARTITION, int NW>
+// holds the arithmetic; this is the real-workgroup driver: NW waves, __syncthreads, static LDS).  The caller has
+// already issued the wave's first K / V tile (Scan::begin) so that those loads fly under its q prologue.
+template <int D, int GROUP, bool PARTITION, int NW, bool POW2>
 __device__ __forceinline__ void decode_attn_body(const DecodeAttnArgs& a, const ChunkInfo& ci, const u32x4 (&qv)[GROUP],
-                                                 int slot, int kvh) {
+                                                 int slot, int kvh, AttnScan<D, GROUP>& st,
+                                                 typename AttnScan<D, GROUP>::Pipe& pipe, float* sm_m, float* sm_l,
+                                                 float* sm_o, int* sm_last_p) {
   typedef AttnScan<D, GROUP> Scan;
   constexpr int NPART = NW * Scan::TPI;  // partial softmax states per workgroup (NW waves)
-  __shared__ float sm_m[NPART * GROUP];
-  __shared__ float sm_l[NPART * GROUP];
-  __shared__ __attribute__((aligned(16))) float sm_o[NPART * GROUP * D];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  Scan st;
-  st.init();
-  st.scan(a, ci, qv, kvh, lane, wave, NW);
+  PK_ATTN_STAMP(a, slot, kvh, 2);
+  st.template finish<POW2>(a, ci, qv, kvh, lane, NW, pipe);
+  PK_ATTN_STAMP(a, slot, kvh, 3);
   // merge the workgroup's NPART partial states
   st.store_state(sm_m, sm_l, sm_o, wave * Scan::TPI + lane / Scan::LPT, lane);
   __syncthreads();
@@ -66,9 +68,10 @@ __device__ __forceinline__ void decode_attn_body(const DecodeAttnArgs& a, const 
     // "last workgroup done" merge without cache-wide fences (guide: sc1 payload -> vmcnt(0) -> counter; the
     // reader uses sc1 loads): every chunk's partials are write-through, the ticket is a relaxed agent atomic,
     // and the workgroup that draws n-1 merges this head group and re-arms the counter for the next launch.
-    __shared__ int sm_last;
+    int& sm_last = *sm_last_p;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    PK_ATTN_STAMP(a, slot, kvh, 4);
     const int b = ci.b, num_kv_heads = a.num_kv_heads, num_qo_heads = a.num_qo_heads;
     const int s0 = a.o_indptr[b], s1 = a.o_indptr[b + 1];
     if (threadIdx.x == 0) {
@@ -78,28 +81,50 @@ __device__ __forceinline__ void decode_attn_body(const DecodeAttnArgs& a, const 
       sm_last = last;
     }
     __syncthreads();
+    PK_ATTN_STAMP(a, slot, kvh, 5);
     if (sm_last) {
       for (int h = wave; h < GROUP; h += NW) {
         const int head = kvh * GROUP + h;
         merge_one<D, true>(a.tmp_v, a.tmp_s, s0, s1, head, num_qo_heads,
                            a.o_out + ((size_t)b * num_qo_heads + head) * D);
       }
+      PK_ATTN_STAMP(a, slot, kvh, 6);
+      if (a.trace && threadIdx.x == 0) a.trace[((size_t)slot * a.num_kv_heads + kvh) * 8 + 7] = 1ull;
     }
   }
 }
 
 // ---- kernels: reference-ABI form (q already normalised + rotated, K/V already in the cache) ----
-template <int D, int GROUP, bool PARTITION, int NW>
-__global__ __launch_bounds__(NW * 64) void decode_attn_kernel(const DecodeAttnArgs a) {
+template <int D, int GROUP, bool PARTITION, int NW, bool POW2>
+__device__ __forceinline__ void decode_attn_run(const DecodeAttnArgs& a, float* sm_m, float* sm_l, float* sm_o,
+                                                int* sm_last) {
   const int slot = blockIdx.x, kvh = blockIdx.y;
   if (PARTITION && a.block_valid_mask && !a.block_valid_mask[slot]) return;
   const ChunkInfo ci = decode_chunk<PARTITION>(a, slot);
-  const int sub = (threadIdx.x & 63) % (D / 8);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  AttnScan<D, GROUP> st;
+  typename AttnScan<D, GROUP>::Pipe pipe;
+  st.init();
+  st.template begin<POW2>(a, ci, kvh, lane, wave, NW, pipe);   // K / V requests leave before the q loads
+  const int sub = lane % (D / 8);
   u32x4 qv[GROUP];
 #pragma unroll
   for (int h = 0; h < GROUP; ++h)
     qv[h] = *reinterpret_cast<const u32x4*>(a.q + ((size_t)ci.b * a.num_qo_heads + kvh * GROUP + h) * D + sub * 8);
-  decode_attn_body<D, GROUP, PARTITION, NW>(a, ci, qv, slot, kvh);
+  decode_attn_body<D, GROUP, PARTITION, NW, POW2>(a, ci, qv, slot, kvh, st, pipe, sm_m, sm_l, sm_o, sm_last);
+}
+// the workgroup's partial-state arrays: declared once per kernel (the two page-size instantiations share them)
+#define PK_ATTN_LDS(D_, GROUP_, NW_)                                                        \
+  constexpr int NPART_ = NW_ * AttnScan<D_, GROUP_>::TPI;                                   \
+  __shared__ float sm_m[NPART_ * GROUP_];                                                   \
+  __shared__ float sm_l[NPART_ * GROUP_];                                                   \
+  __shared__ __attribute__((aligned(16))) float sm_o[NPART_ * GROUP_ * D_];                 \
+  __shared__ int sm_last
+template <int D, int GROUP, bool PARTITION, int NW>
+__global__ __launch_bounds__(NW * 64) void decode_attn_kernel(const DecodeAttnArgs a) {
+  PK_ATTN_LDS(D, GROUP, NW);
+  if (a.page_shift >= 0) decode_attn_run<D, GROUP, PARTITION, NW, true>(a, sm_m, sm_l, sm_o, &sm_last);
+  else decode_attn_run<D, GROUP, PARTITION, NW, false>(a, sm_m, sm_l, sm_o, &sm_last);
 }
 
 // ---- fused form (head_dim 128): per-head q/k RMSNorm + RoPE and the KV append folded into the prologue.
@@ -107,36 +132,48 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(const DecodeAttnAr
 // the request's chunks); the one workgroup per (request, kv head) whose chunk contains the new position also
 // normalises + rotates the new K row, writes K and V into the page (same bytes paged_kv_scatter_cuda would
 // write) and only then scans.  Replaces qk_norm_rope + paged_kv_scatter + decode attention: 3 launches -> 1.
-template <int GROUP, bool PARTITION, int NW>
-__global__ __launch_bounds__(NW * 64) void fused_decode_attn_kernel(const DecodeAttnArgs a) {
+//
+// The launch is a chain of dependent memory round trips (67 % of its wave cycles were waits at bs 1), so the order
+// is: slot record (ONE 64-byte load: chunk, position and the chunk's page ids) -> the wave's K / V tile AND the
+// qkv / cos / sin rows together -> q prologue under the K / V flight -> scan.
+template <int GROUP, bool PARTITION, int NW, bool POW2>
+__device__ __forceinline__ void fused_decode_attn_run(const DecodeAttnArgs& a, float* sm_m, float* sm_l, float* sm_o,
+                                                      int* sm_last) {
   constexpr int D = 128;
   const int slot = blockIdx.x, kvh = blockIdx.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   ChunkInfo ci;
   int pos;
+  PK_ATTN_STAMP(a, slot, kvh, 0);
   if (a.slot_desc) {
-    const u32x4 d0 = *reinterpret_cast<const u32x4*>(a.slot_desc + 8 * slot);
-    const u32x2 d1 = *reinterpret_cast<const u32x2*>(a.slot_desc + 8 * slot + 4);
-    ci.b = (int)d0.x; ci.lo = (int)d0.y; ci.hi = (int)d0.z; ci.pbase = (int)d0.w;
-    pos = (int)d1.x; ci.kv_len = (int)d1.y;
+    ci.rec = a.slot_desc[16 * slot + (lane & 15)];
+    ci.b = __builtin_amdgcn_readlane(ci.rec, 0); ci.lo = __builtin_amdgcn_readlane(ci.rec, 1);
+    ci.hi = __builtin_amdgcn_readlane(ci.rec, 2); ci.pbase = __builtin_amdgcn_readlane(ci.rec, 3);
+    pos = __builtin_amdgcn_readlane(ci.rec, 4); ci.kv_len = __builtin_amdgcn_readlane(ci.rec, 5);
     if (ci.lo < 0) return;
+    ci.inline_pages = POW2 && ci.hi > ci.lo && ((ci.hi - 1) >> a.page_shift) - (ci.lo >> a.page_shift) < 8;
   } else {
     if (PARTITION && a.block_valid_mask && !a.block_valid_mask[slot]) return;
     ci = decode_chunk<PARTITION>(a, slot);
     pos = a.positions[ci.b];
   }
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int sub = lane & 15, grp = lane >> 4;
   const int q_dim = a.num_qo_heads * D, kv_dim = a.num_kv_heads * D;
   const Half* row = a.qkv + (size_t)ci.b * (q_dim + 2 * kv_dim);
   const Half* crow = a.cos_cache + (size_t)pos * D;
   const Half* srow = a.sin_cache + (size_t)pos * D;
+  AttnScan<D, GROUP> st;
+  typename AttnScan<D, GROUP>::Pipe pipe;
+  st.init();
+  const bool owns_new = pos >= ci.lo && pos < ci.hi;  // workgroup-uniform
+  PK_ATTN_STAMP(a, slot, kvh, 1);
+  if (!owns_new) st.template begin<POW2>(a, ci, kvh, lane, wave, NW, pipe);
   u32x4 qv[GROUP];
 #pragma unroll
   for (int h = 0; h < GROUP; ++h) {
     const u32x4 x = *reinterpret_cast<const u32x4*>(row + (size_t)(kvh * GROUP + h) * D + sub * 8);
     qv[h] = head_norm_rope16(x, a.q_norm_w, crow, srow, sub, a.eps);
   }
-  const bool owns_new = pos >= ci.lo && pos < ci.hi;  // workgroup-uniform
   if (owns_new) {
     if (wave == 0 && grp == 0) {
       const u32x4 xk = *reinterpret_cast<const u32x4*>(row + q_dim + (size_t)kvh * D + sub * 8);
@@ -149,8 +186,15 @@ __global__ __launch_bounds__(NW * 64) void fused_decode_attn_kernel(const Decode
       *reinterpret_cast<u32x4*>(kvw + base + a.v_off) = xv;
     }
     __syncthreads();  // workgroup-scope release/acquire: the new row is visible to the scanning waves
+    st.template begin<POW2>(a, ci, kvh, lane, wave, NW, pipe);
   }
-  decode_attn_body<D, GROUP, PARTITION, NW>(a, ci, qv, slot, kvh);
+  decode_attn_body<D, GROUP, PARTITION, NW, POW2>(a, ci, qv, slot, kvh, st, pipe, sm_m, sm_l, sm_o, sm_last);
+}
+template <int GROUP, bool PARTITION, int NW>
+__global__ __launch_bounds__(NW * 64) void fused_decode_attn_kernel(const DecodeAttnArgs a) {
+  PK_ATTN_LDS(128, GROUP, NW);
+  if (a.page_shift >= 0) fused_decode_attn_run<GROUP, PARTITION, NW, true>(a, sm_m, sm_l, sm_o, &sm_last);
+  else fused_decode_attn_run<GROUP, PARTITION, NW, false>(a, sm_m, sm_l, sm_o, &sm_last);
 }
 
 // merge of the partition-KV partial states: one wave per (request, q head).  Lanes first fetch all
@@ -170,6 +214,8 @@ __global__ __launch_bounds__(256) void merge_states_kernel(const Half* __restric
                out + ((size_t)b * num_qo_heads + head) * D);
 }
 
+static unsigned long long* g_attn_trace = nullptr;  // pegainfer_debug_attn_trace
+
 static void fill_args(DecodeAttnArgs& a, const Half* q, Half* output, const Half* kv, long k_off, long v_off,
                       const int* pi, const int* pip, const int* lpl, const int* ri, const int* kti, const int* kcs,
                       const uint8_t* mask, Half* tmp_v, float* tmp_s, int hq, int hkv, int page_size,
@@ -180,6 +226,12 @@ static void fill_args(DecodeAttnArgs& a, const Half* q, Half* output, const Half
   a.kv_tile_indices = kti; a.kv_chunk_size_ptr = kcs; a.block_valid_mask = mask; a.tmp_v = tmp_v; a.tmp_s = tmp_s;
   a.num_qo_heads = hq; a.num_kv_heads = hkv; a.page_size = page_size; a.stride_page = stride_page;
   a.scale_log2 = sm_scale * 1.4426950408889634f;
+  a.trace = g_attn_trace;
+  a.page_shift = -1;
+  if (page_size > 0 && (page_size & (page_size - 1)) == 0) {
+    a.page_shift = 0;
+    while ((1 << a.page_shift) < page_size) ++a.page_shift;
+  }
 }
 
 template <int D, bool PARTITION, bool FUSED>
@@ -222,6 +274,11 @@ static int launch_decode(const DecodeAttnArgs& a, const int* o_indptr, int batch
 using namespace pk;
 
 extern "C" {
+
+// Debug: device buffer of slots * kv_heads * 8 uint64 that every later decode-attention launch stamps with the
+// 100 MHz wall clock at its phase boundaries (entry, record read, q prologue, scan, partials published, ticket,
+// merge; word 7 = 1 for the merging workgroup); nullptr switches it off.  Not part of the reference ABI.
+void pegainfer_debug_attn_trace(uint64_t* buf) { g_attn_trace = reinterpret_cast<unsigned long long*>(buf); }
 
 int32_t paged_attention_decode_cuda(const Half* q, Half* output, const Half* kv_data, int64_t k_offset_elems,
                                     int64_t v_offset_elems, const int32_t* page_indices,

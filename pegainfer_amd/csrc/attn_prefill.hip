@@ -24,23 +24,51 @@ namespace pk {
 constexpr int TKV = 64;           // KV tokens per LDS tile
 constexpr int VT_PITCH = 68;      // bf16 elements per V^T row (64 tokens + 4 pad) = 136 B
 
+constexpr int kPgLdsMax = 2048;   // page ids held in LDS at a time (a 32k-token window at page_size 16)
+
+// Row addressing.  row(t) is called 8 times per thread and KV tile, so it must be a handful of integer ops: the
+// paged form keeps a window of the request's page ids in LDS and, for a power-of-two page size (shift >= 0),
+// splits t with a shift and a mask - reading the page id from global memory behind a 32-bit division per row cost
+// 340 VALU instructions per thread and tile, a third of the whole loop.  load_window() is executed by every
+// thread of the workgroup between two barriers; covers(t_end) says whether tokens < t_end are inside the window.
+template <bool POW2>
 struct PagedAddr {
-  const int* page_indices; int pbase; int page_size; long stride_page; long row_stride; long head_off;
-  long k_off, v_off;
+  const int* page_indices; int pbase; int page_size; int stride_page /* elements, < 2^31 (host-checked) */;
+  int row_stride; int shift; int* pg; int win0; int n_pages_total;
+  __device__ __forceinline__ int page_of_token(int t) const { return POW2 ? t >> shift : t / page_size; }
+  __device__ __forceinline__ void load_window(int first_token) {
+    win0 = page_of_token(first_token);
+    const int n = n_pages_total - win0 < kPgLdsMax ? n_pages_total - win0 : kPgLdsMax;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) pg[i] = page_indices[pbase + win0 + i];
+  }
+  __device__ __forceinline__ bool covers(int t_end) const { return page_of_token(t_end - 1) < win0 + kPgLdsMax; }
+  // element offset of token t's row inside the cache, without the (uniform) layer / head / K-V offsets
   __device__ __forceinline__ long row(int t) const {
-    const int page = page_indices[pbase + t / page_size];
-    return (long)page * stride_page + (long)(t % page_size) * row_stride + head_off;
+    const int pi = page_of_token(t);
+    const int in_page = POW2 ? t & (page_size - 1) : t - pi * page_size;
+    return (long)pg[pi - win0] * (long)stride_page + (long)(in_page * row_stride);
   }
 };
-struct ContigAddr {  // HND: cache[head][pos][dim]
-  long head_base; int D; long k_off, v_off;
-  __device__ __forceinline__ long row(int t) const { return head_base + (long)t * D; }
+struct ContigAddr {  // HND: cache[head][pos][dim]; the head base is folded into the buffer pointers
+  int D;
+  __device__ __forceinline__ void load_window(int) {}
+  __device__ __forceinline__ bool covers(int) const { return true; }
+  __device__ __forceinline__ long row(int t) const { return (long)(t * D); }
 };
+
+__device__ __forceinline__ float exp2_raw(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f32, no denormal fix-up
+// fmaxf() on MFMA results makes hipcc canonicalise every operand first (a v_max_f32 x, x, x each: 54 extra VALU
+// instructions per tile here); the raw three-input instruction does not
+__device__ __forceinline__ float max3_raw(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
 
 template <int QBLK, int D, int NW, typename Addr>
 __device__ __forceinline__ void prefill_tile(const Half* __restrict__ q_base, Half* __restrict__ o_base,
                                              const Half* __restrict__ kbuf, const Half* __restrict__ vbuf,
-                                             const Addr& addr, int qo_len, int kv_len, int tile_row0,
+                                             Addr& addr, int qo_len, int kv_len, int tile_row0,
                                              int tile_rows, int group, long q_stride_n, float scale_log2,
                                              u32x4* ks /*[TKV*D/8]*/, Half* vt /*[D*VT_PITCH]*/) {
   constexpr int KCH = D / 8;               // 16-byte chunks per K/V row
@@ -57,6 +85,10 @@ __device__ __forceinline__ void prefill_tile(const Half* __restrict__ q_base, Ha
   const int packed_len = qo_len * group;
   const int tile_end = (tile_row0 + tile_rows) < packed_len ? (tile_row0 + tile_rows) : packed_len;
   const int causal_off = kv_len - qo_len;
+  const int cta_kv_end_raw = (tile_end - 1) / group + causal_off + 1;
+  const int cta_kv_end = cta_kv_end_raw < kv_len ? cta_kv_end_raw : kv_len;
+
+  addr.load_window(0);                     // page ids -> LDS; visible after the barrier in front of the first load
 
   // per-lane query rows (one per 16-row block)
   int qtok[QBLK];
@@ -75,13 +107,14 @@ __device__ __forceinline__ void prefill_tile(const Half* __restrict__ q_base, Ha
     for (int s = 0; s < KS; ++s)
       qf[qb][s] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(q_base + off + s * 32 + g * 8));
   }
-  // wave-uniform bound on the KV positions this wave can attend to
+  // wave-uniform bounds on the KV positions this wave attends to: [0, wave_kv_end) is visible to its last row,
+  // [0, wave_kv_full) to every one of its rows (tiles below that line need no causal mask)
   int wave_last_row = tile_row0 + (wave * QBLK + QBLK) * 16 - 1;
   if (wave_last_row >= tile_end) wave_last_row = tile_end - 1;
   const bool wave_active = tile_row0 + wave * QBLK * 16 < tile_end;
   const int wave_kv_end = wave_active ? wave_last_row / group + causal_off + 1 : 0;
-  const int cta_kv_end_raw = (tile_end - 1) / group + causal_off + 1;
-  const int cta_kv_end = cta_kv_end_raw < kv_len ? cta_kv_end_raw : kv_len;
+  const int wave_kv_full_raw = (tile_row0 + wave * QBLK * 16) / group + causal_off + 1;
+  const int wave_kv_full = wave_kv_full_raw < kv_len ? wave_kv_full_raw : kv_len;
 
   f32x4 acc_o[QBLK][DB];
   float m_run[QBLK], l_run[QBLK];
@@ -96,12 +129,13 @@ __device__ __forceinline__ void prefill_tile(const Half* __restrict__ q_base, Ha
   // staging roles
   u32x4 kreg[KPT], vreg[VPT][4];
   auto load_tile = [&](int kv0) {
+    const int t_last = kv_len - 1;
 #pragma unroll
     for (int j = 0; j < KPT; ++j) {
       const int cid = threadIdx.x + j * NT, row = cid / KCH, slot = cid % KCH;
       int t = kv0 + row;
-      t = t < kv_len ? t : kv_len - 1;
-      kreg[j] = *reinterpret_cast<const u32x4*>(kbuf + addr.row(t) + addr.k_off + slot * 8);
+      t = t < t_last ? t : t_last;
+      kreg[j] = *reinterpret_cast<const u32x4*>(kbuf + addr.row(t) + slot * 8);
     }
 #pragma unroll
     for (int j = 0; j < VPT; ++j) {
@@ -109,8 +143,8 @@ __device__ __forceinline__ void prefill_tile(const Half* __restrict__ q_base, Ha
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         int tv = kv0 + v_tq * 4 + i;
-        tv = tv < kv_len ? tv : kv_len - 1;
-        vreg[j][i] = *reinterpret_cast<const u32x4*>(vbuf + addr.row(tv) + addr.v_off + v_dc * 8);
+        tv = tv < t_last ? tv : t_last;
+        vreg[j][i] = *reinterpret_cast<const u32x4*>(vbuf + addr.row(tv) + v_dc * 8);
       }
     }
   };
@@ -147,12 +181,23 @@ __device__ __forceinline__ void prefill_tile(const Half* __restrict__ q_base, Ha
     }
   };
 
-  if (cta_kv_end > 0) load_tile(0);
+  if (cta_kv_end > 0) {
+    __syncthreads();  // page-id window staged
+    load_tile(0);
+  }
   for (int kv0 = 0; kv0 < cta_kv_end; kv0 += TKV) {
     __syncthreads();  // previous tile fully consumed
     store_tile();
     __syncthreads();
-    if (kv0 + TKV < cta_kv_end) load_tile(kv0 + TKV);  // prefetch under the MFMAs
+    if (kv0 + TKV < cta_kv_end) {
+      const int next_end = kv0 + 2 * TKV < kv_len ? kv0 + 2 * TKV : kv_len;
+      if (!addr.covers(next_end)) {  // workgroup-uniform, once per kPgLdsMax pages
+        __syncthreads();
+        addr.load_window(kv0 + TKV);
+        __syncthreads();
+      }
+      load_tile(kv0 + TKV);  // prefetch under the MFMAs
+    }
     if (!wave_active || kv0 >= wave_kv_end) continue;
 
     // ---- S^T = K . Q^T ----
@@ -172,40 +217,54 @@ __device__ __forceinline__ void prefill_tile(const Half* __restrict__ q_base, Ha
           sacc[qb][tb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qb][s], sacc[qb][tb], 0, 0, 0);
       }
     }
-    // ---- online softmax per query row (= per lane column) ----
+    // ---- online softmax per query row (= per lane column), exp2 domain with the scale folded into one fma.
+    //      The causal / length mask is applied only on the tiles that cross this wave's diagonal or the end of
+    //      the sequence (wave-uniform test); interior tiles - nearly all of a long prompt - take no compare at all.
+    const bool need_mask = kv0 + TKV > wave_kv_full;
     bf16x8_t pf[QBLK][2];
 #pragma unroll
     for (int qb = 0; qb < QBLK; ++qb) {
-      const int limit = qok[qb] ? qtok[qb] + causal_off : -1;  // last visible kv index
-      float mx = -INFINITY;
+      if (need_mask) {
+        const int lim_c = qok[qb] ? qtok[qb] + causal_off : -1;  // last visible kv index
+        const int limit = lim_c < kv_len - 1 ? lim_c : kv_len - 1;
 #pragma unroll
-      for (int tb = 0; tb < 4; ++tb)
+        for (int tb = 0; tb < 4; ++tb)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int kvt = kv0 + tb * 16 + g * 4 + i;
-          float v = sacc[qb][tb][i] * scale_log2;
-          v = (kvt <= limit && kvt < kv_len) ? v : -INFINITY;
-          sacc[qb][tb][i] = v;
-          mx = fmaxf(mx, v);
-        }
+          for (int i = 0; i < 4; ++i) {
+            const int kvt = kv0 + tb * 16 + g * 4 + i;
+            sacc[qb][tb][i] = kvt <= limit ? sacc[qb][tb][i] : -INFINITY;
+          }
+      }
+      float mx = max3_raw(sacc[qb][0][0], sacc[qb][0][1], sacc[qb][0][2]);
+      mx = max3_raw(mx, sacc[qb][0][3], sacc[qb][1][0]);
+      mx = max3_raw(mx, sacc[qb][1][1], sacc[qb][1][2]);
+      mx = max3_raw(mx, sacc[qb][1][3], sacc[qb][2][0]);
+      mx = max3_raw(mx, sacc[qb][2][1], sacc[qb][2][2]);
+      mx = max3_raw(mx, sacc[qb][2][3], sacc[qb][3][0]);
+      mx = max3_raw(mx, sacc[qb][3][1], sacc[qb][3][2]);
+      mx = max3_raw(mx, sacc[qb][3][3], mx);
       mx = fmaxf(mx, __shfl_xor(mx, 16, kWave));
       mx = fmaxf(mx, __shfl_xor(mx, 32, kWave));
-      const float mn = fmaxf(m_run[qb], mx);
+      const float mn = fmaxf(m_run[qb], mx * scale_log2);   // scale_log2 > 0: the max commutes with the scaling
       const float msafe = mn == -INFINITY ? 0.f : mn;
-      const float alpha = exp2f(m_run[qb] - msafe);
-      m_run[qb] = mn;
-      float ps = 0.f;
+      // rescale only when some row's running max grew (alpha == 1 exactly otherwise): wave-uniform branch
+      if (__builtin_amdgcn_ballot_w64(mn > m_run[qb]) != 0ull) {
+        const float alpha = exp2_raw(m_run[qb] - msafe);
+        l_run[qb] *= alpha;
+#pragma unroll
+        for (int d = 0; d < DB; ++d) acc_o[qb][d] *= alpha;
+        m_run[qb] = mn;
+      }
       float p[4][4];
+      float ps0 = 0.f, ps1 = 0.f;
 #pragma unroll
-      for (int tb = 0; tb < 4; ++tb)
+      for (int tb = 0; tb < 4; ++tb) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          p[tb][i] = exp2f(sacc[qb][tb][i] - msafe);
-          ps += p[tb][i];
-        }
-      l_run[qb] = l_run[qb] * alpha + ps;  // lane-partial; summed over g at the end
-#pragma unroll
-      for (int d = 0; d < DB; ++d) acc_o[qb][d] *= alpha;
+        for (int i = 0; i < 4; ++i) p[tb][i] = exp2_raw(fmaf(sacc[qb][tb][i], scale_log2, -msafe));
+        ps0 += p[tb][0] + p[tb][1];
+        ps1 += p[tb][2] + p[tb][3];
+      }
+      l_run[qb] += ps0 + ps1;  // lane-partial; summed over g at the end
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
         u32x4 pk4;
@@ -250,30 +309,53 @@ __device__ __forceinline__ void prefill_tile(const Half* __restrict__ q_base, Ha
   }
 }
 
-template <int QBLK, int D, int NW = 4>
-__global__ __launch_bounds__(NW * 64) void batch_prefill_paged_kernel(
+// GROUPED = number of consecutive plan tiles one workgroup takes (1 or 2).  The reference model crates plan with
+// 64-row tiles (config.rs:5), i.e. 16 packed rows per wave: every K / V^T fragment read from LDS then feeds ONE MFMA
+// and a staged KV tile is shared by only 64 rows.  With GROUPED = 2 a workgroup takes plan tiles 2i and 2i + 1; when
+// they are adjacent rows of the same request (all but the seams between requests) they run as ONE 2 x cta_tile_q
+// tile, 32 rows per wave; otherwise one after the other.  Per-row arithmetic does not depend on the grouping.
+template <int QBLK, int D, bool POW2, int GROUPED = 1, int NW = 4>
+__global__ __launch_bounds__(NW * 64, D == 128 ? 2 : 1) void batch_prefill_paged_kernel(
     const Half* __restrict__ q, Half* __restrict__ out, const Half* __restrict__ kv, long k_off, long v_off,
     const int* __restrict__ page_indices, const int* __restrict__ page_indptr,
     const int* __restrict__ last_page_len, const int* __restrict__ q_indptr,
     const int* __restrict__ request_indices, const int* __restrict__ qo_tile_indices, int num_qo_heads,
-    int num_kv_heads, int page_size, long stride_page, float scale_log2, int cta_tile_q) {
+    int num_kv_heads, int page_size, long stride_page, float scale_log2, int cta_tile_q, int page_shift,
+    int num_plan_tiles) {
   __shared__ __attribute__((aligned(16))) u32x4 ks[TKV * D / 8];
   __shared__ __attribute__((aligned(16))) Half vt[D * VT_PITCH];
-  const int tile = blockIdx.x, kvh = blockIdx.y;
-  const int req = request_indices[tile];
+  __shared__ int lds_pg[kPgLdsMax];
+  // longest tiles first: within a request the plan lists tiles by ascending row, i.e. ascending causal KV length;
+  // dispatching them in reverse keeps the tail of the launch made of short tiles
+  const int kvh = blockIdx.y;
   const int group = num_qo_heads / num_kv_heads;
-  const int q0 = q_indptr[req];
-  const int qo_len = q_indptr[req + 1] - q0;
-  const int pbase = page_indptr[req];
-  const int npages = page_indptr[req + 1] - pbase;
-  const int kv_len = npages > 0 ? (npages - 1) * page_size + last_page_len[req] : 0;
-  const int row0 = qo_tile_indices[tile] * cta_tile_q;
-  if (row0 >= qo_len * group || kv_len <= 0) return;
-  PagedAddr addr{page_indices, pbase, page_size, stride_page, (long)num_kv_heads * D, (long)kvh * D, k_off, v_off};
-  const long q_stride_n = (long)num_qo_heads * D;
-  const long qo_base = (long)q0 * q_stride_n + (long)kvh * group * D;
-  prefill_tile<QBLK, D, NW>(q + qo_base, out + qo_base, kv, kv, addr, qo_len, kv_len, row0, cta_tile_q, group,
-                     q_stride_n, scale_log2, ks, vt);
+  const int first = (gridDim.x - 1 - blockIdx.x) * GROUPED;
+  int req[GROUPED], row0[GROUPED];
+#pragma unroll
+  for (int k = 0; k < GROUPED; ++k) {
+    const int tile = first + k;
+    req[k] = tile < num_plan_tiles ? request_indices[tile] : -1;
+    row0[k] = tile < num_plan_tiles ? qo_tile_indices[tile] * cta_tile_q : 0;
+  }
+  const bool fuse = GROUPED == 2 && req[0] >= 0 && req[GROUPED - 1] == req[0] && row0[GROUPED - 1] == row0[0] + cta_tile_q;
+  for (int k = 0; k < GROUPED; ++k) {
+    if (fuse && k > 0) break;
+    const int r = req[k];
+    if (r < 0) continue;
+    const int q0 = q_indptr[r];
+    const int qo_len = q_indptr[r + 1] - q0;
+    const int pbase = page_indptr[r];
+    const int npages = page_indptr[r + 1] - pbase;
+    const int kv_len = npages > 0 ? (npages - 1) * page_size + last_page_len[r] : 0;
+    if (row0[k] >= qo_len * group || kv_len <= 0) continue;
+    if (GROUPED > 1 && k > 0) __syncthreads();  // the previous tile's LDS (page window, K / V^T) is done with
+    PagedAddr<POW2> addr{page_indices, pbase, page_size, (int)stride_page, num_kv_heads * D, page_shift, lds_pg, 0, npages};
+    const long q_stride_n = (long)num_qo_heads * D;
+    const long qo_base = (long)q0 * q_stride_n + (long)kvh * group * D;
+    const Half* kvh_base = kv + (long)kvh * D;
+    prefill_tile<QBLK, D, NW>(q + qo_base, out + qo_base, kvh_base + k_off, kvh_base + v_off, addr, qo_len, kv_len, row0[k],
+                              fuse ? 2 * cta_tile_q : cta_tile_q, group, q_stride_n, scale_log2, ks, vt);
+  }
 }
 
 template <int QBLK>
@@ -286,13 +368,21 @@ __global__ __launch_bounds__(256) void single_prefill_kernel(const Half* __restr
   __shared__ __attribute__((aligned(16))) Half vt[128 * VT_PITCH];
   const int kvh = blockIdx.y;
   const int group = num_qo_heads / num_kv_heads;
-  const int row0 = blockIdx.x * cta_tile_q;
+  const int row0 = (gridDim.x - 1 - blockIdx.x) * cta_tile_q;
   if (row0 >= seq_len * group || kv_len <= 0) return;
-  ContigAddr addr{(long)kvh * max_seq_len * 128, 128, 0, 0};
+  ContigAddr addr{128};
   const long q_stride_n = (long)num_qo_heads * 128;
   const long qo_base = (long)kvh * group * 128;
-  prefill_tile<QBLK, 128, 4>(q + qo_base, out + qo_base, k_cache, v_cache, addr, seq_len, kv_len, row0, cta_tile_q,
-                     group, q_stride_n, scale_log2, ks, vt);
+  const long head_base = (long)kvh * max_seq_len * 128;
+  prefill_tile<QBLK, 128, 4>(q + qo_base, out + qo_base, k_cache + head_base, v_cache + head_base, addr, seq_len, kv_len,
+                             row0, cta_tile_q, group, q_stride_n, scale_log2, ks, vt);
+}
+
+static inline int page_shift_of(int page_size) {  // log2 for powers of two, -1 otherwise (division path)
+  if (page_size <= 0 || (page_size & (page_size - 1)) != 0) return -1;
+  int s = 0;
+  while ((1 << s) < page_size) ++s;
+  return s;
 }
 
 // ---- host plan helpers: FlashInfer FA2DetermineCtaTileQ restated (utils.cuh, un-vendored) ----
@@ -349,18 +439,29 @@ int32_t batch_prefill_paged_cuda_with_cta_tile_q(
   if (cta == 0) return -1;
   if (padded_batch_size <= 0) return 0;
   const float scale_log2 = sm_scale * 1.4426950408889634f;
-  dim3 grid(padded_batch_size, num_kv_heads);
   hipStream_t s = as_stream(stream);
-  if (cta == 128)
-    batch_prefill_paged_kernel<2, 128><<<grid, 256, 0, s>>>(q, output, kv_data, k_offset_elems, v_offset_elems,
-                                                       page_indices, page_indptr, last_page_len_d, q_indptr,
-                                                       request_indices, qo_tile_indices, num_qo_heads,
-                                                       num_kv_heads, page_size, stride_page, scale_log2, 128);
-  else
-    batch_prefill_paged_kernel<1, 128><<<grid, 256, 0, s>>>(q, output, kv_data, k_offset_elems, v_offset_elems,
-                                                       page_indices, page_indptr, last_page_len_d, q_indptr,
-                                                       request_indices, qo_tile_indices, num_qo_heads,
-                                                       num_kv_heads, page_size, stride_page, scale_log2, (int)cta);
+  if (stride_page <= 0 || stride_page > 0x7fffffffLL) return (int32_t)hipErrorInvalidValue;
+  const int shift = page_shift_of(page_size);
+  // two 64-row plan tiles per workgroup once that still leaves >= 2 workgroups per CU (PEGAINFER_PREFILL_GROUP = 1 | 2
+  // forces either form; per-row results are identical)
+  static const int group_env = [] { const char* e = getenv("PEGAINFER_PREFILL_GROUP"); return e && *e ? atoi(e) : 0; }();
+  const bool pair = cta == 64 && (group_env == 2 || (group_env == 0 && (long)padded_batch_size * num_kv_heads >= 1024));
+#define PK_PREFILL(QB, P2, G, CTA)                                                                           \
+  batch_prefill_paged_kernel<QB, 128, P2, G><<<dim3((padded_batch_size + G - 1) / G, num_kv_heads), 256, 0, s>>>( \
+      q, output, kv_data, k_offset_elems, v_offset_elems, page_indices, page_indptr, last_page_len_d, q_indptr, \
+      request_indices, qo_tile_indices, num_qo_heads, num_kv_heads, page_size, stride_page, scale_log2, CTA, shift, \
+      padded_batch_size)
+  if (cta == 128) {
+    if (shift >= 0) PK_PREFILL(2, true, 1, 128);
+    else PK_PREFILL(2, false, 1, 128);
+  } else if (pair) {
+    if (shift >= 0) PK_PREFILL(2, true, 2, 64);
+    else PK_PREFILL(2, false, 2, 64);
+  } else {
+    if (shift >= 0) PK_PREFILL(1, true, 1, (int)cta);
+    else PK_PREFILL(1, false, 1, (int)cta);
+  }
+#undef PK_PREFILL
   return (int32_t)hipGetLastError();
 }
 
@@ -397,10 +498,19 @@ int32_t batch_prefill_paged_cuda_hd256(
   const uint32_t cta = fa2_cta_tile_q((int64_t)seq_len * group, head_dim);
   if (padded_batch_size <= 0) return 0;
   dim3 grid(padded_batch_size, num_kv_heads);
-  batch_prefill_paged_kernel<1, 256><<<grid, 256, 0, as_stream(stream)>>>(
-      q, output, kv_data, k_offset_elems, v_offset_elems, page_indices, page_indptr, last_page_len_d, q_indptr,
-      request_indices, qo_tile_indices, num_qo_heads, num_kv_heads, page_size, stride_page,
-      sm_scale * 1.4426950408889634f, (int)cta);
+  if (stride_page <= 0 || stride_page > 0x7fffffffLL) return (int32_t)hipErrorInvalidValue;
+  const int shift = page_shift_of(page_size);
+  const float scale_log2 = sm_scale * 1.4426950408889634f;
+  if (shift >= 0)
+    batch_prefill_paged_kernel<1, 256, true><<<grid, 256, 0, as_stream(stream)>>>(
+        q, output, kv_data, k_offset_elems, v_offset_elems, page_indices, page_indptr, last_page_len_d, q_indptr,
+        request_indices, qo_tile_indices, num_qo_heads, num_kv_heads, page_size, stride_page, scale_log2, (int)cta, shift,
+        padded_batch_size);
+  else
+    batch_prefill_paged_kernel<1, 256, false><<<grid, 256, 0, as_stream(stream)>>>(
+        q, output, kv_data, k_offset_elems, v_offset_elems, page_indices, page_indptr, last_page_len_d, q_indptr,
+        request_indices, qo_tile_indices, num_qo_heads, num_kv_heads, page_size, stride_page, scale_log2, (int)cta, shift,
+        padded_batch_size);
   return (int32_t)hipGetLastError();
 }
 

@@ -27,8 +27,11 @@ __device__ __forceinline__ uint16_t f2bf(float f) {
 }
 __device__ __forceinline__ float bf_lo(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t w) { return __builtin_bit_cast(float, w & 0xFFFF0000u); }
+// two roundings in ONE v_cvt_pk_bf16_f32 (the scalar form costs a cvt per value plus a merge)
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
-  return static_cast<uint32_t>(f2bf(lo)) | (static_cast<uint32_t>(f2bf(hi)) << 16);
+  typedef __attribute__((ext_vector_type(2))) float f32x2_cv;
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_cv;
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_cv{lo, hi}, bf16x2_cv));
 }
 __device__ __forceinline__ float bf16_round_f(float f) { return bf2f(f2bf(f)); }
 // SiLU exactly as the reference writes it: g / (1 + expf(-g))  (csrc/fused_proj.cu:57-62)
