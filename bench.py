@@ -420,7 +420,10 @@ def main():
     mp8 = None
     if world > 1:
         try:   # never let the side measurement take the headline line down with it
-            mp8 = parallel.bench_mp8_collectives(parallel.Comm(), device=torch.device("cuda", local))
+            ncomm = parallel.NativeComm(device=local)   # include/pegainfer_comm.h: RCCL on the caller's stream
+            mp8 = parallel.bench_mp8_collectives(ncomm, device=torch.device("cuda", local))
+            mp8["transport"] = "native C ABI over RCCL (pegainfer_comm.h)"
+            ncomm.close()
         except Exception as e:  # noqa: BLE001
             mp8 = {"error": f"{type(e).__name__}: {e}"[:300]}
     ctx_mid = args.ctx + args.warmup + args.steps / 2

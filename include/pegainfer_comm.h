@@ -90,6 +90,8 @@ int32_t pegainfer_ep_dispatch_recv(pegainfer_ep_t ep, int32_t* out_num_tokens, H
 int32_t pegainfer_ep_combine_send(pegainfer_ep_t ep, const Half* expert_x, int64_t expert_x_stride_elems, pegainfer_stream_t stream);
 int32_t pegainfer_ep_combine_recv(pegainfer_ep_t ep, int32_t num_tokens, Half* out_tokens, int64_t out_stride_elems, const int32_t* indices, const float* weights, int32_t accumulate, pegainfer_stream_t stream);
 const uint32_t* pegainfer_ep_tokens_per_expert(pegainfer_ep_t ep);
+/* host mirror of the same counters after dispatch_recv (n = num_experts / world entries) */
+int32_t pegainfer_ep_tokens_per_expert_host(pegainfer_ep_t ep, uint32_t* out, int32_t n);
 int32_t pegainfer_ep_num_recv_tokens(pegainfer_ep_t ep);   /* host copy of the last dispatch's received row count */
 
 #ifdef __cplusplus

@@ -90,6 +90,11 @@ pegainfer_status_t pegainfer_gemm_add(const Half* W, const Half* X, Half* y_scra
  * rows of requests that own no slot (padding columns) are then left untouched.  Same bits either way. */
 int32_t pegainfer_fused_decode_attention(const Half* qkv, Half* output, const Half* kv_data, int64_t k_offset_elems, int64_t v_offset_elems, const int32_t* page_indices, const int32_t* page_indptr, const int32_t* last_page_len_d, const int32_t* positions, const Half* q_norm_weight, const Half* k_norm_weight, const Half* cos_cache, const Half* sin_cache, float rms_eps, int32_t use_split, const int32_t* split_request_indices, const int32_t* split_kv_tile_indices, const int32_t* split_kv_chunk_size_ptr, const int32_t* split_o_indptr, const uint8_t* split_block_valid_mask, Half* tmp_v, float* tmp_s, int32_t num_qo_heads, int32_t num_kv_heads, int32_t head_dim, int32_t page_size, int32_t batch_size, int32_t split_slots, int64_t stride_page, float sm_scale, const int32_t* slot_desc, int32_t* merge_counters, pegainfer_stream_t stream);
 
+/* Debug aid (not in ffi.rs): buf = device array of (workgroups per launch, <= 4096) * 8 uint64, or NULL.  Every later
+ * dot2-GEMV launch stamps it with the 100 MHz wall clock per workgroup: [0] entry, [1] x staged, [2] first weight block
+ * consumed, [3] K loop of the last row group done, [4] exit, [5] XCC id.  tools/gemv_probe.py prints the breakdown. */
+void pegainfer_debug_gemv_trace(uint64_t* buf);
+
 /* Debug aid (not in ffi.rs): buf = device array of slots * num_kv_heads * 8 uint64, or NULL to switch off.  Every later
  * decode-attention launch stamps it with the 100 MHz wall clock at its phase boundaries: [0] entry, [1] slot record
  * read, [2] q prologue done, [3] KV scan done, [4] partials published, [5] ticket drawn, [6] merge done, [7] = 1 for

@@ -56,14 +56,15 @@ __device__ __forceinline__ void decode_attn_body(const DecodeAttnArgs& a, const 
   PK_ATTN_STAMP(a, slot, kvh, 2);
   st.template finish<POW2>(a, ci, qv, kvh, lane, NW, pipe);
   PK_ATTN_STAMP(a, slot, kvh, 3);
-  // merge the workgroup's NPART partial states
-  st.store_state(sm_m, sm_l, sm_o, wave * Scan::TPI + lane / Scan::LPT, lane);
+  // merge the workgroup's partial states: only the waves that saw a token contribute
+  const int live = Scan::live_waves(ci, NW);
+  if (wave < live) st.store_state(sm_m, sm_l, sm_o, wave * Scan::TPI + lane / Scan::LPT, lane);
   __syncthreads();
   // one thread per (head, 8 output dims): 16-byte stores.  With merge_counters the partials are published
   // write-through (sc1): they are read by a workgroup on another XCD later in this same launch.
   const bool publish = PARTITION && a.merge_counters != nullptr;
   for (int e = threadIdx.x; e < GROUP * (D / 8); e += NW * 64)
-    attn_finish_part<D, GROUP, PARTITION>(a, ci.b, slot, kvh, e, NPART, sm_m, sm_l, sm_o, publish);
+    attn_finish_part<D, GROUP, PARTITION>(a, ci.b, slot, kvh, e, live * Scan::TPI, sm_m, sm_l, sm_o, publish);
   if (publish) {
     // "last workgroup done" merge without cache-wide fences (guide: sc1 payload -> vmcnt(0) -> counter; the
     // reader uses sc1 loads): every chunk's partials are write-through, the ticket is a relaxed agent atomic,
@@ -169,10 +170,23 @@ __device__ __forceinline__ void fused_decode_attn_run(const DecodeAttnArgs& a, f
   PK_ATTN_STAMP(a, slot, kvh, 1);
   if (!owns_new) st.template begin<POW2>(a, ci, kvh, lane, wave, NW, pipe);
   u32x4 qv[GROUP];
+  if constexpr (GROUP == 4) {
+    // the four 16-lane rows of a wave normalise + rotate ONE head each (the per-head core works on 16 lanes) and
+    // hand the result round: a quarter of the serial prologue work per lane, same bits
+    const u32x4 x = *reinterpret_cast<const u32x4*>(row + (size_t)(kvh * GROUP + grp) * D + sub * 8);
+    const u32x4 r = head_norm_rope16(x, a.q_norm_w, crow, srow, sub, a.eps);
 #pragma unroll
-  for (int h = 0; h < GROUP; ++h) {
-    const u32x4 x = *reinterpret_cast<const u32x4*>(row + (size_t)(kvh * GROUP + h) * D + sub * 8);
-    qv[h] = head_norm_rope16(x, a.q_norm_w, crow, srow, sub, a.eps);
+    for (int h = 0; h < GROUP; ++h) {
+      const int src = h * 16 + sub;
+      qv[h].x = __shfl(r.x, src, kWave); qv[h].y = __shfl(r.y, src, kWave);
+      qv[h].z = __shfl(r.z, src, kWave); qv[h].w = __shfl(r.w, src, kWave);
+    }
+  } else {
+#pragma unroll
+    for (int h = 0; h < GROUP; ++h) {
+      const u32x4 x = *reinterpret_cast<const u32x4*>(row + (size_t)(kvh * GROUP + h) * D + sub * 8);
+      qv[h] = head_norm_rope16(x, a.q_norm_w, crow, srow, sub, a.eps);
+    }
   }
   if (owns_new) {
     if (wave == 0 && grp == 0) {

@@ -260,6 +260,13 @@ struct AttnScan {
     finish<POW2>(a, ci, qv, kvh, lane, NW, p);
   }
 
+  // number of (real or virtual) scan waves of an NW-wave plan that see at least one token of the chunk
+  __device__ static __forceinline__ int live_waves(const ChunkInfo& ci, int NW) {
+    if (ci.hi <= ci.lo) return 0;
+    const int n = (ci.hi - (ci.lo / TB) * TB + TB - 1) / TB;
+    return n < NW ? n : NW;
+  }
+
   // this lane row's state -> the workgroup's partial-state arrays (part = wave * TPI + grp)
   __device__ __forceinline__ void store_state(float* sm_m, float* sm_l, float* sm_o, int part, int lane) const {
     const int sub = lane % LPT;
@@ -282,19 +289,41 @@ __device__ __forceinline__ void attn_finish_part(const DecodeAttnArgs& a, int b,
                                                  const float* sm_m, const float* sm_l, const float* sm_o, bool publish,
                                                  bool coherent_out = false) {
   const int h = e / (D / 8), d0 = (e - h * (D / 8)) * 8;
+  // `npart` = the LIVE partial states (parts of waves that saw no token hold m = -inf, l = 0, o = 0 and would add
+  // exact zeros: the caller leaves them out).  LDS reads go four parts at a time so their latencies overlap - this
+  // loop is one thread per output element walking the parts serially and was 1.3 of the 2.3 us between the end of
+  // the scan and the published partial at bs 1; the accumulation order (part order) is unchanged.
   float M = -INFINITY;
-  for (int p = 0; p < npart; ++p) M = fmaxf(M, sm_m[p * GROUP + h]);
+  for (int p0 = 0; p0 < npart; p0 += 4) {
+    float mv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) mv[j] = p0 + j < npart ? sm_m[(p0 + j) * GROUP + h] : -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) M = fmaxf(M, mv[j]);
+  }
   float L = 0.f, O[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) O[i] = 0.f;
   if (M != -INFINITY) {
-    for (int p = 0; p < npart; ++p) {
-      const float w = exp2f(sm_m[p * GROUP + h] - M);
-      L = fmaf(sm_l[p * GROUP + h], w, L);
-      const f32x4 x0 = *reinterpret_cast<const f32x4*>(&sm_o[((size_t)p * GROUP + h) * D + d0]);
-      const f32x4 x1 = *reinterpret_cast<const f32x4*>(&sm_o[((size_t)p * GROUP + h) * D + d0 + 4]);
-      O[0] = fmaf(x0[0], w, O[0]); O[1] = fmaf(x0[1], w, O[1]); O[2] = fmaf(x0[2], w, O[2]); O[3] = fmaf(x0[3], w, O[3]);
-      O[4] = fmaf(x1[0], w, O[4]); O[5] = fmaf(x1[1], w, O[5]); O[6] = fmaf(x1[2], w, O[6]); O[7] = fmaf(x1[3], w, O[7]);
+    for (int p0 = 0; p0 < npart; p0 += 4) {
+      float mv[4], lv[4];
+      f32x4 xa[4], xb[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int p = p0 + j < npart ? p0 + j : npart - 1;   // clamped re-read, dropped below
+        mv[j] = sm_m[p * GROUP + h];
+        lv[j] = sm_l[p * GROUP + h];
+        xa[j] = *reinterpret_cast<const f32x4*>(&sm_o[((size_t)p * GROUP + h) * D + d0]);
+        xb[j] = *reinterpret_cast<const f32x4*>(&sm_o[((size_t)p * GROUP + h) * D + d0 + 4]);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (p0 + j >= npart) break;
+        const float w = exp2f(mv[j] - M);
+        L = fmaf(lv[j], w, L);
+        O[0] = fmaf(xa[j][0], w, O[0]); O[1] = fmaf(xa[j][1], w, O[1]); O[2] = fmaf(xa[j][2], w, O[2]); O[3] = fmaf(xa[j][3], w, O[3]);
+        O[4] = fmaf(xb[j][0], w, O[4]); O[5] = fmaf(xb[j][1], w, O[5]); O[6] = fmaf(xb[j][2], w, O[6]); O[7] = fmaf(xb[j][3], w, O[7]);
+      }
     }
   }
   u32x4 pk;

@@ -51,7 +51,14 @@ struct GemvFusedArgs {
   int I;                  // kEpiSilu: W = [gate(I rows); up(I rows)], Y = [T, I]
   int KT;                 // x tile width (gemv_pick_kt)
   int flags;              // kGemvNormOffset | kGemvRoundSum | kGemvSiluRound (dot2 GEMV path only)
+  unsigned long long* trace;  // debug (pegainfer_debug_gemv_trace): 8 wall-clock stamps per workgroup, else null
 };
+// process-wide debug hook, defined in linear.hip; copied into the launch arguments by gemv_launch_one
+extern unsigned long long* g_gemv_trace;
+#define PK_GEMV_STAMP(a, i)                                                                        \
+  do {                                                                                             \
+    if ((a).trace && threadIdx.x == 0) (a).trace[(size_t)blockIdx.x * 8 + (i)] = wall_clock64();   \
+  } while (0)
 // Qwen3.5 forms of the fused pieces (pegainfer_gemv_fused_ex): (1 + w) norm weight; residual sum rounded to bf16
 // before the norm ("add, then norm" instead of FlashInfer's fused add+norm); silu rounded to bf16 before * up
 enum { kGemvNormOffset = 1, kGemvRoundSum = 2, kGemvSiluRound = 4 };
@@ -133,6 +140,7 @@ __global__ __launch_bounds__(256) void gemv_fused_kernel(const GemvFusedArgs a) 
   const int bfirst = KSPLIT == 1 ? 0 : wave;
   const int kt0 = K < KT ? K : KT;
   int g = blockIdx.x;
+  PK_GEMV_STAMP(a, 0);
   set_rows(g);
   issue(0, kt0, bfirst);  // HBM requests leave before the prologue touches anything
 
@@ -182,6 +190,8 @@ __global__ __launch_bounds__(256) void gemv_fused_kernel(const GemvFusedArgs a) 
   };
   stage(0, kt0);
   __syncthreads();
+  PK_GEMV_STAMP(a, 1);
+  bool first_group = true;
 
   for (;;) {
     zero_acc();
@@ -189,6 +199,7 @@ __global__ __launch_bounds__(256) void gemv_fused_kernel(const GemvFusedArgs a) 
     {
       const int nblk = (kt0 + 511) >> 9;
       consume(kt0, nblk, bfirst);
+      if (first_group) { PK_GEMV_STAMP(a, 2); first_group = false; }
       for (int b0 = bfirst + U * KSPLIT; b0 < nblk; b0 += U * KSPLIT) {
         issue(0, kt0, b0);
         consume(kt0, nblk, b0);
@@ -208,6 +219,7 @@ __global__ __launch_bounds__(256) void gemv_fused_kernel(const GemvFusedArgs a) 
     }
     const int g_next = g + gridDim.x;
     const bool has_next = g_next < ngroups;
+    if (!has_next) PK_GEMV_STAMP(a, 3);
     const int row0 = (KSPLIT == 1 ? g * 4 + wave : g) * RPW;  // rows of the group being finished
     if (has_next) {
       set_rows(g_next);
@@ -267,6 +279,12 @@ __global__ __launch_bounds__(256) void gemv_fused_kernel(const GemvFusedArgs a) 
     if (!has_next) break;
     g = g_next;
   }
+  PK_GEMV_STAMP(a, 4);
+  if (a.trace && threadIdx.x == 0) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    a.trace[(size_t)blockIdx.x * 8 + 5] = xcc & 0xfu;
+  }
 }
 
 // Grid sizing: every workgroup should be co-resident (no second, half-empty scheduling round) and all of them
@@ -295,7 +313,9 @@ inline void gemv_launch_one(const GemvFusedArgs& a, hipStream_t s) {
     const int rounds = ceil_div(ngroups, cached_cap);
     grid = ceil_div(ngroups, rounds);
   }
-  kern<<<grid, 256, lds, s>>>(a);
+  GemvFusedArgs b = a;
+  b.trace = g_gemv_trace;
+  kern<<<grid, 256, lds, s>>>(b);
 }
 
 template <int NT, int EPI>

@@ -475,6 +475,12 @@ void pegainfer_ep_destroy(pegainfer_ep_t h) {
 }
 const char* pegainfer_ep_last_error(pegainfer_ep_t h) { return h ? static_cast<Ep*>(h)->err.c_str() : "null ep"; }
 const uint32_t* pegainfer_ep_tokens_per_expert(pegainfer_ep_t h) { return h ? static_cast<Ep*>(h)->d_tokens_per_expert : nullptr; }
+int32_t pegainfer_ep_tokens_per_expert_host(pegainfer_ep_t h, uint32_t* out, int32_t n) {
+  Ep* e = static_cast<Ep*>(h);
+  if (!e || !out || n != e->epr) return -1;
+  std::memcpy(out, e->h_tokens_per_expert, (size_t)n * 4);
+  return 0;
+}
 int32_t pegainfer_ep_num_recv_tokens(pegainfer_ep_t h) { return h ? static_cast<Ep*>(h)->num_recv : -1; }
 
 int32_t pegainfer_ep_dispatch_send(pegainfer_ep_t h, int32_t num_tokens, const Half* x, int64_t x_stride_elems,
@@ -530,9 +536,7 @@ int32_t pegainfer_ep_dispatch_recv(pegainfer_ep_t h, int32_t* out_num_tokens, Ha
       if (!p || !p->sent) { e->err = "loopback dispatch_recv before every virtual rank's dispatch_send"; return -1; }
       for (int le = 0; le < e->epr; ++le) e->h_counts_recv[r * e->epr + le] = p->h_counts[e->rank * e->epr + le];
     }
-    // my own send layout (needed by the combine) and the receive layout
-    for (int i = 0; i < e->num_experts; ++i) (void)e->h_counts[i];
-    ep_layout(e);
+    ep_layout(e);   // my own send layout (needed by the combine) and the receive layout
     if (e->num_recv > e->max_recv) { e->err = "dispatch: received rows exceed max_recv_tokens"; return -1; }
     for (int r = 0; r < e->world; ++r) {
       Ep* p = e->hub->eps[r];

@@ -22,6 +22,7 @@
 
 #include "common.h"
 #include "gemv_core.h"
+namespace pk { unsigned long long* g_gemv_trace = nullptr; }
 #include "gemm_skinny.h"
 #include "pegainfer_kernels_ext.h"
 
@@ -650,6 +651,12 @@ static void gemm_dispatch(const Half* W, const Half* X, Half* Y, int M, int T, i
 }  // namespace pk
 
 extern "C" {
+
+// Debug: device buffer of (workgroups of the launch) * 8 uint64 stamped by every later dot2-GEMV launch with the
+// 100 MHz wall clock: [0] entry, [1] x staged, [2] first weight block consumed, [3] last row group's K loop done,
+// [4] exit, [5] XCC id; nullptr switches it off (tools/gemv_probe.py).  Not part of the reference ABI.
+void pegainfer_debug_gemv_trace(uint64_t* buf) { pk::g_gemv_trace = reinterpret_cast<unsigned long long*>(buf); }
+
 
 int32_t cuda_set_device(int32_t device_ordinal) { return static_cast<int32_t>(hipSetDevice(device_ordinal)); }
 

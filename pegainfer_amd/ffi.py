@@ -19,7 +19,8 @@ _SCALARS = {
     "uint64_t": ctypes.c_uint64, "float": ctypes.c_float, "int": ctypes.c_int,
     "pegainfer_stream_t": ctypes.c_void_p, "pegainfer_status_t": ctypes.c_int32,
     "pegainfer_qwen3_t": ctypes.c_void_p, "pegainfer_qwen35_t": ctypes.c_void_p, "size_t": ctypes.c_size_t,
-    "pegainfer_sched_t": ctypes.c_void_p,
+    "pegainfer_sched_t": ctypes.c_void_p, "pegainfer_comm_t": ctypes.c_void_p, "pegainfer_ep_hub_t": ctypes.c_void_p,
+    "pegainfer_ep_t": ctypes.c_void_p,
     "double": ctypes.c_double,
 }
 
@@ -102,8 +103,9 @@ def lib():
 
 
 def host_lib():
-    """libpegainfer_qwen3.so (include/pegainfer_qwen3.h + pegainfer_qwen35.h)."""
+    """libpegainfer_qwen3.so (include/pegainfer_qwen3.h, pegainfer_qwen35.h, pegainfer_scheduler.h, pegainfer_comm.h)."""
     if "h" not in _cache:
         lib()
-        _cache["h"] = _Lib("libpegainfer_qwen3.so", "pegainfer_qwen3.h", "pegainfer_qwen35.h", "pegainfer_scheduler.h")
+        _cache["h"] = _Lib("libpegainfer_qwen3.so", "pegainfer_qwen3.h", "pegainfer_qwen35.h", "pegainfer_scheduler.h",
+                           "pegainfer_comm.h")
     return _cache["h"]

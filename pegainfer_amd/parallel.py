@@ -217,6 +217,187 @@ class Comm:
         return out
 
 
+class NativeComm:
+    """The MP8 verbs on the C ABI of include/pegainfer_comm.h (csrc/host/comm.cpp): RCCL on the caller's HIP stream,
+    fused bf16 <-> f32 casts around the f32 reduce, a comm stream with event fences.  Tensors are CUDA torch tensors
+    (device memory only: torch is plumbing here).  The unique id is drawn on rank 0 and broadcast over the
+    torch.distributed group that launched the ranks (collectives.rs:8-287, moe.rs:1327-1461, core.rs:560-609)."""
+
+    def __init__(self, group=None, device=None):
+        import ctypes
+
+        import torch
+        import torch.distributed as dist
+        from . import ffi
+        self.lib = ffi.host_lib()
+        self.dist, self.group = dist, group     # bootstrap / barrier only; no payload travels through torch
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        uid = (ctypes.c_ubyte * 128)()
+        if self.world > 1:
+            buf = torch.zeros(128, dtype=torch.uint8)
+            if self.rank == 0:
+                if self.lib.pegainfer_comm_unique_id(ctypes.addressof(uid)) != 0:
+                    raise RuntimeError("ncclGetUniqueId failed")
+                buf = torch.tensor(list(uid), dtype=torch.uint8)
+            dev = torch.device("cuda", self.device) if dist.get_backend(group) == "nccl" else "cpu"
+            buf = buf.to(dev)
+            dist.broadcast(buf, src=0, group=group)
+            for i, b in enumerate(buf.cpu().tolist()):
+                uid[i] = b
+        self.h = self.lib.pegainfer_comm_create(self.device, self.rank, self.world,
+                                                ctypes.addressof(uid) if self.world > 1 else None)
+        if not self.h:
+            raise RuntimeError("pegainfer_comm_create failed")
+
+    def close(self):
+        if self.h:
+            self.lib.pegainfer_comm_destroy(self.h)
+            self.h = None
+
+    def _s(self, stream=None):
+        import torch
+        return (stream or torch.cuda.current_stream()).cuda_stream
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what}: {self.lib.pegainfer_comm_last_error(self.h).decode()}")
+
+    def all_reduce_in_place(self, t, stream=None):
+        import torch
+        if t.dtype == torch.bfloat16:
+            self._chk(self.lib.pegainfer_comm_all_reduce_bf16(self.h, t.data_ptr(), t.numel(), self._s(stream)), "all_reduce_bf16")
+        elif t.dtype == torch.float32:
+            self._chk(self.lib.pegainfer_comm_all_reduce_f32(self.h, t.data_ptr(), t.numel(), self._s(stream)), "all_reduce_f32")
+        else:
+            raise TypeError(t.dtype)
+        return t
+
+    def all_reduce_hidden_fp32_in_place(self, hidden_bf16, stream=None):
+        self._chk(self.lib.pegainfer_comm_all_reduce_bf16_via_f32(self.h, hidden_bf16.data_ptr(), hidden_bf16.numel(),
+                                                                  self._s(stream)), "all_reduce_bf16_via_f32")
+        return hidden_bf16
+
+    def all_reduce_hidden_to_f32(self, hidden_bf16, out_f32, stream=None):
+        self._chk(self.lib.pegainfer_comm_all_reduce_bf16_to_f32(self.h, hidden_bf16.data_ptr(), out_f32.data_ptr(),
+                                                                 hidden_bf16.numel(), self._s(stream)), "all_reduce_bf16_to_f32")
+        return out_f32
+
+    def all_gather(self, t, stream=None):
+        import torch
+        out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        self._chk(self.lib.pegainfer_comm_all_gather(self.h, t.data_ptr(), out.data_ptr(), t.numel(), t.element_size(),
+                                                     self._s(stream)), "all_gather")
+        return out
+
+    def reduce_scatter(self, t, stream=None):
+        import torch
+        n = t.shape[0] // self.world
+        out = torch.empty((n,) + tuple(t.shape[1:]), dtype=torch.float32, device=t.device)
+        self._chk(self.lib.pegainfer_comm_reduce_scatter_f32(self.h, t.data_ptr(), out.data_ptr(), out.numel(),
+                                                             self._s(stream)), "reduce_scatter_f32")
+        return out
+
+    def all_to_all(self, send, stream=None):
+        import torch
+        out = torch.empty_like(send)
+        self._chk(self.lib.pegainfer_comm_all_to_all(self.h, send.data_ptr(), out.data_ptr(), send.numel() // self.world,
+                                                     send.element_size(), self._s(stream)), "all_to_all")
+        return out
+
+    def all_gather_logits(self, local_logits_f32, stream=None):
+        return self.all_gather(local_logits_f32, stream)
+
+    def moe_all_gather_reduce_scatter(self, hidden_bf16, expert_fn, shared_fn=None):
+        """moe.rs:1327-1461: the all-gather runs on the comm stream between two event fences while the compute
+        stream runs the shared expert; the reduce-scatter of the f32 partials follows on the compute stream."""
+        import torch
+        cur = torch.cuda.current_stream()
+        comm_stream = torch.cuda.ExternalStream(self.lib.pegainfer_comm_stream(self.h))
+        gathered = torch.empty((self.world * hidden_bf16.shape[0],) + tuple(hidden_bf16.shape[1:]), dtype=hidden_bf16.dtype,
+                               device=hidden_bf16.device)   # allocated on the compute stream: no cross-stream reuse
+        self._chk(self.lib.pegainfer_comm_fence_in(self.h, cur.cuda_stream), "fence_in")
+        self._chk(self.lib.pegainfer_comm_all_gather(self.h, hidden_bf16.data_ptr(), gathered.data_ptr(), hidden_bf16.numel(),
+                                                     2, comm_stream.cuda_stream), "all_gather")
+        hidden_bf16.record_stream(comm_stream)
+        shared = shared_fn(hidden_bf16) if shared_fn else None
+        self._chk(self.lib.pegainfer_comm_fence_out(self.h, cur.cuda_stream), "fence_out")
+        routed = self.reduce_scatter(expert_fn(gathered))
+        return routed if shared is None else routed + shared.float()
+
+
+class EpEndpoint:
+    """One rank of the expert-parallel dispatch / combine (ep_backend.rs:213-331) on include/pegainfer_comm.h.
+    comm = NativeComm (RCCL transport) or hub = handle from EpEndpoint.hub(world) (loopback: virtual ranks in one
+    process, for single-GPU tests of the multi-rank routing)."""
+
+    @staticmethod
+    def hub(world):
+        from . import ffi
+        h = ffi.host_lib().pegainfer_ep_hub_create(world)
+        if not h:
+            raise RuntimeError("pegainfer_ep_hub_create failed")
+        return h
+
+    def __init__(self, hidden, max_tokens, max_recv, num_experts, topk, comm=None, hub=None, rank=0):
+        from . import ffi
+        self.lib = ffi.host_lib()
+        self.hidden, self.topk, self.max_recv = hidden, topk, max_recv
+        self.world = comm.world if comm is not None else None
+        self.h = self.lib.pegainfer_ep_create(comm.h if comm is not None else None, hub, rank, hidden, max_tokens, max_recv,
+                                              num_experts, topk)
+        if not self.h:
+            raise RuntimeError("pegainfer_ep_create failed")
+
+    def close(self):
+        if self.h:
+            self.lib.pegainfer_ep_destroy(self.h)
+            self.h = None
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what}: {self.lib.pegainfer_ep_last_error(self.h).decode()}")
+
+    def _s(self):
+        import torch
+        return torch.cuda.current_stream().cuda_stream
+
+    def dispatch_send(self, x, indices, weights):
+        self._chk(self.lib.pegainfer_ep_dispatch_send(self.h, x.shape[0], x.data_ptr(), x.stride(0) if x.shape[0] else self.hidden,
+                                                      indices.data_ptr(), weights.data_ptr(), self._s()), "dispatch_send")
+
+    def dispatch_recv(self):
+        import ctypes
+
+        import torch
+        out = torch.empty((self.max_recv, self.hidden), dtype=torch.bfloat16, device="cuda")
+        n = ctypes.c_int32(0)
+        self._chk(self.lib.pegainfer_ep_dispatch_recv(self.h, ctypes.addressof(n), out.data_ptr(), self.hidden, self._s()),
+                  "dispatch_recv")
+        return out[:n.value], n.value
+
+    def tokens_per_expert(self, n_local):
+        """host copy of the per-local-expert row counts of the last dispatch_recv (the reference reads its device
+        counter with a D2H copy; the device pointer is pegainfer_ep_tokens_per_expert)"""
+        import ctypes
+
+        import numpy as np
+        buf = (ctypes.c_uint32 * n_local)()
+        self._chk(self.lib.pegainfer_ep_tokens_per_expert_host(self.h, ctypes.addressof(buf), n_local), "tokens_per_expert")
+        return np.frombuffer(buf, dtype=np.uint32).copy()
+
+    def combine_send(self, expert_x):
+        self._chk(self.lib.pegainfer_ep_combine_send(self.h, expert_x.data_ptr(), expert_x.stride(0) if expert_x.shape[0] else self.hidden,
+                                                     self._s()), "combine_send")
+
+    def combine_recv(self, out_tokens, indices, weights, accumulate=False):
+        self._chk(self.lib.pegainfer_ep_combine_recv(self.h, out_tokens.shape[0], out_tokens.data_ptr(),
+                                                     out_tokens.stride(0) if out_tokens.shape[0] else self.hidden, indices.data_ptr(),
+                                                     weights.data_ptr(), int(bool(accumulate)), self._s()), "combine_recv")
+        return out_tokens
+
+
 def bench_mp8_collectives(comm, hidden=4096, token_counts=(1, 8, 32, 256, 4096), iters=10, device="cuda"):
     """BASELINE.json configs[4] (DeepSeek-V4 MP8, collectives only, synthetic): per-layer f32 all-reduce of
     [T, hidden], bf16 all-gather [T, hidden] -> x world, f32 reduce-scatter of [world*T, hidden]; average us per
@@ -230,7 +411,8 @@ def bench_mp8_collectives(comm, hidden=4096, token_counts=(1, 8, 32, 256, 4096),
         if cuda:
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            comm.dist.barrier(group=comm.group)
+            if comm.world > 1:
+                comm.dist.barrier(group=comm.group)
             e0.record()
             for _ in range(iters):
                 fn()

@@ -19,7 +19,11 @@ def test_host_library_exports_every_declared_symbol(built_libs):
     import subprocess
     out = subprocess.run(["nm", "-D", "--defined-only", built_libs[1]], stdout=subprocess.PIPE, text=True).stdout
     exported = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
-    missing = sorted(set(ffi.declared_symbols("pegainfer_qwen3.h")) - exported)
+    declared = []
+    for header in ("pegainfer_qwen3.h", "pegainfer_qwen35.h", "pegainfer_scheduler.h", "pegainfer_comm.h"):
+        declared += ffi.declared_symbols(header)
+    assert "pegainfer_comm_all_reduce_bf16_via_f32" in declared and "pegainfer_ep_dispatch_send" in declared
+    missing = sorted(set(declared) - exported)
     assert not missing, missing
 
 
