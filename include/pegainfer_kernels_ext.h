@@ -80,10 +80,9 @@ pegainfer_status_t pegainfer_gemm_add(const Half* W, const Half* X, Half* y_scra
  * and V rows into the paged cache and the attention output [bs, Hq*128].  Bit-identical to
  * qk_norm_rope_batched_decode_cuda + paged_kv_scatter_cuda + paged_attention_decode[_split_kv]_cuda
  * (ops/attention.rs:469-511, 572-796).  use_split selects the partition-KV plan arrays.
- * slot_desc (optional, 16-byte aligned): one record of 16 int32 per slot {b, lo, hi, page_indptr[b], position,
- * kv_len, o_indptr[b], o_indptr[b+1], page ids of the chunk's first 8 pages (0 beyond the request's last page)},
- * lo < 0 for padding slots - the same plan, pre-resolved on the host so a workgroup needs ONE metadata load
- * instead of four dependent ones and, for chunks of at most 8 pages, no page-table load in front of K / V.
+ * slot_desc (optional, 16-byte aligned): one record of 8 int32 per slot {b, lo, hi, page_indptr[b], position,
+ * kv_len, o_indptr[b], o_indptr[b+1]}, lo < 0 for padding slots - the same plan, pre-resolved on the host so a
+ * workgroup needs one metadata load instead of four dependent ones.
  * merge_counters (optional, use_split only): batch_size * num_kv_heads int32, zero before the first call.  When
  * given, the last workgroup of each (request, kv head) to finish merges that head group's partials in the
  * same launch (agent-scope release/acquire around one atomic) and re-arms the counter; no merge launch.  Output
@@ -96,9 +95,9 @@ int32_t pegainfer_fused_decode_attention(const Half* qkv, Half* output, const Ha
 void pegainfer_debug_gemv_trace(uint64_t* buf);
 
 /* Debug aid (not in ffi.rs): buf = device array of slots * num_kv_heads * 8 uint64, or NULL to switch off.  Every later
- * decode-attention launch stamps it with the 100 MHz wall clock at its phase boundaries: [0] entry, [1] slot record
- * read, [2] q prologue done, [3] KV scan done, [4] partials published, [5] ticket drawn, [6] merge done, [7] = 1 for
- * the workgroup that merged.  tools/attn_probe.py prints the per-phase means. */
+ * fused decode-attention launch stamps it with the 100 MHz wall clock at its phase boundaries: [0] entry, [1] slot
+ * record read, [2] q prologue done, [3] KV scan done, [4] partials published, [5] ticket drawn, [6] merge done,
+ * [7] = 1 for the workgroup that merged.  tools/attn_probe.py prints the per-phase means. */
 void pegainfer_debug_attn_trace(uint64_t* buf);
 
 /* Partition-KV decode attention at head_dim 256 (Qwen3.5 full-attention layers).  No counterpart in ffi.rs (its
@@ -117,7 +116,7 @@ int32_t pegainfer_paged_attention_decode_split_kv_hd256(const Half* q, Half* out
  *   layer_table: device array [layers]; sync: layers*5*8 uint32, status: 4 uint32 - both ZERO before every launch
  *   (memset nodes); status[0] != 0 after the launch = the engine gave up (a bounded spin expired: the grid was not
  *   co-resident) and every output of the step is invalid.
- *   slot_desc records (16 int32 each) {b, lo, hi, page_indptr[b], position, kv_len, o_indptr[b], o_indptr[b+1], 8 page ids} as for
+ *   slot_desc records {b, lo, hi, page_indptr[b], position, kv_len, o_indptr[b], o_indptr[b+1]} as for
  *   pegainfer_fused_decode_attention; num_slots / use_split = that call's split_slots (or batch_size) / use_split. */
 typedef struct {
   const Half *qkv, *o, *gate_up, *down, *ln1, *ln2, *q_norm, *k_norm;

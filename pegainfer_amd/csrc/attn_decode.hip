@@ -25,8 +25,6 @@ namespace pk {
 template <bool PARTITION>
 __device__ __forceinline__ ChunkInfo decode_chunk(const DecodeAttnArgs& a, int slot) {
   ChunkInfo c;
-  c.rec = 0;
-  c.inline_pages = false;
   c.b = a.request_indices ? a.request_indices[slot] : slot;
   c.pbase = a.page_indptr[c.b];
   const int npages = a.page_indptr[c.b + 1] - c.pbase;
@@ -43,33 +41,34 @@ __device__ __forceinline__ ChunkInfo decode_chunk(const DecodeAttnArgs& a, int s
 }
 
 // The KV scan + in-workgroup merge, given the (already normalised / rotated) bf16 q fragments (attn_decode_core.h
-// holds the arithmetic; this is the real-workgroup driver: NW waves, __syncthreads, static LDS).  The caller has
-// already issued the wave's first K / V tile (Scan::begin) so that those loads fly under its q prologue.
-template <int D, int GROUP, bool PARTITION, int NW, bool POW2>
+// holds the arithmetic; this is the real-workgroup driver: NW waves, __syncthreads, static LDS).
+template <int D, int GROUP, bool PARTITION, int NW>
 __device__ __forceinline__ void decode_attn_body(const DecodeAttnArgs& a, const ChunkInfo& ci, const u32x4 (&qv)[GROUP],
-                                                 int slot, int kvh, AttnScan<D, GROUP>& st,
-                                                 typename AttnScan<D, GROUP>::Pipe& pipe, float* sm_m, float* sm_l,
-                                                 float* sm_o, int* sm_last_p) {
+                                                 int slot, int kvh) {
   typedef AttnScan<D, GROUP> Scan;
   constexpr int NPART = NW * Scan::TPI;  // partial softmax states per workgroup (NW waves)
+  __shared__ float sm_m[NPART * GROUP];
+  __shared__ float sm_l[NPART * GROUP];
+  __shared__ __attribute__((aligned(16))) float sm_o[NPART * GROUP * D];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  Scan st;
+  st.init();
   PK_ATTN_STAMP(a, slot, kvh, 2);
-  st.template finish<POW2>(a, ci, qv, kvh, lane, NW, pipe);
+  st.scan(a, ci, qv, kvh, lane, wave, NW);
   PK_ATTN_STAMP(a, slot, kvh, 3);
-  // merge the workgroup's partial states: only the waves that saw a token contribute
-  const int live = Scan::live_waves(ci, NW);
-  if (wave < live) st.store_state(sm_m, sm_l, sm_o, wave * Scan::TPI + lane / Scan::LPT, lane);
+  // merge the workgroup's NPART partial states
+  st.store_state(sm_m, sm_l, sm_o, wave * Scan::TPI + lane / Scan::LPT, lane);
   __syncthreads();
   // one thread per (head, 8 output dims): 16-byte stores.  With merge_counters the partials are published
   // write-through (sc1): they are read by a workgroup on another XCD later in this same launch.
   const bool publish = PARTITION && a.merge_counters != nullptr;
   for (int e = threadIdx.x; e < GROUP * (D / 8); e += NW * 64)
-    attn_finish_part<D, GROUP, PARTITION>(a, ci.b, slot, kvh, e, live * Scan::TPI, sm_m, sm_l, sm_o, publish);
+    attn_finish_part<D, GROUP, PARTITION>(a, ci.b, slot, kvh, e, NPART, sm_m, sm_l, sm_o, publish);
   if (publish) {
     // "last workgroup done" merge without cache-wide fences (guide: sc1 payload -> vmcnt(0) -> counter; the
     // reader uses sc1 loads): every chunk's partials are write-through, the ticket is a relaxed agent atomic,
     // and the workgroup that draws n-1 merges this head group and re-arms the counter for the next launch.
-    int& sm_last = *sm_last_p;
+    __shared__ int sm_last;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     PK_ATTN_STAMP(a, slot, kvh, 4);
@@ -96,36 +95,17 @@ __device__ __forceinline__ void decode_attn_body(const DecodeAttnArgs& a, const 
 }
 
 // ---- kernels: reference-ABI form (q already normalised + rotated, K/V already in the cache) ----
-template <int D, int GROUP, bool PARTITION, int NW, bool POW2>
-__device__ __forceinline__ void decode_attn_run(const DecodeAttnArgs& a, float* sm_m, float* sm_l, float* sm_o,
-                                                int* sm_last) {
+template <int D, int GROUP, bool PARTITION, int NW>
+__global__ __launch_bounds__(NW * 64) void decode_attn_kernel(const DecodeAttnArgs a) {
   const int slot = blockIdx.x, kvh = blockIdx.y;
   if (PARTITION && a.block_valid_mask && !a.block_valid_mask[slot]) return;
   const ChunkInfo ci = decode_chunk<PARTITION>(a, slot);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  AttnScan<D, GROUP> st;
-  typename AttnScan<D, GROUP>::Pipe pipe;
-  st.init();
-  st.template begin<POW2>(a, ci, kvh, lane, wave, NW, pipe);   // K / V requests leave before the q loads
-  const int sub = lane % (D / 8);
+  const int sub = (threadIdx.x & 63) % (D / 8);
   u32x4 qv[GROUP];
 #pragma unroll
   for (int h = 0; h < GROUP; ++h)
     qv[h] = *reinterpret_cast<const u32x4*>(a.q + ((size_t)ci.b * a.num_qo_heads + kvh * GROUP + h) * D + sub * 8);
-  decode_attn_body<D, GROUP, PARTITION, NW, POW2>(a, ci, qv, slot, kvh, st, pipe, sm_m, sm_l, sm_o, sm_last);
-}
-// the workgroup's partial-state arrays: declared once per kernel (the two page-size instantiations share them)
-#define PK_ATTN_LDS(D_, GROUP_, NW_)                                                        \
-  constexpr int NPART_ = NW_ * AttnScan<D_, GROUP_>::TPI;                                   \
-  __shared__ float sm_m[NPART_ * GROUP_];                                                   \
-  __shared__ float sm_l[NPART_ * GROUP_];                                                   \
-  __shared__ __attribute__((aligned(16))) float sm_o[NPART_ * GROUP_ * D_];                 \
-  __shared__ int sm_last
-template <int D, int GROUP, bool PARTITION, int NW>
-__global__ __launch_bounds__(NW * 64) void decode_attn_kernel(const DecodeAttnArgs a) {
-  PK_ATTN_LDS(D, GROUP, NW);
-  if (a.page_shift >= 0) decode_attn_run<D, GROUP, PARTITION, NW, true>(a, sm_m, sm_l, sm_o, &sm_last);
-  else decode_attn_run<D, GROUP, PARTITION, NW, false>(a, sm_m, sm_l, sm_o, &sm_last);
+  decode_attn_body<D, GROUP, PARTITION, NW>(a, ci, qv, slot, kvh);
 }
 
 // ---- fused form (head_dim 128): per-head q/k RMSNorm + RoPE and the KV append folded into the prologue.
@@ -133,61 +113,38 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(const DecodeAttnAr
 // the request's chunks); the one workgroup per (request, kv head) whose chunk contains the new position also
 // normalises + rotates the new K row, writes K and V into the page (same bytes paged_kv_scatter_cuda would
 // write) and only then scans.  Replaces qk_norm_rope + paged_kv_scatter + decode attention: 3 launches -> 1.
-//
-// The launch is a chain of dependent memory round trips (67 % of its wave cycles were waits at bs 1), so the order
-// is: slot record (ONE 64-byte load: chunk, position and the chunk's page ids) -> the wave's K / V tile AND the
-// qkv / cos / sin rows together -> q prologue under the K / V flight -> scan.
-template <int GROUP, bool PARTITION, int NW, bool POW2>
-__device__ __forceinline__ void fused_decode_attn_run(const DecodeAttnArgs& a, float* sm_m, float* sm_l, float* sm_o,
-                                                      int* sm_last) {
+template <int GROUP, bool PARTITION, int NW>
+__global__ __launch_bounds__(NW * 64) void fused_decode_attn_kernel(const DecodeAttnArgs a) {
   constexpr int D = 128;
   const int slot = blockIdx.x, kvh = blockIdx.y;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   ChunkInfo ci;
   int pos;
   PK_ATTN_STAMP(a, slot, kvh, 0);
   if (a.slot_desc) {
-    ci.rec = a.slot_desc[16 * slot + (lane & 15)];
-    ci.b = __builtin_amdgcn_readlane(ci.rec, 0); ci.lo = __builtin_amdgcn_readlane(ci.rec, 1);
-    ci.hi = __builtin_amdgcn_readlane(ci.rec, 2); ci.pbase = __builtin_amdgcn_readlane(ci.rec, 3);
-    pos = __builtin_amdgcn_readlane(ci.rec, 4); ci.kv_len = __builtin_amdgcn_readlane(ci.rec, 5);
+    const u32x4 d0 = *reinterpret_cast<const u32x4*>(a.slot_desc + 8 * slot);
+    const u32x2 d1 = *reinterpret_cast<const u32x2*>(a.slot_desc + 8 * slot + 4);
+    ci.b = (int)d0.x; ci.lo = (int)d0.y; ci.hi = (int)d0.z; ci.pbase = (int)d0.w;
+    pos = (int)d1.x; ci.kv_len = (int)d1.y;
     if (ci.lo < 0) return;
-    ci.inline_pages = POW2 && ci.hi > ci.lo && ((ci.hi - 1) >> a.page_shift) - (ci.lo >> a.page_shift) < 8;
   } else {
     if (PARTITION && a.block_valid_mask && !a.block_valid_mask[slot]) return;
     ci = decode_chunk<PARTITION>(a, slot);
     pos = a.positions[ci.b];
   }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int sub = lane & 15, grp = lane >> 4;
   const int q_dim = a.num_qo_heads * D, kv_dim = a.num_kv_heads * D;
   const Half* row = a.qkv + (size_t)ci.b * (q_dim + 2 * kv_dim);
   const Half* crow = a.cos_cache + (size_t)pos * D;
   const Half* srow = a.sin_cache + (size_t)pos * D;
-  AttnScan<D, GROUP> st;
-  typename AttnScan<D, GROUP>::Pipe pipe;
-  st.init();
-  const bool owns_new = pos >= ci.lo && pos < ci.hi;  // workgroup-uniform
   PK_ATTN_STAMP(a, slot, kvh, 1);
-  if (!owns_new) st.template begin<POW2>(a, ci, kvh, lane, wave, NW, pipe);
   u32x4 qv[GROUP];
-  if constexpr (GROUP == 4) {
-    // the four 16-lane rows of a wave normalise + rotate ONE head each (the per-head core works on 16 lanes) and
-    // hand the result round: a quarter of the serial prologue work per lane, same bits
-    const u32x4 x = *reinterpret_cast<const u32x4*>(row + (size_t)(kvh * GROUP + grp) * D + sub * 8);
-    const u32x4 r = head_norm_rope16(x, a.q_norm_w, crow, srow, sub, a.eps);
 #pragma unroll
-    for (int h = 0; h < GROUP; ++h) {
-      const int src = h * 16 + sub;
-      qv[h].x = __shfl(r.x, src, kWave); qv[h].y = __shfl(r.y, src, kWave);
-      qv[h].z = __shfl(r.z, src, kWave); qv[h].w = __shfl(r.w, src, kWave);
-    }
-  } else {
-#pragma unroll
-    for (int h = 0; h < GROUP; ++h) {
-      const u32x4 x = *reinterpret_cast<const u32x4*>(row + (size_t)(kvh * GROUP + h) * D + sub * 8);
-      qv[h] = head_norm_rope16(x, a.q_norm_w, crow, srow, sub, a.eps);
-    }
+  for (int h = 0; h < GROUP; ++h) {
+    const u32x4 x = *reinterpret_cast<const u32x4*>(row + (size_t)(kvh * GROUP + h) * D + sub * 8);
+    qv[h] = head_norm_rope16(x, a.q_norm_w, crow, srow, sub, a.eps);
   }
+  const bool owns_new = pos >= ci.lo && pos < ci.hi;  // workgroup-uniform
   if (owns_new) {
     if (wave == 0 && grp == 0) {
       const u32x4 xk = *reinterpret_cast<const u32x4*>(row + q_dim + (size_t)kvh * D + sub * 8);
@@ -200,15 +157,8 @@ __device__ __forceinline__ void fused_decode_attn_run(const DecodeAttnArgs& a, f
       *reinterpret_cast<u32x4*>(kvw + base + a.v_off) = xv;
     }
     __syncthreads();  // workgroup-scope release/acquire: the new row is visible to the scanning waves
-    st.template begin<POW2>(a, ci, kvh, lane, wave, NW, pipe);
   }
-  decode_attn_body<D, GROUP, PARTITION, NW, POW2>(a, ci, qv, slot, kvh, st, pipe, sm_m, sm_l, sm_o, sm_last);
-}
-template <int GROUP, bool PARTITION, int NW>
-__global__ __launch_bounds__(NW * 64) void fused_decode_attn_kernel(const DecodeAttnArgs a) {
-  PK_ATTN_LDS(128, GROUP, NW);
-  if (a.page_shift >= 0) fused_decode_attn_run<GROUP, PARTITION, NW, true>(a, sm_m, sm_l, sm_o, &sm_last);
-  else fused_decode_attn_run<GROUP, PARTITION, NW, false>(a, sm_m, sm_l, sm_o, &sm_last);
+  decode_attn_body<D, GROUP, PARTITION, NW>(a, ci, qv, slot, kvh);
 }
 
 // merge of the partition-KV partial states: one wave per (request, q head).  Lanes first fetch all
@@ -241,11 +191,6 @@ static void fill_args(DecodeAttnArgs& a, const Half* q, Half* output, const Half
   a.num_qo_heads = hq; a.num_kv_heads = hkv; a.page_size = page_size; a.stride_page = stride_page;
   a.scale_log2 = sm_scale * 1.4426950408889634f;
   a.trace = g_attn_trace;
-  a.page_shift = -1;
-  if (page_size > 0 && (page_size & (page_size - 1)) == 0) {
-    a.page_shift = 0;
-    while ((1 << a.page_shift) < page_size) ++a.page_shift;
-  }
 }
 
 template <int D, bool PARTITION, bool FUSED>
@@ -289,7 +234,7 @@ using namespace pk;
 
 extern "C" {
 
-// Debug: device buffer of slots * kv_heads * 8 uint64 that every later decode-attention launch stamps with the
+// Debug: device buffer of slots * kv_heads * 8 uint64 that every later fused decode-attention launch stamps with the
 // 100 MHz wall clock at its phase boundaries (entry, record read, q prologue, scan, partials published, ticket,
 // merge; word 7 = 1 for the merging workgroup); nullptr switches it off.  Not part of the reference ABI.
 void pegainfer_debug_attn_trace(uint64_t* buf) { g_attn_trace = reinterpret_cast<unsigned long long*>(buf); }

@@ -36,9 +36,6 @@ struct DecodeAttnArgs {
   // finish merges that head group's partials itself (no merge_states_kernel launch).  One int per
   // (request, kv head), zero before the first launch; the merging workgroup leaves it zero again.
   int* merge_counters; const int* o_indptr;
-  // log2(page_size) when it is a power of two, else -1 (fill_args); the scan then splits a token index with a shift
-  // and a mask instead of two 32-bit divisions per load
-  int page_shift;
   // debug: 8 wall-clock stamps (100 MHz) per (slot, kv head) written by thread 0 (pegainfer_debug_attn_trace)
   unsigned long long* trace;
 };
@@ -48,10 +45,7 @@ struct DecodeAttnArgs {
       (a).trace[((size_t)(slot) * (a).num_kv_heads + (kvh)) * 8 + (i)] = wall_clock64();                       \
   } while (0)
 
-// rec / inline_pages: the fused form's 16-dword slot record, dword `lane & 15` in every lane; dwords 8..15 hold the
-// page ids of the chunk's first 8 pages, so when the chunk spans at most 8 pages (inline_pages) a token's page id is
-// a cross-lane read of a register instead of a dependent global load in front of every K / V load.
-struct ChunkInfo { int b, pbase, kv_len, lo, hi; int rec; bool inline_pages; };
+struct ChunkInfo { int b, pbase, kv_len, lo, hi; };
 
 // One wave merges the partition-KV partials of one (request, q head): lanes first fetch all log2-sum-exps of
 // the request's slots in parallel (<= 64 slots), then every lane accumulates its D/64 output dims over the
@@ -71,20 +65,6 @@ __device__ __forceinline__ void merge_one(const Half* __restrict__ tmp_v, const 
   for (int i = 0; i < EPL; ++i) acc[i] = 0.f;
   // both split plans cap a request at 64 chunks (batch_decode_buffers.rs:15); launch_decode rejects more
   const int n = s1 - s0 < 64 ? s1 - s0 : 64;
-  // all partials of a batch are in flight before the first one is consumed, and the first batch leaves together
-  // with the log2-sum-exp loads: one memory round trip for up to MB slots (a plain load-then-accumulate loop paid
-  // one per slot); accumulation order is slot order
-  constexpr int MB = 32;
-  auto load_pv = [&](int j) {
-    j = j < n ? j : n - 1;  // clamped reload of a valid slot; its weight is dropped below
-    const word_t* v = reinterpret_cast<const word_t*>(tmp_v + ((size_t)(s0 + j) * num_qo_heads + head) * D + lane * EPL);
-    return COHERENT ? __hip_atomic_load(v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *v;
-  };
-  word_t pv[MB];
-  if (n > 0) {
-#pragma unroll
-    for (int u = 0; u < MB; ++u) pv[u] = load_pv(u);
-  }
   float lse = -INFINITY;
   if (lane < n) {
     const float* ps = tmp_s + (size_t)(s0 + lane) * num_qo_heads + head;
@@ -97,10 +77,17 @@ __device__ __forceinline__ void merge_one(const Half* __restrict__ tmp_v, const 
   const float M = wave_max(lse);
   if (M != -INFINITY) {
     const float w_lane = exp2f(lse - M);
+    // 16 partials per batch: all loads of a batch are in flight before the first one is consumed (a plain
+    // load-then-accumulate loop paid one memory round trip per slot); accumulation order is still slot order
+    constexpr int MB = 16;
     for (int j0 = 0; j0 < n; j0 += MB) {
-      if (j0 > 0) {
+      word_t pv[MB];
 #pragma unroll
-        for (int u = 0; u < MB; ++u) pv[u] = load_pv(j0 + u);
+      for (int u = 0; u < MB; ++u) {
+        int j = j0 + u;
+        j = j < n ? j : n - 1;  // clamped reload of a valid slot; its weight is dropped below
+        const word_t* v = reinterpret_cast<const word_t*>(tmp_v + ((size_t)(s0 + j) * num_qo_heads + head) * D + lane * EPL);
+        pv[u] = COHERENT ? __hip_atomic_load(v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *v;
       }
 #pragma unroll
       for (int u = 0; u < MB; ++u) {
@@ -153,7 +140,6 @@ struct AttnScan {
     }
   }
 
-  template <bool POW2>
   __device__ __forceinline__ void load_tile(const DecodeAttnArgs& a, const ChunkInfo& ci, int kvh, int lane, int t0,
                                             u32x4 (&kx)[U], u32x4 (&vx)[U], bool (&ok)[U]) const {
     const int sub = lane % LPT, grp = lane / LPT;
@@ -164,16 +150,8 @@ struct AttnScan {
       const int t = t0 + u * TPI + grp;
       ok[u] = t >= ci.lo && t < ci.hi;
       const int tc = ok[u] ? t : ci.lo;  // clamp to a valid token of this chunk (hi > lo here)
-      int page, in_page;
-      if (POW2) {
-        const int pi = tc >> a.page_shift;
-        in_page = tc & (a.page_size - 1);
-        page = ci.inline_pages ? __shfl(ci.rec, 8 + pi - (ci.lo >> a.page_shift), kWave) : a.page_indices[ci.pbase + pi];
-      } else {
-        page = a.page_indices[ci.pbase + tc / a.page_size];
-        in_page = tc % a.page_size;
-      }
-      const long base = (long)page * a.stride_page + (long)in_page * row_stride + head_off;
+      const int page = a.page_indices[ci.pbase + tc / a.page_size];
+      const long base = (long)page * a.stride_page + (long)(tc % a.page_size) * row_stride + head_off;
       kx[u] = *reinterpret_cast<const u32x4*>(a.kv + base + a.k_off);
       vx[u] = *reinterpret_cast<const u32x4*>(a.kv + base + a.v_off);
     }
@@ -221,50 +199,28 @@ struct AttnScan {
     }
   }
 
-  // software-pipelined scan: the next tile's 2*U loads are in flight while the current one is reduced.  begin()
-  // issues the first tile's loads (a caller may put independent work - the q prologue - between begin and finish).
-  struct Pipe { u32x4 k[U], v[U]; bool ok[U]; int t0; bool live; };
-  template <bool POW2>
-  __device__ __forceinline__ void begin(const DecodeAttnArgs& a, const ChunkInfo& ci, int kvh, int lane, int wave, int NW,
-                                        Pipe& p) const {
-    p.t0 = (ci.lo / TB) * TB + wave * TB;
-    p.live = ci.lo < ci.hi && p.t0 < ci.hi;
-    if (p.live) load_tile<POW2>(a, ci, kvh, lane, p.t0, p.k, p.v, p.ok);
-  }
-  template <bool POW2>
-  __device__ __forceinline__ void finish(const DecodeAttnArgs& a, const ChunkInfo& ci, const u32x4 (&qv)[GROUP], int kvh,
-                                         int lane, int NW, Pipe& p) {
-    if (!p.live) return;
-    const int hi = ci.hi;
-    int t0 = p.t0;
-    u32x4 kB[U], vB[U];
-    bool okB[U];
-    for (;;) {
-      int t1 = t0 + NW * TB;
-      bool more = t1 < hi;
-      if (more) load_tile<POW2>(a, ci, kvh, lane, t1, kB, vB, okB);
-      compute_tile(qv, p.k, p.v, p.ok, a.scale_log2);
-      if (!more) break;
-      t0 = t1 + NW * TB;
-      more = t0 < hi;
-      if (more) load_tile<POW2>(a, ci, kvh, lane, t0, p.k, p.v, p.ok);
-      compute_tile(qv, kB, vB, okB, a.scale_log2);
-      if (!more) break;
-    }
-  }
-  template <bool POW2 = false>
+  // software-pipelined scan: the next tile's 2*U loads are in flight while the current one is reduced
   __device__ __forceinline__ void scan(const DecodeAttnArgs& a, const ChunkInfo& ci, const u32x4 (&qv)[GROUP], int kvh,
                                        int lane, int wave, int NW) {
-    Pipe p;
-    begin<POW2>(a, ci, kvh, lane, wave, NW, p);
-    finish<POW2>(a, ci, qv, kvh, lane, NW, p);
-  }
-
-  // number of (real or virtual) scan waves of an NW-wave plan that see at least one token of the chunk
-  __device__ static __forceinline__ int live_waves(const ChunkInfo& ci, int NW) {
-    if (ci.hi <= ci.lo) return 0;
-    const int n = (ci.hi - (ci.lo / TB) * TB + TB - 1) / TB;
-    return n < NW ? n : NW;
+    const int lo = ci.lo, hi = ci.hi;
+    int t0 = (lo / TB) * TB + wave * TB;
+    if (lo < hi && t0 < hi) {
+      u32x4 kA[U], vA[U], kB[U], vB[U];
+      bool okA[U], okB[U];
+      load_tile(a, ci, kvh, lane, t0, kA, vA, okA);
+      for (;;) {
+        int t1 = t0 + NW * TB;
+        bool more = t1 < hi;
+        if (more) load_tile(a, ci, kvh, lane, t1, kB, vB, okB);
+        compute_tile(qv, kA, vA, okA, a.scale_log2);
+        if (!more) break;
+        t0 = t1 + NW * TB;
+        more = t0 < hi;
+        if (more) load_tile(a, ci, kvh, lane, t0, kA, vA, okA);
+        compute_tile(qv, kB, vB, okB, a.scale_log2);
+        if (!more) break;
+      }
+    }
   }
 
   // this lane row's state -> the workgroup's partial-state arrays (part = wave * TPI + grp)
@@ -289,41 +245,19 @@ __device__ __forceinline__ void attn_finish_part(const DecodeAttnArgs& a, int b,
                                                  const float* sm_m, const float* sm_l, const float* sm_o, bool publish,
                                                  bool coherent_out = false) {
   const int h = e / (D / 8), d0 = (e - h * (D / 8)) * 8;
-  // `npart` = the LIVE partial states (parts of waves that saw no token hold m = -inf, l = 0, o = 0 and would add
-  // exact zeros: the caller leaves them out).  LDS reads go four parts at a time so their latencies overlap - this
-  // loop is one thread per output element walking the parts serially and was 1.3 of the 2.3 us between the end of
-  // the scan and the published partial at bs 1; the accumulation order (part order) is unchanged.
   float M = -INFINITY;
-  for (int p0 = 0; p0 < npart; p0 += 4) {
-    float mv[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) mv[j] = p0 + j < npart ? sm_m[(p0 + j) * GROUP + h] : -INFINITY;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) M = fmaxf(M, mv[j]);
-  }
+  for (int p = 0; p < npart; ++p) M = fmaxf(M, sm_m[p * GROUP + h]);
   float L = 0.f, O[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) O[i] = 0.f;
   if (M != -INFINITY) {
-    for (int p0 = 0; p0 < npart; p0 += 4) {
-      float mv[4], lv[4];
-      f32x4 xa[4], xb[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int p = p0 + j < npart ? p0 + j : npart - 1;   // clamped re-read, dropped below
-        mv[j] = sm_m[p * GROUP + h];
-        lv[j] = sm_l[p * GROUP + h];
-        xa[j] = *reinterpret_cast<const f32x4*>(&sm_o[((size_t)p * GROUP + h) * D + d0]);
-        xb[j] = *reinterpret_cast<const f32x4*>(&sm_o[((size_t)p * GROUP + h) * D + d0 + 4]);
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (p0 + j >= npart) break;
-        const float w = exp2f(mv[j] - M);
-        L = fmaf(lv[j], w, L);
-        O[0] = fmaf(xa[j][0], w, O[0]); O[1] = fmaf(xa[j][1], w, O[1]); O[2] = fmaf(xa[j][2], w, O[2]); O[3] = fmaf(xa[j][3], w, O[3]);
-        O[4] = fmaf(xb[j][0], w, O[4]); O[5] = fmaf(xb[j][1], w, O[5]); O[6] = fmaf(xb[j][2], w, O[6]); O[7] = fmaf(xb[j][3], w, O[7]);
-      }
+    for (int p = 0; p < npart; ++p) {
+      const float w = exp2f(sm_m[p * GROUP + h] - M);
+      L = fmaf(sm_l[p * GROUP + h], w, L);
+      const f32x4 x0 = *reinterpret_cast<const f32x4*>(&sm_o[((size_t)p * GROUP + h) * D + d0]);
+      const f32x4 x1 = *reinterpret_cast<const f32x4*>(&sm_o[((size_t)p * GROUP + h) * D + d0 + 4]);
+      O[0] = fmaf(x0[0], w, O[0]); O[1] = fmaf(x0[1], w, O[1]); O[2] = fmaf(x0[2], w, O[2]); O[3] = fmaf(x0[3], w, O[3]);
+      O[4] = fmaf(x1[0], w, O[4]); O[5] = fmaf(x1[1], w, O[5]); O[6] = fmaf(x1[2], w, O[6]); O[7] = fmaf(x1[3], w, O[7]);
     }
   }
   u32x4 pk;

@@ -429,10 +429,9 @@ __device__ __forceinline__ bool eng_attention(EngCtx& c, int layer, float* scrat
   const int nwv = n_items <= 256 ? 8 : 4;
   for (int item = c.wg; item < n_items; item += c.nwg) {
     const int slot = item / Hkv, kvh = item - slot * Hkv;
-    const u32x4 d0 = *reinterpret_cast<const u32x4*>(a.slot_desc + 16 * slot);
-    const u32x4 d1 = *reinterpret_cast<const u32x4*>(a.slot_desc + 16 * slot + 4);
+    const u32x4 d0 = *reinterpret_cast<const u32x4*>(a.slot_desc + 8 * slot);
+    const u32x4 d1 = *reinterpret_cast<const u32x4*>(a.slot_desc + 8 * slot + 4);
     ChunkInfo ci;
-    ci.rec = 0; ci.inline_pages = false;
     ci.b = (int)d0.x; ci.lo = (int)d0.y; ci.hi = (int)d0.z; ci.pbase = (int)d0.w;
     const int pos = (int)d1.x;
     ci.kv_len = (int)d1.y;

@@ -37,9 +37,10 @@ __host__ __device__ inline int gemv_xs_bytes(int K, int KT) {
   return (NT * kt * 2 + 15) & ~15;
 }
 template <int NT, int RPW, int KSPLIT, int EPI>
-inline int gemv_lds_bytes(int K, int KT) {
+inline int gemv_lds_bytes(int K, int KT, bool residual) {
   constexpr int NW = EPI == kEpiSilu ? 2 : 1;
-  return gemv_xs_bytes<NT>(K, KT) + ((KSPLIT == 1 ? 0 : 4 * NW * RPW * NT) + 16) * 4;  // + 16 floats: inv_rms per token
+  // x tile (+ the raw residual rows of the early prologue) + K-split partials + 16 floats: inv_rms per token
+  return gemv_xs_bytes<NT>(K, KT) * (residual ? 2 : 1) + ((KSPLIT == 1 ? 0 : 4 * NW * RPW * NT) + 16) * 4;
 }
 
 struct GemvFusedArgs {
@@ -61,7 +62,7 @@ extern unsigned long long* g_gemv_trace;
   } while (0)
 // Qwen3.5 forms of the fused pieces (pegainfer_gemv_fused_ex): (1 + w) norm weight; residual sum rounded to bf16
 // before the norm ("add, then norm" instead of FlashInfer's fused add+norm); silu rounded to bf16 before * up
-enum { kGemvNormOffset = 1, kGemvRoundSum = 2, kGemvSiluRound = 4 };
+enum { kGemvNormOffset = 1, kGemvRoundSum = 2, kGemvSiluRound = 4, kGemvXWait = 8 /* PEGAINFER_GEMV_XWAIT probe */ };
 
 template <int NT, int RPW, int KSPLIT, int EPI>
 __global__ __launch_bounds__(256) void gemv_fused_kernel(const GemvFusedArgs a) {
@@ -73,7 +74,9 @@ __global__ __launch_bounds__(256) void gemv_fused_kernel(const GemvFusedArgs a) 
   // GEMV needs 5 KB, not the 32 KB tile capacity, which is what lets 5+ workgroups share a CU.
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   u32x4* xs = reinterpret_cast<u32x4*>(smem_raw);
-  float* part = reinterpret_cast<float*>(smem_raw + gemv_xs_bytes<NT>(a.K, a.KT));
+  const int xs_bytes = gemv_xs_bytes<NT>(a.K, a.KT);
+  u32x4* rs = reinterpret_cast<u32x4*>(smem_raw + xs_bytes);   // raw residual rows (early prologue), when given
+  float* part = reinterpret_cast<float*>(smem_raw + xs_bytes * (a.residual ? 2 : 1));
   float* red = part + (KSPLIT == 1 ? 0 : 4 * NW * RPW * NT);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int K = a.K, T = a.T;
@@ -142,13 +145,98 @@ __global__ __launch_bounds__(256) void gemv_fused_kernel(const GemvFusedArgs a) 
   int g = blockIdx.x;
   PK_GEMV_STAMP(a, 0);
   set_rows(g);
-  issue(0, kt0, bfirst);  // HBM requests leave before the prologue touches anything
-
-  // ---- prologue: per-token inverse RMS (canonical one-wave-per-row order), only when a norm weight is given:
-  //      wave w takes tokens t == w (mod 4), results meet in LDS, one barrier ----
+  // ---- prologue.  A wave's loads retire in order, so anything loaded AFTER the weight group waits for the weights
+  //      (cold HBM, and the whole matrix is requested at once): with the weights issued first the x vector was staged
+  //      only when they had all landed - 5.8 of the 9.0 us of the fused qkv GEMV, 6.1 of gate_up's 21.5 (in-kernel
+  //      stamps, tools/gemv_probe.py) - and the dot products started after the stream instead of under it.  The
+  //      resident-x form therefore moves the raw x (and residual) rows global -> LDS by LDS-DMA FIRST (1 KiB pieces,
+  //      no staging registers: the kernel stays at its 4-workgroups-per-CU register budget), issues the weight group
+  //      right behind them, and waits with a COUNTED vmcnt for exactly the DMAs:
+  //        raw rows in LDS | barrier | canonical one-wave sum of squares read back from LDS (every wave computes
+  //        it, same bits as norm_core.h) | barrier | scale own vectors in place | barrier.
   float inv[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) inv[t] = 0.f;
+  const float nbias = (a.flags & kGemvNormOffset) ? 1.f : 0.f;
+  const bool round_sum = (a.flags & kGemvRoundSum) != 0;
+  const int nvec_row = K >> 3;
+  const bool early = NT <= 2 && K <= KT && (K & 511) == 0 && nvec_row <= 2 * 256 * (a.norm_w ? 1 : 4);
+  if (early) {
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    const uint32_t xs_lds = (uint32_t)(uintptr_t)(lds_ptr_t)xs, rs_lds = (uint32_t)(uintptr_t)(lds_ptr_t)rs;
+    constexpr int XP = 2;
+    u32x4 gx[XP];
+    if (a.norm_w) {
+#pragma unroll
+      for (int i = 0; i < XP; ++i) {
+        const int c = threadIdx.x + i * 256;
+        if (c < nvec_row) gx[i] = reinterpret_cast<const u32x4*>(a.norm_w)[c];
+      }
+    }
+    const int pieces = K >> 9;   // 1 KiB pieces per row; wave w moves pieces w, w + 4, ...
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      if (t >= T) continue;
+      for (int p = wave; p < pieces; p += 4) {
+        const uint32_t off = (uint32_t)(t * pitch * 16 + p * 1024);
+        const Half* src = a.X + (size_t)t * K + p * 512 + lane * 8;
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                     :: "v"(src), "s"(__builtin_amdgcn_readfirstlane(xs_lds + off)) : "memory", "m0");
+        if (a.residual) {
+          const Half* rsrc = a.residual + (size_t)t * K + p * 512 + lane * 8;
+          asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                       :: "v"(rsrc), "s"(__builtin_amdgcn_readfirstlane(rs_lds + off)) : "memory", "m0");
+        }
+      }
+    }
+    if (a.flags & kGemvXWait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // probe: x lands before any weight request leaves
+    issue(0, kt0, bfirst);
+    // the U * NW * RPW weight loads issued last may stay in flight; everything older (the DMAs) has landed
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(U * NW * RPW) : "memory");
+    __syncthreads();
+    if (a.norm_w) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        if (t >= T) continue;
+        float ss = 0.f;
+        if (a.residual && round_sum) {
+          for (int j = lane; j < nvec_row; j += 64) add_round_sq8(xs[t * pitch + j], rs[t * pitch + j], ss);
+        } else if (a.residual) {
+          for (int j = lane; j < nvec_row; j += 64) add_sq8(xs[t * pitch + j], rs[t * pitch + j], ss);
+        } else {
+          for (int j = lane; j < nvec_row; j += 64) sq8(xs[t * pitch + j], ss);
+        }
+        ss = wave_sum(ss);
+        inv[t] = rsqrtf(__fadd_rn(ss / (float)K, a.eps));
+      }
+      __syncthreads();  // every wave has read the raw rows
+#pragma unroll
+      for (int i = 0; i < XP; ++i) {
+        const int c = threadIdx.x + i * 256;
+        if (c < nvec_row) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            if (t >= T) continue;
+            const u32x4 h = xs[t * pitch + c];
+            u32x4 v;
+            if (a.residual) {
+              const u32x4 r = rs[t * pitch + c];
+              u32x4 nh;
+              v = norm_scale8(h, &r, gx[i], inv[t], nbias, &nh, round_sum);
+              if (blockIdx.x == 0) reinterpret_cast<u32x4*>(a.hidden_out + (size_t)t * K)[c] = nh;
+            } else {
+              v = norm_scale8(h, nullptr, gx[i], inv[t], nbias, nullptr);
+            }
+            xs[t * pitch + c] = v;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  } else {
+  issue(0, kt0, bfirst);  // weights first; the x-side loads queue behind them (wide-batch / tiled-x forms)
+  // per-token inverse RMS (canonical one-wave-per-row order), only when a norm weight is given:
+  // wave w takes tokens t == w (mod 4), results meet in LDS, one barrier
   if (a.norm_w) {
     for (int t = wave; t < T; t += 4) {
       const float v = wave_row_inv_rms(a.X + (size_t)t * K, a.residual ? a.residual + (size_t)t * K : nullptr, K, a.eps,
@@ -160,8 +248,7 @@ __global__ __launch_bounds__(256) void gemv_fused_kernel(const GemvFusedArgs a) 
     for (int t = 0; t < NT; ++t)
       if (t < T) inv[t] = red[t];
   }
-  const float nbias = (a.flags & kGemvNormOffset) ? 1.f : 0.f;
-  const bool round_sum = (a.flags & kGemvRoundSum) != 0;
+  }
   auto stage = [&](int k0, int kt) {
     const int nvec = (kt + 7) >> 3;  // lanes beyond kt never read their slot (consume() zeroes them)
 #pragma unroll
@@ -188,8 +275,10 @@ __global__ __launch_bounds__(256) void gemv_fused_kernel(const GemvFusedArgs a) 
       }
     }
   };
-  stage(0, kt0);
-  __syncthreads();
+  if (!early) {
+    stage(0, kt0);
+    __syncthreads();
+  }
   PK_GEMV_STAMP(a, 1);
   bool first_group = true;
 
@@ -295,7 +384,7 @@ inline void gemv_launch_one(const GemvFusedArgs& a, hipStream_t s) {
   constexpr int ROWS_PER_GROUP = (KSPLIT == 1 ? 4 : 1) * RPW;
   const int rows = EPI == kEpiSilu ? a.I : a.M;
   const int ngroups = ceil_div(rows, ROWS_PER_GROUP);
-  const int lds = gemv_lds_bytes<NT, RPW, KSPLIT, EPI>(a.K, a.KT);
+  const int lds = gemv_lds_bytes<NT, RPW, KSPLIT, EPI>(a.K, a.KT, a.residual != nullptr);
   auto kern = &gemv_fused_kernel<NT, RPW, KSPLIT, EPI>;
   static const bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
@@ -315,6 +404,8 @@ inline void gemv_launch_one(const GemvFusedArgs& a, hipStream_t s) {
   }
   GemvFusedArgs b = a;
   b.trace = g_gemv_trace;
+  static const bool xwait = [] { const char* e = getenv("PEGAINFER_GEMV_XWAIT"); return e && *e == '1'; }();
+  if (xwait) b.flags |= kGemvXWait;
   kern<<<grid, 256, lds, s>>>(b);
 }
 

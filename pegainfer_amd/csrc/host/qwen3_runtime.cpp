@@ -65,7 +65,7 @@ struct Layer {
 struct MetaLayout {
   size_t token_ids, positions, page_indptr, last_page_len, request_indices, kv_tile_indices, kv_chunk_size,
       split_request_indices, split_kv_tile_indices, split_kv_chunk_size, split_o_indptr, split_valid /*u8*/,
-      slot_desc /*16 x int32 per slot*/, page_indices, total;
+      slot_desc /*8 x int32 per slot*/, page_indices, total;
 };
 
 struct Model {
@@ -219,7 +219,7 @@ struct Model {
     ml.split_kv_chunk_size = off; off = al(off + 4);
     ml.split_o_indptr = off; off = al(off + (bs + 1) * 4);
     ml.split_valid = off; off = al(off + slots);
-    ml.slot_desc = off; off = al(off + slots * 64);
+    ml.slot_desc = off; off = al(off + slots * 32);
     ml.page_indices = off; off = al(off + ((size_t)num_pages + bs) * 4);
     ml.total = off;
     PQ_HIP(hipHostMalloc(reinterpret_cast<void**>(&meta_host), ml.total, hipHostMallocDefault));
@@ -725,10 +725,10 @@ struct Model {
       auto* sd = mh<int32_t>(ml.slot_desc);
       const int nslots = plan.use_split ? plan.slots : padded;
       for (int sl = 0; sl < nslots; ++sl) {
-        int32_t* r = sd + 16 * sl;
+        int32_t* r = sd + 8 * sl;
         int b, lo, hi;
         if (plan.use_split) {
-          if (!plan.valid[sl]) { std::memset(r, 0, 64); r[1] = -1; r[2] = -1; continue; }
+          if (!plan.valid[sl]) { r[0] = 0; r[1] = -1; r[2] = -1; r[3] = 0; r[4] = 0; r[5] = 0; r[6] = r[7] = 0; continue; }
           b = plan.request_indices[sl];
           const int len = kcs[b];
           lo = plan.kv_tile_indices[sl] * plan.chunk;
@@ -739,9 +739,6 @@ struct Model {
         }
         r[0] = b; r[1] = lo; r[2] = hi; r[3] = indptr[b]; r[4] = pos[b]; r[5] = kcs[b];
         r[6] = plan.o_indptr[b]; r[7] = plan.o_indptr[b + 1];   // partial slots of this request (engine merge)
-        // the chunk's first 8 page ids ride in the record: the kernel then needs no page-table load at all
-        const int first_page = lo / layout.page_size, have = indptr[b + 1] - indptr[b];
-        for (int i = 0; i < 8; ++i) r[8 + i] = first_page + i < have ? pgs[indptr[b] + first_page + i] : 0;
       }
     }
     const size_t upload = ml.page_indices + (size_t)np * 4;

@@ -145,20 +145,15 @@ def test_fused_decode_attention_matches_unfused(built_libs, lens, split):
     assert np.array_equal(bf16_bits(from_dev(out_b)), bf16_bits(from_dev(out_a)))
     # ---- fused with host-resolved slot descriptors: same bits again ----
     nslots = slots if split else bs
-    desc = np.zeros((nslots, 16), np.int32)
+    desc = np.zeros((nslots, 8), np.int32)
     desc[:, 1] = -1
-
-    def record(b, lo, hi):   # {b, lo, hi, pbase, pos, kv_len, s0, s1, the chunk's first 8 page ids}
-        have = int(indptr[b + 1] - indptr[b])
-        pg = [int(pages[indptr[b] + lo // 16 + i]) if lo // 16 + i < have else 0 for i in range(8)]
-        return [b, lo, hi, indptr[b], pos[b], lens[b], 0, 0] + pg
     if split:
         for sl in range(int(plan["o_indptr"][bs])):
             b = int(plan["request_indices"][sl]); t = int(plan["kv_tile_indices"][sl]); c = plan["kv_chunk_size"]
-            desc[sl] = record(b, t * c, min((t + 1) * c, lens[b]))
+            desc[sl] = [b, t * c, min((t + 1) * c, lens[b]), indptr[b], pos[b], lens[b], 0, 0]
     else:
         for b in range(bs):
-            desc[b] = record(b, 0, lens[b])
+            desc[b] = [b, 0, lens[b], indptr[b], pos[b], lens[b], 0, 0]
     dd = i32(desc.reshape(-1))
     kv_c = to_dev(kv)
     out_c = torch.zeros_like(out_a)
