@@ -461,22 +461,27 @@ def main():
         gate_up_bytes = 2 * I * H * 2 + args.batch * (2 * H * 2 + H * 2 + I * 2) + H * 2
         ms = eng.bench_gemv(5 if fused else 2, 360, args.batch)
         achieved = gate_up_bytes / (ms * 1e-3) / 1e9
+        # HBM bytes per launch from the PMC counters: collected in their own rocprofv3 --pmc passes (tools/
+        # gpu_refresh_profiles.sh) and REPLAYED here from the committed CSVs of the newest round - not measured in this run
         traffic, traffic_src = None, None
-        prof = os.path.join(ROOT, "profiles", "r1_fused_pmc_FETCH_SIZE.csv")
-        if fused and args.batch == 1 and args.model == "qwen3-4b" and os.path.exists(prof):
+        prof = next((q for q in (os.path.join(ROOT, "profiles", f"r{r}_fused_pmc_FETCH_SIZE.csv") for r in (5, 4, 3, 2, 1))
+                     if os.path.exists(q)), None)
+        if prof and fused and args.batch == 1 and args.model == "qwen3-4b":
             import csv
             fetch = {r["kernel"]: float(r["avg_value"]) for r in csv.DictReader(open(prof)) if r["counter"] == "FETCH_SIZE"}
-            wprof = os.path.join(ROOT, "profiles", "r1_fused_pmc_WRITE_SIZE.csv")
+            wprof = prof.replace("FETCH_SIZE", "WRITE_SIZE")
             wr = {r["kernel"]: float(r["avg_value"]) for r in csv.DictReader(open(wprof))} if os.path.exists(wprof) else {}
             kname = "gemv_fused_kernel<1, 1, 1, 1>"
             if kname in fetch:   # KiB per dispatch; gfx950 FETCH_SIZE reports 1/2 of a wide coalesced stream -> x2
                 traffic = int(2 * fetch[kname] * 1024 + wr.get(kname, 0.0) * 1024)
-                traffic_src = "profiles/r1_fused_pmc_FETCH_SIZE.csv (x2 gfx950 correction) + WRITE_SIZE, rocprofv3 --pmc"
+                traffic_src = ("replayed from " + os.path.relpath(prof, ROOT) + " (x2 gfx950 correction) + WRITE_SIZE, separate "
+                               "rocprofv3 --pmc passes; not measured in this run")
         out["roofline"] = {"bound": "hbm",
                            "kernel": ("gemv_fused_kernel<NT=1,RPW=1,KSPLIT=1,EPI=silu> (gate_up, M=%d K=%d N=%d)" if fused
                                       else "gemv_fused_kernel<NT,RPW=2,KSPLIT=1,EPI=store> (gate_up, M=%d K=%d N=%d)") % (2 * I, H, args.batch),
                            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_replayed": traffic is not None,
+                           "traffic_source": traffic_src,
                            "bytes_per_launch": gate_up_bytes, "avg_launch_us": round(ms * 1e3, 2)}
         per_site = {}
         for which, name, M, K in [(0, "qkv", (cfg["num_attention_heads"] + 2 * cfg["num_key_value_heads"]) * cfg["head_dim"], H),

@@ -83,6 +83,11 @@ int32_t pegainfer_qwen3_max_batch_size(pegainfer_qwen3_t m);
 int32_t pegainfer_qwen3_prefill(pegainfer_qwen3_t m, int32_t n_requests, const int32_t* request_ids,
                                 const int32_t* prompt_lens, const uint32_t* tokens_concat, int32_t* out_tokens,
                                 void* out_logits_host);
+/* batch_prefill with echo = true (prefill.rs:196-261, compute_all_position_logits): additionally the final-norm +
+ * lm_head logits of EVERY prompt position, bf16 bits [total_tokens, vocab] on the host (prompt log-probabilities). */
+int32_t pegainfer_qwen3_prefill_echo(pegainfer_qwen3_t m, int32_t n_requests, const int32_t* request_ids,
+                                     const int32_t* prompt_lens, const uint32_t* tokens_concat, int32_t* out_tokens,
+                                     void* out_logits_host, void* out_all_logits_host);
 /* unified_step (unified_forward.rs:78-198): new prompts arrive while decodes are active.  ids / lens / tokens
  * list the n_prefill prompt requests first, then n_decode requests with exactly one token each (lens == 1).
  * All token columns share the GEMMs / norms / RoPE / KV append; attention is one batch-prefill call over the

@@ -138,7 +138,8 @@ class Qwen3Oracle:
         return self._reduce(ops.gemm(L["down"], act))
 
     # -- prefill (prefill.rs:220-285) ----------------------------------------
-    def batch_prefill(self, prompts, states):
+    def batch_prefill(self, prompts, states, echo=False):
+        """echo=True also returns compute_all_position_logits (prefill.rs:196-212): [total_tokens, vocab]."""
         c = self.cfg
         seq_lens = [len(p) for p in prompts]
         starts = [st.seq_len for st in states]
@@ -163,6 +164,8 @@ class Qwen3Oracle:
             last = hidden[int(q_indptr[b + 1]) - 1][None, :]
             normed = ops.rms_norm(last, self.norm, c.rms_norm_eps)
             logits.append(ops.gemm(self.lm_head, normed)[0])
+        if echo:
+            return logits, ops.gemm(self.lm_head, ops.rms_norm(hidden, self.norm, c.rms_norm_eps))
         return logits
 
     # -- decode (batch_decode.rs:17-145) --------------------------------------

@@ -62,7 +62,7 @@ extern unsigned long long* g_gemv_trace;
   } while (0)
 // Qwen3.5 forms of the fused pieces (pegainfer_gemv_fused_ex): (1 + w) norm weight; residual sum rounded to bf16
 // before the norm ("add, then norm" instead of FlashInfer's fused add+norm); silu rounded to bf16 before * up
-enum { kGemvNormOffset = 1, kGemvRoundSum = 2, kGemvSiluRound = 4, kGemvXWait = 8 /* PEGAINFER_GEMV_XWAIT probe */ };
+enum { kGemvNormOffset = 1, kGemvRoundSum = 2, kGemvSiluRound = 4 };
 
 template <int NT, int RPW, int KSPLIT, int EPI>
 __global__ __launch_bounds__(256) void gemv_fused_kernel(const GemvFusedArgs a) {
@@ -189,7 +189,6 @@ __global__ __launch_bounds__(256) void gemv_fused_kernel(const GemvFusedArgs a) 
         }
       }
     }
-    if (a.flags & kGemvXWait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // probe: x lands before any weight request leaves
     issue(0, kt0, bfirst);
     // the U * NW * RPW weight loads issued last may stay in flight; everything older (the DMAs) has landed
     asm volatile("s_waitcnt vmcnt(%0)" :: "n"(U * NW * RPW) : "memory");
@@ -398,14 +397,14 @@ inline void gemv_launch_one(const GemvFusedArgs& a, hipStream_t s) {
     cached_lds = lds;
   }
   int grid = ngroups;
-  if (a.K <= a.KT && ngroups > cached_cap) {
+  // PEGAINFER_GEMV_PERSIST=0: one row group per workgroup, the hardware dispatcher balances (A/B probe knob)
+  static const bool persist = [] { const char* e = getenv("PEGAINFER_GEMV_PERSIST"); return !(e && *e == '0'); }();
+  if (persist && a.K <= a.KT && ngroups > cached_cap) {
     const int rounds = ceil_div(ngroups, cached_cap);
     grid = ceil_div(ngroups, rounds);
   }
   GemvFusedArgs b = a;
   b.trace = g_gemv_trace;
-  static const bool xwait = [] { const char* e = getenv("PEGAINFER_GEMV_XWAIT"); return e && *e == '1'; }();
-  if (xwait) b.flags |= kGemvXWait;
   kern<<<grid, 256, lds, s>>>(b);
 }
 

@@ -817,7 +817,7 @@ struct Model {
   // token each and attend through the decode kernel; everything else (GEMMs, norms, RoPE, KV append, MLP) is
   // shared by all token columns.
   int prefill(int n, const int32_t* ids, const int32_t* lens, const uint32_t* tokens, int32_t* out_tokens,
-              void* out_logits_host, int n_decode_tail = 0) {
+              void* out_logits_host, int n_decode_tail = 0, void* out_all_logits_host = nullptr) {
     if (!finalized) { set_error("model not finalized"); return -1; }
     if (n <= 0) { set_error("empty prefill"); return -1; }
     if (n > max_bs) { set_error("prefill batch larger than max_batch_size"); return -1; }
@@ -948,6 +948,20 @@ struct Model {
         set_error("pegainfer_gemm_add (prefill down_proj) failed"); return -1;
       }
       std::swap(hid, hid_out);  // prefill.rs:183-185
+    }
+    // echo = true (compute_all_position_logits, prefill.rs:196-212): final RMSNorm + lm_head over EVERY position,
+    // [total_tokens, vocab] bf16 to the host.  The GEMM output is staged through the gate|up scratch (pf_cap_tokens x
+    // 2I elements) in token chunks, so no T x vocab device buffer is ever allocated (1024 tokens = 311 MB).
+    if (out_all_logits_host) {
+      const size_t chunk = std::max<size_t>(1, std::min<size_t>(T, pf_cap_tokens * (size_t)(2 * I) / (size_t)V));
+      for (size_t i0 = 0; i0 < T; i0 += chunk) {
+        const int nb = (int)std::min(chunk, T - i0);
+        rms_norm_batched_cuda(hid + i0 * H, final_norm, pf_normed + i0 * H, H, nb, eps, S());
+        gemm_cuda(lm_head, pf_normed + i0 * H, pf_gate_up, V, nb, H, S());   // void in ffi.rs (same as the reference symbol)
+        PQ_HIP(hipMemcpyAsync(static_cast<Half*>(out_all_logits_host) + i0 * V, pf_gate_up, (size_t)nb * V * 2,
+                              hipMemcpyDeviceToHost, stream));
+        PQ_HIP(hipStreamSynchronize(stream));   // the scratch is reused by the next chunk
+      }
     }
     // per request: last token -> final norm -> lm_head GEMV (prefill.rs:267-282); batched in groups that stay
     // on the decode-GEMV path so each column is bit-identical to the reference's per-request call.
@@ -1144,6 +1158,11 @@ int32_t pegainfer_qwen3_max_batch_size(pegainfer_qwen3_t m) { return M(m)->max_b
 int32_t pegainfer_qwen3_prefill(pegainfer_qwen3_t m, int32_t n, const int32_t* ids, const int32_t* lens,
                                 const uint32_t* tokens, int32_t* out_tokens, void* out_logits_host) {
   return M(m)->prefill(n, ids, lens, tokens, out_tokens, out_logits_host);
+}
+int32_t pegainfer_qwen3_prefill_echo(pegainfer_qwen3_t m, int32_t n, const int32_t* ids, const int32_t* lens,
+                                     const uint32_t* tokens, int32_t* out_tokens, void* out_logits_host,
+                                     void* out_all_logits_host) {
+  return M(m)->prefill(n, ids, lens, tokens, out_tokens, out_logits_host, 0, out_all_logits_host);
 }
 int32_t pegainfer_qwen3_unified_step(pegainfer_qwen3_t m, int32_t n_prefill, int32_t n_decode, const int32_t* ids,
                                      const int32_t* lens, const uint32_t* tokens, int32_t* out_tokens,

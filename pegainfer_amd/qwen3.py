@@ -106,12 +106,20 @@ class Qwen3Engine:
         return self.lib.pegainfer_qwen3_available_pages(self.h)
 
     # ---- forward ----
-    def prefill(self, request_ids, prompts, return_logits=False):
+    def prefill(self, request_ids, prompts, return_logits=False, echo=False):
+        """batch_prefill (prefill.rs:220-285).  echo=True (prefill.rs:196-212) also returns the logits of every prompt
+        position, bf16 bits [total_tokens, vocab]: -> (tokens, last_logits, all_logits)."""
         ids = _i32(request_ids)
         lens = _i32([len(p) for p in prompts])
         toks = np.ascontiguousarray(np.concatenate([np.asarray(p, dtype=np.uint32) for p in prompts]))
         out = np.zeros(len(ids), dtype=np.int32)
-        lg = np.zeros((len(ids), self.vocab), dtype=np.uint16) if return_logits else None
+        lg = np.zeros((len(ids), self.vocab), dtype=np.uint16) if (return_logits or echo) else None
+        if echo:
+            allg = np.zeros((int(lens.sum()), self.vocab), dtype=np.uint16)
+            self._chk(self.lib.pegainfer_qwen3_prefill_echo(self.h, len(ids), ids.ctypes.data, lens.ctypes.data,
+                                                            toks.ctypes.data, out.ctypes.data, lg.ctypes.data,
+                                                            allg.ctypes.data), "prefill_echo")
+            return out, lg, allg
         self._chk(self.lib.pegainfer_qwen3_prefill(self.h, len(ids), ids.ctypes.data, lens.ctypes.data, toks.ctypes.data,
                                                    out.ctypes.data, lg.ctypes.data if return_logits else None), "prefill")
         return (out, lg) if return_logits else out
