@@ -40,7 +40,7 @@ template <int NT, int RPW, int KSPLIT, int EPI>
 inline int gemv_lds_bytes(int K, int KT, bool residual) {
   constexpr int NW = EPI == kEpiSilu ? 2 : 1;
   // x tile (+ the raw residual rows of the early prologue) + K-split partials + 16 floats: inv_rms per token
-  return gemv_xs_bytes<NT>(K, KT) * (residual ? 2 : 1) + ((KSPLIT == 1 ? 0 : 4 * NW * RPW * NT) + 16) * 4;
+  return gemv_xs_bytes<NT>(K, KT) * (residual && NT <= 2 ? 2 : 1) + ((KSPLIT == 1 ? 0 : 4 * NW * RPW * NT) + 16) * 4;
 }
 
 struct GemvFusedArgs {
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void gemv_fused_kernel(const GemvFusedArgs a) 
   u32x4* xs = reinterpret_cast<u32x4*>(smem_raw);
   const int xs_bytes = gemv_xs_bytes<NT>(a.K, a.KT);
   u32x4* rs = reinterpret_cast<u32x4*>(smem_raw + xs_bytes);   // raw residual rows (early prologue), when given
-  float* part = reinterpret_cast<float*>(smem_raw + xs_bytes * (a.residual ? 2 : 1));
+  float* part = reinterpret_cast<float*>(smem_raw + xs_bytes * (a.residual && NT <= 2 ? 2 : 1));
   float* red = part + (KSPLIT == 1 ? 0 : 4 * NW * RPW * NT);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int K = a.K, T = a.T;
