@@ -17,6 +17,8 @@
 //   * global->register prefetch of the next KV tile overlaps the MFMAs of the current one.
 //   * online softmax in the exp2 domain (sm_scale*log2e folded), fp32 accumulation, bf16 output.
 // kv_len comes from the page table; the causal rule is kv_idx <= q_idx + (kv_len - qo_len).
+#include <type_traits>
+
 #include "common.h"
 
 namespace pk {
@@ -128,7 +130,33 @@ __device__ __forceinline__ void prefill_tile(const Half* __restrict__ q_base, Ha
 
   // staging roles
   u32x4 kreg[KPT], vreg[VPT][4];
+  // Full tiles of the common layout (head_dim 128, 16-token pages, power-of-two path): thread t stages K rows
+  // t/16 + 16 j - row t/16 of page kv0/16 + j - and the four V rows 4 (t/16) .. + 3 of page kv0/16 + t/64, so a tile
+  // needs five page ids and two loop-invariant in-page offsets instead of eight general row addresses
+  // (100 -> ~30 VALU instructions per tile).
+  constexpr bool kFastPaged = std::is_same<Addr, PagedAddr<true>>::value && D == 128 && NT == 256;
+  int fast_k_off = 0, fast_v_off = 0, fast_v_pg = 0;
+  bool fast_ok = false;
+  if constexpr (kFastPaged) {
+    fast_ok = addr.page_size == 16;
+    const int r0 = threadIdx.x >> 4, c0 = threadIdx.x & 15;
+    fast_k_off = r0 * addr.row_stride + c0 * 8;
+    fast_v_off = ((r0 & 3) * 4) * addr.row_stride + c0 * 8;
+    fast_v_pg = r0 >> 2;
+  }
   auto load_tile = [&](int kv0) {
+    if constexpr (kFastPaged) {
+      if (fast_ok && kv0 + TKV <= kv_len) {   // workgroup-uniform
+        const int* pgw = addr.pg + ((kv0 >> 4) - addr.win0);
+#pragma unroll
+        for (int j = 0; j < KPT; ++j)
+          kreg[j] = *reinterpret_cast<const u32x4*>(kbuf + (long)pgw[j] * (long)addr.stride_page + fast_k_off);
+        const Half* vp = vbuf + (long)pgw[fast_v_pg] * (long)addr.stride_page + fast_v_off;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) vreg[0][i] = *reinterpret_cast<const u32x4*>(vp + i * addr.row_stride);
+        return;
+      }
+    }
     const int t_last = kv_len - 1;
 #pragma unroll
     for (int j = 0; j < KPT; ++j) {
@@ -200,7 +228,9 @@ __device__ __forceinline__ void prefill_tile(const Half* __restrict__ q_base, Ha
     }
     if (!wave_active || kv0 >= wave_kv_end) continue;
 
-    // ---- S^T = K . Q^T ----
+    // ---- S^T = K . Q^T ----  (raised issue priority around the MFMA clusters: the other resident wave of the SIMD is
+    //      in its softmax / staging VALU segment and should not delay these)
+    __builtin_amdgcn_s_setprio(1);
     f32x4 sacc[QBLK][4];
 #pragma unroll
     for (int qb = 0; qb < QBLK; ++qb)
@@ -217,6 +247,7 @@ __device__ __forceinline__ void prefill_tile(const Half* __restrict__ q_base, Ha
           sacc[qb][tb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qb][s], sacc[qb][tb], 0, 0, 0);
       }
     }
+    __builtin_amdgcn_s_setprio(0);
     // ---- online softmax per query row (= per lane column), exp2 domain with the scale folded into one fma.
     //      The causal / length mask is applied only on the tiles that cross this wave's diagonal or the end of
     //      the sequence (wave-uniform test); interior tiles - nearly all of a long prompt - take no compare at all.
@@ -276,6 +307,7 @@ __device__ __forceinline__ void prefill_tile(const Half* __restrict__ q_base, Ha
       }
     }
     // ---- O^T += V^T . P^T ----
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int db = 0; db < DB; ++db) {
 #pragma unroll
@@ -290,6 +322,7 @@ __device__ __forceinline__ void prefill_tile(const Half* __restrict__ q_base, Ha
           acc_o[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qb][kb], acc_o[qb][db], 0, 0, 0);
       }
     }
+    __builtin_amdgcn_s_setprio(0);
   }
   // ---- epilogue: O = acc / l ; lane (row l15, g) holds dims db*16 + g*4 .. +3 ----
 #pragma unroll
@@ -321,15 +354,20 @@ __global__ __launch_bounds__(NW * 64, D == 128 ? 2 : 1) void batch_prefill_paged
     const int* __restrict__ last_page_len, const int* __restrict__ q_indptr,
     const int* __restrict__ request_indices, const int* __restrict__ qo_tile_indices, int num_qo_heads,
     int num_kv_heads, int page_size, long stride_page, float scale_log2, int cta_tile_q, int page_shift,
-    int num_plan_tiles) {
+    int num_plan_tiles, int xcd_heads) {
   __shared__ __attribute__((aligned(16))) u32x4 ks[TKV * D / 8];
   __shared__ __attribute__((aligned(16))) Half vt[D * VT_PITCH];
   __shared__ int lds_pg[kPgLdsMax];
   // longest tiles first: within a request the plan lists tiles by ascending row, i.e. ascending causal KV length;
   // dispatching them in reverse keeps the tail of the launch made of short tiles
-  const int kvh = blockIdx.y;
+  // 1-D grid, kv head fastest: workgroup b runs on XCD b % 8, so with 8 kv heads every XCD keeps ONE head's K / V in its
+  // L2 (5 MB at 10 k tokens against a 4 MB L2) instead of all eight streaming through each (xcd_heads = 0 keeps the
+  // tile-fastest order for the A/B)
+  const int n_slots = gridDim.x / num_kv_heads;
+  const int kvh = xcd_heads ? blockIdx.x % num_kv_heads : blockIdx.x / n_slots;
+  const int slot = xcd_heads ? blockIdx.x / num_kv_heads : blockIdx.x % n_slots;
   const int group = num_qo_heads / num_kv_heads;
-  const int first = (gridDim.x - 1 - blockIdx.x) * GROUPED;
+  const int first = (n_slots - 1 - slot) * GROUPED;
   int req[GROUPED], row0[GROUPED];
 #pragma unroll
   for (int k = 0; k < GROUPED; ++k) {
@@ -445,12 +483,13 @@ int32_t batch_prefill_paged_cuda_with_cta_tile_q(
   // two 64-row plan tiles per workgroup once that still leaves >= 2 workgroups per CU (PEGAINFER_PREFILL_GROUP = 1 | 2
   // forces either form; per-row results are identical)
   static const int group_env = [] { const char* e = getenv("PEGAINFER_PREFILL_GROUP"); return e && *e ? atoi(e) : 0; }();
+  static const int xcd_heads = [] { const char* e = getenv("PEGAINFER_PREFILL_XCD_HEADS"); return e && *e == '0' ? 0 : 1; }();
   const bool pair = cta == 64 && (group_env == 2 || (group_env == 0 && (long)padded_batch_size * num_kv_heads >= 1024));
 #define PK_PREFILL(QB, P2, G, CTA)                                                                           \
-  batch_prefill_paged_kernel<QB, 128, P2, G><<<dim3((padded_batch_size + G - 1) / G, num_kv_heads), 256, 0, s>>>( \
+  batch_prefill_paged_kernel<QB, 128, P2, G><<<((padded_batch_size + G - 1) / G) * num_kv_heads, 256, 0, s>>>( \
       q, output, kv_data, k_offset_elems, v_offset_elems, page_indices, page_indptr, last_page_len_d, q_indptr, \
       request_indices, qo_tile_indices, num_qo_heads, num_kv_heads, page_size, stride_page, scale_log2, CTA, shift, \
-      padded_batch_size)
+      padded_batch_size, xcd_heads)
   if (cta == 128) {
     if (shift >= 0) PK_PREFILL(2, true, 1, 128);
     else PK_PREFILL(2, false, 1, 128);
@@ -497,7 +536,7 @@ int32_t batch_prefill_paged_cuda_hd256(
   const int group = num_qo_heads / num_kv_heads;
   const uint32_t cta = fa2_cta_tile_q((int64_t)seq_len * group, head_dim);
   if (padded_batch_size <= 0) return 0;
-  dim3 grid(padded_batch_size, num_kv_heads);
+  const int grid = padded_batch_size * num_kv_heads;
   if (stride_page <= 0 || stride_page > 0x7fffffffLL) return (int32_t)hipErrorInvalidValue;
   const int shift = page_shift_of(page_size);
   const float scale_log2 = sm_scale * 1.4426950408889634f;
@@ -505,12 +544,12 @@ int32_t batch_prefill_paged_cuda_hd256(
     batch_prefill_paged_kernel<1, 256, true><<<grid, 256, 0, as_stream(stream)>>>(
         q, output, kv_data, k_offset_elems, v_offset_elems, page_indices, page_indptr, last_page_len_d, q_indptr,
         request_indices, qo_tile_indices, num_qo_heads, num_kv_heads, page_size, stride_page, scale_log2, (int)cta, shift,
-        padded_batch_size);
+        padded_batch_size, 1);
   else
     batch_prefill_paged_kernel<1, 256, false><<<grid, 256, 0, as_stream(stream)>>>(
         q, output, kv_data, k_offset_elems, v_offset_elems, page_indices, page_indptr, last_page_len_d, q_indptr,
         request_indices, qo_tile_indices, num_qo_heads, num_kv_heads, page_size, stride_page, scale_log2, (int)cta, shift,
-        padded_batch_size);
+        padded_batch_size, 1);
   return (int32_t)hipGetLastError();
 }
 
