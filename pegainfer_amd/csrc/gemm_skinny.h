@@ -335,19 +335,100 @@ __global__ __launch_bounds__(kSkinnyThreads) void skinny_resident_kernel(const G
       }
     }
   };
-  if (total > 0) issue(0, avA);   // the first two chunks leave before the prologue
-  if (total > CH) issue(CH, avB);
-
-  // ---- prologue + one-time staging of x ----
-  if (a.norm_w) {
-    for (int t = L.wave; t < T; t += kSkinnyWaves) {
-      const float v = wave_row_inv_rms(a.X + (size_t)t * K, a.residual ? a.residual + (size_t)t * K : nullptr, K, a.eps);
-      if (L.lane == 0) sm_inv[t] = v;
+  // ---- prologue + one-time staging of x.  A wave's loads retire in order: x-side loads issued behind the first
+  //      weight chunks cannot be consumed before those have landed from cold HBM (the finding of the GEMV phase
+  //      trace), so wherever it fits the x side goes FIRST:
+  //        plain x (o_proj, down_proj): rows -> swizzled LDS by LDS-DMA (lane l of piece q fetches chunk
+  //          (64 q + l) ^ (t & 15), which is what the swizzled slot 64 q + l holds), weights behind, one counted wait;
+  //        add + RMSNorm (qkv, gate_up; K <= 2560, T <= 16): wave w's token rows w, w + 8 (+ residual, + norm weight)
+  //          into registers first, weights behind; the wave holds its rows in the canonical distribution of
+  //          norm_core.h (lane l: vectors l, l + 64, ...), so the sum of squares needs no second pass - same bits.
+  constexpr int XV = 5;   // 16-byte vectors per lane and row of the register-staged form (K <= 2560)
+  const int nvec_row = K >> 3;
+  const bool early_plain = !a.norm_w && (K & 511) == 0;
+  const bool early_norm = a.norm_w && nvec_row <= 64 * XV && T <= 2 * kSkinnyWaves;
+  if (early_plain) {
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    const uint32_t xs_lds = (uint32_t)(uintptr_t)(lds_ptr_t)xs;
+    const int pieces = K >> 9;
+    for (int t = L.wave; t < T; t += kSkinnyWaves)
+      for (int q = 0; q < pieces; ++q) {
+        const Half* src = a.X + (size_t)t * K + (size_t)(((q << 6) + L.lane) ^ (t & 15)) * 8;
+        const uint32_t dst = xs_lds + (uint32_t)(t * pitch + (q << 6)) * 16u;
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                     :: "v"(src), "s"(__builtin_amdgcn_readfirstlane(dst)) : "memory", "m0");
+      }
+    if (total > 0) issue(0, avA);
+    if (total > CH) issue(CH, avB);
+    // everything older than the weight loads just issued (the DMAs) has landed
+    if (total > CH) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * CH * 2 * NW) : "memory");
+    else if (total > 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(CH * 2 * NW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  } else if (early_norm) {
+    u32x4 hx[2][XV], rx[2][XV], gx[XV];
+#pragma unroll
+    for (int j = 0; j < XV; ++j) {
+      const int c = L.lane + 64 * j;
+      if (c < nvec_row) {
+        gx[j] = reinterpret_cast<const u32x4*>(a.norm_w)[c];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int t = L.wave + u * kSkinnyWaves;
+          if (t < T) {
+            hx[u][j] = reinterpret_cast<const u32x4*>(a.X + (size_t)t * K)[c];
+            if (a.residual) rx[u][j] = reinterpret_cast<const u32x4*>(a.residual + (size_t)t * K)[c];
+          }
+        }
+      }
+    }
+    asm volatile("" ::: "memory");   // the x-side loads stay in front of the weight loads
+    if (total > 0) issue(0, avA);
+    if (total > CH) issue(CH, avB);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int t = L.wave + u * kSkinnyWaves;
+      if (t >= T) continue;
+      float ss = 0.f;
+#pragma unroll
+      for (int j = 0; j < XV; ++j) {
+        if (L.lane + 64 * j < nvec_row) {
+          if (a.residual) add_sq8(hx[u][j], rx[u][j], ss);
+          else sq8(hx[u][j], ss);
+        }
+      }
+      ss = wave_sum(ss);
+      const float inv = rsqrtf(__fadd_rn(ss / (float)K, a.eps));
+#pragma unroll
+      for (int j = 0; j < XV; ++j) {
+        const int c = L.lane + 64 * j;
+        if (c < nvec_row) {
+          u32x4 v;
+          if (a.residual) {
+            u32x4 nh;
+            v = norm_scale8(hx[u][j], &rx[u][j], gx[j], inv, 0.f, &nh);
+            if (blockIdx.x == 0) reinterpret_cast<u32x4*>(a.hidden_out + (size_t)t * K)[c] = nh;
+          } else {
+            v = norm_scale8(hx[u][j], nullptr, gx[j], inv, 0.f, nullptr);
+          }
+          xs[t * pitch + (c ^ (t & 15))] = v;
+        }
+      }
     }
     __syncthreads();
+  } else {
+    if (total > 0) issue(0, avA);   // the first two chunks leave before the prologue
+    if (total > CH) issue(CH, avB);
+    if (a.norm_w) {
+      for (int t = L.wave; t < T; t += kSkinnyWaves) {
+        const float v = wave_row_inv_rms(a.X + (size_t)t * K, a.residual ? a.residual + (size_t)t * K : nullptr, K, a.eps);
+        if (L.lane == 0) sm_inv[t] = v;
+      }
+      __syncthreads();
+    }
+    skinny_stage_x<NB>(a, xs, sm_inv, pitch, 0, K, L.wave, L.lane);
+    __syncthreads();
   }
-  skinny_stage_x<NB>(a, xs, sm_inv, pitch, 0, K, L.wave, L.lane);
-  __syncthreads();
 
   f32x4 acc[NW][NB][2][2];
   auto zero = [&]() {

@@ -189,6 +189,10 @@ class Comm:
                 gathered = self.all_gather(hidden_bf16)
                 done = torch.cuda.Event()
                 done.record()
+            # both tensors cross streams: tell the caching allocator, or a block could be handed out again while the
+            # other stream still reads it
+            hidden_bf16.record_stream(self.comm_stream)
+            gathered.record_stream(torch.cuda.current_stream())
             shared = shared_fn(hidden_bf16) if shared_fn else None   # overlaps with the all-gather
             torch.cuda.current_stream().wait_event(done)
         else:
