@@ -252,6 +252,78 @@ __global__ __launch_bounds__(kSkinnyThreads) void skinny_mfma_kernel(const GemvF
     skinny_stage_x<NB>(a, xs, sm_inv, pitch, k0, kt, L.wave, L.lane);
     __syncthreads();
   };
+  // Plain x, <= 16 token columns, 2048-wide tiles (down_proj at 7..16 requests): the x tiles travel by LDS-DMA into
+  // TWO tile buffers, each tile's DMA issued BEFORE the weight loads of the same tile (loads retire in order: an x tile
+  // staged behind two tiles of in-flight weights waited for all of them, every tile).  Every wave issues exactly
+  // kDmaPerTile DMAs per tile (absent token rows / pieces past a short last tile re-send a valid piece), so the waits
+  // are counted: x(k) has landed when at most W(k) [+ x(k+1) + W(k+1)] are outstanding.
+  constexpr bool kDmaForm = kPipe && NB == 1 && RB == 1 && NW == 1;
+  constexpr int kDmaPerTile = 2 * 4;   // 2 token rows per wave x 4 pieces of 1 KiB
+  if constexpr (kDmaForm) {
+    if (!a.norm_w && KT == 2048 && (K & 511) == 0 && T <= 2 * kSkinnyWaves) {   // launcher doubled the tile region
+      typedef __attribute__((address_space(3))) void* lds_ptr_t;
+      const uint32_t xs_lds = (uint32_t)(uintptr_t)(lds_ptr_t)xs;
+      const uint32_t buf_bytes = (uint32_t)skinny_xs_bytes(NB, T, KT);
+      u32x4* xbuf[2] = {xs, reinterpret_cast<u32x4*>(smem_raw + buf_bytes)};
+      auto dma = [&](int k0, int b) {
+        const int kt = (K - k0) < KT ? (K - k0) : KT;
+        const int pieces = kt >> 9;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          int t = L.wave + u * kSkinnyWaves;
+          t = t < T ? t : T - 1;
+#pragma unroll
+          for (int q0 = 0; q0 < 4; ++q0) {
+            const int q = q0 < pieces ? q0 : pieces - 1;
+            const Half* src = a.X + (size_t)t * K + k0 + (size_t)(((q << 6) + L.lane) ^ (t & 15)) * 8;
+            const uint32_t dst = xs_lds + (uint32_t)b * buf_bytes + (uint32_t)(t * pitch + (q << 6)) * 16u;
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                         :: "v"(src), "s"(__builtin_amdgcn_readfirstlane(dst)) : "memory", "m0");
+          }
+        }
+      };
+      auto compute_b = [&](int k0, const u32x4 (&av)[NW][RB][JP][2], const u32x4* xb) {
+        const int kt = (K - k0) < KT ? (K - k0) : KT;
+        const int npairs = kt >> 6;
+#pragma unroll
+        for (int j = 0; j < JP; ++j) {
+          const int p = L.wave + kSkinnyWaves * j;
+          if (p < npairs) {
+            int t = L.l15;
+            t = t < T ? t : T - 1;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const bf16x8_t b = __builtin_bit_cast(bf16x8_t, xb[t * pitch + ((p * 8 + 2 * L.g + h) ^ L.l15)]);
+#pragma unroll
+              for (int rh = 0; rh < 2; ++rh)
+                acc[0][0][0][rh][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    __builtin_bit_cast(bf16x8_t, av[0][0][j][rh]), b, acc[0][0][0][rh][h], 0, 0, 0);
+            }
+          }
+        }
+      };
+      constexpr int kW = NW * RB * JP * 2;   // weight loads per tile and wave (8)
+      dma(0, 0);
+      issue(0, avA);
+      if (KT < K) { dma(KT, 1); issue(KT, avB); }
+      for (int k0 = 0; k0 < K; k0 += 2 * KT) {
+        if (k0 + KT < K) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * kW + kDmaPerTile) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kW) : "memory");
+        __syncthreads();                       // x(k0) of every wave is in buffer 0
+        compute_b(k0, avA, xbuf[0]);
+        __syncthreads();                       // buffer 0 is free again
+        if (k0 + 2 * KT < K) { dma(k0 + 2 * KT, 0); issue(k0 + 2 * KT, avA); }
+        if (k0 + KT >= K) break;
+        if (k0 + 2 * KT < K) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * kW + kDmaPerTile) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kW) : "memory");
+        __syncthreads();
+        compute_b(k0 + KT, avB, xbuf[1]);
+        __syncthreads();
+        if (k0 + 3 * KT < K) { dma(k0 + 3 * KT, 1); issue(k0 + 3 * KT, avB); }
+      }
+      goto skinny_tiles_done;
+    }
+  }
   if constexpr (kPipe) {
     issue(0, avA);   // the loads of the first TWO tiles leave before the first x tile is staged; after that a
     if (KT < K) issue(KT, avB);   // register set is refilled (two tiles ahead) as soon as its tile is multiplied
@@ -272,6 +344,7 @@ __global__ __launch_bounds__(kSkinnyThreads) void skinny_mfma_kernel(const GemvF
     }
   }
 
+skinny_tiles_done:
   // ---- combine the 8 waves (fixed order) and store, one row block at a time through the same LDS buffer ----
   f32x4* red = reinterpret_cast<f32x4*>(smem_raw);  // [wave][NW][NB][64 lanes]
 #pragma unroll
@@ -515,7 +588,9 @@ inline void skinny_launch_resident(GemvFusedArgs a, hipStream_t s) {
 template <int NB, int EPI, int RB>
 inline void skinny_launch_rb(const GemvFusedArgs& a, hipStream_t s) {
   const int rows = EPI == kEpiSilu ? a.I : a.M;
-  const int lds = skinny_xs_bytes(NB, a.T, a.KT) + (64 + 4) * 4;
+  // the LDS-DMA form of the kernel (plain x, <= 16 columns, 2048-wide tiles) keeps two x tile buffers
+  const bool dma_form = NB == 1 && RB == 1 && EPI != kEpiSilu && !a.norm_w && a.KT == 2048 && (a.K & 511) == 0 && a.T <= 16;
+  const int lds = skinny_xs_bytes(NB, a.T, a.KT) * (dma_form ? 2 : 1) + (64 + 4) * 4;
   auto kern = &skinny_mfma_kernel<NB, EPI, RB>;
   static const bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
