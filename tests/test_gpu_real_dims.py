@@ -165,6 +165,40 @@ def test_batch_prefill_paged_long(P, seq_lens, starts):
     assert err <= 2 * (2.0 ** -7 * np.abs(ref).max() + 1e-3), err
 
 
+@pytest.mark.parametrize("ps,seq_lens,starts", [(16, [300, 77], [0, 41]),      # 16-token pages: the full-tile fast path
+                                                 (32, [300, 77], [0, 41]),      # other power of two: shift / mask path
+                                                 (12, [300, 77], [0, 41]),      # not a power of two: division path
+                                                 (2, [4700], [0])])             # 2350 pages: the 2048-entry LDS window reloads
+def test_batch_prefill_paged_page_sizes(P, ps, seq_lens, starts):
+    """The prefill kernel's three page-addressing forms and the page-id window in LDS (a request with more than 2048
+    pages - 32 k tokens at the usual page size, here 4700 tokens on 2-token pages) against the oracle."""
+    import torch
+    from pegainfer_amd import ffi
+    rng = np.random.default_rng(ps * 1000 + sum(seq_lens))
+    lens = [s + n for s, n in zip(starts, seq_lens)]
+    lay, kv, pages, indptr, last = make_paged(rng, lens, ps=ps)
+    T = sum(seq_lens)
+    q = rnd(rng, T, 32 * 128)
+    page_lists = [pages[indptr[i]:indptr[i + 1]].tolist() for i in range(len(lens))]
+    oplan = O.prefill_paged_plan(page_lists, last.tolist(), starts, seq_lens, 32, 8, 128, 64)   # page-size agnostic
+    i32 = lambda a: torch.tensor(np.asarray(a), dtype=torch.int32, device="cuda")
+    L = P.PagedKvLayout(2, 8, 128, ps)
+    out = torch.zeros((T, 32 * 128), dtype=torch.bfloat16, device="cuda")
+    qd, kvd = to_dev(q), to_dev(kv)
+    keep = [i32(pages), i32(indptr), i32(last), i32(oplan["q_indptr"]), i32(oplan["request_indices"]),
+            i32(oplan["qo_tile_indices"]), i32(oplan["kv_tile_indices"]), i32(oplan["kv_chunk_size"]), i32([T])]
+    sm = 1.0 / np.sqrt(128.0)
+    rc = ffi.lib().batch_prefill_paged_cuda_with_cta_tile_q(
+        qd.data_ptr(), out.data_ptr(), kvd.data_ptr(), L.layer_stride, L.layer_stride + L.kv_block_len,
+        keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr(), keep[3].data_ptr(), keep[4].data_ptr(),
+        keep[5].data_ptr(), keep[6].data_ptr(), keep[7].data_ptr(), keep[8].data_ptr(), 32, 8, 128, ps, T, len(lens),
+        int(oplan["num_tiles"]), L.page_stride, sm, 64, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    ref = O.batch_prefill_paged(q, kv, lay, 1, pages, indptr, last, oplan["q_indptr"], 32, sm)
+    err = np.abs(from_dev(out) - ref).max()
+    assert err <= 2 * (2.0 ** -7 * np.abs(ref).max() + 1e-3), (ps, err)
+
+
 # ------------------------------------------------------------------ (a) Qwen3-4B real dims, 2 layers
 CFG2 = dict(hidden_size=2560, num_hidden_layers=2, num_attention_heads=32, num_key_value_heads=8, head_dim=128,
             intermediate_size=9728, vocab_size=151936, rms_norm_eps=1e-6, rope_theta=1e6, tie_word_embeddings=True,
