@@ -63,8 +63,8 @@ __global__ __launch_bounds__(512) void mfma_gemm256_kernel(const Half* __restric
       for (int hi = 0; hi < 2; ++hi) {
         int row;
         if (SILU) {  // tile = 128 gate rows + their 128 up rows: the wave's m-tiles 0-3 are gate rows, 4-7 the up rows
-          int gr = mt * 128 + wr_ * 64 + r;
-          gr = gr < so.silu_I ? gr : so.silu_I - 1;
+          int gr = so.silu_c0 + mt * 128 + wr_ * 64 + r;
+          gr = gr < silu_cols_end(so) ? gr : silu_cols_end(so) - 1;
           row = gr + (hi ? so.silu_I : 0);
         } else {
           row = m0 + wr_ * 128 + hi * 64 + r;
@@ -187,14 +187,14 @@ __global__ __launch_bounds__(512) void mfma_gemm256_kernel(const Half* __restric
       if (t >= T) continue;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int m = mt * 128 + wr * 64 + i * 16 + g * 4;
+        const int m = so.silu_c0 + mt * 128 + wr * 64 + i * 16 + g * 4;
         float r[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {  // the GEMM output is bf16 before SwiGLU (fused_proj.cu:57-62)
           const float sg = silu_f(bf16_round_f(acc[i][j][e]));
           r[e] = (so.silu_round ? bf16_round_f(sg) : sg) * bf16_round_f(acc[i + 4][j][e]);
         }
-        if (m + 3 < so.silu_I) {
+        if (m + 3 < silu_cols_end(so)) {
           u32x2 o;
           o.x = pack_bf2(r[0], r[1]);
           o.y = pack_bf2(r[2], r[3]);
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(512) void mfma_gemm256_kernel(const Half* __restric
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e)
-            if (m + e < so.silu_I) Y[(size_t)t * so.silu_I + m + e] = f2bf(r[e]);
+            if (m + e < silu_cols_end(so)) Y[(size_t)t * so.silu_I + m + e] = f2bf(r[e]);
         }
       }
     }
@@ -243,7 +243,7 @@ inline bool gemm256_ok(int M, int T, int K) { return (K % 128) == 0 && K >= 256 
 
 inline void gemm256_launch(const Half* W, const Half* X, Half* Y, int M, int T, int K, SplitOut so, hipStream_t s) {
   const bool silu = so.silu_I > 0;
-  const int m_tiles = silu ? ceil_div(so.silu_I, 128) : ceil_div(M, G256_BM), t_tiles = ceil_div(T, G256_BT);
+  const int m_tiles = silu ? ceil_div(silu_cols_end(so) - so.silu_c0, 128) : ceil_div(M, G256_BM), t_tiles = ceil_div(T, G256_BT);
   if (silu) {
     static const bool once = [] {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_gemm256_kernel<true>),

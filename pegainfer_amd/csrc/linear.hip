@@ -157,7 +157,10 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(const Half* __restrict__
 // workgroup then owns 64 gate rows AND the 64 up rows below them (each wave 32 + 32, so gate and up of an element
 // meet in one lane's accumulators); per-element K order is unchanged, so the result equals gemm + silu_mul_fused.
 // silu_round: the Qwen3.5 activation bf16(bf16(silu(g)) * u) (elementwise.cu:28-42) instead of one rounding.
-struct SplitOut { Half* Y1; Half* Y2; Half* Y3; int M0; int M1; int M2; int silu_I; int silu_round; };
+// silu_c0 / silu_c1: the activation columns [c0, c1) this launch computes (0, 0 = all of [0, silu_I)): lets two launches
+// with different tile shapes share one SwiGLU GEMM (the thin last round of the 256 x 256 tiling, glds_gemm_launch)
+struct SplitOut { Half* Y1; Half* Y2; Half* Y3; int M0; int M1; int M2; int silu_I; int silu_round; int silu_c0; int silu_c1; };
+__host__ __device__ inline int silu_cols_end(const SplitOut& so) { return so.silu_c1 > 0 ? so.silu_c1 : so.silu_I; }
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -203,8 +206,8 @@ __global__ __launch_bounds__(256) void mfma_gemm_glds_kernel(const Half* __restr
     const int row = (wave + 4 * j) * 8 + lr;
     int mr;
     if (so.silu_I > 0) {  // tile row -> (wave group, 16-row block i, r16): blocks 0,1 = gate rows, 2,3 = up rows
-      int gr = mt * 64 + (row >> 6) * 32 + ((row >> 4) & 1) * 16 + (row & 15);
-      gr = gr < so.silu_I ? gr : so.silu_I - 1;
+      int gr = so.silu_c0 + mt * 64 + (row >> 6) * 32 + ((row >> 4) & 1) * 16 + (row & 15);
+      gr = gr < silu_cols_end(so) ? gr : silu_cols_end(so) - 1;
       mr = gr + (((row >> 4) & 2) ? so.silu_I : 0);
     } else {
       mr = m0 + row; mr = mr < M ? mr : M - 1;
@@ -299,7 +302,7 @@ __global__ __launch_bounds__(256) void mfma_gemm_glds_kernel(const Half* __restr
       if (t >= T) continue;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const int m = mt * 64 + (wave >> 1) * 32 + i * 16 + g * 4;
+        const int m = so.silu_c0 + mt * 64 + (wave >> 1) * 32 + i * 16 + g * 4;
         float r[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e)  // the GEMM output is bf16 before SwiGLU (fused_proj.cu:57-62)
@@ -307,7 +310,7 @@ __global__ __launch_bounds__(256) void mfma_gemm_glds_kernel(const Half* __restr
           const float sg = silu_f(bf16_round_f(acc[i][j][e]));
           r[e] = (so.silu_round ? bf16_round_f(sg) : sg) * bf16_round_f(acc[i + 2][j][e]);
         }
-        if (m + 3 < so.silu_I) {
+        if (m + 3 < silu_cols_end(so)) {
           u32x2 o;
           o.x = pack_bf2(r[0], r[1]);
           o.y = pack_bf2(r[2], r[3]);
@@ -315,7 +318,7 @@ __global__ __launch_bounds__(256) void mfma_gemm_glds_kernel(const Half* __restr
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e)
-            if (m + e < so.silu_I) Y[(size_t)t * so.silu_I + m + e] = f2bf(r[e]);
+            if (m + e < silu_cols_end(so)) Y[(size_t)t * so.silu_I + m + e] = f2bf(r[e]);
         }
       }
     }
@@ -470,7 +473,7 @@ static void glds_gemm_launch_t(const Half* W, const Half* X, Half* Y, int M, int
     return true;
   }();
   (void)once;
-  const int m_tiles = so.silu_I > 0 ? ceil_div(so.silu_I, 64) : ceil_div(M, BM), t_tiles = ceil_div(T, TT);
+  const int m_tiles = so.silu_I > 0 ? ceil_div(silu_cols_end(so) - so.silu_c0, 64) : ceil_div(M, BM), t_tiles = ceil_div(T, TT);
   mfma_gemm_glds_kernel<TT, ST><<<m_tiles * t_tiles, 256, kLds, s>>>(W, X, Y, M, T, K, m_tiles, t_tiles, so);
 }
 // Split-K plans (nk_slice == 0: not applicable), both chosen by shape only:
@@ -548,8 +551,28 @@ static void glds_gemm_launch(const Half* W, const Half* X, Half* Y, int M, int T
     // 1 whenever the shape allows, N = from N tiles on; A/B probe knob)
     static const int g256_min = [] { const char* e = getenv("PEGAINFER_GEMM256"); return e && *e ? atoi(e) : 224; }();
     if (g256_min > 0 && gemm256_ok(M, T, K)) {
-      const long tiles256 = (long)(so.silu_I > 0 ? ceil_div(so.silu_I, 128) : ceil_div(M, G256_BM)) * ceil_div(T, G256_BT);
-      if (tiles256 >= g256_min) { gemm256_launch(W, X, Y, M, T, K, so, s); return; }
+      const int mt256 = so.silu_I > 0 ? ceil_div(so.silu_I, 128) : ceil_div(M, G256_BM), tt256 = ceil_div(T, G256_BT);
+      const long tiles256 = (long)mt256 * tt256;
+      if (tiles256 >= g256_min) {
+        // A thin last round: 304 tiles (gate_up at 1024 tokens) are one full round of the 256 CUs plus 48 tiles that
+        // cost a second full tile time (127 us for 102 GFLOP).  The SwiGLU form can hand the activation columns of
+        // that remainder to the 128-row kernel (192 quarter-size tiles: one short round) - both kernels keep the same
+        // per-element K order, so the result does not depend on the cut.  PEGAINFER_GEMM256_TAIL=0 switches it off.
+        static const bool tail_on = [] { const char* e = getenv("PEGAINFER_GEMM256_TAIL"); return !(e && *e == '0'); }();
+        constexpr int kCus = 256;
+        const int rem = (int)(tiles256 % kCus);
+        const int m_head = (int)((tiles256 / kCus) * kCus / tt256);   // whole activation-column tiles in full rounds
+        if (tail_on && so.silu_I > 0 && so.silu_c1 == 0 && rem > 0 && rem * 2 <= kCus && m_head > 0 && m_head < mt256) {
+          SplitOut head = so, tail = so;
+          head.silu_c0 = 0; head.silu_c1 = m_head * 128;
+          tail.silu_c0 = m_head * 128; tail.silu_c1 = so.silu_I;
+          gemm256_launch(W, X, Y, M, T, K, head, s);
+          glds_gemm_launch_t<128, 2>(W, X, Y, M, T, K, tail, s);
+          return;
+        }
+        gemm256_launch(W, X, Y, M, T, K, so, s);
+        return;
+      }
     }
     // Measured on MI355X (tools/bench_prefill_gemm.py, T = 1024): co-resident workgroups hide DMA latency better
     // than a deeper ring, so the ring only goes to 3 when every 64-token tile is resident at once (<= 2 per CU);
