@@ -47,7 +47,8 @@ def main():
     ns = 10.0  # 100 MHz
     for i, name in enumerate(NAMES):
         a, b = t[:, i], t[:, i + 1]
-        ok = (b > 0) & (a > 0) if name != "merge" else (t[:, 7] > 0)
+        # merge: only the workgroups that merged in THIS launch (an earlier layer's launch may have left its [6] / [7])
+        ok = (b > 0) & (a > 0) if name != "merge" else ((t[:, 7] > 0) & (b > a))
         if ok.any():
             d = (b[ok] - a[ok]) * ns / 1e3
             print(f"  {name:<11} mean {d.mean():6.2f} us  max {d.max():6.2f} us  (n={ok.sum()})")
