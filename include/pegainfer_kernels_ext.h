@@ -83,7 +83,8 @@ pegainfer_status_t pegainfer_gemm_add(const Half* W, const Half* X, Half* y_scra
  * slot_desc (optional, 16-byte aligned): one record of 8 int32 per slot {b, lo, hi, page_indptr[b], position,
  * kv_len, o_indptr[b], o_indptr[b+1]}, lo < 0 for padding slots - the same plan, pre-resolved on the host so a
  * workgroup needs one metadata load instead of four dependent ones.
- * merge_counters (optional, use_split only): batch_size * num_kv_heads int32, zero before the first call.  When
+ * merge_counters (optional, use_split only): batch_size * num_kv_heads * 32 int32 (one cache line per (request, kv head)
+ * counter, the counter itself at index (b * num_kv_heads + kvh) * 32), zero before the first call.  When
  * given, the last workgroup of each (request, kv head) to finish merges that head group's partials in the
  * same launch (agent-scope release/acquire around one atomic) and re-arms the counter; no merge launch.  Output
  * rows of requests that own no slot (padding columns) are then left untouched.  Same bits either way. */
@@ -113,7 +114,7 @@ int32_t pegainfer_paged_attention_decode_split_kv_hd256(const Half* q, Half* out
  * counters (no kernel boundary, no fence).  Replaces, per layer, the five launches of the fused path
  * (pegainfer_gemv_fused x4 + pegainfer_fused_decode_attention) and produces the same bits.  The caller runs the final
  * norm + lm_head + sampling as before, on hidden_a (residual stream) and mlp_out (last residual).
- *   layer_table: device array [layers]; sync: layers*5*8 uint32, status: 4 uint32 - both ZERO before every launch
+ *   layer_table: device array [layers]; sync: layers*5*8*32 uint32 (one cache line per shard counter), status: 4 uint32 - both ZERO before every launch
  *   (memset nodes); status[0] != 0 after the launch = the engine gave up (a bounded spin expired: the grid was not
  *   co-resident) and every output of the step is invalid.
  *   slot_desc records {b, lo, hi, page_indptr[b], position, kv_len, o_indptr[b], o_indptr[b+1]} as for

@@ -75,7 +75,7 @@ __device__ __forceinline__ void decode_attn_body(const DecodeAttnArgs& a, const 
     const int b = ci.b, num_kv_heads = a.num_kv_heads, num_qo_heads = a.num_qo_heads;
     const int s0 = a.o_indptr[b], s1 = a.o_indptr[b + 1];
     if (threadIdx.x == 0) {
-      int* ctr = a.merge_counters + b * num_kv_heads + kvh;
+      int* ctr = a.merge_counters + (size_t)(b * num_kv_heads + kvh) * kMergeCtrStride;
       const int last = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == s1 - s0 - 1;
       if (last) __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       sm_last = last;

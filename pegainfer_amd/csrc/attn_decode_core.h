@@ -35,6 +35,8 @@ struct DecodeAttnArgs {
   // partition form, optional: when merge_counters is non-null the LAST workgroup of a (request, kv head) to
   // finish merges that head group's partials itself (no merge_states_kernel launch).  One int per
   // (request, kv head), zero before the first launch; the merging workgroup leaves it zero again.
+  // The counters are kMergeCtrStride ints apart (a cache line each): at bs 1 the 8 kv heads' counters shared ONE
+  // line and their 8 x 17 arrivals serialised on it (the 1.0-1.1 us "ticket" phase of the in-kernel stamps).
   int* merge_counters; const int* o_indptr;
   // debug: 8 wall-clock stamps (100 MHz) per (slot, kv head) written by thread 0 (pegainfer_debug_attn_trace)
   unsigned long long* trace;
@@ -44,6 +46,8 @@ struct DecodeAttnArgs {
     if ((a).trace && threadIdx.x == 0)                                                                         \
       (a).trace[((size_t)(slot) * (a).num_kv_heads + (kvh)) * 8 + (i)] = wall_clock64();                       \
   } while (0)
+
+constexpr int kMergeCtrStride = 32;   // ints between the merge counters of two (request, kv head) pairs
 
 struct ChunkInfo { int b, pbase, kv_len, lo, hi; };
 

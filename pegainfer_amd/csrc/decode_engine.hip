@@ -112,13 +112,17 @@ __device__ __forceinline__ bool eng_cbar(EngCtx& c) {
 }
 
 // ---- arrival / wait on an op's sharded counters (global, agent scope) ----
+// The 8 shard counters of an (layer, op) edge sit kEngCtrStride words apart - a cache line each: arrivals on eight
+// counters that share one line serialise like arrivals on one (measured on the GEMV ticket counters: 1024 atomics on
+// one line = 12 us).
+constexpr int kEngCtrStride = 32;
 __device__ __forceinline__ unsigned* eng_ctr(const EngArgs& a, int layer, int op) {
-  return a.sync + ((size_t)layer * kEngOps + op) * kEngShards;
+  return a.sync + ((size_t)layer * kEngOps + op) * kEngShards * kEngCtrStride;
 }
 __device__ __forceinline__ void eng_arrive(EngCtx& c, int layer, int op, int shard) {
   // caller: every wave that stored payload has drained it (s_waitcnt vmcnt(0)) and met at a consumer barrier
   if (c.lane == 0)
-    __hip_atomic_fetch_add(eng_ctr(*c.a, layer, op) + shard, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(eng_ctr(*c.a, layer, op) + shard * kEngCtrStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // consumer wave 0 polls the 8 words (one 32-byte sc1 load per poll); everybody then meets at the barrier
 __device__ __forceinline__ bool eng_wait_op(EngCtx& c, int layer, int op, unsigned per_shard, unsigned shard0_only) {
@@ -129,7 +133,7 @@ __device__ __forceinline__ bool eng_wait_op(EngCtx& c, int layer, int op, unsign
     for (;;) {
       unsigned v = want;
       if (c.lane < kEngShards && !(shard0_only && c.lane != 0))
-        v = __hip_atomic_load(p + c.lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v = __hip_atomic_load(p + c.lane * kEngCtrStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (__all(v >= want)) break;
       if (!eng_spin_check(c, spins, kEngErrPoll, (unsigned)(layer * kEngOps + op))) break;
     }
@@ -475,7 +479,7 @@ __device__ __forceinline__ bool eng_attention(EngCtx& c, int layer, float* scrat
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (split) {
         if (c.lane == 0) {
-          int* ctr = a.merge_counters + ci.b * Hkv + kvh;
+          int* ctr = a.merge_counters + (size_t)(ci.b * Hkv + kvh) * kMergeCtrStride;
           const int last = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == s1 - s0 - 1;
           if (last) __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           lds_store_rel(c.sy + kSyFlag, (unsigned)last);

@@ -197,7 +197,7 @@ struct Model35 {
         dalloc(&top1_state, bs * 16) || dalloc(&start_pos_d, 1) ||
         dalloc(&wide, (size_t)std::max(C + Z + 2 * vh, 2 * q_dim + 2 * kv_dim)) ||
         dalloc(&split_tmp_v, bs * pq::kSplitMaxChunksPerRequest * q_dim) ||
-        dalloc(&split_tmp_s, bs * pq::kSplitMaxChunksPerRequest * Hq) || dalloc(&merge_ctr, bs * (size_t)Hkv) || dalloc(&pf_last, H) ||
+        dalloc(&split_tmp_s, bs * pq::kSplitMaxChunksPerRequest * Hq) || dalloc(&merge_ctr, bs * (size_t)Hkv * 32) || dalloc(&pf_last, H) ||
         dalloc(&pf_last_normed, H) || dalloc(&pf_logits, V))
       return -1;
     auto al = [](size_t x) { return (x + 63) & ~size_t(63); };
@@ -411,7 +411,7 @@ struct Model35 {
   // ------------------------------------------------------------------ decode (batch_decode.rs:198-365)
   int decode_kernels(int bs, const std::vector<Request35*>& rs, bool split) {
     auto md = [&](size_t off) { return reinterpret_cast<int32_t*>(meta_dev + off); };
-    if (split) P35_HIP(hipMemsetAsync(merge_ctr, 0, (size_t)max_bs * Hkv * sizeof(int32_t), stream));
+    if (split) P35_HIP(hipMemsetAsync(merge_ctr, 0, (size_t)max_bs * Hkv * 32 * sizeof(int32_t), stream));
     if (embedding_batched_cuda(embed, reinterpret_cast<uint32_t*>(meta_dev + m_tok), hidden, H, bs, S())) {
       set_error("embedding failed"); return -1;
     }
@@ -475,7 +475,7 @@ struct Model35 {
   // stacked outputs take contiguous [bs, dim] tensors in the reference ABI).
   int decode_kernels_fused1(Request35* r, bool split) {
     auto md = [&](size_t off) { return reinterpret_cast<int32_t*>(meta_dev + off); };
-    if (split) P35_HIP(hipMemsetAsync(merge_ctr, 0, (size_t)max_bs * Hkv * sizeof(int32_t), stream));
+    if (split) P35_HIP(hipMemsetAsync(merge_ctr, 0, (size_t)max_bs * Hkv * 32 * sizeof(int32_t), stream));
     if (embedding_batched_cuda(embed, reinterpret_cast<uint32_t*>(meta_dev + m_tok), hidden, H, 1, S())) {
       set_error("embedding failed"); return -1;
     }

@@ -200,7 +200,7 @@ struct Model {
         dalloc(&mlp_act, bs * I) || dalloc(&mlp_out, bs * H) || dalloc(&hidden, bs * H) ||
         dalloc(&hidden2, bs * H) || dalloc(&qkv_out, bs * (size_t)(q_dim + 2 * kv_dim)) ||
         dalloc(&logits, bs * (size_t)V) || dalloc(&split_tmp_v, slots * q_dim) || dalloc(&split_tmp_s, slots * Hq) ||
-        dalloc(&tokens_out_d, bs) || dalloc(&top1_state, bs * 16) || dalloc(&merge_ctr, bs * (size_t)Hkv) || dalloc(&probs_scratch, (size_t)V) ||
+        dalloc(&tokens_out_d, bs) || dalloc(&top1_state, bs * 16) || dalloc(&merge_ctr, bs * (size_t)Hkv * 32) || dalloc(&probs_scratch, (size_t)V) ||
         dalloc(&top1_value, 1) || dalloc(&row_states, 1024 * 1024) || dalloc(&valid_scratch, 1) ||
         dalloc(&sample_out_d, 1))
       return -1;
@@ -232,7 +232,7 @@ struct Model {
       const char* e = getenv("PEGAINFER_ENGINE_WGS");
       eng_wgs = e && *e ? atoi(e) : cus;
       if (eng_wgs > cus) eng_wgs = cus;   // one workgroup per CU, all co-resident: the engine's hand-offs spin
-      if (dalloc(&eng_layers_d, (size_t)L) || dalloc(&eng_sync, (size_t)L * 5 * 8) || dalloc(&eng_status, 4) ||
+      if (dalloc(&eng_layers_d, (size_t)L) || dalloc(&eng_sync, (size_t)L * 5 * 8 * 32) || dalloc(&eng_status, 4) ||
           dalloc(&eng_act, (size_t)I))
         return -1;
       PQ_HIP(hipHostMalloc(reinterpret_cast<void**>(&eng_status_host), 16, hipHostMallocDefault));
@@ -270,9 +270,9 @@ struct Model {
     return pegainfer_decode_engine_supported(&a, eng_wgs) == 0;
   }
   int decode_kernels_engine(bool split, int split_slots) {
-    PQ_HIP(hipMemsetAsync(eng_sync, 0, (size_t)L * 5 * 8 * sizeof(uint32_t), stream));
+    PQ_HIP(hipMemsetAsync(eng_sync, 0, (size_t)L * 5 * 8 * 32 * sizeof(uint32_t), stream));
     PQ_HIP(hipMemsetAsync(eng_status, 0, 16, stream));
-    if (split) PQ_HIP(hipMemsetAsync(merge_ctr, 0, (size_t)max_bs * Hkv * sizeof(int32_t), stream));
+    if (split) PQ_HIP(hipMemsetAsync(merge_ctr, 0, (size_t)max_bs * Hkv * 32 * sizeof(int32_t), stream));
     pegainfer_engine_args_t a;
     engine_args(&a, split, split_slots);
     if (pegainfer_decode_engine_step(&a, eng_wgs, S())) { set_error("pegainfer_decode_engine_step failed"); return -1; }
@@ -581,7 +581,7 @@ struct Model {
   // kernel.  Every fused kernel shares its arithmetic core with the reference-named op it replaces, so the
   // logits are bit-identical to decode_mode 0 (tests/test_gpu_fused.py).
   int decode_kernels_fused(int bs, bool split, int split_slots) {
-    if (fused_merge && split) PQ_HIP(hipMemsetAsync(merge_ctr, 0, (size_t)max_bs * Hkv * sizeof(int32_t), stream));
+    if (fused_merge && split) PQ_HIP(hipMemsetAsync(merge_ctr, 0, (size_t)max_bs * Hkv * 32 * sizeof(int32_t), stream));
     if (embedding_batched_cuda(embed, md<uint32_t>(ml.token_ids), hidden, H, bs, S())) {
       set_error("embedding_batched_cuda failed");
       return -1;
@@ -638,7 +638,7 @@ struct Model {
     }
     rms_norm_batched_cuda(hidden, layers[0].ln1, normed, H, bs, eps, S());
     const bool mid = stacked_qkv(bs) && D == 128 && mid_batch_fused;
-    if (mid && fused_merge && split) PQ_HIP(hipMemsetAsync(merge_ctr, 0, (size_t)max_bs * Hkv * sizeof(int32_t), stream));
+    if (mid && fused_merge && split) PQ_HIP(hipMemsetAsync(merge_ctr, 0, (size_t)max_bs * Hkv * 32 * sizeof(int32_t), stream));
     for (int li = 0; li < L; ++li) {
       const Half* next_w = li + 1 < L ? layers[li + 1].ln1 : final_norm;
       if (mid) {

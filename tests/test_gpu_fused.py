@@ -170,7 +170,7 @@ def test_fused_decode_attention_matches_unfused(built_libs, lens, split):
     # ---- partials merged by the last workgroup of each (request, kv head) instead of a merge launch: same bits,
     #      counters re-armed (run twice on the same counters) ----
     if split:
-        ctr = torch.zeros(bs * Hkv, dtype=torch.int32, device="cuda")
+        ctr = torch.zeros(bs * Hkv * 32, dtype=torch.int32, device="cuda")   # one cache line per (request, kv head)
         for _ in range(2):
             kv_d = to_dev(kv)
             out_d = torch.zeros_like(out_a)
