@@ -36,7 +36,8 @@ struct G256Out { Half* Y; int ld; };
 template <bool SILU>
 __global__ __launch_bounds__(512) void mfma_gemm256_kernel(const Half* __restrict__ W, const Half* __restrict__ X,
                                                            Half* __restrict__ Y, int M, int T, int K, int m_tiles,
-                                                           int t_tiles, SplitOut so) {
+                                                           int t_tiles, SplitOut so, float* __restrict__ part = nullptr,
+                                                           int nk_slice = 0) {
   extern __shared__ __attribute__((aligned(16))) u32x4 g256_smem[];
   const int ntiles = m_tiles * t_tiles;
   int tile = blockIdx.x;
@@ -86,7 +87,16 @@ __global__ __launch_bounds__(512) void mfma_gemm256_kernel(const Half* __restric
   }
   typedef __attribute__((address_space(3))) void* lptr_t;
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)&g256_smem[0];
-  const int nk = K / G256_BK;
+  // split-K form (part != null): blockIdx.y = K slice of nk_slice K tiles (even, like the last, shorter one: the
+  // tiles are walked in pairs); the workgroup's fp32 tile goes to part[z][T][M] and a slice-sum launch adds the slices
+  // in z order (down_proj at 1-2 k tokens: 40-80 tiles of 256 x 256 for 256 CUs)
+  const int kt_begin = part ? (int)blockIdx.y * nk_slice : 0;
+  const int nk_total = K / G256_BK;
+  const int nk = part ? (nk_total - kt_begin < nk_slice ? nk_total - kt_begin : nk_slice) : nk_total;
+#pragma unroll
+  for (int w = 0; w < 4; ++w)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) src[w][j] += (size_t)kt_begin * G256_BK;
   // stage half-tile `which` of K tile kt (clamped: past the end the slot is dead, the load only keeps vmcnt uniform)
   auto stage = [&](int which, int kt) {
     const int ktc = kt < nk ? kt : nk - 1;
@@ -208,6 +218,26 @@ __global__ __launch_bounds__(512) void mfma_gemm256_kernel(const Half* __restric
     }
     return;
   }
+  if (part) {
+    float* pz = part + (size_t)blockIdx.y * T * M;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int t = t0 + wc * 64 + j * 16 + l15;
+      if (t >= T) continue;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int m = m0 + wr * 128 + i * 16 + g * 4;
+        if (m + 3 < M) {
+          *reinterpret_cast<f32x4*>(pz + (size_t)t * M + m) = acc[i][j];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (m + e < M) pz[(size_t)t * M + m + e] = acc[i][j][e];
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int t = t0 + wc * 64 + j * 16 + l15;
@@ -261,6 +291,20 @@ inline void gemm256_launch(const Half* W, const Half* X, Half* Y, int M, int T, 
     (void)once;
     mfma_gemm256_kernel<false><<<m_tiles * t_tiles, 512, kG256LdsBytes, s>>>(W, X, Y, M, T, K, m_tiles, t_tiles, so);
   }
+}
+
+// split-K launch of the plain form: fp32 partials into `part` ([ksplit][T][M]); the caller sums the slices
+inline void gemm256_splitk_launch(const Half* W, const Half* X, int M, int T, int K, float* part, int ksplit, int nk_slice,
+                                  hipStream_t s) {
+  const int m_tiles = ceil_div(M, G256_BM), t_tiles = ceil_div(T, G256_BT);
+  static const bool once = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_gemm256_kernel<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kG256LdsBytes);
+    return true;
+  }();
+  (void)once;
+  mfma_gemm256_kernel<false><<<dim3(m_tiles * t_tiles, ksplit), 512, kG256LdsBytes, s>>>(
+      W, X, nullptr, M, T, K, m_tiles, t_tiles, SplitOut{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0}, part, nk_slice);
 }
 
 }  // namespace pk

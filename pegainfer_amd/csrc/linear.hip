@@ -491,6 +491,22 @@ static SplitKPlan splitk_plan(int M, int T, int K) {
   if (!enabled || !g_splitk_ws || T <= 16) return {0, 0, 0};
   const int m_tiles = ceil_div(M, BM), nk_all = K / BK;
   if (T > 64) {
+    // long-K matrices at ~1.3-3 k tokens (down_proj: 50-128 tiles of 256 x 256): the 8-phase kernel over 2-5 K
+    // slices, one workgroup per CU (tt == 256 marks this plan; PEGAINFER_SPLITK256=0 switches it off).  Same-box A/B of
+    // TTFT: 2048 tokens 23.05 -> 21.4 ms; 1024 tokens (40 tiles, 6 slices: 63 MB of partials each way) 12.60 vs 12.56,
+    // 512 tokens (8 slices) 9.17 vs 9.33 - so only above 40 tiles.
+    static const bool s256 = [] { const char* e = getenv("PEGAINFER_SPLITK256"); return !(e && e[0] == '0'); }();
+    if (s256 && K >= 8192 && gemm256_ok(M, T, K)) {
+      const long tiles256 = (long)ceil_div(M, G256_BM) * ceil_div(T, G256_BT);
+      if (tiles256 > 40 && tiles256 <= 128) {
+        int want = (int)(256 / tiles256);
+        want = want > 8 ? 8 : want;
+        int nk_slice = (ceil_div(nk_all, want) + 1) & ~1;   // K tiles are walked in pairs
+        nk_slice = nk_slice < 16 ? 16 : nk_slice;
+        const int ksplit = ceil_div(nk_all, nk_slice);
+        if (ksplit >= 2 && (size_t)ksplit * T * M * 4 <= kSplitKWorkspaceBytes) return {ksplit, nk_slice, 256};
+      }
+    }
     const int tt = T <= 256 ? 64 : 128;
     const long tiles = (long)m_tiles * ceil_div(T, tt);
     if (tiles > 170) return {0, 0, 0};
@@ -517,7 +533,9 @@ static SplitKPlan splitk_plan(int M, int T, int K) {
 static void glds_splitk_launch(const Half* W, const Half* X, Half* Y, int M, int T, int K, SplitOut so, SplitKPlan pl,
                                hipStream_t s, bool reduce = true) {
   const int m_tiles = ceil_div(M, BM);
-  if (pl.tt == 64) {
+  if (pl.tt == 256) {
+    gemm256_splitk_launch(W, X, M, T, K, g_splitk_ws, pl.ksplit, pl.nk_slice, s);
+  } else if (pl.tt == 64) {
     constexpr int kLds = 3 * (BM + 64) * 8 * 16;
     static const bool once = [] {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_gemm_glds_kernel<64, 3, true>),
