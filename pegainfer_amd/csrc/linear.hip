@@ -496,7 +496,8 @@ static SplitKPlan splitk_plan(int M, int T, int K) {
     // TTFT: 2048 tokens 23.05 -> 21.4 ms; 1024 tokens (40 tiles, 6 slices: 63 MB of partials each way) 12.60 vs 12.56,
     // 512 tokens (8 slices) 9.17 vs 9.33 - so only above 40 tiles.
     static const bool s256 = [] { const char* e = getenv("PEGAINFER_SPLITK256"); return !(e && e[0] == '0'); }();
-    if (s256 && K >= 8192 && gemm256_ok(M, T, K)) {
+    static const int s256_mink = [] { const char* e = getenv("PEGAINFER_SPLITK256_MINK"); return e && *e ? atoi(e) : 4096; }();   // o_proj (K 4096) included: TTFT(2048) 21.72 -> 21.29 ms
+    if (s256 && K >= s256_mink && gemm256_ok(M, T, K)) {
       const long tiles256 = (long)ceil_div(M, G256_BM) * ceil_div(T, G256_BT);
       if (tiles256 > 40 && tiles256 <= 128) {
         int want = (int)(256 / tiles256);
