@@ -239,7 +239,12 @@ struct Model35 {
     else if (name == "norm.weight") set(final_norm, H);
     else if (name.rfind("layers.", 0) == 0) {
       const size_t p0 = 7, p1 = name.find('.', p0);
-      const int li = std::stoi(name.substr(p0, p1 - p0));
+      if (p1 == std::string::npos || p1 == p0 || p1 - p0 > 6) { set_error("bad layer index in tensor name: " + name); return -1; }
+      int li = 0;   // digits only: nothing may throw through the extern "C" boundary
+      for (size_t i = p0; i < p1; ++i) {
+        if (name[i] < '0' || name[i] > '9') { set_error("bad layer index in tensor name: " + name); return -1; }
+        li = li * 10 + (name[i] - '0');
+      }
       if (li < 0 || li >= L) { set_error("layer index out of range: " + name); return -1; }
       const std::string r = name.substr(p1 + 1);
       Layer35& ly = layers[li];

@@ -96,8 +96,12 @@ def lib():
     """libpegainfer_kernels_hip.so (include/pegainfer_kernels.h)."""
     if "k" not in _cache:
         _cache["k"] = _Lib("libpegainfer_kernels_hip.so", "pegainfer_kernels.h", "pegainfer_kernels_ext.h")
-        import torch
-        if torch.cuda.is_available():   # a reference rank thread calls this before its first op (executor.rs:438-458)
+        try:
+            import torch
+            has_gpu = torch.cuda.is_available()
+        except ImportError:   # symbol/ABI checks work without torch; compute entry points need a device anyway
+            has_gpu = False
+        if has_gpu:   # a reference rank thread calls this before its first op (executor.rs:438-458)
             _cache["k"].cublas_init()
     return _cache["k"]
 
