@@ -63,6 +63,7 @@ extern unsigned long long* g_gemv_trace;
 // Qwen3.5 forms of the fused pieces (pegainfer_gemv_fused_ex): (1 + w) norm weight; residual sum rounded to bf16
 // before the norm ("add, then norm" instead of FlashInfer's fused add+norm); silu rounded to bf16 before * up
 enum { kGemvNormOffset = 1, kGemvRoundSum = 2, kGemvSiluRound = 4 };
+constexpr int kGemvNormAllWaves = 32;   // launcher-only bit (PEGAINFER_GEMV_NORM1W=0): every wave sums the squares (A/B probe)
 
 template <int NT, int RPW, int KSPLIT, int EPI>
 __global__ __launch_bounds__(256) void gemv_fused_kernel(const GemvFusedArgs a) {
@@ -166,12 +167,18 @@ __global__ __launch_bounds__(256) void gemv_fused_kernel(const GemvFusedArgs a) 
     const uint32_t xs_lds = (uint32_t)(uintptr_t)(lds_ptr_t)xs, rs_lds = (uint32_t)(uintptr_t)(lds_ptr_t)rs;
     constexpr int XP = 2;
     u32x4 gx[XP];
+    // Who does what in the norm prologue.  Measured (stamps, tools/gemv_probe.py sites 8 / 9): the 2.6 us the norm
+    // sites need beyond a plain site's 1.4 us are not memory - one hot norm weight for every launch changes nothing -
+    // but VALU time: every wave of every co-resident workgroup summed the squares redundantly (4 waves per SIMD x ~200
+    // instructions) and wave 0 scaled two vectors per lane.  So ONE wave per token row sums (the canonical one-wave
+    // order needs exactly one), its neighbour takes the vectors beyond 256, and the roles rotate with blockIdx / 256 -
+    // the workgroups sharing a CU differ in that - so they land on different SIMDs.
+    const int w0 = (a.flags & kGemvNormAllWaves) ? 0 : (int)((blockIdx.x >> 8) & 3);
+    const int cvec[XP] = {(int)threadIdx.x, 256 + ((((wave - w0 - 1) & 3) << 6) | lane)};
     if (a.norm_w) {
 #pragma unroll
-      for (int i = 0; i < XP; ++i) {
-        const int c = threadIdx.x + i * 256;
-        if (c < nvec_row) gx[i] = reinterpret_cast<const u32x4*>(a.norm_w)[c];
-      }
+      for (int i = 0; i < XP; ++i)
+        if (cvec[i] < nvec_row) gx[i] = reinterpret_cast<const u32x4*>(a.norm_w)[cvec[i]];
     }
     const int pieces = K >> 9;   // 1 KiB pieces per row; wave w moves pieces w, w + 4, ...
 #pragma unroll
@@ -192,11 +199,14 @@ __global__ __launch_bounds__(256) void gemv_fused_kernel(const GemvFusedArgs a) 
     issue(0, kt0, bfirst);
     // the U * NW * RPW weight loads issued last may stay in flight; everything older (the DMAs) has landed
     asm volatile("s_waitcnt vmcnt(%0)" :: "n"(U * NW * RPW) : "memory");
+    PK_GEMV_STAMP(a, 6);   // wave 0's own x-side loads have landed
     __syncthreads();
+    PK_GEMV_STAMP(a, 7);   // every wave's have
     if (a.norm_w) {
+      const bool all_waves = (a.flags & kGemvNormAllWaves) != 0;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        if (t >= T) continue;
+        if (t >= T || !(all_waves || wave == ((w0 + t) & 3))) continue;
         float ss = 0.f;
         if (a.residual && round_sum) {
           for (int j = lane; j < nvec_row; j += 64) add_round_sq8(xs[t * pitch + j], rs[t * pitch + j], ss);
@@ -207,11 +217,17 @@ __global__ __launch_bounds__(256) void gemv_fused_kernel(const GemvFusedArgs a) 
         }
         ss = wave_sum(ss);
         inv[t] = rsqrtf(__fadd_rn(ss / (float)K, a.eps));
+        if (!all_waves && lane == 0) red[t] = inv[t];
       }
-      __syncthreads();  // every wave has read the raw rows
+      __syncthreads();  // the raw rows have been read; the inverse RMS values are in LDS
+      if (!all_waves) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+          if (t < T) inv[t] = red[t];
+      }
 #pragma unroll
       for (int i = 0; i < XP; ++i) {
-        const int c = threadIdx.x + i * 256;
+        const int c = cvec[i];
         if (c < nvec_row) {
 #pragma unroll
           for (int t = 0; t < NT; ++t) {
@@ -405,6 +421,8 @@ inline void gemv_launch_one(const GemvFusedArgs& a, hipStream_t s) {
   }
   GemvFusedArgs b = a;
   b.trace = g_gemv_trace;
+  static const bool norm1w = [] { const char* e = getenv("PEGAINFER_GEMV_NORM1W"); return !(e && *e == '0'); }();
+  if (!norm1w) b.flags |= kGemvNormAllWaves;
   kern<<<grid, 256, lds, s>>>(b);
 }
 

@@ -999,7 +999,11 @@ struct Model {
         // the kernels the fused decode step really launches (decode_mode 1):
         case 5: pegainfer_gemv_fused(ly.gate_up, hidden, mlp_act, 2 * I, bs, H, attn_proj, ly.ln2, hidden2, eps, I, S()); break;
         case 6: pegainfer_gemv_fused(ly.qkv, hidden, qkv_out, q_dim + 2 * kv_dim, bs, H, mlp_out, ly.ln1, hidden2, eps, 0, S()); break;
-        default: pegainfer_gemv_fused(lm_head, hidden, logits, V, bs, H, mlp_out, final_norm, hidden2, eps, 0, S()); break;
+        case 7: pegainfer_gemv_fused(lm_head, hidden, logits, V, bs, H, mlp_out, final_norm, hidden2, eps, 0, S()); break;
+        // 8 / 9 = 5 / 6 with ONE norm weight for every launch (hot in L2) while the matrices still cycle: isolates
+        // what the cold norm weight costs the prologue (tools/gemv_probe.py)
+        case 8: pegainfer_gemv_fused(ly.gate_up, hidden, mlp_act, 2 * I, bs, H, attn_proj, layers[0].ln2, hidden2, eps, I, S()); break;
+        default: pegainfer_gemv_fused(ly.qkv, hidden, qkv_out, q_dim + 2 * kv_dim, bs, H, mlp_out, layers[0].ln1, hidden2, eps, 0, S()); break;
       }
     };
     for (int i = 0; i < 3; ++i) launch(i);

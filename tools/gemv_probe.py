@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Timeline of one decode GEMV launch on a real MI355X from the in-kernel wall-clock stamps of
 pegainfer_debug_gemv_trace (100 MHz): per workgroup entry -> x staged -> first weight block consumed -> K loops done ->
-exit.  Sites: 1 = o_proj, 3 = down_proj, 5 = fused gate_up (add + RMSNorm prologue, SwiGLU), 6 = fused qkv, 7 = lm_head.
+exit.  Sites: 1 = o_proj, 3 = down_proj, 5 = fused gate_up (add + RMSNorm prologue, SwiGLU), 6 = fused qkv, 7 = lm_head,
+8 / 9 = 5 / 6 with one (hot) norm weight for every launch.
 usage: python tools/gemv_probe.py [--sites 6 1 5 3] [--layers 4]"""
 import argparse
 import os
@@ -11,12 +12,14 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 NAMES = {0: "qkv (plain)", 1: "o_proj", 2: "gate_up (plain)", 3: "down_proj", 4: "lm_head (plain)", 5: "gate_up fused",
-         6: "qkv fused", 7: "lm_head fused"}
+         6: "qkv fused", 7: "lm_head fused", 8: "gate_up fused, ONE hot norm weight", 9: "qkv fused, ONE hot norm weight"}
 BYTES = lambda c: {1: 2 * c["hidden_size"] * c["num_attention_heads"] * c["head_dim"],
                    3: 2 * c["hidden_size"] * c["intermediate_size"],
                    5: 4 * c["hidden_size"] * c["intermediate_size"],
                    6: 2 * c["hidden_size"] * (c["num_attention_heads"] + 2 * c["num_key_value_heads"]) * c["head_dim"],
-                   7: 2 * c["hidden_size"] * c["vocab_size"]}
+                   7: 2 * c["hidden_size"] * c["vocab_size"],
+                   8: 4 * c["hidden_size"] * c["intermediate_size"],
+                   9: 2 * c["hidden_size"] * (c["num_attention_heads"] + 2 * c["num_key_value_heads"]) * c["head_dim"]}
 
 
 def main():
@@ -50,6 +53,10 @@ def main():
               f" | first block consumed at {us(t[:, 2].mean() - t0):.2f} (max {us(t[:, 2].max() - t0):.2f})"
               f" | K loops done at {us(t[:, 3].mean() - t0):.2f} (max {us(t[:, 3].max() - t0):.2f})"
               f" | exit mean {us(t[:, 4].mean() - t0):.2f} min {us(t[:, 4].min() - t0):.2f} max {us(t[:, 4].max() - t0):.2f}")
+        if (t[:, 6] > 0).all():   # resident-x prologue: where its time goes
+            print(f"   prologue: wave 0's x-side loads landed at {us(t[:, 6].mean() - t0):.2f} (max {us(t[:, 6].max() - t0):.2f}) | "
+                  f"all waves' at {us(t[:, 7].mean() - t0):.2f} (max {us(t[:, 7].max() - t0):.2f}) | norm arithmetic + barriers "
+                  f"{us((t[:, 1] - t[:, 7]).mean()):.2f} (max {us((t[:, 1] - t[:, 7]).max()):.2f})")
         per_xcc = [us(t[t[:, 5] == x][:, 4].max() - t0) for x in range(8) if (t[:, 5] == x).any()]
         print("   last exit per XCC:", " ".join(f"{v:.2f}" for v in per_xcc))
     eng.close()
