@@ -417,15 +417,31 @@ def main():
     tokens = args.steps * args.batch * (1 if tp else world)
     value = tokens / elapsed
     # configs[4] side measurement (not part of `value`): the DeepSeek-V4 MP8 collective verbs over the N ranks
-    mp8 = None
+    mp8, mp8_hung = None, False
     if world > 1:
-        try:   # never let the side measurement take the headline line down with it
-            ncomm = parallel.NativeComm(device=local)   # include/pegainfer_comm.h: RCCL on the caller's stream
-            mp8 = parallel.bench_mp8_collectives(ncomm, device=torch.device("cuda", local))
-            mp8["transport"] = "native C ABI over RCCL (pegainfer_comm.h)"
-            ncomm.close()
-        except Exception as e:  # noqa: BLE001
-            mp8 = {"error": f"{type(e).__name__}: {e}"[:300]}
+        # never let the side measurement take the headline line down with it: exceptions are reported in the line, and a
+        # collective that never completes (a rank missing, a fabric problem) is abandoned after a deadline - every rank
+        # runs the same watchdog, prints / exits on its own and skips the process-group teardown that would block too
+        import threading
+        box = {}
+
+        def side():
+            try:
+                torch.cuda.set_device(local)
+                ncomm = parallel.NativeComm(device=local)   # include/pegainfer_comm.h: RCCL on the caller's stream
+                r = parallel.bench_mp8_collectives(ncomm, device=torch.device("cuda", local))
+                r["transport"] = "native C ABI over RCCL (pegainfer_comm.h)"
+                ncomm.close()
+                box["mp8"] = r
+            except Exception as e:  # noqa: BLE001
+                box["mp8"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+
+        deadline = float(os.environ.get("PEGAINFER_BENCH_MP8_TIMEOUT", "120"))
+        th = threading.Thread(target=side, daemon=True)
+        th.start()
+        th.join(timeout=deadline)
+        mp8_hung = th.is_alive()
+        mp8 = {"error": f"collective microbench did not finish within {deadline:.0f} s; abandoned"} if mp8_hung else box.get("mp8")
     ctx_mid = args.ctx + args.warmup + args.steps / 2
     step_bytes = algorithmic_bytes_per_token(full_cfg, ctx_mid, args.batch)
 
@@ -490,7 +506,8 @@ def main():
             t = eng.bench_gemv(which, 72 if which != 4 else 20, args.batch)
             per_site[name] = {"us": round(t * 1e3, 2), "GBps": round(M * K * 2 / (t * 1e-3) / 1e9, 1)}
         out["gemv_sites"] = per_site
-    eng.close()
+    if not mp8_hung:   # freeing device memory synchronises the device - behind a stuck collective it never returns
+        eng.close()
     if rank == 0:
         if args.cpu_steps > 0 and world == 1:
             threads = os.cpu_count() or 1
@@ -501,7 +518,9 @@ def main():
                                        "sample": "skipped: host RAM too small for the fp32 oracle weights"}
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    if mp8_hung:
+        os._exit(0)   # a stuck collective would also block the teardown; the line is out
     if world > 1:
         dist.destroy_process_group()
 
