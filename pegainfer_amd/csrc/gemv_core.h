@@ -63,6 +63,7 @@ extern unsigned long long* g_gemv_trace;
 // Qwen3.5 forms of the fused pieces (pegainfer_gemv_fused_ex): (1 + w) norm weight; residual sum rounded to bf16
 // before the norm ("add, then norm" instead of FlashInfer's fused add+norm); silu rounded to bf16 before * up
 enum { kGemvNormOffset = 1, kGemvRoundSum = 2, kGemvSiluRound = 4 };
+constexpr int kGemvProloguePrio = 64;   // launcher-only bit (PEGAINFER_GEMV_PRIO=0 clears it): see the prologue
 constexpr int kGemvNormAllWaves = 32;   // launcher-only bit (PEGAINFER_GEMV_NORM1W=0): every wave sums the squares (A/B probe)
 
 template <int NT, int RPW, int KSPLIT, int EPI>
@@ -162,6 +163,11 @@ __global__ __launch_bounds__(256) void gemv_fused_kernel(const GemvFusedArgs a) 
   const bool round_sum = (a.flags & kGemvRoundSum) != 0;
   const int nvec_row = K >> 3;
   const bool early = NT <= 2 && K <= KT && (K & 511) == 0 && nvec_row <= 2 * 256 * (a.norm_w ? 1 : 4);
+  // The prologue is a serial chain (loads -> barrier -> sum -> barrier -> scale -> barrier) that runs next to the dot
+  // products of the workgroups already streaming on this CU; those are waiting on HBM most of the time, so the
+  // prologue's instructions go first.
+  const bool prio = (a.flags & kGemvProloguePrio) != 0;
+  if (prio) __builtin_amdgcn_s_setprio(3);
   if (early) {
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     const uint32_t xs_lds = (uint32_t)(uintptr_t)(lds_ptr_t)xs, rs_lds = (uint32_t)(uintptr_t)(lds_ptr_t)rs;
@@ -294,6 +300,7 @@ __global__ __launch_bounds__(256) void gemv_fused_kernel(const GemvFusedArgs a) 
     stage(0, kt0);
     __syncthreads();
   }
+  if (prio) __builtin_amdgcn_s_setprio(0);
   PK_GEMV_STAMP(a, 1);
   bool first_group = true;
 
@@ -423,6 +430,8 @@ inline void gemv_launch_one(const GemvFusedArgs& a, hipStream_t s) {
   b.trace = g_gemv_trace;
   static const bool norm1w = [] { const char* e = getenv("PEGAINFER_GEMV_NORM1W"); return !(e && *e == '0'); }();
   if (!norm1w) b.flags |= kGemvNormAllWaves;
+  static const bool prio = [] { const char* e = getenv("PEGAINFER_GEMV_PRIO"); return !(e && *e == '0'); }();
+  if (prio) b.flags |= kGemvProloguePrio;
   kern<<<grid, 256, lds, s>>>(b);
 }
 
