@@ -81,6 +81,15 @@ int32_t pegainfer_sched_num_deferred(pegainfer_sched_t s);
 /* message of the most recent ERROR / REJECTED event */
 const char* pegainfer_sched_last_message(pegainfer_sched_t s);
 
+/* The random_val stream the scheduler hands to its executor: the reference's StdRng::seed_from_u64(seed) +
+ * `rng.random::<f32>()` (scheduler.rs:104, plan.rs:46-70), restated from the published algorithms of the crates pinned in
+ * Cargo.lock (rand 0.10.1, chacha20 0.10.0, rand_core 0.10.1): ChaCha12 keyed by a PCG32 expansion of the seed, f32 = top
+ * 24 bits of a word * 2^-24.  pegainfer_std_rng_stream writes the first n draws (as f32 and / or the raw words; either
+ * pointer may be NULL); pegainfer_chacha_block is the block function alone (rounds = 8 / 12 / 20) so it can be checked
+ * against the published keystreams.  The seed expansion has no offline vector: "parity unpinned". */
+void pegainfer_chacha_block(const uint32_t* key8, uint64_t counter, int32_t rounds, uint32_t* out16);
+void pegainfer_std_rng_stream(uint64_t seed, int32_t n, float* out_f32, uint32_t* out_u32);
+
 #ifdef __cplusplus
 }
 #endif

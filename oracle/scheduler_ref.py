@@ -20,26 +20,13 @@ def pages_needed(tokens, page_size):
     return -(-tokens // page_size)
 
 
-class SplitMix:
-    """random_val stream: the reference draws f32 from StdRng(seed) (ChaCha, not reproduced - greedy ignores it);
-    both this oracle and the C++ scheduler use splitmix64 -> 24-bit uniform so their streams agree."""
-
-    def __init__(self, seed):
-        self.s = seed & 0xFFFFFFFFFFFFFFFF
-
-    def next_f32(self):
-        self.s = (self.s + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
-        z = self.s
-        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
-        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
-        z ^= z >> 31
-        return (z >> 40) / 16777216.0
+from .std_rng import StdRng   # noqa: E402  the reference's StdRng::seed_from_u64 stream (restated; oracle/std_rng.py)
 
 
 class SchedulerOracle:
     def __init__(self, executor, seed=42):
         self.ex = executor
-        self.rng = SplitMix(seed)
+        self.rng = StdRng(seed)
         self.active = []     # dicts: id, closed, last_token, generated, max_tokens, prompt_len, params
         self.deferred = []   # dicts: id, prompt, params, max_tokens, closed
         self.next_id = 0

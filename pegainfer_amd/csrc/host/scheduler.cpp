@@ -25,17 +25,59 @@ struct Pending {  // PendingRequest (scheduler.rs:43-51)
 
 static inline int pages_needed(long tokens, int page_size) { return (int)((tokens + page_size - 1) / page_size); }
 
-// splitmix64 -> 24-bit uniform (the reference's StdRng stream is not reproduced; greedy ignores random_val)
+// The reference's random_val stream: rand::rngs::StdRng::seed_from_u64(seed), one f32 per sampled request
+// (scheduler.rs:104, plan.rs:46-70).  The generator is third-party (rand 0.10.1 / chacha20 0.10.0 / rand_core 0.10.1 in
+// Cargo.lock, sources not vendored), restated from the published algorithms: ChaCha with 12 rounds, key = 32 seed bytes
+// from a PCG32 expansion of the u64, 64-bit block counter from 0, stream id 0, words handed out in order; f32 = the top
+// 24 bits of a word * 2^-24.  The block function is pinned by the published zero-key keystreams
+// (tests/test_std_rng.py, against oracle/std_rng.py and this code through pegainfer_chacha_block / pegainfer_std_rng_stream); the seed
+// expansion has no offline vector ("parity unpinned").  Greedy decoding never reads these values.
 struct Rng {
-  uint64_t s;
-  float next_f32() {
-    s += 0x9E3779B97F4A7C15ull;
-    uint64_t z = s;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z ^= z >> 31;
-    return (float)(z >> 40) * (1.0f / 16777216.0f);
+  uint32_t key[8] = {0};
+  uint64_t counter = 0;
+  uint32_t buf[16] = {0};
+  int idx = 16;
+
+  void seed(uint64_t state) {
+    const uint64_t MUL = 6364136223846793005ull, INC = 11634580027462260723ull;
+    for (int i = 0; i < 8; ++i) {
+      state = state * MUL + INC;
+      const uint32_t xorshifted = (uint32_t)(((state >> 18) ^ state) >> 27);
+      const uint32_t rot = (uint32_t)(state >> 59);
+      key[i] = (xorshifted >> rot) | (xorshifted << ((32 - rot) & 31));
+    }
+    counter = 0;
+    idx = 16;
   }
+  static inline uint32_t rotl(uint32_t x, int n) { return (x << n) | (x >> (32 - n)); }
+  static inline void quarter(uint32_t* s, int a, int b, int c, int d) {
+    s[a] += s[b]; s[d] = rotl(s[d] ^ s[a], 16);
+    s[c] += s[d]; s[b] = rotl(s[b] ^ s[c], 12);
+    s[a] += s[b]; s[d] = rotl(s[d] ^ s[a], 8);
+    s[c] += s[d]; s[b] = rotl(s[b] ^ s[c], 7);
+  }
+  static void block(const uint32_t* key8, uint64_t ctr, int rounds, uint32_t* out16) {
+    uint32_t init[16] = {0x61707865u, 0x3320646Eu, 0x79622D32u, 0x6B206574u};
+    for (int i = 0; i < 8; ++i) init[4 + i] = key8[i];
+    init[12] = (uint32_t)ctr; init[13] = (uint32_t)(ctr >> 32); init[14] = 0; init[15] = 0;
+    uint32_t s[16];
+    for (int i = 0; i < 16; ++i) s[i] = init[i];
+    for (int r = 0; r < rounds / 2; ++r) {   // one column + one diagonal round per iteration
+      quarter(s, 0, 4, 8, 12); quarter(s, 1, 5, 9, 13); quarter(s, 2, 6, 10, 14); quarter(s, 3, 7, 11, 15);
+      quarter(s, 0, 5, 10, 15); quarter(s, 1, 6, 11, 12); quarter(s, 2, 7, 8, 13); quarter(s, 3, 4, 9, 14);
+    }
+    for (int i = 0; i < 16; ++i) out16[i] = s[i] + init[i];
+  }
+  void refill() {
+    block(key, counter, 12, buf);
+    ++counter;
+    idx = 0;
+  }
+  uint32_t next_u32() {
+    if (idx >= 16) refill();
+    return buf[idx++];
+  }
+  float next_f32() { return (float)(next_u32() >> 8) * (1.0f / 16777216.0f); }
 };
 
 // executor bound to the Qwen3 host runtime (executor.rs:541-760 for one rank)
@@ -312,7 +354,7 @@ pegainfer_sched_t pegainfer_sched_create(const pegainfer_executor_vtbl* executor
     return nullptr;
   Scheduler* s = new Scheduler();
   s->ex = *executor;
-  s->rng.s = seed;
+  s->rng.seed(seed);
   return s;
 }
 pegainfer_sched_t pegainfer_sched_create_qwen3(void* model, uint64_t seed, const uint32_t* stop_tokens, int32_t n_stop) {
@@ -375,5 +417,19 @@ int32_t pegainfer_sched_poll(pegainfer_sched_t s, pegainfer_token_event* out, in
 int32_t pegainfer_sched_num_active(pegainfer_sched_t s) { return (int32_t)SC(s)->active.size(); }
 int32_t pegainfer_sched_num_deferred(pegainfer_sched_t s) { return (int32_t)SC(s)->deferred.size(); }
 const char* pegainfer_sched_last_message(pegainfer_sched_t s) { return SC(s)->last_message.c_str(); }
+
+void pegainfer_chacha_block(const uint32_t* key8, uint64_t counter, int32_t rounds, uint32_t* out16) {
+  psched::Rng::block(key8, counter, rounds, out16);
+}
+
+void pegainfer_std_rng_stream(uint64_t seed, int32_t n, float* out_f32, uint32_t* out_u32) {
+  psched::Rng r;
+  r.seed(seed);
+  for (int32_t i = 0; i < n; ++i) {
+    const uint32_t w = r.next_u32();
+    if (out_u32) out_u32[i] = w;
+    if (out_f32) out_f32[i] = (float)(w >> 8) * (1.0f / 16777216.0f);
+  }
+}
 
 }  // extern "C"
