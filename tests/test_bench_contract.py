@@ -1,0 +1,82 @@
+"""bench.py's host-side contract, checked without a GPU: the algorithmic-bytes and FLOP models the roofline objects
+are priced with, the launcher re-exec for `--gpus N`, and the refusal to run without a device
+(the product path has no CPU fallback)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def qwen3_4b():
+    from pegainfer_amd.qwen3 import QWEN3_4B
+    return dict(QWEN3_4B)
+
+
+def test_algorithmic_bytes_per_token_qwen3_4b():
+    c = qwen3_4b()
+    H, L, I, V, D = c["hidden_size"], c["num_hidden_layers"], c["intermediate_size"], c["vocab_size"], c["head_dim"]
+    qd, kvd = c["num_attention_heads"] * D, c["num_key_value_heads"] * D
+    # weights read once: per layer qkv + o + gate_up + down, tied lm_head, norm vectors (bf16)
+    weights = 2 * (L * ((qd + 2 * kvd) * H + H * qd + 3 * I * H) + V * H + L * (2 * H + 2 * D) + H)
+    kv_per_token = L * 2 * kvd * 2
+    ctx = 1024
+    want = weights + kv_per_token * ctx + kv_per_token + 2 * H + 2 * V
+    assert bench.algorithmic_bytes_per_token(c, ctx, 1) == want
+    assert 8.0e9 < want < 8.3e9              # the 8.2 GB per token the 8 TB/s step roofline is priced on
+    # a second request adds its own KV scan, KV append, embedding row and logits - the weights are shared
+    assert bench.algorithmic_bytes_per_token(c, ctx, 2) - want == kv_per_token * (ctx + 1) + 2 * H + 2 * V
+
+
+def test_prefill_roofline_flop_model():
+    c = qwen3_4b()
+    r = bench.prefill_roofline(c, 1024, 10.0)
+    H, L, I, V, D = c["hidden_size"], c["num_hidden_layers"], c["intermediate_size"], c["vocab_size"], c["head_dim"]
+    qd, kvd = c["num_attention_heads"] * D, c["num_key_value_heads"] * D
+    flops = 2.0 * ((qd + 2 * kvd) * H + H * qd + 3 * I * H) * L * 1024 + 2.0 * V * H + 2.0 * qd * 1024 * 1024 * L
+    assert r["flops"] == flops and r["bound"] == "mfma" and r["peak"] == 2500.0   # dense bf16, never the sparse figure
+    assert r["frac"] == round(flops / 10e-3 / 1e12 / 2500.0, 4)
+    assert bench.prefill_roofline(c, 1024, 10.0, tp_world=2)["peak"] == 5000.0
+
+
+def test_synthetic_prompt_is_the_reference_profile():
+    p = bench.synthetic_prompt(2048)
+    assert p[:3] == [100, 101, 102] and p[999] == 1099 and p[1000] == 100 and len(p) == 2048  # bench_serving.rs
+
+
+def test_gpus_flag_becomes_the_launcher(monkeypatch):
+    """`python bench.py --gpus 4` without WORLD_SIZE re-executes itself under torch.distributed.run on 127.0.0.1 with
+    one process per GPU and the same arguments (the flag was parsed and ignored)."""
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7", "--warmup", "2"])
+    assert bench.main() == 0
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert 0 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    tail = cmd[cmd.index(os.path.join(ROOT, "bench.py")) + 1:]
+    assert tail == ["--gpus", "4", "--steps", "7", "--warmup", "2"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+
+def test_world_size_mismatch_and_missing_gpu_are_loud(monkeypatch):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("CPU-only check")
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "1"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "needs a GPU" in str(e.value)       # no silent CPU path behind the bench line
