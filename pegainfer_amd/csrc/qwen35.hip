@@ -16,32 +16,38 @@ namespace pk {
 // =====================================================================================================
 constexpr int kConvMaxK = 5;
 
-__global__ __launch_bounds__(256) void conv1d_kernel(const Half* __restrict__ x, const Half* __restrict__ w,
-                                                     const Half* __restrict__ state, Half* __restrict__ out,
-                                                     int C, int T, int K) {
+// Shapes the vector kernel below does not take (K != 4, C % 8 != 0, misaligned): the decode-step kernel's sliding
+// window, walked over a segment of tokens.  One lane owns one channel and kConvSeg consecutive tokens: the window starts
+// from the K-1 inputs before the segment (x rows, or conv_state for the rows before token 0), every token appends one
+// x element, multiplies the window by the channel's taps in order k = 0..K-1 and shifts.  Neighbouring lanes are
+// neighbouring channels, so every x / out access of a wave is one contiguous row piece.
+constexpr int kConvSeg = 64;
+
+__global__ __launch_bounds__(256) void conv1d_window_kernel(const Half* __restrict__ x, const Half* __restrict__ w,
+                                                            const Half* __restrict__ state, Half* __restrict__ out,
+                                                            int C, int T, int K) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
   const int sw = K - 1;
-  const long total = (long)C * T;
-  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-    const int c = (int)(idx % C), t = (int)(idx / C);
+  const int t_begin = blockIdx.y * kConvSeg;
+  const int t_end = t_begin + kConvSeg < T ? t_begin + kConvSeg : T;
+  float taps[kConvMaxK], win[kConvMaxK];
+  for (int k = 0; k < K; ++k) taps[k] = bf2f(w[(size_t)c * K + k]);
+  for (int i = 0; i < sw; ++i) {   // the K-1 inputs that precede the segment
+    const int src_t = t_begin - sw + i;
+    win[i] = src_t >= 0 ? bf2f(x[(size_t)src_t * C + c]) : bf2f(state[(size_t)c * sw + (sw + src_t)]);
+  }
+  for (int t = t_begin; t < t_end; ++t) {
+    win[sw] = bf2f(x[(size_t)t * C + c]);
     float sum = 0.f;
-    for (int k = 0; k < K; ++k) {
-      const int src_t = t - sw + k;
-      float v;
-      if (src_t < 0) {
-        const int si = sw + src_t;
-        v = si >= 0 ? bf2f(state[(size_t)c * sw + si]) : 0.f;
-      } else {
-        v = bf2f(x[(size_t)src_t * C + c]);
-      }
-      sum += v * bf2f(w[(size_t)c * K + k]);
-    }
-    const float r = bf16_round_f(sum);
-    out[(size_t)t * C + c] = f2bf(silu_f(r));
+    for (int k = 0; k < K; ++k) sum += win[k] * taps[k];
+    out[(size_t)t * C + c] = f2bf(silu_f(bf16_round_f(sum)));
+    for (int i = 0; i < sw; ++i) win[i] = win[i + 1];
   }
 }
 
 // 8 channels x 1 token per lane (C % 8 == 0, K == 4, 16-byte aligned): 16-byte loads of the K source rows and of the
-// 8 x 4 weights, one 16-byte store.  Per element the taps are summed in the same order as conv1d_kernel.
+// 8 x 4 weights, one 16-byte store.  Per element the taps are summed in the same order as conv1d_window_kernel.
 __global__ __launch_bounds__(256) void conv1d_vec4_kernel(const Half* __restrict__ x, const Half* __restrict__ w,
                                                           const Half* __restrict__ state, Half* __restrict__ out,
                                                           int C, int T) {
@@ -85,7 +91,7 @@ __global__ __launch_bounds__(256) void conv1d_vec4_kernel(const Half* __restrict
     *reinterpret_cast<u32x4*>(out + (size_t)t * C + c0) = u32x4{o[0], o[1], o[2], o[3]};
   }
 }
-// T == 1 (decode, recurrent.rs:49-79): output and window shift in one pass, same arithmetic as conv1d_kernel
+// T == 1 (decode, recurrent.rs:49-79): output and window shift in one pass, same arithmetic as conv1d_window_kernel
 __global__ __launch_bounds__(256) void conv1d_step_kernel(const Half* __restrict__ x, const Half* __restrict__ w,
                                                           Half* __restrict__ state, Half* __restrict__ out, int C,
                                                           int K) {
@@ -357,8 +363,8 @@ void conv1d_prefill_cuda(const Half* x_seq, const Half* conv_weight, Half* conv_
     conv1d_vec4_kernel<<<grid_cap((long)(num_channels >> 3) * seq_len, 256), 256, 0, s>>>(
         x_seq, conv_weight, conv_state, out_seq, num_channels, seq_len);
   else
-    conv1d_kernel<<<grid_cap((long)num_channels * seq_len, 256), 256, 0, s>>>(x_seq, conv_weight, conv_state, out_seq,
-                                                                             num_channels, seq_len, kernel_size);
+    conv1d_window_kernel<<<dim3(ceil_div(num_channels, 256), ceil_div(seq_len, kConvSeg)), 256, 0, s>>>(
+        x_seq, conv_weight, conv_state, out_seq, num_channels, seq_len, kernel_size);
   if (kernel_size > 1)
     conv1d_state_kernel<<<ceil_div(num_channels, 256), 256, 0, s>>>(x_seq, conv_state, num_channels, seq_len,
                                                                     kernel_size);
