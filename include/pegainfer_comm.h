@@ -78,7 +78,10 @@ int32_t pegainfer_comm_fence_out(pegainfer_comm_t c, pegainfer_stream_t compute_
  *   combine_send  : expert_x rows in the SAME order as out_x travel back to the ranks they came from
  *   combine_recv  : out_tokens[t] (+)= sum_k weights[t][k] * y(t, k), f32 accumulation in k order, bf16 result
  * A dispatch_send synchronises the calling stream once with the host (the per-peer row counts size the exchange),
- * exactly where the reference's worker thread waits for the route counts. */
+ * exactly where the reference's worker thread waits for the route counts.
+ * Row buffers (x, out_x, expert_x, out_tokens) are moved as 16-byte vectors: base pointers 16-byte aligned, strides a
+ * multiple of 8 elements (else -1 + last_error).  A pair whose index is not in [0, num_experts) is routed nowhere and
+ * contributes zero to its token's combine. */
 pegainfer_ep_hub_t pegainfer_ep_hub_create(int32_t world);   /* loopback transport: `world` virtual ranks, one process */
 void pegainfer_ep_hub_destroy(pegainfer_ep_hub_t hub);
 /* exactly one of (comm, hub) is non-NULL; with a hub, `rank` is the virtual rank of this endpoint */

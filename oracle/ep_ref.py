@@ -9,6 +9,8 @@ contract its call sites rely on (pegainfer-comm/tests + the doc comments of ep_b
     then by (token, k) order on the source - the order the MI355X implementation guarantees (the reference leaves
     it unspecified beyond "grouped by expert").
   * combine: out[t] (+)= sum_k weights[t, k] * y(t, k), where y(t, k) is the expert output of that pair's row.
+  * a pair whose index is not an expert id travels nowhere and contributes zero (defensive rule of this implementation;
+    the reference does not define it).
 Parity unpinned against reference golden vectors: the reference ships none for this path (its tests need 8 GPUs +
 RDMA); pinned instead by the algebraic properties tested in tests/test_ep_oracle.py.
 """
@@ -54,5 +56,6 @@ def combine(expert_rows, origins, weights, num_tokens, hidden, prev=None):
         w = w.reshape(num_tokens[r], w.shape[-1] if w.ndim > 1 else 1)
         for t in range(num_tokens[r]):
             for k in range(w.shape[1]):
-                outs[r][t] += w[t, k] * ys[r][(t, k)]
+                if (t, k) in ys[r]:      # a pair with an index outside [0, num_experts) was routed nowhere: zero
+                    outs[r][t] += w[t, k] * ys[r][(t, k)]
     return outs

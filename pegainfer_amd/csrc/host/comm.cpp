@@ -116,9 +116,15 @@ __global__ __launch_bounds__(256) void ep_pack_kernel(const Half* __restrict__ x
                                                       const int32_t* __restrict__ indices,
                                                       const int32_t* __restrict__ rank_in_bucket,
                                                       const int32_t* __restrict__ offsets, int topk, int hidden,
-                                                      Half* __restrict__ send, int32_t* __restrict__ slot) {
+                                                      int num_experts, Half* __restrict__ send,
+                                                      int32_t* __restrict__ slot) {
   const int p = blockIdx.x, t = p / topk;
-  const int pos = offsets[indices[p]] + rank_in_bucket[p];
+  const int ex = indices[p];
+  if ((unsigned)ex >= (unsigned)num_experts) {   // not an expert id: the pair is routed nowhere and combines as zero
+    if (threadIdx.x == 0) slot[p] = -1;
+    return;
+  }
+  const int pos = offsets[ex] + rank_in_bucket[p];
   if (threadIdx.x == 0) slot[p] = pos;
   const uint4* src = reinterpret_cast<const uint4*>(x + (long)t * x_stride);
   uint4* dst = reinterpret_cast<uint4*>(send + (long)pos * hidden);
@@ -155,7 +161,9 @@ __global__ __launch_bounds__(256) void ep_combine_kernel(const Half* __restrict_
     }
     for (int k = 0; k < topk; ++k) {
       const float w = weights[t * topk + k];
-      const uint4 v = reinterpret_cast<const uint4*>(back + (long)slot[t * topk + k] * hidden)[i];
+      const int sl = slot[t * topk + k];
+      if (sl < 0) continue;   // pair with an invalid expert id (ep_pack_kernel)
+      const uint4 v = reinterpret_cast<const uint4*>(back + (long)sl * hidden)[i];
       acc[0] = fmaf(w, bf_lo(v.x), acc[0]); acc[1] = fmaf(w, bf_hi(v.x), acc[1]);
       acc[2] = fmaf(w, bf_lo(v.y), acc[2]); acc[3] = fmaf(w, bf_hi(v.y), acc[3]);
       acc[4] = fmaf(w, bf_lo(v.z), acc[4]); acc[5] = fmaf(w, bf_hi(v.z), acc[5]);
@@ -198,6 +206,11 @@ struct Ep {
     ncclResult_t r_ = (expr);                                                                    \
     if (r_ != ncclSuccess) { (e)->err = std::string(#expr) + ": " + ncclGetErrorString(r_); return -1; } \
   } while (0)
+
+// the row kernels move 16-byte vectors: row starts must be 16-byte aligned
+static bool rows_aligned(const void* p, int64_t stride_elems) {
+  return (reinterpret_cast<uintptr_t>(p) & 15u) == 0 && (stride_elems & 7) == 0;
+}
 
 static void ep_free(Ep* e) {
   void* dev[] = {e->d_rank_in_bucket, e->d_counts, e->d_offsets, e->d_slot, e->d_counts_recv, e->d_row_map,
@@ -489,6 +502,7 @@ int32_t pegainfer_ep_dispatch_send(pegainfer_ep_t h, int32_t num_tokens, const H
   (void)weights;  // the weights stay with the source rank: they are applied in combine_recv
   if (!e || num_tokens < 0 || num_tokens > e->max_tokens || (num_tokens > 0 && (!x || !indices)) || x_stride_elems < e->hidden)
     return -1;
+  if (num_tokens > 0 && !rows_aligned(x, x_stride_elems)) { e->err = "dispatch_send: x rows must be 16-byte aligned"; return -1; }
   hipStream_t s = st(stream);
   e->num_pairs = num_tokens * e->topk;
   e->sent = false;
@@ -497,7 +511,7 @@ int32_t pegainfer_ep_dispatch_send(pegainfer_ep_t h, int32_t num_tokens, const H
   ep_offsets_kernel<<<1, 256, 0, s>>>(e->d_counts, e->num_experts, e->d_offsets);
   if (e->num_pairs > 0)
     ep_pack_kernel<<<e->num_pairs, 256, 0, s>>>(x, x_stride_elems, indices, e->d_rank_in_bucket, e->d_offsets, e->topk,
-                                                e->hidden, e->d_send, e->d_slot);
+                                                e->hidden, e->num_experts, e->d_send, e->d_slot);
   PE_HIP(e, hipGetLastError());
   PE_HIP(e, hipMemcpyAsync(e->h_counts, e->d_counts, (size_t)e->num_experts * 4, hipMemcpyDeviceToHost, s));
   if (e->comm) {
@@ -528,6 +542,7 @@ int32_t pegainfer_ep_dispatch_recv(pegainfer_ep_t h, int32_t* out_num_tokens, Ha
                                    pegainfer_stream_t stream) {
   Ep* e = static_cast<Ep*>(h);
   if (!e || !e->sent || !out_x || out_x_stride_elems < e->hidden) return -1;
+  if (!rows_aligned(out_x, out_x_stride_elems)) { e->err = "dispatch_recv: out_x rows must be 16-byte aligned"; return -1; }
   hipStream_t s = st(stream);
   if (e->hub) {
     // loopback transport: pull what every virtual rank routed to this one
@@ -559,6 +574,10 @@ int32_t pegainfer_ep_combine_send(pegainfer_ep_t h, const Half* expert_x, int64_
                                   pegainfer_stream_t stream) {
   Ep* e = static_cast<Ep*>(h);
   if (!e || !e->sent || (e->num_recv > 0 && !expert_x) || expert_x_stride_elems < e->hidden) return -1;
+  if (e->num_recv > 0 && !rows_aligned(expert_x, expert_x_stride_elems)) {
+    e->err = "combine_send: expert_x rows must be 16-byte aligned";
+    return -1;
+  }
   hipStream_t s = st(stream);
   // expert-major rows back into the source-major order they arrived in, then home
   if (e->num_recv > 0)
@@ -577,6 +596,10 @@ int32_t pegainfer_ep_combine_recv(pegainfer_ep_t h, int32_t num_tokens, Half* ou
   if (!e || !e->sent || num_tokens * e->topk != e->num_pairs || (num_tokens > 0 && (!out_tokens || !weights)) ||
       out_stride_elems < e->hidden)
     return -1;
+  if (num_tokens > 0 && !rows_aligned(out_tokens, out_stride_elems)) {
+    e->err = "combine_recv: out_tokens rows must be 16-byte aligned";
+    return -1;
+  }
   hipStream_t s = st(stream);
   if (e->hub) {
     for (int r = 0; r < e->world; ++r) {

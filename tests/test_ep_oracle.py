@@ -49,3 +49,19 @@ def test_combine_accumulate_is_linear():
     b = ep_ref.combine([o[0] for o in out], [o[2] for o in out], w, [len(x) for x in xs], 8, prev=prev)
     for r in range(4):
         assert np.allclose(b[r] - a[r], 1.0)
+
+
+def test_pairs_with_invalid_expert_ids_travel_nowhere_and_combine_as_zero():
+    xs, idx, w = _case(4)
+    idx[0][1, 2] = -1          # not expert ids
+    idx[2][0, 0] = 16
+    out = ep_ref.dispatch(xs, idx, 16)
+    assert sum(len(o[0]) for o in out) == sum(len(x) for x in xs) * 3 - 2
+    res = ep_ref.combine([o[0] for o in out], [o[2] for o in out], w, [len(x) for x in xs], 8)
+    for r in range(4):
+        wr = w[r].astype(np.float64).copy()
+        if r == 0:
+            wr[1, 2] = 0.0
+        if r == 2:
+            wr[0, 0] = 0.0
+        assert np.allclose(res[r], xs[r].astype(np.float64) * wr.sum(axis=1, keepdims=True), atol=1e-12)
