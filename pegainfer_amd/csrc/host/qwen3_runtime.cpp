@@ -953,6 +953,7 @@ struct Model {
     // [total_tokens, vocab] bf16 to the host.  The GEMM output is staged through the gate|up scratch (pf_cap_tokens x
     // 2I elements) in token chunks, so no T x vocab device buffer is ever allocated (1024 tokens = 311 MB).
     if (out_all_logits_host) {
+      if ((size_t)pf_cap_tokens * (size_t)(2 * I) < (size_t)V) { set_error("echo: prefill scratch smaller than one vocab row"); return -1; }
       const size_t chunk = std::max<size_t>(1, std::min<size_t>(T, pf_cap_tokens * (size_t)(2 * I) / (size_t)V));
       for (size_t i0 = 0; i0 < T; i0 += chunk) {
         const int nb = (int)std::min(chunk, T - i0);
