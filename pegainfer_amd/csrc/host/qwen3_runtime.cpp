@@ -840,7 +840,9 @@ struct Model {
       T += lens[i];
     }
     if (pages_short > pool.available()) { set_error("KvState: out of pages"); return -2; }
-    if (ensure_prefill_ws(T, n)) return -1;
+    // echo stages [tokens, vocab] logits through the gate|up scratch: it must hold at least one vocab row
+    const size_t echo_min = out_all_logits_host ? ((size_t)V + (size_t)(2 * I) - 1) / (size_t)(2 * I) : 0;
+    if (ensure_prefill_ws(std::max(T, echo_min), n)) return -1;
     for (int i = 0; i < n; ++i) {  // ensure_capacity + advance (prefill.rs:236-240)
       if (!st[i]->ensure_capacity(&pool, starts[i] + lens[i], layout.page_size)) { set_error("KvState: out of pages"); return -2; }
       st[i]->seq_len += lens[i];
