@@ -8,7 +8,7 @@ batches=${1:-"1 16"}; steps=${2:-96}
 cd $repo
 sw() { # dir label
   for b in $batches; do
-    (cd $1 && timeout 200 python bench.py --batch $b --steps $steps --cpu-steps 0 --ttft-iters 1 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$2 bs', d['config']['batch_per_gpu'], 'tok/s', d['value'], 'device_ms', d['tpot_ms']['device_p50'], 'ttft_ms', d['ttft_ms']['p50'])")
+    (cd $1 && timeout 200 python bench.py --batch $b --steps $steps --cpu-steps 0 --ttft-iters 1 --profile-iters 0 --ttft10k-iters 0 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$2 bs', d['config']['batch_per_gpu'], 'tok/s', d['value'], 'device_ms', d['tpot_ms']['device_p50'], 'ttft_ms', d['ttft_ms']['p50'])")
   done
 }
 sw _ab base; sw . new; sw _ab base; sw . new

@@ -23,33 +23,33 @@ SQ="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT 
 if [ $part = a ] || [ $part = all ]; then
   kt ${R}_fused_decode_mode1 --steps 64 --cpu-steps 0
   kt ${R}_baseline_decode_mode0 --steps 64 --cpu-steps 0 --decode-mode 0
-  kt ${R}_ctx10000 --ctx 10000 --steps 8 --cpu-steps 0 --ttft-iters 2
-  pmc ${R}_fused_pmc_FETCH_SIZE FETCH_SIZE --steps 8 --ttft-iters 1
-  pmc ${R}_fused_pmc_WRITE_SIZE WRITE_SIZE --steps 8 --ttft-iters 1
-  pmc ${R}_fused_pmc_sq "$SQ" --steps 8 --ttft-iters 2
-  pmc ${R}_ctx10000_pmc_sq "$SQ" --ctx 10000 --steps 4 --ttft-iters 1
+  kt ${R}_ctx10000 --ctx 10000 --steps 8 --cpu-steps 0 --ttft-iters 2 --profile-iters 0 --ttft10k-iters 0
+  pmc ${R}_fused_pmc_FETCH_SIZE FETCH_SIZE --steps 8 --ttft-iters 1 --profile-iters 0 --ttft10k-iters 0
+  pmc ${R}_fused_pmc_WRITE_SIZE WRITE_SIZE --steps 8 --ttft-iters 1 --profile-iters 0 --ttft10k-iters 0
+  pmc ${R}_fused_pmc_sq "$SQ" --steps 8 --ttft-iters 2 --profile-iters 0 --ttft10k-iters 0
+  pmc ${R}_ctx10000_pmc_sq "$SQ" --ctx 10000 --steps 4 --ttft-iters 1 --profile-iters 0 --ttft10k-iters 0
   cd $repo
   timeout 300 python bench.py > $out/${R}_bench_default_run.json 2>/dev/null
   timeout 200 python tools/attn_probe.py --ctx 1024 2>&1 | grep -v amdgpu.ids > $out/${R}_attn_phase_trace.txt
   timeout 200 python tools/attn_probe.py --ctx 1024 --batch 16 2>&1 | grep -v amdgpu.ids >> $out/${R}_attn_phase_trace.txt
   timeout 200 python tools/gemv_probe.py --sites 6 1 5 3 7 2>&1 | grep -v amdgpu.ids > $out/${R}_gemv_phase_trace.txt
   for p in 1 0 1 0; do
-    PEGAINFER_GEMV_PERSIST=$p timeout 200 python bench.py --steps 96 --cpu-steps 0 --ttft-iters 1 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('gemv persistent grid $p: tok/s', d['value'], 'device_ms', d['tpot_ms']['device_p50'])"
+    PEGAINFER_GEMV_PERSIST=$p timeout 200 python bench.py --steps 96 --cpu-steps 0 --ttft-iters 1 --profile-iters 0 --ttft10k-iters 0 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('gemv persistent grid $p: tok/s', d['value'], 'device_ms', d['tpot_ms']['device_p50'])"
   done > $out/${R}_gemv_persist_ab.txt
 fi
 if [ $part = b ] || [ $part = all ]; then
   cd $repo
   for b in 2 4 8 16 32 64; do
-    timeout 200 python bench.py --batch $b --steps 48 --cpu-steps 0 --ttft-iters 1 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('bs', d['config']['batch_per_gpu'], 'tok/s', d['value'], 'device_ms', d['tpot_ms']['device_p50'])"
+    timeout 200 python bench.py --batch $b --steps 48 --cpu-steps 0 --ttft-iters 1 --profile-iters 0 --ttft10k-iters 0 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('bs', d['config']['batch_per_gpu'], 'tok/s', d['value'], 'device_ms', d['tpot_ms']['device_p50'])"
   done > $out/${R}_batch_sweep.txt
   for c in 128 512 2048 4096 8192 10000; do
-    timeout 250 python bench.py --ctx $c --steps 32 --cpu-steps 0 --ttft-iters 2 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('ctx', d['config']['ctx'], 'tok/s', d['value'], 'device_ms', d['tpot_ms']['device_p50'], 'ttft_ms', d['ttft_ms']['p50'])"
+    timeout 250 python bench.py --ctx $c --steps 32 --cpu-steps 0 --ttft-iters 2 --profile-iters 0 --ttft10k-iters 0 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('ctx', d['config']['ctx'], 'tok/s', d['value'], 'device_ms', d['tpot_ms']['device_p50'], 'ttft_ms', d['ttft_ms']['p50'])"
   done > $out/${R}_context_sweep.txt
   timeout 250 python bench.py --model qwen3-8b --steps 64 --cpu-steps 0 2>/dev/null | tail -1 > $out/${R}_qwen3_8b_greedy.json
-  timeout 250 python bench.py --model qwen3-8b --sampling topk_topp --steps 64 --cpu-steps 0 --ttft-iters 1 2>/dev/null | tail -1 > $out/${R}_qwen3_8b_topk_topp.json
+  timeout 250 python bench.py --model qwen3-8b --sampling topk_topp --steps 64 --cpu-steps 0 --ttft-iters 1 --profile-iters 0 --ttft10k-iters 0 2>/dev/null | tail -1 > $out/${R}_qwen3_8b_topk_topp.json
   timeout 250 python bench.py --model qwen3.5-4b 2>/dev/null | tail -1 > $out/${R}_qwen35_4b_bench.json
   cd /tmp
-  kt ${R}_batch16 --batch 16 --steps 32 --cpu-steps 0 --ttft-iters 1
-  kt ${R}_batch32 --batch 32 --steps 32 --cpu-steps 0 --ttft-iters 1
+  kt ${R}_batch16 --batch 16 --steps 32 --cpu-steps 0 --ttft-iters 1 --profile-iters 0 --ttft10k-iters 0
+  kt ${R}_batch32 --batch 32 --steps 32 --cpu-steps 0 --ttft-iters 1 --profile-iters 0 --ttft10k-iters 0
 fi
 ls -la $out

@@ -6,6 +6,6 @@ cd $repo
 bash tools/gpu_tests.sh
 for x in 1 0 1 0; do
   for c in $ctxs; do
-    env $knob=$x timeout 300 python bench.py --ctx $c --steps 4 --cpu-steps 0 --ttft-iters 4 2>/dev/null | tail -1 | python -c "import sys,json;d=json.loads(sys.stdin.read());print('$knob=$x ctx',$c,d.get('ttft_ms'))"
+    env $knob=$x timeout 300 python bench.py --ctx $c --steps 4 --cpu-steps 0 --ttft-iters 4 --profile-iters 0 --ttft10k-iters 0 2>/dev/null | tail -1 | python -c "import sys,json;d=json.loads(sys.stdin.read());print('$knob=$x ctx',$c,d.get('ttft_ms'))"
   done
 done
