@@ -112,6 +112,9 @@ int32_t pegainfer_qwen3_last_attention_path(pegainfer_qwen3_t m);
  * [0..17] consumer wave 0 {wait, stage, gemv, store} x {qkv, attention, o, gate|up, down}, [18] its wait for landed
  * fills, [20] loader wait for free slots, [21] loader total, [22] consumer total) and returns the word count */
 int32_t pegainfer_qwen3_engine_active(pegainfer_qwen3_t m);
+/* steps on which the engine gave up (a bounded spin expired) and the SAME decode call re-ran on the decode_mode 1
+ * kernels; the engine stays disabled afterwards.  PEGAINFER_ENGINE_INJECT_FAIL=1 forces that path (tests). */
+int32_t pegainfer_qwen3_engine_fallbacks(pegainfer_qwen3_t m);
 int32_t pegainfer_qwen3_engine_trace(pegainfer_qwen3_t m, uint64_t* out, int32_t max_words); /* 0 non-partition, 1 split-KV */
 /* average ms per launch of one GEMM call site over the layers' real weights, hipEvents on the model
  * stream (bench.py roofline).  which: 0 fused qkv, 1 o, 2 gate_up, 3 down, 4 lm_head (plain GEMM call sites);

@@ -13,6 +13,7 @@
 #ifndef PEGAINFER_SCHEDULER_H
 #define PEGAINFER_SCHEDULER_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -27,6 +28,10 @@ typedef void* pegainfer_sched_t;
  * or an error (last_error() then describes it).  n_prefill == 0 -> execute_decode, n_decode == 0 -> execute_prefill,
  * both > 0 -> execute_unified. */
 typedef struct {
+  /* sizeof(pegainfer_executor_vtbl) as the CALLER's build sees it.  pegainfer_sched_create copies that many bytes
+   * and treats every later field as NULL, so the table can grow at the end (as it did with max_batch_size) without
+   * the library reading past an older caller's struct; a size that does not reach `last_error` is rejected. */
+  size_t struct_size;
   void* user;
   int32_t (*page_size)(void* user);
   int32_t (*max_request_pages)(void* user);

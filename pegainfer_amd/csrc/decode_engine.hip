@@ -15,7 +15,7 @@
 // (add + RMSNorm staging, SwiGLU epilogue) -> down GEMV.  Every arithmetic core is shared with the kernels of
 // decode_mode 1 (norm_core.h, rope_core.h, attn_decode_core.h, the per-lane dot2 chains and wave butterflies of
 // gemv_core.h restated for one consumer wave emulating the four K-split waves), so logits are bit-identical to
-// decode_mode 0 / 1 (tests/test_gpu_engine.py).
+// decode_mode 0 / 1 (tests/test_gpu_real_dims.py::test_engine_*).
 //
 // Correctness does not depend on placement or dispatch order: one workgroup per CU by LDS size, grid <= CU count, every
 // spin bounded (status word != 0 -> all waves leave, the host falls back to decode_mode 1).

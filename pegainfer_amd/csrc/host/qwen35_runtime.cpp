@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -226,16 +227,64 @@ struct Model35 {
   }
 
   // ------------------------------------------------------------------ weights (weights.rs:118-296)
-  int load_tensor(const char* name_c, const void* host, int64_t numel, int is_f32) {
+  // every tensor the forward pass reads, by destination pointer: load_tensor() marks, finalize() checks (the weights
+  // are hipMalloc'ed uninitialised, so a checkpoint missing a tensor would otherwise produce silent garbage)
+  std::vector<std::pair<const void*, std::string>> expected_tensors() const {
+    std::vector<std::pair<const void*, std::string>> v;
+    const std::string wp = "model.language_model.";
+    v.push_back({embed, wp + "embed_tokens.weight"});
+    v.push_back({final_norm, wp + "norm.weight"});
+    for (int li = 0; li < L; ++li) {
+      const Layer35& ly = layers[li];
+      const std::string lp = wp + "layers." + std::to_string(li) + ".";
+      v.push_back({ly.ln1, lp + "input_layernorm.weight"});
+      v.push_back({ly.ln2, lp + "post_attention_layernorm.weight"});
+      v.push_back({ly.gate, lp + "mlp.gate_proj.weight"});
+      v.push_back({ly.up, lp + "mlp.up_proj.weight"});
+      v.push_back({ly.down, lp + "mlp.down_proj.weight"});
+      if (ly.full) {
+        v.push_back({ly.q_proj, lp + "self_attn.q_proj.weight"});
+        v.push_back({ly.k_proj, lp + "self_attn.k_proj.weight"});
+        v.push_back({ly.v_proj, lp + "self_attn.v_proj.weight"});
+        v.push_back({ly.o_proj, lp + "self_attn.o_proj.weight"});
+        v.push_back({ly.q_norm, lp + "self_attn.q_norm.weight"});
+        v.push_back({ly.k_norm, lp + "self_attn.k_norm.weight"});
+      } else {
+        v.push_back({ly.in_qkv, lp + "linear_attn.in_proj_qkv.weight"});
+        v.push_back({ly.in_z, lp + "linear_attn.in_proj_z.weight"});
+        v.push_back({ly.in_b, lp + "linear_attn.in_proj_b.weight"});
+        v.push_back({ly.in_a, lp + "linear_attn.in_proj_a.weight"});
+        v.push_back({ly.conv_w, lp + "linear_attn.conv1d.weight"});
+        v.push_back({ly.dt_bias, lp + "linear_attn.dt_bias"});
+        v.push_back({ly.a_log, lp + "linear_attn.A_log"});
+        v.push_back({ly.norm_w, lp + "linear_attn.norm.weight"});
+        v.push_back({ly.out_proj, lp + "linear_attn.out_proj.weight"});
+      }
+    }
+    return v;
+  }
+  std::set<const void*> loaded;
+  bool all_loaded = false;   // fill_synthetic() wrote every tensor
+  int check_all_loaded() {
+    if (all_loaded) return 0;
+    for (const auto& e : expected_tensors())
+      if (!loaded.count(e.first)) { set_error("checkpoint is missing tensor " + e.second); return -1; }
+    return 0;
+  }
+
+  // shape / ndim given (native loader): a transposed or re-shaped tensor with the right element count is still wrong.
+  // The depthwise conv weight is [C, 1, K] in HF checkpoints ([C, K] accepted too).
+  int load_tensor(const char* name_c, const void* host, int64_t numel, int is_f32, const int64_t* shape = nullptr,
+                  int ndim = 0) {
     std::string name(name_c);
     const std::string wp = "model.language_model.";
     if (name.rfind(wp, 0) != 0) { set_error("tensor outside " + wp + ": " + name); return -1; }
     name = name.substr(wp.size());
     void* dst = nullptr;
-    int64_t expect = 0;
+    int64_t rows = 0, cols = 0;
     bool f32 = false;
-    auto set = [&](void* p, int64_t n, bool isf = false) { dst = p; expect = n; f32 = isf; };
-    if (name == "embed_tokens.weight") set(embed, (int64_t)V * H);
+    auto set = [&](void* p, int64_t r, int64_t c = 1, bool isf = false) { dst = p; rows = r; cols = c; f32 = isf; };
+    if (name == "embed_tokens.weight") set(embed, V, H);
     else if (name == "norm.weight") set(final_norm, H);
     else if (name.rfind("layers.", 0) == 0) {
       const size_t p0 = 7, p1 = name.find('.', p0);
@@ -250,31 +299,40 @@ struct Model35 {
       Layer35& ly = layers[li];
       if (r == "input_layernorm.weight") set(ly.ln1, H);
       else if (r == "post_attention_layernorm.weight") set(ly.ln2, H);
-      else if (r == "mlp.gate_proj.weight") set(ly.gate, (int64_t)I * H);
-      else if (r == "mlp.up_proj.weight") set(ly.up, (int64_t)I * H);
-      else if (r == "mlp.down_proj.weight") set(ly.down, (int64_t)H * I);
+      else if (r == "mlp.gate_proj.weight") set(ly.gate, I, H);
+      else if (r == "mlp.up_proj.weight") set(ly.up, I, H);
+      else if (r == "mlp.down_proj.weight") set(ly.down, H, I);
       else if (ly.full) {
-        if (r == "self_attn.q_proj.weight") set(ly.q_proj, (int64_t)2 * q_dim * H);
-        else if (r == "self_attn.k_proj.weight") set(ly.k_proj, (int64_t)kv_dim * H);
-        else if (r == "self_attn.v_proj.weight") set(ly.v_proj, (int64_t)kv_dim * H);
-        else if (r == "self_attn.o_proj.weight") set(ly.o_proj, (int64_t)H * q_dim);
+        if (r == "self_attn.q_proj.weight") set(ly.q_proj, (int64_t)2 * q_dim, H);
+        else if (r == "self_attn.k_proj.weight") set(ly.k_proj, kv_dim, H);
+        else if (r == "self_attn.v_proj.weight") set(ly.v_proj, kv_dim, H);
+        else if (r == "self_attn.o_proj.weight") set(ly.o_proj, H, q_dim);
         else if (r == "self_attn.q_norm.weight") set(ly.q_norm, D);
         else if (r == "self_attn.k_norm.weight") set(ly.k_norm, D);
       } else {
-        if (r == "linear_attn.in_proj_qkv.weight") set(ly.in_qkv, (int64_t)C * H);
-        else if (r == "linear_attn.in_proj_z.weight") set(ly.in_z, (int64_t)Z * H);
-        else if (r == "linear_attn.in_proj_b.weight") set(ly.in_b, (int64_t)vh * H);
-        else if (r == "linear_attn.in_proj_a.weight") set(ly.in_a, (int64_t)vh * H);
-        else if (r == "linear_attn.conv1d.weight") set(ly.conv_w, (int64_t)C * convK);
+        if (r == "linear_attn.in_proj_qkv.weight") set(ly.in_qkv, C, H);
+        else if (r == "linear_attn.in_proj_z.weight") set(ly.in_z, Z, H);
+        else if (r == "linear_attn.in_proj_b.weight") set(ly.in_b, vh, H);
+        else if (r == "linear_attn.in_proj_a.weight") set(ly.in_a, vh, H);
+        else if (r == "linear_attn.conv1d.weight") set(ly.conv_w, C, convK);
         else if (r == "linear_attn.dt_bias") set(ly.dt_bias, vh);
-        else if (r == "linear_attn.A_log") set(ly.a_log, vh, true);
-        else if (r == "linear_attn.norm.weight") set(ly.norm_w, LK, true);
-        else if (r == "linear_attn.out_proj.weight") set(ly.out_proj, (int64_t)H * Z);
+        else if (r == "linear_attn.A_log") set(ly.a_log, vh, 1, true);
+        else if (r == "linear_attn.norm.weight") set(ly.norm_w, LK, 1, true);
+        else if (r == "linear_attn.out_proj.weight") set(ly.out_proj, H, Z);
       }
     }
     if (!dst) { set_error("unknown tensor name: " + std::string(name_c)); return -1; }
-    if (numel != expect || (is_f32 != 0) != f32) { set_error("shape/dtype mismatch for " + std::string(name_c)); return -1; }
+    if (numel != rows * cols || (is_f32 != 0) != f32) { set_error("shape/dtype mismatch for " + std::string(name_c)); return -1; }
+    if (shape) {
+      bool ok;
+      if (cols == 1) ok = ndim == 1 && shape[0] == rows;
+      else if (ndim == 3) ok = shape[0] == rows && shape[1] == 1 && shape[2] == cols;   // conv1d [C, 1, K]
+      else ok = ndim == 2 && shape[0] == rows && shape[1] == cols;
+      if (!ok) { set_error("tensor " + std::string(name_c) + " has the wrong shape (expected [" + std::to_string(rows) +
+                           (cols == 1 ? "]" : ", " + std::to_string(cols) + "]") + ")"); return -1; }
+    }
     P35_HIP(hipMemcpy(dst, host, (size_t)numel * (f32 ? 4 : 2), hipMemcpyHostToDevice));
+    loaded.insert(dst);
     return 0;
   }
 
@@ -288,7 +346,8 @@ struct Model35 {
       const pst::TensorView& t = kv.second;
       const bool f32 = t.dtype == "F32";
       if (!f32 && t.dtype != "BF16") { set_error("tensor " + kv.first + " has dtype " + t.dtype); return -1; }
-      if (load_tensor(kv.first.c_str(), t.data, t.numel(), f32 ? 1 : 0)) return -1;
+      if ((int64_t)t.nbytes != t.numel() * (f32 ? 4 : 2)) { set_error("tensor " + kv.first + ": data_offsets do not match its shape"); return -1; }
+      if (load_tensor(kv.first.c_str(), t.data, t.numel(), f32 ? 1 : 0, t.shape.data(), (int)t.shape.size())) return -1;
     }
     return finalize();
   }
@@ -300,6 +359,7 @@ struct Model35 {
     fill_normal35_kernel<float><<<64, 256, 0, stream>>>(p, (long)n, seed, std, mean);
   }
   int fill_synthetic(uint64_t seed, float std) {
+    all_loaded = true;
     uint64_t s = seed * 1000003ull;
     fill(embed, (size_t)V * H, ++s, std, 0.f);
     fill(final_norm, H, ++s, 0.1f, 0.f);
@@ -334,6 +394,7 @@ struct Model35 {
   // partial-RoPE tables: rows of rotary_dim, cos/sin duplicated in both halves (weights.rs:296-297 ->
   // weight_loader.rs:210-244 with head_dim = rotary_dim)
   int finalize() {
+    if (check_all_loaded()) return -1;
     const int half = rotary / 2;
     std::vector<float> inv(half);
     for (int i = 0; i < half; ++i) inv[i] = 1.0f / std::pow(theta, (float)i * 2.0f / (float)rotary);

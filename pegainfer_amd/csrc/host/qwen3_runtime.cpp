@@ -113,6 +113,7 @@ struct Model {
   uint64_t* eng_trace = nullptr;   // PEGAINFER_ENGINE_TRACE=1: per-workgroup phase cycle sums of the last engine step
   int eng_wgs = 0;
   bool eng_disabled = false, eng_used = false;
+  int eng_fallbacks = 0;   // steps the engine gave up on and the decode_mode 1 kernels re-ran
   // sampling scratch (ops/sampling.rs)
   float* probs_scratch = nullptr;
   Half* top1_value = nullptr;
@@ -125,6 +126,7 @@ struct Model {
   uint8_t* meta_dev = nullptr;
   int32_t* tokens_out_host = nullptr;  // pinned
   hipGraphExec_t graphs[kNumBuckets][2];
+  bool graph_engine[kNumBuckets][2] = {};   // the captured step runs on the decode_mode 2 engine
   // prefill workspace (grow-only)
   size_t pf_cap_tokens = 0;
   Half *pf_hidden = nullptr, *pf_hidden_out = nullptr, *pf_normed = nullptr, *pf_q = nullptr, *pf_k = nullptr,
@@ -276,6 +278,9 @@ struct Model {
     pegainfer_engine_args_t a;
     engine_args(&a, split, split_slots);
     if (pegainfer_decode_engine_step(&a, eng_wgs, S())) { set_error("pegainfer_decode_engine_step failed"); return -1; }
+    // fault injection for the fallback test: the status word reads as "a bounded spin expired"
+    if (const char* f = getenv("PEGAINFER_ENGINE_INJECT_FAIL"); f && f[0] == '1')
+      PQ_HIP(hipMemsetAsync(eng_status, 0x01, 4, stream));
     if (pegainfer_gemv_fused(lm_head, hidden, logits, V, 1, H, mlp_out, final_norm, hidden2, eps, 0, S())) {
       set_error("fused lm_head failed");
       return -1;
@@ -746,39 +751,49 @@ struct Model {
     const bool split = plan.use_split;
     last_path = split ? 1 : 0;
 
-    PQ_HIP(hipEventRecord(ev0, stream));
-    if (enable_graph) {
-      const int bi = bucket_index(padded);
-      hipGraphExec_t& exec = graphs[bi][split ? 1 : 0];
-      if (!exec) {  // capture once (cuda_graph.rs:36-55), thread-local mode
-        hipGraph_t graph = nullptr;
-        PQ_HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-        const int rc = decode_kernels(padded, split, plan.slots);
-        hipError_t e = hipStreamEndCapture(stream, &graph);
-        if (rc || e != hipSuccess) { set_error("graph capture failed: " + err); return -1; }
-        PQ_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-        PQ_HIP(hipGraphDestroy(graph));
+    // one attempt = graph replay (or eager launches) + token D2H + sync.  A decode_mode 2 step whose bounded spins
+    // expired is re-run in the SAME call on the decode_mode 1 kernels: the metadata block is already on the device,
+    // the step recomputes everything from the embedding and the KV append rewrites the same slots with the same
+    // bits, so the request state the caller sees (seq_len advanced, pages held) matches the tokens it gets back.
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      bool engine_step = false;
+      PQ_HIP(hipEventRecord(ev0, stream));
+      if (enable_graph) {
+        const int bi = bucket_index(padded);
+        hipGraphExec_t& exec = graphs[bi][split ? 1 : 0];
+        if (!exec) {  // capture once (cuda_graph.rs:36-55), thread-local mode
+          hipGraph_t graph = nullptr;
+          PQ_HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+          const int rc = decode_kernels(padded, split, plan.slots);
+          hipError_t e = hipStreamEndCapture(stream, &graph);
+          if (rc || e != hipSuccess) { set_error("graph capture failed: " + err); return -1; }
+          PQ_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+          PQ_HIP(hipGraphDestroy(graph));
+          graph_engine[bi][split ? 1 : 0] = eng_used;   // decode_kernels() recorded which path it captured
+        }
+        engine_step = graph_engine[bi][split ? 1 : 0];
+        PQ_HIP(hipGraphLaunch(exec, stream));
+      } else {
+        if (decode_kernels(padded, split, plan.slots)) return -1;
+        engine_step = eng_used;
       }
-      PQ_HIP(hipGraphLaunch(exec, stream));
-    } else {
-      if (decode_kernels(padded, split, plan.slots)) return -1;
-    }
-    PQ_HIP(hipEventRecord(ev1, stream));
-    PQ_HIP(hipMemcpyAsync(tokens_out_host, tokens_out_d, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
-    const bool engine_step = decode_mode == 2 && !eng_disabled && padded == 1 && engine_ok(padded);
-    if (engine_step) PQ_HIP(hipMemcpyAsync(eng_status_host, eng_status, 16, hipMemcpyDeviceToHost, stream));
-    PQ_HIP(hipStreamSynchronize(stream));
-    hipEventElapsedTime(&last_step_ms, ev0, ev1);
-    if (engine_step && eng_status_host[0] != 0) {
-      // a bounded spin expired (the grid was not co-resident, or a hand-off never completed): the step's outputs are
-      // invalid.  Report it and run every later step on the decode_mode 1 kernels.
+      eng_used = engine_step;   // what THIS step ran on (pegainfer_qwen3_engine_active), replayed graphs included
+      PQ_HIP(hipEventRecord(ev1, stream));
+      PQ_HIP(hipMemcpyAsync(tokens_out_host, tokens_out_d, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
+      if (engine_step) PQ_HIP(hipMemcpyAsync(eng_status_host, eng_status, 16, hipMemcpyDeviceToHost, stream));
+      PQ_HIP(hipStreamSynchronize(stream));
+      hipEventElapsedTime(&last_step_ms, ev0, ev1);
+      if (!(engine_step && eng_status_host[0] != 0)) break;
+      // a bounded spin expired (the grid was not co-resident, or a hand-off never completed): this attempt's outputs
+      // are invalid.  Disable the engine for good, drop the graphs that captured it and take the second attempt.
       eng_disabled = true;
-      for (auto& bkt : graphs)
-        for (auto& g : bkt)
-          if (g) { hipGraphExecDestroy(g); g = nullptr; }
-      set_error("decode engine gave up: code " + std::to_string(eng_status_host[0] & 0xff) + " at " +
-                std::to_string(eng_status_host[1]) + " (falling back to decode_mode 1 for later steps)");
-      return -3;
+      eng_fallbacks += 1;
+      for (int b = 0; b < kNumBuckets; ++b)
+        for (int q = 0; q < 2; ++q)
+          if (graphs[b][q]) { hipGraphExecDestroy(graphs[b][q]); graphs[b][q] = nullptr; graph_engine[b][q] = false; }
+      err = "decode engine gave up: code " + std::to_string(eng_status_host[0] & 0xff) + " at " +
+            std::to_string(eng_status_host[1]) + " (step re-run on the decode_mode 1 kernels; engine disabled)";
+      if (attempt == 1) { set_error("decode engine reported a failure after it was disabled"); return -3; }
     }
     for (int i = 0; i < n; ++i) out_tokens[i] = tokens_out_host[i];
     last_logits = logits;
@@ -1206,6 +1221,7 @@ int32_t pegainfer_qwen3_engine_trace(pegainfer_qwen3_t m, uint64_t* out, int32_t
   return n;
 }
 int32_t pegainfer_qwen3_engine_active(pegainfer_qwen3_t m) { return M(m)->eng_used ? 1 : 0; }
+int32_t pegainfer_qwen3_engine_fallbacks(pegainfer_qwen3_t m) { return M(m)->eng_fallbacks; }
 int64_t pegainfer_qwen3_weight_bytes(pegainfer_qwen3_t m) { return M(m)->weight_bytes; }
 void* pegainfer_qwen3_stream(pegainfer_qwen3_t m) { return M(m)->S(); }
 

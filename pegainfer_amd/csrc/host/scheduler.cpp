@@ -1,6 +1,7 @@
 // Continuous-batching scheduler (include/pegainfer_scheduler.h): the reference's scheduler_loop, one iteration
 // per step() call, over an executor given as a callback table or bound to the Qwen3 host runtime.
 #include <algorithm>
+#include <cstddef>
 #include <cstring>
 #include <deque>
 #include <string>
@@ -349,11 +350,17 @@ static Scheduler* SC(pegainfer_sched_t s) { return static_cast<Scheduler*>(s); }
 extern "C" {
 
 pegainfer_sched_t pegainfer_sched_create(const pegainfer_executor_vtbl* executor, uint64_t seed) {
-  if (!executor || !executor->page_size || !executor->max_request_pages || !executor->available_pages ||
-      !executor->is_stop_token || !executor->drop_request || !executor->execute)
+  if (!executor) return nullptr;
+  // versioned copy: only the bytes the caller's build knows about; optional trailing callbacks default to NULL
+  const size_t mandatory = offsetof(pegainfer_executor_vtbl, last_error) + sizeof(executor->last_error);
+  if (executor->struct_size < mandatory) return nullptr;
+  pegainfer_executor_vtbl v;
+  std::memset(&v, 0, sizeof(v));
+  std::memcpy(&v, executor, std::min(executor->struct_size, sizeof(v)));
+  if (!v.page_size || !v.max_request_pages || !v.available_pages || !v.is_stop_token || !v.drop_request || !v.execute)
     return nullptr;
   Scheduler* s = new Scheduler();
-  s->ex = *executor;
+  s->ex = v;
   s->rng.seed(seed);
   return s;
 }
@@ -362,7 +369,7 @@ pegainfer_sched_t pegainfer_sched_create_qwen3(void* model, uint64_t seed, const
   auto* e = new psched::Qwen3Exec();
   e->model = model;
   for (int i = 0; i < n_stop; ++i) e->stop.insert(stop_tokens[i]);
-  pegainfer_executor_vtbl v{e, &psched::Qwen3Exec::page_size, &psched::Qwen3Exec::max_request_pages,
+  pegainfer_executor_vtbl v{sizeof(pegainfer_executor_vtbl), e, &psched::Qwen3Exec::page_size, &psched::Qwen3Exec::max_request_pages,
                             &psched::Qwen3Exec::available_pages, &psched::Qwen3Exec::is_stop_token,
                             &psched::Qwen3Exec::drop_request, &psched::Qwen3Exec::execute, &psched::Qwen3Exec::last_error,
                             &psched::Qwen3Exec::max_batch_size};
@@ -375,7 +382,7 @@ pegainfer_sched_t pegainfer_sched_create_qwen35(void* model, uint64_t seed, cons
   auto* e = new psched::Qwen35Exec();
   e->model = model;
   for (int i = 0; i < n_stop; ++i) e->stop.insert(stop_tokens[i]);
-  pegainfer_executor_vtbl v{e, &psched::Qwen35Exec::page_size, &psched::Qwen35Exec::max_request_pages,
+  pegainfer_executor_vtbl v{sizeof(pegainfer_executor_vtbl), e, &psched::Qwen35Exec::page_size, &psched::Qwen35Exec::max_request_pages,
                             &psched::Qwen35Exec::available_pages, &psched::Qwen35Exec::is_stop_token,
                             &psched::Qwen35Exec::drop_request, &psched::Qwen35Exec::execute, &psched::Qwen35Exec::last_error,
                             &psched::Qwen35Exec::max_batch_size};

@@ -31,7 +31,7 @@ _ERR = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_void_p)   # const char*: a poi
 
 
 class ExecutorVtbl(ctypes.Structure):
-    _fields_ = [("user", ctypes.c_void_p), ("page_size", _I32_V), ("max_request_pages", _I32_V),
+    _fields_ = [("struct_size", ctypes.c_size_t), ("user", ctypes.c_void_p), ("page_size", _I32_V), ("max_request_pages", _I32_V),
                 ("available_pages", _I32_V), ("is_stop_token", _STOP), ("drop_request", _DROP), ("execute", _EXEC),
                 ("last_error", _ERR), ("max_batch_size", _I32_V)]
 
@@ -86,7 +86,10 @@ class Scheduler:
         if hasattr(ex, "max_batch_size"):   # optional callback: NULL = unlimited
             cbs["max_batch_size"] = _I32_V(lambda _u: ex.max_batch_size())
             keys.append("max_batch_size")
-        vt = ExecutorVtbl(None, *[cbs[k] for k in keys])
+        # struct_size = the bytes this caller fills: without the optional trailing callback the table ends at last_error,
+        # exactly what a caller built against the older header would pass
+        size = ctypes.sizeof(ExecutorVtbl) if "max_batch_size" in cbs else ExecutorVtbl.max_batch_size.offset
+        vt = ExecutorVtbl(size, None, *[cbs[k] for k in keys])
         h = lib.pegainfer_sched_create(ctypes.addressof(vt), seed)
         return cls(h, keep=(vt, cbs, state, ex))
 

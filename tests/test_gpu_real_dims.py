@@ -352,9 +352,12 @@ def test_engine_bit_identical_to_fused_decode_path(built_libs, real2, ctx, polic
     prompt = rng.integers(0, CFG2["vocab_size"], ctx).tolist()
     e1 = _engine(state, decode_mode=1, split_policy=policy, enable_graph=graph, max_batch_size=4)
     toks1, bits1 = _decode_bits(e1, prompt, 12)
-    e1.close()
     e2 = _engine(state, decode_mode=2, split_policy=policy, enable_graph=graph, max_batch_size=4)
     toks2, bits2 = _decode_bits(e2, prompt, 12, feed=toks1[:-1])
+    # the comparison is vacuous if engine_ok() silently routed the steps to the decode_mode 1 kernels
+    assert e2.lib.pegainfer_qwen3_engine_active(e2.h) == 1 and e2.lib.pegainfer_qwen3_engine_fallbacks(e2.h) == 0
+    assert e1.lib.pegainfer_qwen3_engine_active(e1.h) == 0
+    e1.close()
     e2.close()
     assert np.array_equal(bits1, bits2), int((bits1 != bits2).sum())
     assert toks1 == toks2
@@ -382,9 +385,40 @@ def test_engine_many_steps_and_interleaved_requests(built_libs, real2):
             last[i] = int(o[0])
             if step % 10 == 0:
                 bits.append(lg[0].copy())
+            # replayed graphs included: the flag says what THIS step ran on
+            assert eng.lib.pegainfer_qwen3_engine_active(eng.h) == (1 if mode == 2 else 0)
         o, lg = eng.decode(rids, last, return_logits=True)        # bs 2: not an engine step
+        assert eng.lib.pegainfer_qwen3_engine_active(eng.h) == 0
         outs[mode].update(toks=toks, bits=np.stack(bits), pair=lg.copy())
         eng.close()
     assert outs[1]["toks"] == outs[2]["toks"]
     assert np.array_equal(outs[1]["bits"], outs[2]["bits"])
     assert np.array_equal(outs[1]["pair"], outs[2]["pair"])
+
+
+@pytest.mark.parametrize("graph", [True, False])
+def test_engine_failure_reruns_the_step_on_the_fused_kernels(built_libs, real2, graph, monkeypatch):
+    """A decode_mode 2 step whose bounded spins expire (injected: the status word is overwritten after the launch) must
+    not cost the caller the step: the SAME decode call re-runs on the decode_mode 1 kernels, returns 0 with the right
+    token and logits, leaves seq_len advanced exactly once, and every later step stays off the engine."""
+    _, state, _ = real2
+    rng = np.random.default_rng(77)
+    prompt = rng.integers(0, CFG2["vocab_size"], 300).tolist()
+    e1 = _engine(state, decode_mode=1, enable_graph=graph, max_batch_size=4)
+    toks1, bits1 = _decode_bits(e1, prompt, 6)
+    e1.close()
+    monkeypatch.setenv("PEGAINFER_ENGINE_INJECT_FAIL", "1")
+    e2 = _engine(state, decode_mode=2, enable_graph=graph, max_batch_size=4)
+    rid = e2.new_request()
+    tok, _ = e2.prefill([rid], [prompt], return_logits=True)
+    assert int(tok[0]) == toks1[0]
+    rows = []
+    for step in range(6):
+        out, lg = e2.decode([rid], [toks1[step]], return_logits=True)   # rc != 0 would raise
+        rows.append(lg[0].copy())
+        assert int(out[0]) == toks1[step + 1]
+        assert e2.seq_len(rid) == len(prompt) + step + 1
+        assert e2.lib.pegainfer_qwen3_engine_active(e2.h) == 0
+        assert e2.lib.pegainfer_qwen3_engine_fallbacks(e2.h) == 1
+    e2.close()
+    assert np.array_equal(np.stack(rows), bits1)

@@ -205,3 +205,34 @@ def test_capped_trace_cxx_equals_oracle():
         evc += [tuple(e[:6]) for e in sc.poll()]
     assert evo == evc and exo.calls == exc.calls and max(a + b for a, b in exo.calls) <= 4
     assert not [e for e in evo if e[1] == ERROR]
+
+
+def test_executor_vtbl_is_size_versioned():
+    """pegainfer_executor_vtbl carries the caller's sizeof: a table that ends before the mandatory callbacks is
+    rejected, and one that ends at last_error (a caller built before max_batch_size was appended) never has the
+    bytes behind it read - here they hold a pointer that would crash if called."""
+    import ctypes
+
+    from pegainfer_amd import ffi
+    from pegainfer_amd.scheduler import ExecutorVtbl, Scheduler
+    lib = ffi.host_lib()
+    ex = FakeExecutor(8)                       # no max_batch_size attribute -> the short table
+    assert not hasattr(ex, "max_batch_size")
+    s = Scheduler.over_callbacks(ex)
+    vt = s._keep[0]
+    assert vt.struct_size == ExecutorVtbl.max_batch_size.offset < ctypes.sizeof(ExecutorVtbl)
+    # poison the slot behind the declared size on a copy and create a second scheduler from it
+    raw = (ctypes.c_char * ctypes.sizeof(ExecutorVtbl)).from_buffer_copy(vt)
+    poisoned = ExecutorVtbl.from_buffer(raw)
+    ctypes.memset(ctypes.addressof(poisoned) + ExecutorVtbl.max_batch_size.offset, 0x41, ctypes.sizeof(ctypes.c_void_p))
+    h = lib.pegainfer_sched_create(ctypes.addressof(poisoned), 42)
+    assert h
+    s2 = Scheduler(h, keep=(poisoned, raw, s))
+    rid = s2.submit([1] * 16, 2)
+    ev = run_until_idle(s2)                     # admission consults max_batch_size when non-NULL: must not be called
+    assert events_of(ev, rid)[-1][1] == FINISHED
+    s2.close()
+    # too short to hold the mandatory callbacks -> NULL
+    poisoned.struct_size = ExecutorVtbl.execute.offset
+    assert not lib.pegainfer_sched_create(ctypes.addressof(poisoned), 42)
+    s.close()
