@@ -23,6 +23,7 @@
 #ifndef PEGAINFER_COMM_H
 #define PEGAINFER_COMM_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -67,35 +68,61 @@ pegainfer_stream_t pegainfer_comm_stream(pegainfer_comm_t c);
 int32_t pegainfer_comm_fence_in(pegainfer_comm_t c, pegainfer_stream_t compute_stream);   /* comm stream waits for compute */
 int32_t pegainfer_comm_fence_out(pegainfer_comm_t c, pegainfer_stream_t compute_stream);  /* compute waits for comm stream */
 
-/* ---- expert-parallel dispatch / combine (ep_backend.rs:213-331) ----
- * Topology as EpTopology: experts are dealt to ranks in contiguous blocks (expert e lives on rank
- * e / (num_experts / world)).  bf16 payload rows of hidden_dim elements.
- *   dispatch_send : x [num_tokens, hidden] (x_stride_elems between rows), indices / weights [num_tokens, topk] ->
- *                   every (token, k) pair is sent to the rank that owns expert indices[t][k]
- *   dispatch_recv : out_x [<= max_recv_tokens, hidden] = the received rows grouped by LOCAL expert (expert-major,
- *                   within an expert by source rank then source order); out_num_tokens[0] = row count;
- *                   tokens_per_expert()[e] = rows of local expert e (device u32, num_experts / world entries)
- *   combine_send  : expert_x rows in the SAME order as out_x travel back to the ranks they came from
- *   combine_recv  : out_tokens[t] (+)= sum_k weights[t][k] * y(t, k), f32 accumulation in k order, bf16 result
- * A dispatch_send synchronises the calling stream once with the host (the per-peer row counts size the exchange),
- * exactly where the reference's worker thread waits for the route counts.
- * Row buffers (x, out_x, expert_x, out_tokens) are moved as 16-byte vectors: base pointers 16-byte aligned, strides a
- * multiple of 8 elements (else -1 + last_error).  A pair whose index is not in [0, num_experts) is routed nowhere and
- * contributes zero to its token's combine. */
+/* ---- expert-parallel dispatch / combine: the EpBackend surface (pegainfer-comm/src/ep_backend.rs), argument for
+ *      argument, so `impl EpBackend` binds each method to the function of the same name ----
+ * Experts are dealt to ranks in contiguous blocks (expert e lives on rank e / (num_experts / world_size),
+ * a2a_dispatch_send.cu:168-170).  Strides follow the reference kernels: BYTES for the row buffers x / out_x / expert_x
+ * (`(uint4*)(x_ptr + token * x_stride)`, moe_pplx.rs:131-133), ELEMENTS for indices, weights, the f32 scale planes and
+ * out_tokens.  bound_m_ptr, when not NULL, is a DEVICE i32: the number of leading tokens that take part
+ * (`bound_m_ptr ? *bound_m_ptr : num_tokens`), read by the kernels, never by the host.
+ *   dispatch_send : every (token, k) pair with token < bound travels to the rank that owns expert indices[t][k]; the
+ *                   payload row (hidden_dim * in_elemsize opaque bytes) and, when x_scale_ptr != NULL, its
+ *                   hidden_dim_scale f32 scales ride in one wire row
+ *   dispatch_recv : out_x rows grouped by LOCAL expert, each expert's group starting at a multiple of expert_padding
+ *                   (a2a_worker.rs:598-606, 669: padded_offset[expert] + running count; inside a group by source rank,
+ *                   then source order - the reference leaves that order to its atomics); out_num_tokens_ptr = DEVICE
+ *                   i32[num_experts / world_size] rows per local expert (a2a_dispatch_recv.cu:220-224); rows in the
+ *                   padding gaps are not written
+ *   combine_send  : expert_x rows in the SAME padded layout travel back to the ranks they came from
+ *                   (hidden_dim * out_elemsize bytes each)
+ *   combine_recv  : out_tokens[t] (+)= sum_k weights[t][k] * y(t, k) for t < bound, f32 fma chain in k order starting
+ *                   from the destination (accumulate) or zero, one rounding to out_dtype (core/combine_utils.cuh);
+ *                   in_dtype = what the experts produced (bf16 | f32, element size == out_elemsize)
+ * Not carried from EpTopology: dp_size > 1 (rejected), node_size and max_private_tokens (RDMA staging knobs: accepted,
+ * unused - one xGMI node, RCCL or loopback transport).  A pair whose index is not in [0, num_experts) is routed nowhere
+ * and contributes zero.  dispatch_send synchronises the calling stream once with the host (the route counts size the
+ * exchange), exactly where the reference's worker thread waits for them; with RCCL the whole (rank, expert) count table
+ * is all-gathered so an overflow of ANY rank's max_recv_tokens fails the call on EVERY rank before a row moves. */
+enum { PEGAINFER_SCALAR_BF16 = 0, PEGAINFER_SCALAR_F16 = 1, PEGAINFER_SCALAR_F32 = 2 };   /* p2p_all_to_all::ScalarType subset */
+typedef struct {   /* EpTopology, ep_backend.rs:24-51, field for field */
+  size_t world_size, rank, node_size, dp_size, num_experts, num_experts_per_token, hidden_dim, hidden_dim_scale,
+         max_num_tokens, max_recv_tokens, max_private_tokens, expert_padding;
+} pegainfer_ep_topology_t;
+typedef struct {   /* EpDtypes, ep_backend.rs:53-66 */
+  size_t in_elemsize, out_elemsize;
+  int32_t out_dtype;
+  size_t scale_elemsize;
+} pegainfer_ep_dtypes_t;
 pegainfer_ep_hub_t pegainfer_ep_hub_create(int32_t world);   /* loopback transport: `world` virtual ranks, one process */
 void pegainfer_ep_hub_destroy(pegainfer_ep_hub_t hub);
-/* exactly one of (comm, hub) is non-NULL; with a hub, `rank` is the virtual rank of this endpoint */
-pegainfer_ep_t pegainfer_ep_create(pegainfer_comm_t comm, pegainfer_ep_hub_t hub, int32_t rank, int32_t hidden_dim, int32_t max_num_tokens, int32_t max_recv_tokens, int32_t num_experts, int32_t num_experts_per_token);
+/* EpBackend::new: exactly one of (comm, hub) is non-NULL; with a hub, topology->rank is the virtual rank */
+pegainfer_ep_t pegainfer_ep_create(pegainfer_comm_t comm, pegainfer_ep_hub_t hub, const pegainfer_ep_topology_t* topology, const pegainfer_ep_dtypes_t* dtypes);
 void pegainfer_ep_destroy(pegainfer_ep_t ep);
 const char* pegainfer_ep_last_error(pegainfer_ep_t ep);
-int32_t pegainfer_ep_dispatch_send(pegainfer_ep_t ep, int32_t num_tokens, const Half* x, int64_t x_stride_elems, const int32_t* indices, const float* weights, pegainfer_stream_t stream);
-int32_t pegainfer_ep_dispatch_recv(pegainfer_ep_t ep, int32_t* out_num_tokens, Half* out_x, int64_t out_x_stride_elems, pegainfer_stream_t stream);
-int32_t pegainfer_ep_combine_send(pegainfer_ep_t ep, const Half* expert_x, int64_t expert_x_stride_elems, pegainfer_stream_t stream);
-int32_t pegainfer_ep_combine_recv(pegainfer_ep_t ep, int32_t num_tokens, Half* out_tokens, int64_t out_stride_elems, const int32_t* indices, const float* weights, int32_t accumulate, pegainfer_stream_t stream);
-const uint32_t* pegainfer_ep_tokens_per_expert(pegainfer_ep_t ep);
-/* host mirror of the same counters after dispatch_recv (n = num_experts / world entries) */
+/* ep_backend.rs:213-246 */
+int32_t pegainfer_ep_dispatch_send(pegainfer_ep_t ep, size_t num_tokens, const void* x_ptr, size_t x_stride, const void* x_scale_ptr, size_t x_scale_stride_elem, size_t x_scale_stride_token, const int32_t* indices, size_t indices_stride, const float* weights, size_t weights_stride, const int32_t* bound_m_ptr, pegainfer_stream_t stream);
+/* ep_backend.rs:252-274 */
+int32_t pegainfer_ep_dispatch_recv(pegainfer_ep_t ep, int32_t* out_num_tokens_ptr, void* out_x_ptr, size_t out_x_stride, void* out_x_scale_ptr, size_t out_x_scale_stride_elem, size_t out_x_scale_stride_token, pegainfer_stream_t stream);
+/* ep_backend.rs:277-286 */
+int32_t pegainfer_ep_combine_send(pegainfer_ep_t ep, const void* expert_x_ptr, size_t expert_x_stride, pegainfer_stream_t stream);
+/* ep_backend.rs:303-331 */
+int32_t pegainfer_ep_combine_recv(pegainfer_ep_t ep, size_t num_tokens, size_t num_recv_tokens, int32_t in_dtype, void* out_tokens_ptr, size_t out_tokens_stride, const int32_t* indices_ptr, size_t indices_stride, const float* weights_ptr, size_t weights_stride, const int32_t* bound_m_ptr, int32_t accumulate, pegainfer_stream_t stream);
+/* ep_backend.rs:292-294: device u32[num_experts / world_size], populated by dispatch_recv */
+const uint32_t* pegainfer_ep_tokens_per_expert_ptr(pegainfer_ep_t ep);
+/* host mirrors of the last dispatch (the reference's caller does a D2H copy of the counter) */
 int32_t pegainfer_ep_tokens_per_expert_host(pegainfer_ep_t ep, uint32_t* out, int32_t n);
-int32_t pegainfer_ep_num_recv_tokens(pegainfer_ep_t ep);   /* host copy of the last dispatch's received row count */
+int32_t pegainfer_ep_num_recv_tokens(pegainfer_ep_t ep);          /* rows received (unpadded) */
+int32_t pegainfer_ep_num_padded_recv_tokens(pegainfer_ep_t ep);   /* extent of the padded expert-major layout in out_x */
 
 #ifdef __cplusplus
 }

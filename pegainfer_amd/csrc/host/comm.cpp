@@ -74,17 +74,40 @@ static int cast_to_bf16(Comm* c, const float* in, Half* out, int64_t n, hipStrea
 }
 
 // ---- expert-parallel kernels ----------------------------------------------------------------------------------
+// Argument meaning follows the reference's a2a kernels (pegainfer-comm-a2a-kernels/src/a2a/*.cu) so EpBackend binds 1:1:
+// byte strides for the row buffers, element strides for indices / weights / scales / out_tokens, an optional DEVICE
+// token bound (`bound_m_ptr ? *bound_m_ptr : num_tokens`, a2a_dispatch_send.cu:172, a2a_combine_recv.cu:52).
+
+__device__ __forceinline__ int ep_bound(int num_tokens, const int32_t* bound_m) {
+  if (!bound_m) return num_tokens;
+  const int b = *bound_m;
+  return b < 0 ? 0 : (b > num_tokens ? num_tokens : b);
+}
+// one row of `nbytes` by the whole workgroup: 16-byte vectors when everything is 16-byte aligned, words or bytes otherwise
+__device__ __forceinline__ void ep_copy_row(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst, int nbytes) {
+  const uintptr_t m = reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst) | (uintptr_t)nbytes;
+  if ((m & 15) == 0) {
+    for (int i = threadIdx.x; i < nbytes / 16; i += blockDim.x) reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(src)[i];
+  } else if ((m & 3) == 0) {
+    for (int i = threadIdx.x; i < nbytes / 4; i += blockDim.x) reinterpret_cast<uint32_t*>(dst)[i] = reinterpret_cast<const uint32_t*>(src)[i];
+  } else {
+    for (int i = threadIdx.x; i < nbytes; i += blockDim.x) dst[i] = src[i];
+  }
+}
 
 // Stable rank of every (token, k) pair inside its expert bucket: wave w scans all pairs for expert w with ballots,
-// so a pair's position is the number of EARLIER pairs routed to the same expert - deterministic, no atomics.
-__global__ __launch_bounds__(256) void ep_rank_kernel(const int32_t* __restrict__ indices, int n_pairs, int num_experts,
+// so a pair's position is the number of EARLIER pairs routed to the same expert - deterministic, no atomics (the
+// reference draws the offset with an atomicAdd, a2a_dispatch_send.cu:186: its order inside an expert is unspecified).
+__global__ __launch_bounds__(256) void ep_rank_kernel(const int32_t* __restrict__ indices, long indices_stride, int topk,
+                                                      int num_tokens, const int32_t* __restrict__ bound_m, int num_experts,
                                                       int32_t* __restrict__ rank_in_bucket, int32_t* __restrict__ counts) {
   const int e = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (e >= num_experts) return;
+  const int n_pairs = ep_bound(num_tokens, bound_m) * topk;
   int base = 0;
   for (int p0 = 0; p0 < n_pairs; p0 += 64) {
     const int p = p0 + lane;
-    const bool hit = p < n_pairs && indices[p] == e;
+    const bool hit = p < n_pairs && indices[(long)(p / topk) * indices_stride + (p % topk)] == e;
     const unsigned long long m = __ballot(hit);
     if (hit) rank_in_bucket[p] = base + __popcll(m & ((1ull << lane) - 1ull));
     base += __popcll(m);
@@ -92,8 +115,7 @@ __global__ __launch_bounds__(256) void ep_rank_kernel(const int32_t* __restrict_
   if (lane == 0) counts[e] = base;
 }
 
-// bucket offsets (expert order = (destination rank, local expert) order) by one workgroup, then the pack: one
-// workgroup per pair copies row x[t] to its slot of the send buffer and records the slot for the combine
+// bucket offsets (expert order = (destination rank, local expert) order) by one workgroup
 __global__ __launch_bounds__(256) void ep_offsets_kernel(const int32_t* __restrict__ counts, int num_experts,
                                                          int32_t* __restrict__ offsets) {
   __shared__ int32_t part[256];
@@ -112,32 +134,50 @@ __global__ __launch_bounds__(256) void ep_offsets_kernel(const int32_t* __restri
     if (e < num_experts) { offsets[e] = base; base += counts[e]; }
   }
 }
-__global__ __launch_bounds__(256) void ep_pack_kernel(const Half* __restrict__ x, long x_stride,
-                                                      const int32_t* __restrict__ indices,
+// the pack: one workgroup per pair copies row x[t] (+ its scale plane, gathered with the caller's element stride) to
+// its slot of the wire buffer and records the slot for the combine.  Wire row = [payload, padded to 16 B][scales f32]
+__global__ __launch_bounds__(256) void ep_pack_kernel(const unsigned char* __restrict__ x, long x_stride_bytes, int payload_bytes,
+                                                      const float* __restrict__ x_scale, long scale_stride_elem,
+                                                      long scale_stride_token, int hidden_scale, int scale_off,
+                                                      const int32_t* __restrict__ indices, long indices_stride,
                                                       const int32_t* __restrict__ rank_in_bucket,
-                                                      const int32_t* __restrict__ offsets, int topk, int hidden,
-                                                      int num_experts, Half* __restrict__ send,
-                                                      int32_t* __restrict__ slot) {
+                                                      const int32_t* __restrict__ offsets, int topk, int num_tokens,
+                                                      const int32_t* __restrict__ bound_m, int num_experts, int row_bytes,
+                                                      unsigned char* __restrict__ send, int32_t* __restrict__ slot) {
   const int p = blockIdx.x, t = p / topk;
-  const int ex = indices[p];
-  if ((unsigned)ex >= (unsigned)num_experts) {   // not an expert id: the pair is routed nowhere and combines as zero
+  int ex = -1;
+  if (t < ep_bound(num_tokens, bound_m)) ex = indices[(long)t * indices_stride + (p % topk)];
+  if ((unsigned)ex >= (unsigned)num_experts) {   // beyond the bound, or not an expert id: routed nowhere, combines as zero
     if (threadIdx.x == 0) slot[p] = -1;
     return;
   }
   const int pos = offsets[ex] + rank_in_bucket[p];
   if (threadIdx.x == 0) slot[p] = pos;
-  const uint4* src = reinterpret_cast<const uint4*>(x + (long)t * x_stride);
-  uint4* dst = reinterpret_cast<uint4*>(send + (long)pos * hidden);
-  for (int i = threadIdx.x; i < hidden / 8; i += 256) dst[i] = src[i];
+  unsigned char* dst = send + (long)pos * row_bytes;
+  ep_copy_row(x + (long)t * x_stride_bytes, dst, payload_bytes);
+  if (x_scale)
+    for (int i = threadIdx.x; i < hidden_scale; i += blockDim.x)
+      reinterpret_cast<float*>(dst + scale_off)[i] = x_scale[(long)t * scale_stride_token + (long)i * scale_stride_elem];
 }
-// out row r = in row map[r] (gather) or out row map[r] = in row r (scatter)
-template <bool SCATTER>
-__global__ __launch_bounds__(256) void ep_rows_kernel(const Half* __restrict__ in, long in_stride, Half* __restrict__ out,
-                                                      long out_stride, const int32_t* __restrict__ map, int hidden) {
+// received wire row r -> caller row map[r] (the expert-major, expert_padding-aligned layout), payload + scale plane
+__global__ __launch_bounds__(256) void ep_unpack_kernel(const unsigned char* __restrict__ recv, int row_bytes, int payload_bytes,
+                                                        int hidden_scale, int scale_off, const int32_t* __restrict__ map,
+                                                        unsigned char* __restrict__ out_x, long out_x_stride_bytes,
+                                                        float* __restrict__ out_scale, long scale_stride_elem,
+                                                        long scale_stride_token) {
   const int r = blockIdx.x, m = map[r];
-  const uint4* src = reinterpret_cast<const uint4*>(in + (long)(SCATTER ? r : m) * in_stride);
-  uint4* dst = reinterpret_cast<uint4*>(out + (long)(SCATTER ? m : r) * out_stride);
-  for (int i = threadIdx.x; i < hidden / 8; i += 256) dst[i] = src[i];
+  const unsigned char* src = recv + (long)r * row_bytes;
+  ep_copy_row(src, out_x + (long)m * out_x_stride_bytes, payload_bytes);
+  if (out_scale)
+    for (int i = threadIdx.x; i < hidden_scale; i += blockDim.x)
+      out_scale[(long)m * scale_stride_token + (long)i * scale_stride_elem] = reinterpret_cast<const float*>(src + scale_off)[i];
+}
+// expert output row map[r] of the caller's (padded, expert-major) buffer -> combine wire row r (source-major)
+__global__ __launch_bounds__(256) void ep_gather_kernel(const unsigned char* __restrict__ expert_x, long stride_bytes,
+                                                        int payload_bytes, const int32_t* __restrict__ map, int row_bytes,
+                                                        unsigned char* __restrict__ back) {
+  const int r = blockIdx.x;
+  ep_copy_row(expert_x + (long)map[r] * stride_bytes, back + (long)r * row_bytes, payload_bytes);
 }
 __device__ __forceinline__ float bf_lo(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t w) { return __builtin_bit_cast(float, w & 0xFFFF0000u); }
@@ -146,32 +186,53 @@ __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
   typedef __attribute__((ext_vector_type(2))) __bf16 b2;
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(f2{lo, hi}, b2));
 }
-// out[t] (+)= sum_k w[t][k] * back[slot[t][k]], f32 accumulation in k order, one bf16 rounding
-__global__ __launch_bounds__(256) void ep_combine_kernel(const Half* __restrict__ back, const int32_t* __restrict__ slot,
-                                                         const float* __restrict__ weights, int topk, int hidden,
-                                                         Half* __restrict__ out, long out_stride, int accumulate) {
+template <typename T> struct EpVec;   // 8 elements <-> 8 floats
+template <> struct EpVec<Half> {
+  static __device__ __forceinline__ void load(const Half* p, float* v) {
+    const uint4 o = *reinterpret_cast<const uint4*>(p);
+    v[0] = bf_lo(o.x); v[1] = bf_hi(o.x); v[2] = bf_lo(o.y); v[3] = bf_hi(o.y);
+    v[4] = bf_lo(o.z); v[5] = bf_hi(o.z); v[6] = bf_lo(o.w); v[7] = bf_hi(o.w);
+  }
+  static __device__ __forceinline__ void store(Half* p, const float* v) {
+    uint4 r;
+    r.x = pack2(v[0], v[1]); r.y = pack2(v[2], v[3]); r.z = pack2(v[4], v[5]); r.w = pack2(v[6], v[7]);
+    *reinterpret_cast<uint4*>(p) = r;
+  }
+};
+template <> struct EpVec<float> {
+  static __device__ __forceinline__ void load(const float* p, float* v) {
+    const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  }
+  static __device__ __forceinline__ void store(float* p, const float* v) {
+    reinterpret_cast<float4*>(p)[0] = make_float4(v[0], v[1], v[2], v[3]);
+    reinterpret_cast<float4*>(p)[1] = make_float4(v[4], v[5], v[6], v[7]);
+  }
+};
+// out[t] (+)= sum_k w[t][k] * back[slot[t][k]]: f32 accumulation in k order, one rounding to the output type
+// (a2a_combine_recv.cu:96-140 + core/combine_utils.cuh Acc::add = fma chain from the destination or from zero)
+template <typename TIN, typename TOUT>
+__global__ __launch_bounds__(256) void ep_combine_kernel(const unsigned char* __restrict__ back, int row_bytes,
+                                                         const int32_t* __restrict__ slot, const float* __restrict__ weights,
+                                                         long weights_stride, int topk, int hidden, int num_tokens,
+                                                         const int32_t* __restrict__ bound_m, TOUT* __restrict__ out,
+                                                         long out_stride, int accumulate) {
   const int t = blockIdx.x;
-  uint4* dst = reinterpret_cast<uint4*>(out + (long)t * out_stride);
-  for (int i = threadIdx.x; i < hidden / 8; i += 256) {
+  if (t >= ep_bound(num_tokens, bound_m)) return;
+  TOUT* dst = out + (long)t * out_stride;
+  for (int i = threadIdx.x * 8; i < hidden; i += 256 * 8) {
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (accumulate) {
-      const uint4 o = dst[i];
-      acc[0] = bf_lo(o.x); acc[1] = bf_hi(o.x); acc[2] = bf_lo(o.y); acc[3] = bf_hi(o.y);
-      acc[4] = bf_lo(o.z); acc[5] = bf_hi(o.z); acc[6] = bf_lo(o.w); acc[7] = bf_hi(o.w);
-    }
+    if (accumulate) EpVec<TOUT>::load(dst + i, acc);
     for (int k = 0; k < topk; ++k) {
-      const float w = weights[t * topk + k];
       const int sl = slot[t * topk + k];
       if (sl < 0) continue;   // pair with an invalid expert id (ep_pack_kernel)
-      const uint4 v = reinterpret_cast<const uint4*>(back + (long)sl * hidden)[i];
-      acc[0] = fmaf(w, bf_lo(v.x), acc[0]); acc[1] = fmaf(w, bf_hi(v.x), acc[1]);
-      acc[2] = fmaf(w, bf_lo(v.y), acc[2]); acc[3] = fmaf(w, bf_hi(v.y), acc[3]);
-      acc[4] = fmaf(w, bf_lo(v.z), acc[4]); acc[5] = fmaf(w, bf_hi(v.z), acc[5]);
-      acc[6] = fmaf(w, bf_lo(v.w), acc[6]); acc[7] = fmaf(w, bf_hi(v.w), acc[7]);
+      const float w = weights[(long)t * weights_stride + k];
+      float v[8];
+      EpVec<TIN>::load(reinterpret_cast<const TIN*>(back + (long)sl * row_bytes) + i, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = fmaf(w, v[j], acc[j]);
     }
-    uint4 r;
-    r.x = pack2(acc[0], acc[1]); r.y = pack2(acc[2], acc[3]); r.z = pack2(acc[4], acc[5]); r.w = pack2(acc[6], acc[7]);
-    dst[i] = r;
+    EpVec<TOUT>::store(dst + i, acc);
   }
 }
 
@@ -181,18 +242,21 @@ struct EpHub { int world = 0; std::vector<Ep*> eps; };
 struct Ep {
   Comm* comm = nullptr;
   EpHub* hub = nullptr;
-  int rank = 0, world = 1, hidden = 0, max_tokens = 0, max_recv = 0, num_experts = 0, topk = 0, epr = 0;
+  int rank = 0, world = 1, hidden = 0, hidden_scale = 0, max_tokens = 0, max_recv = 0, num_experts = 0, topk = 0, epr = 0;
+  int pad = 1, in_elem = 2, out_elem = 2, out_dtype = PEGAINFER_SCALAR_BF16;
+  int pay_bytes = 0, scale_off = 0, wrow = 0;   // dispatch wire row: payload bytes, offset of the scale plane, row bytes
+  int cpay_bytes = 0, crow = 0;                 // combine wire row
   // device
   int32_t *d_rank_in_bucket = nullptr, *d_counts = nullptr, *d_offsets = nullptr, *d_slot = nullptr;
-  int32_t *d_counts_recv = nullptr, *d_row_map = nullptr;
+  int32_t *d_counts_all = nullptr, *d_row_map = nullptr;
   uint32_t* d_tokens_per_expert = nullptr;
-  Half *d_send = nullptr, *d_recv = nullptr, *d_back_send = nullptr, *d_back_recv = nullptr;
+  unsigned char *d_send = nullptr, *d_recv = nullptr, *d_back_send = nullptr, *d_back_recv = nullptr;
   // pinned host mirrors
-  int32_t *h_counts = nullptr, *h_counts_recv = nullptr, *h_row_map = nullptr;
+  int32_t *h_counts = nullptr, *h_counts_recv = nullptr, *h_counts_all = nullptr, *h_row_map = nullptr;
   uint32_t* h_tokens_per_expert = nullptr;
   std::vector<int64_t> send_off, send_tot, recv_off, recv_tot;   // rows per peer
-  int num_pairs = 0, num_recv = 0;
-  bool sent = false;
+  int num_tokens = 0, num_recv = 0, num_recv_padded = 0;
+  bool sent = false, received = false, combine_sent = false;
   std::string err;
 };
 
@@ -207,17 +271,26 @@ struct Ep {
     if (r_ != ncclSuccess) { (e)->err = std::string(#expr) + ": " + ncclGetErrorString(r_); return -1; } \
   } while (0)
 
-// the row kernels move 16-byte vectors: row starts must be 16-byte aligned
-static bool rows_aligned(const void* p, int64_t stride_elems) {
-  return (reinterpret_cast<uintptr_t>(p) & 15u) == 0 && (stride_elems & 7) == 0;
-}
+static inline int round16(int64_t n) { return static_cast<int>((n + 15) / 16 * 16); }
 
 static void ep_free(Ep* e) {
-  void* dev[] = {e->d_rank_in_bucket, e->d_counts, e->d_offsets, e->d_slot, e->d_counts_recv, e->d_row_map,
+  void* dev[] = {e->d_rank_in_bucket, e->d_counts, e->d_offsets, e->d_slot, e->d_counts_all, e->d_row_map,
                  e->d_tokens_per_expert, e->d_send, e->d_recv, e->d_back_send, e->d_back_recv};
   for (void* p : dev) if (p) (void)hipFree(p);
-  void* host[] = {e->h_counts, e->h_counts_recv, e->h_row_map, e->h_tokens_per_expert};
+  void* host[] = {e->h_counts, e->h_counts_recv, e->h_counts_all, e->h_row_map, e->h_tokens_per_expert};
   for (void* p : host) if (p) (void)hipHostFree(p);
+}
+
+// rows a rank receives for the (source-major) count table `recv` [world][epr], with every local expert's group padded
+// to a multiple of expert_padding (a2a_worker.rs:598-606)
+static int64_t ep_padded_rows(const Ep* e, const int32_t* recv) {
+  int64_t tot = 0;
+  for (int le = 0; le < e->epr; ++le) {
+    int64_t n = 0;
+    for (int r = 0; r < e->world; ++r) n += recv[r * e->epr + le];
+    tot += (n + e->pad - 1) / e->pad * e->pad;
+  }
+  return tot;
 }
 
 // per-peer row totals and offsets from the (rank, local expert) count tables
@@ -230,22 +303,25 @@ static void ep_layout(Ep* e) {
     e->recv_off[r] = ro; e->recv_tot[r] = v; ro += v;
   }
   e->num_recv = static_cast<int>(ro);
+  e->num_recv_padded = static_cast<int>(ep_padded_rows(e, e->h_counts_recv));
 }
 
-// expert-major row order of the received (source-major) rows + tokens per local expert
+// destination row of every received (source-major) wire row in the caller's buffers: expert-major, each expert's group
+// starting at a multiple of expert_padding, inside a group by source rank then source order; + tokens per local expert
 static int ep_build_row_map(Ep* e, hipStream_t s) {
-  if (e->num_recv > e->max_recv) { e->err = "dispatch: received rows exceed max_recv_tokens"; return -1; }
-  int dst = 0;
+  if (e->num_recv_padded > e->max_recv) { e->err = "dispatch: received rows (expert groups padded) exceed max_recv_tokens"; return -1; }
+  int64_t base = 0;
   for (int le = 0; le < e->epr; ++le) {
     uint32_t n_le = 0;
     for (int r = 0; r < e->world; ++r) {
       int64_t within = 0;
       for (int l2 = 0; l2 < le; ++l2) within += e->h_counts_recv[r * e->epr + l2];
       const int n = e->h_counts_recv[r * e->epr + le];
-      for (int i = 0; i < n; ++i) e->h_row_map[dst++] = static_cast<int32_t>(e->recv_off[r] + within + i);
+      for (int i = 0; i < n; ++i) e->h_row_map[e->recv_off[r] + within + i] = static_cast<int32_t>(base + n_le + i);
       n_le += static_cast<uint32_t>(n);
     }
     e->h_tokens_per_expert[le] = n_le;
+    base += ((int64_t)n_le + e->pad - 1) / e->pad * e->pad;
   }
   if (e->num_recv > 0)
     PE_HIP(e, hipMemcpyAsync(e->d_row_map, e->h_row_map, (size_t)e->num_recv * 4, hipMemcpyHostToDevice, s));
@@ -254,17 +330,18 @@ static int ep_build_row_map(Ep* e, hipStream_t s) {
 }
 
 // RCCL transport: rows [off[r], off[r] + tot[r]) of `send` go to rank r, `recv` is filled peer by peer
-static int ep_exchange_rows(Ep* e, const Half* send, const std::vector<int64_t>& soff, const std::vector<int64_t>& stot,
-                            Half* recv, const std::vector<int64_t>& roff, const std::vector<int64_t>& rtot, hipStream_t s) {
-  const size_t row = (size_t)e->hidden;
+static int ep_exchange_rows(Ep* e, int row_bytes, const unsigned char* send, const std::vector<int64_t>& soff,
+                            const std::vector<int64_t>& stot, unsigned char* recv, const std::vector<int64_t>& roff,
+                            const std::vector<int64_t>& rtot, hipStream_t s) {
+  const size_t row = (size_t)row_bytes;
   if (e->world == 1) {
-    if (stot[0] > 0) PE_HIP(e, hipMemcpyAsync(recv, send, (size_t)stot[0] * row * 2, hipMemcpyDeviceToDevice, s));
+    if (stot[0] > 0) PE_HIP(e, hipMemcpyAsync(recv, send, (size_t)stot[0] * row, hipMemcpyDeviceToDevice, s));
     return 0;
   }
   PE_NCCL(e, ncclGroupStart());
   for (int r = 0; r < e->world; ++r) {
-    if (stot[r] > 0) PE_NCCL(e, ncclSend(send + soff[r] * row, (size_t)stot[r] * row, ncclBfloat16, r, e->comm->nccl, s));
-    if (rtot[r] > 0) PE_NCCL(e, ncclRecv(recv + roff[r] * row, (size_t)rtot[r] * row, ncclBfloat16, r, e->comm->nccl, s));
+    if (stot[r] > 0) PE_NCCL(e, ncclSend(send + soff[r] * row, (size_t)stot[r] * row, ncclInt8, r, e->comm->nccl, s));
+    if (rtot[r] > 0) PE_NCCL(e, ncclRecv(recv + roff[r] * row, (size_t)rtot[r] * row, ncclInt8, r, e->comm->nccl, s));
   }
   PE_NCCL(e, ncclGroupEnd());
   return 0;
@@ -444,35 +521,51 @@ pegainfer_ep_hub_t pegainfer_ep_hub_create(int32_t world) {
 }
 void pegainfer_ep_hub_destroy(pegainfer_ep_hub_t h) { delete static_cast<EpHub*>(h); }
 
-pegainfer_ep_t pegainfer_ep_create(pegainfer_comm_t comm, pegainfer_ep_hub_t hub_h, int32_t rank, int32_t hidden_dim,
-                                   int32_t max_num_tokens, int32_t max_recv_tokens, int32_t num_experts,
-                                   int32_t num_experts_per_token) {
+static int ep_elem_of(int32_t dtype) {
+  return dtype == PEGAINFER_SCALAR_BF16 || dtype == PEGAINFER_SCALAR_F16 ? 2 : dtype == PEGAINFER_SCALAR_F32 ? 4 : 0;
+}
+
+pegainfer_ep_t pegainfer_ep_create(pegainfer_comm_t comm, pegainfer_ep_hub_t hub_h, const pegainfer_ep_topology_t* t,
+                                   const pegainfer_ep_dtypes_t* d) {
   Comm* c = static_cast<Comm*>(comm);
   EpHub* hub = static_cast<EpHub*>(hub_h);
-  if ((c == nullptr) == (hub == nullptr)) return nullptr;
+  if ((c == nullptr) == (hub == nullptr) || !t || !d) return nullptr;
   const int world = c ? c->world : hub->world;
-  if (c) rank = c->rank;
-  if (rank < 0 || rank >= world || hidden_dim <= 0 || hidden_dim % 8 || max_num_tokens <= 0 || max_recv_tokens <= 0 ||
-      num_experts <= 0 || num_experts % world || num_experts_per_token <= 0)
+  const int rank = c ? c->rank : static_cast<int>(t->rank);
+  // what this port carries: pure EP (dp_size 1) inside one xGMI node; payload rows are opaque bytes of 1 / 2 / 4-byte
+  // elements, scale planes are f32 (the reference reads them through float*, a2a_dispatch_send.cu:270); the combine
+  // sums bf16 or f32 expert outputs into bf16 or f32 tokens
+  if ((int)t->world_size != world || (int)t->rank != rank || t->dp_size != 1 || t->hidden_dim == 0 || t->hidden_dim % 8 ||
+      t->max_num_tokens == 0 || t->max_recv_tokens == 0 || t->num_experts == 0 || t->num_experts % world ||
+      t->num_experts_per_token == 0 || t->expert_padding == 0 || t->hidden_dim > (1u << 24) || t->num_experts > (1u << 20))
+    return nullptr;
+  if ((d->in_elemsize != 1 && d->in_elemsize != 2 && d->in_elemsize != 4) || (d->out_elemsize != 2 && d->out_elemsize != 4) ||
+      ep_elem_of(d->out_dtype) == 0 || (t->hidden_dim_scale != 0 && d->scale_elemsize != 4) || d->out_dtype == PEGAINFER_SCALAR_F16)
     return nullptr;
   Ep* e = new Ep();
-  e->comm = c; e->hub = hub; e->rank = rank; e->world = world; e->hidden = hidden_dim; e->max_tokens = max_num_tokens;
-  e->max_recv = max_recv_tokens; e->num_experts = num_experts; e->topk = num_experts_per_token; e->epr = num_experts / world;
-  const size_t pairs = (size_t)max_num_tokens * num_experts_per_token, row = (size_t)hidden_dim * 2;
+  e->comm = c; e->hub = hub; e->rank = rank; e->world = world;
+  e->hidden = (int)t->hidden_dim; e->hidden_scale = (int)t->hidden_dim_scale; e->max_tokens = (int)t->max_num_tokens;
+  e->max_recv = (int)t->max_recv_tokens; e->num_experts = (int)t->num_experts; e->topk = (int)t->num_experts_per_token;
+  e->epr = e->num_experts / world; e->pad = (int)t->expert_padding;
+  e->in_elem = (int)d->in_elemsize; e->out_elem = (int)d->out_elemsize; e->out_dtype = d->out_dtype;
+  e->pay_bytes = e->hidden * e->in_elem; e->scale_off = round16(e->pay_bytes);
+  e->wrow = e->scale_off + round16((int64_t)e->hidden_scale * 4);
+  e->cpay_bytes = e->hidden * e->out_elem; e->crow = round16(e->cpay_bytes);
+  const size_t pairs = (size_t)e->max_tokens * e->topk, ne = (size_t)e->num_experts;
   bool ok = hipMalloc((void**)&e->d_rank_in_bucket, pairs * 4) == hipSuccess &&
-            hipMalloc((void**)&e->d_counts, (size_t)num_experts * 4) == hipSuccess &&
-            hipMalloc((void**)&e->d_offsets, (size_t)num_experts * 4) == hipSuccess &&
+            hipMalloc((void**)&e->d_counts, ne * 4) == hipSuccess && hipMalloc((void**)&e->d_offsets, ne * 4) == hipSuccess &&
             hipMalloc((void**)&e->d_slot, pairs * 4) == hipSuccess &&
-            hipMalloc((void**)&e->d_counts_recv, (size_t)num_experts * 4) == hipSuccess &&
-            hipMalloc((void**)&e->d_row_map, (size_t)max_recv_tokens * 4) == hipSuccess &&
+            hipMalloc((void**)&e->d_counts_all, ne * world * 4) == hipSuccess &&
+            hipMalloc((void**)&e->d_row_map, (size_t)e->max_recv * 4) == hipSuccess &&
             hipMalloc((void**)&e->d_tokens_per_expert, (size_t)e->epr * 4) == hipSuccess &&
-            hipMalloc((void**)&e->d_send, pairs * row) == hipSuccess &&
-            hipMalloc((void**)&e->d_recv, (size_t)max_recv_tokens * row) == hipSuccess &&
-            hipMalloc((void**)&e->d_back_send, (size_t)max_recv_tokens * row) == hipSuccess &&
-            hipMalloc((void**)&e->d_back_recv, pairs * row) == hipSuccess &&
-            hipHostMalloc((void**)&e->h_counts, (size_t)num_experts * 4) == hipSuccess &&
-            hipHostMalloc((void**)&e->h_counts_recv, (size_t)num_experts * 4) == hipSuccess &&
-            hipHostMalloc((void**)&e->h_row_map, (size_t)max_recv_tokens * 4) == hipSuccess &&
+            hipMalloc((void**)&e->d_send, pairs * e->wrow) == hipSuccess &&
+            hipMalloc((void**)&e->d_recv, (size_t)e->max_recv * e->wrow) == hipSuccess &&
+            hipMalloc((void**)&e->d_back_send, (size_t)e->max_recv * e->crow) == hipSuccess &&
+            hipMalloc((void**)&e->d_back_recv, pairs * e->crow) == hipSuccess &&
+            hipHostMalloc((void**)&e->h_counts, ne * 4) == hipSuccess &&
+            hipHostMalloc((void**)&e->h_counts_recv, ne * 4) == hipSuccess &&
+            hipHostMalloc((void**)&e->h_counts_all, ne * world * 4) == hipSuccess &&
+            hipHostMalloc((void**)&e->h_row_map, (size_t)e->max_recv * 4) == hipSuccess &&
             hipHostMalloc((void**)&e->h_tokens_per_expert, (size_t)e->epr * 4) == hipSuccess;
   if (!ok) { ep_free(e); delete e; return nullptr; }
   e->send_off.assign(world, 0); e->send_tot.assign(world, 0); e->recv_off.assign(world, 0); e->recv_tot.assign(world, 0);
@@ -487,7 +580,7 @@ void pegainfer_ep_destroy(pegainfer_ep_t h) {
   delete e;
 }
 const char* pegainfer_ep_last_error(pegainfer_ep_t h) { return h ? static_cast<Ep*>(h)->err.c_str() : "null ep"; }
-const uint32_t* pegainfer_ep_tokens_per_expert(pegainfer_ep_t h) { return h ? static_cast<Ep*>(h)->d_tokens_per_expert : nullptr; }
+const uint32_t* pegainfer_ep_tokens_per_expert_ptr(pegainfer_ep_t h) { return h ? static_cast<Ep*>(h)->d_tokens_per_expert : nullptr; }
 int32_t pegainfer_ep_tokens_per_expert_host(pegainfer_ep_t h, uint32_t* out, int32_t n) {
   Ep* e = static_cast<Ep*>(h);
   if (!e || !out || n != e->epr) return -1;
@@ -495,54 +588,78 @@ int32_t pegainfer_ep_tokens_per_expert_host(pegainfer_ep_t h, uint32_t* out, int
   return 0;
 }
 int32_t pegainfer_ep_num_recv_tokens(pegainfer_ep_t h) { return h ? static_cast<Ep*>(h)->num_recv : -1; }
+int32_t pegainfer_ep_num_padded_recv_tokens(pegainfer_ep_t h) { return h ? static_cast<Ep*>(h)->num_recv_padded : -1; }
 
-int32_t pegainfer_ep_dispatch_send(pegainfer_ep_t h, int32_t num_tokens, const Half* x, int64_t x_stride_elems,
-                                   const int32_t* indices, const float* weights, pegainfer_stream_t stream) {
+int32_t pegainfer_ep_dispatch_send(pegainfer_ep_t h, size_t num_tokens, const void* x_ptr, size_t x_stride,
+                                   const void* x_scale_ptr, size_t x_scale_stride_elem, size_t x_scale_stride_token,
+                                   const int32_t* indices, size_t indices_stride, const float* weights,
+                                   size_t weights_stride, const int32_t* bound_m_ptr, pegainfer_stream_t stream) {
   Ep* e = static_cast<Ep*>(h);
-  (void)weights;  // the weights stay with the source rank: they are applied in combine_recv
-  if (!e || num_tokens < 0 || num_tokens > e->max_tokens || (num_tokens > 0 && (!x || !indices)) || x_stride_elems < e->hidden)
+  (void)weights; (void)weights_stride;  // the weights stay with the source rank: they are applied in combine_recv
+  if (!e) return -1;
+  if (num_tokens > (size_t)e->max_tokens) { e->err = "dispatch_send: num_tokens exceeds max_num_tokens"; return -1; }
+  if (num_tokens > 0 && (!x_ptr || !indices || x_stride < (size_t)e->pay_bytes || indices_stride < (size_t)e->topk)) {
+    e->err = "dispatch_send: null x / indices or a stride shorter than a row";
     return -1;
-  if (num_tokens > 0 && !rows_aligned(x, x_stride_elems)) { e->err = "dispatch_send: x rows must be 16-byte aligned"; return -1; }
+  }
+  if (x_scale_ptr && e->hidden_scale == 0) { e->err = "dispatch_send: scale plane given but hidden_dim_scale == 0"; return -1; }
   hipStream_t s = st(stream);
-  e->num_pairs = num_tokens * e->topk;
-  e->sent = false;
+  e->num_tokens = (int)num_tokens;
+  e->sent = e->received = e->combine_sent = false;
+  const int pairs = e->num_tokens * e->topk;
   // route: stable rank inside each expert bucket, bucket offsets, pack
-  ep_rank_kernel<<<(e->num_experts + 3) / 4, 256, 0, s>>>(indices, e->num_pairs, e->num_experts, e->d_rank_in_bucket, e->d_counts);
+  ep_rank_kernel<<<(e->num_experts + 3) / 4, 256, 0, s>>>(indices, (long)indices_stride, e->topk, e->num_tokens, bound_m_ptr,
+                                                          e->num_experts, e->d_rank_in_bucket, e->d_counts);
   ep_offsets_kernel<<<1, 256, 0, s>>>(e->d_counts, e->num_experts, e->d_offsets);
-  if (e->num_pairs > 0)
-    ep_pack_kernel<<<e->num_pairs, 256, 0, s>>>(x, x_stride_elems, indices, e->d_rank_in_bucket, e->d_offsets, e->topk,
-                                                e->hidden, e->num_experts, e->d_send, e->d_slot);
+  if (pairs > 0)
+    ep_pack_kernel<<<pairs, 256, 0, s>>>(static_cast<const unsigned char*>(x_ptr), (long)x_stride, e->pay_bytes,
+                                         static_cast<const float*>(x_scale_ptr), (long)x_scale_stride_elem,
+                                         (long)x_scale_stride_token, e->hidden_scale, e->scale_off, indices,
+                                         (long)indices_stride, e->d_rank_in_bucket, e->d_offsets, e->topk, e->num_tokens,
+                                         bound_m_ptr, e->num_experts, e->wrow, e->d_send, e->d_slot);
   PE_HIP(e, hipGetLastError());
-  PE_HIP(e, hipMemcpyAsync(e->h_counts, e->d_counts, (size_t)e->num_experts * 4, hipMemcpyDeviceToHost, s));
   if (e->comm) {
-    // route counts: epr ints to / from every peer, then the payload rows they announce
+    // route counts: every rank learns the WHOLE (source rank, expert) table with one all-gather, so the overflow decision
+    // below is the same on every rank and nobody is left waiting in a send / recv group for a peer that bailed out
+    const size_t ne = (size_t)e->num_experts;
     if (e->world == 1) {
-      PE_HIP(e, hipMemcpyAsync(e->h_counts_recv, e->d_counts, (size_t)e->num_experts * 4, hipMemcpyDeviceToHost, s));
+      PE_HIP(e, hipMemcpyAsync(e->h_counts_all, e->d_counts, ne * 4, hipMemcpyDeviceToHost, s));
     } else {
-      PE_NCCL(e, ncclGroupStart());
-      for (int r = 0; r < e->world; ++r) {
-        PE_NCCL(e, ncclSend(e->d_counts + r * e->epr, e->epr, ncclInt32, r, e->comm->nccl, s));
-        PE_NCCL(e, ncclRecv(e->d_counts_recv + r * e->epr, e->epr, ncclInt32, r, e->comm->nccl, s));
-      }
-      PE_NCCL(e, ncclGroupEnd());
-      PE_HIP(e, hipMemcpyAsync(e->h_counts_recv, e->d_counts_recv, (size_t)e->num_experts * 4, hipMemcpyDeviceToHost, s));
+      PE_NCCL(e, ncclAllGather(e->d_counts, e->d_counts_all, ne, ncclInt32, e->comm->nccl, s));
+      PE_HIP(e, hipMemcpyAsync(e->h_counts_all, e->d_counts_all, ne * e->world * 4, hipMemcpyDeviceToHost, s));
     }
     PE_HIP(e, hipStreamSynchronize(s));   // the per-peer row counts size the exchange (reference: worker-thread wait)
+    std::memcpy(e->h_counts, e->h_counts_all + (size_t)e->rank * ne, ne * 4);
+    std::vector<int32_t> tmp((size_t)e->world * e->epr);
+    int overflow_rank = -1;
+    for (int dst = 0; dst < e->world; ++dst) {
+      for (int r = 0; r < e->world; ++r)
+        for (int le = 0; le < e->epr; ++le) tmp[(size_t)r * e->epr + le] = e->h_counts_all[(size_t)r * ne + (size_t)dst * e->epr + le];
+      if (dst == e->rank) std::memcpy(e->h_counts_recv, tmp.data(), tmp.size() * 4);
+      if (overflow_rank < 0 && ep_padded_rows(e, tmp.data()) > e->max_recv) overflow_rank = dst;
+    }
     ep_layout(e);
-    if (e->num_recv > e->max_recv) { e->err = "dispatch: received rows exceed max_recv_tokens"; return -1; }
-    if (ep_exchange_rows(e, e->d_send, e->send_off, e->send_tot, e->d_recv, e->recv_off, e->recv_tot, s)) return -1;
+    if (overflow_rank >= 0) {   // collective: every rank sees the same table and returns here, before any row moves
+      e->err = "dispatch: rank " + std::to_string(overflow_rank) + " would receive more rows than max_recv_tokens";
+      return -1;
+    }
+    if (ep_exchange_rows(e, e->wrow, e->d_send, e->send_off, e->send_tot, e->d_recv, e->recv_off, e->recv_tot, s)) return -1;
   } else {
+    PE_HIP(e, hipMemcpyAsync(e->h_counts, e->d_counts, (size_t)e->num_experts * 4, hipMemcpyDeviceToHost, s));
     PE_HIP(e, hipStreamSynchronize(s));   // loopback: peers pull from d_send in their dispatch_recv
   }
   e->sent = true;
   return 0;
 }
 
-int32_t pegainfer_ep_dispatch_recv(pegainfer_ep_t h, int32_t* out_num_tokens, Half* out_x, int64_t out_x_stride_elems,
+int32_t pegainfer_ep_dispatch_recv(pegainfer_ep_t h, int32_t* out_num_tokens_ptr, void* out_x_ptr, size_t out_x_stride,
+                                   void* out_x_scale_ptr, size_t out_x_scale_stride_elem, size_t out_x_scale_stride_token,
                                    pegainfer_stream_t stream) {
   Ep* e = static_cast<Ep*>(h);
-  if (!e || !e->sent || !out_x || out_x_stride_elems < e->hidden) return -1;
-  if (!rows_aligned(out_x, out_x_stride_elems)) { e->err = "dispatch_recv: out_x rows must be 16-byte aligned"; return -1; }
+  if (!e) return -1;
+  if (!e->sent) { e->err = "dispatch_recv before dispatch_send"; return -1; }
+  if (!out_x_ptr || out_x_stride < (size_t)e->pay_bytes) { e->err = "dispatch_recv: null out_x or a stride shorter than a row"; return -1; }
+  if (out_x_scale_ptr && e->hidden_scale == 0) { e->err = "dispatch_recv: scale plane given but hidden_dim_scale == 0"; return -1; }
   hipStream_t s = st(stream);
   if (e->hub) {
     // loopback transport: pull what every virtual rank routed to this one
@@ -552,68 +669,97 @@ int32_t pegainfer_ep_dispatch_recv(pegainfer_ep_t h, int32_t* out_num_tokens, Ha
       for (int le = 0; le < e->epr; ++le) e->h_counts_recv[r * e->epr + le] = p->h_counts[e->rank * e->epr + le];
     }
     ep_layout(e);   // my own send layout (needed by the combine) and the receive layout
-    if (e->num_recv > e->max_recv) { e->err = "dispatch: received rows exceed max_recv_tokens"; return -1; }
+    if (e->num_recv_padded > e->max_recv) { e->err = "dispatch: received rows (expert groups padded) exceed max_recv_tokens"; return -1; }
     for (int r = 0; r < e->world; ++r) {
       Ep* p = e->hub->eps[r];
       int64_t off = 0;
       for (int i = 0; i < e->rank * e->epr; ++i) off += p->h_counts[i];
       if (e->recv_tot[r] > 0)
-        PE_HIP(e, hipMemcpyAsync(e->d_recv + e->recv_off[r] * e->hidden, p->d_send + off * e->hidden,
-                                 (size_t)e->recv_tot[r] * e->hidden * 2, hipMemcpyDeviceToDevice, s));
+        PE_HIP(e, hipMemcpyAsync(e->d_recv + e->recv_off[r] * e->wrow, p->d_send + off * e->wrow,
+                                 (size_t)e->recv_tot[r] * e->wrow, hipMemcpyDeviceToDevice, s));
     }
   }
   if (ep_build_row_map(e, s)) return -1;
   if (e->num_recv > 0)
-    ep_rows_kernel<false><<<e->num_recv, 256, 0, s>>>(e->d_recv, e->hidden, out_x, out_x_stride_elems, e->d_row_map, e->hidden);
+    ep_unpack_kernel<<<e->num_recv, 256, 0, s>>>(e->d_recv, e->wrow, e->pay_bytes, e->hidden_scale, e->scale_off, e->d_row_map,
+                                                 static_cast<unsigned char*>(out_x_ptr), (long)out_x_stride,
+                                                 static_cast<float*>(out_x_scale_ptr), (long)out_x_scale_stride_elem,
+                                                 (long)out_x_scale_stride_token);
   PE_HIP(e, hipGetLastError());
-  if (out_num_tokens) *out_num_tokens = e->num_recv;
+  // the per-local-expert counts go to the caller's DEVICE array (a2a_dispatch_recv.cu:220-224)
+  if (out_num_tokens_ptr)
+    PE_HIP(e, hipMemcpyAsync(out_num_tokens_ptr, e->d_tokens_per_expert, (size_t)e->epr * 4, hipMemcpyDeviceToDevice, s));
+  e->received = true;
   return 0;
 }
 
-int32_t pegainfer_ep_combine_send(pegainfer_ep_t h, const Half* expert_x, int64_t expert_x_stride_elems,
-                                  pegainfer_stream_t stream) {
+int32_t pegainfer_ep_combine_send(pegainfer_ep_t h, const void* expert_x_ptr, size_t expert_x_stride, pegainfer_stream_t stream) {
   Ep* e = static_cast<Ep*>(h);
-  if (!e || !e->sent || (e->num_recv > 0 && !expert_x) || expert_x_stride_elems < e->hidden) return -1;
-  if (e->num_recv > 0 && !rows_aligned(expert_x, expert_x_stride_elems)) {
-    e->err = "combine_send: expert_x rows must be 16-byte aligned";
+  if (!e) return -1;
+  if (!e->received) { e->err = "combine_send before dispatch_recv"; return -1; }
+  if (e->num_recv > 0 && (!expert_x_ptr || expert_x_stride < (size_t)e->cpay_bytes)) {
+    e->err = "combine_send: null expert_x or a stride shorter than a row";
     return -1;
   }
   hipStream_t s = st(stream);
-  // expert-major rows back into the source-major order they arrived in, then home
+  // the caller's padded expert-major rows back into the source-major order they arrived in, then home
   if (e->num_recv > 0)
-    ep_rows_kernel<true><<<e->num_recv, 256, 0, s>>>(expert_x, expert_x_stride_elems, e->d_back_send, e->hidden, e->d_row_map, e->hidden);
+    ep_gather_kernel<<<e->num_recv, 256, 0, s>>>(static_cast<const unsigned char*>(expert_x_ptr), (long)expert_x_stride,
+                                                 e->cpay_bytes, e->d_row_map, e->crow, e->d_back_send);
   PE_HIP(e, hipGetLastError());
-  if (e->comm) return ep_exchange_rows(e, e->d_back_send, e->recv_off, e->recv_tot, e->d_back_recv, e->send_off, e->send_tot, s);
-  PE_HIP(e, hipStreamSynchronize(s));   // loopback: peers pull from d_back_send in their combine_recv
+  if (e->comm) {
+    if (ep_exchange_rows(e, e->crow, e->d_back_send, e->recv_off, e->recv_tot, e->d_back_recv, e->send_off, e->send_tot, s)) return -1;
+  } else {
+    PE_HIP(e, hipStreamSynchronize(s));   // loopback: peers pull from d_back_send in their combine_recv
+  }
+  e->combine_sent = true;
   return 0;
 }
 
-int32_t pegainfer_ep_combine_recv(pegainfer_ep_t h, int32_t num_tokens, Half* out_tokens, int64_t out_stride_elems,
-                                  const int32_t* indices, const float* weights, int32_t accumulate,
-                                  pegainfer_stream_t stream) {
+int32_t pegainfer_ep_combine_recv(pegainfer_ep_t h, size_t num_tokens, size_t num_recv_tokens, int32_t in_dtype,
+                                  void* out_tokens_ptr, size_t out_tokens_stride, const int32_t* indices_ptr,
+                                  size_t indices_stride, const float* weights_ptr, size_t weights_stride,
+                                  const int32_t* bound_m_ptr, int32_t accumulate, pegainfer_stream_t stream) {
   Ep* e = static_cast<Ep*>(h);
-  (void)indices;  // the route is remembered from dispatch_send (slot of every (token, k) pair)
-  if (!e || !e->sent || num_tokens * e->topk != e->num_pairs || (num_tokens > 0 && (!out_tokens || !weights)) ||
-      out_stride_elems < e->hidden)
+  (void)num_recv_tokens;                  // "currently ignored by the a2a combine_recv kernel" (moe_pplx.rs:238)
+  (void)indices_ptr; (void)indices_stride;  // the route is remembered from dispatch_send (slot of every (token, k) pair)
+  if (!e) return -1;
+  if (!e->combine_sent) { e->err = "combine_recv before combine_send"; return -1; }
+  if ((int)num_tokens != e->num_tokens) { e->err = "combine_recv: num_tokens differs from the dispatch"; return -1; }
+  if (ep_elem_of(in_dtype) != e->out_elem || in_dtype == PEGAINFER_SCALAR_F16) {
+    e->err = "combine_recv: in_dtype does not match out_elemsize (bf16 or f32 expert outputs)";
     return -1;
-  if (num_tokens > 0 && !rows_aligned(out_tokens, out_stride_elems)) {
-    e->err = "combine_recv: out_tokens rows must be 16-byte aligned";
+  }
+  const int oel = ep_elem_of(e->out_dtype);
+  if (num_tokens > 0 && (!out_tokens_ptr || !weights_ptr || out_tokens_stride < (size_t)e->hidden || weights_stride < (size_t)e->topk ||
+                         (reinterpret_cast<uintptr_t>(out_tokens_ptr) & 15u) || (out_tokens_stride * oel) % 16)) {
+    e->err = "combine_recv: out_tokens rows must be 16-byte aligned, strides at least a row";
     return -1;
   }
   hipStream_t s = st(stream);
   if (e->hub) {
     for (int r = 0; r < e->world; ++r) {
       Ep* p = e->hub->eps[r];
-      if (!p) { e->err = "loopback combine_recv: missing virtual rank"; return -1; }
+      if (!p || !p->combine_sent) { e->err = "loopback combine_recv before every virtual rank's combine_send"; return -1; }
       // rank r holds my rows at its source-major offset recv_off[me]
       if (e->send_tot[r] > 0)
-        PE_HIP(e, hipMemcpyAsync(e->d_back_recv + e->send_off[r] * e->hidden, p->d_back_send + p->recv_off[e->rank] * e->hidden,
-                                 (size_t)e->send_tot[r] * e->hidden * 2, hipMemcpyDeviceToDevice, s));
+        PE_HIP(e, hipMemcpyAsync(e->d_back_recv + e->send_off[r] * e->crow, p->d_back_send + p->recv_off[e->rank] * e->crow,
+                                 (size_t)e->send_tot[r] * e->crow, hipMemcpyDeviceToDevice, s));
     }
   }
-  if (num_tokens > 0)
-    ep_combine_kernel<<<num_tokens, 256, 0, s>>>(e->d_back_recv, e->d_slot, weights, e->topk, e->hidden, out_tokens,
-                                                 out_stride_elems, accumulate);
+  if (num_tokens > 0) {
+    const int nt = e->num_tokens;
+#define EP_COMBINE(TIN, TOUT)                                                                                              \
+  ep_combine_kernel<TIN, TOUT><<<nt, 256, 0, s>>>(e->d_back_recv, e->crow, e->d_slot, weights_ptr, (long)weights_stride,   \
+                                                  e->topk, e->hidden, nt, bound_m_ptr, static_cast<TOUT*>(out_tokens_ptr), \
+                                                  (long)out_tokens_stride, accumulate)
+    const bool in32 = in_dtype == PEGAINFER_SCALAR_F32, out32 = e->out_dtype == PEGAINFER_SCALAR_F32;
+    if (in32 && out32) EP_COMBINE(float, float);
+    else if (in32) EP_COMBINE(float, Half);
+    else if (out32) EP_COMBINE(Half, float);
+    else EP_COMBINE(Half, Half);
+#undef EP_COMBINE
+  }
   PE_HIP(e, hipGetLastError());
   return 0;
 }

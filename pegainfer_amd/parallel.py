@@ -17,6 +17,7 @@ What the reference does and where it lives here:
   at bs=1): latency-bound, so each verb is ONE collective call (no bucketing), and xGMI is point-to-point, so
   nothing here assumes a switch.
 """
+import ctypes
 import numpy as np
 
 
@@ -331,10 +332,28 @@ class NativeComm:
         return routed if shared is None else routed + shared.float()
 
 
+class EpTopology(ctypes.Structure):
+    """pegainfer_ep_topology_t = EpTopology (ep_backend.rs:24-51), field for field"""
+    _fields_ = [(n, ctypes.c_size_t) for n in ("world_size", "rank", "node_size", "dp_size", "num_experts",
+                                                "num_experts_per_token", "hidden_dim", "hidden_dim_scale",
+                                                "max_num_tokens", "max_recv_tokens", "max_private_tokens",
+                                                "expert_padding")]
+
+
+class EpDtypes(ctypes.Structure):
+    """pegainfer_ep_dtypes_t = EpDtypes (ep_backend.rs:53-66)"""
+    _fields_ = [("in_elemsize", ctypes.c_size_t), ("out_elemsize", ctypes.c_size_t), ("out_dtype", ctypes.c_int32),
+                ("scale_elemsize", ctypes.c_size_t)]
+
+
+SCALAR_BF16, SCALAR_F16, SCALAR_F32 = 0, 1, 2
+
+
 class EpEndpoint:
-    """One rank of the expert-parallel dispatch / combine (ep_backend.rs:213-331) on include/pegainfer_comm.h.
-    comm = NativeComm (RCCL transport) or hub = handle from EpEndpoint.hub(world) (loopback: virtual ranks in one
-    process, for single-GPU tests of the multi-rank routing)."""
+    """One rank of the expert-parallel dispatch / combine on include/pegainfer_comm.h - the EpBackend surface of the
+    reference (ep_backend.rs:213-331), argument for argument.  comm = NativeComm (RCCL transport) or hub = handle from
+    EpEndpoint.hub(world) (loopback: virtual ranks in one process, for single-GPU tests of the multi-rank routing).
+    Tensors are torch CUDA tensors; payload dtype bf16 or f32 (rows travel as opaque bytes)."""
 
     @staticmethod
     def hub(world):
@@ -344,13 +363,22 @@ class EpEndpoint:
             raise RuntimeError("pegainfer_ep_hub_create failed")
         return h
 
-    def __init__(self, hidden, max_tokens, max_recv, num_experts, topk, comm=None, hub=None, rank=0):
+    def __init__(self, hidden, max_tokens, max_recv, num_experts, topk, comm=None, hub=None, rank=0, world=None,
+                 expert_padding=1, hidden_scale=0, in_elemsize=2, out_elemsize=2, max_private_tokens=0):
         from . import ffi
         self.lib = ffi.host_lib()
-        self.hidden, self.topk, self.max_recv = hidden, topk, max_recv
-        self.world = comm.world if comm is not None else None
-        self.h = self.lib.pegainfer_ep_create(comm.h if comm is not None else None, hub, rank, hidden, max_tokens, max_recv,
-                                              num_experts, topk)
+        self.hidden, self.topk, self.max_recv, self.hidden_scale = hidden, topk, max_recv, hidden_scale
+        self.world = comm.world if comm is not None else world
+        if self.world is None:
+            raise ValueError("loopback endpoints need world=")
+        self.rank = comm.rank if comm is not None else rank
+        self.epr = num_experts // self.world
+        self.in_el, self.out_el = in_elemsize, out_elemsize
+        topo = EpTopology(self.world, self.rank, self.world, 1, num_experts, topk, hidden, hidden_scale, max_tokens, max_recv,
+                          max_private_tokens, expert_padding)
+        dt = EpDtypes(in_elemsize, out_elemsize, SCALAR_F32 if out_elemsize == 4 else SCALAR_BF16, 4 if hidden_scale else 0)
+        self.h = self.lib.pegainfer_ep_create(comm.h if comm is not None else None, hub, ctypes.addressof(topo),
+                                              ctypes.addressof(dt))
         if not self.h:
             raise RuntimeError("pegainfer_ep_create failed")
 
@@ -367,38 +395,59 @@ class EpEndpoint:
         import torch
         return torch.cuda.current_stream().cuda_stream
 
-    def dispatch_send(self, x, indices, weights):
-        self._chk(self.lib.pegainfer_ep_dispatch_send(self.h, x.shape[0], x.data_ptr(), x.stride(0) if x.shape[0] else self.hidden,
-                                                      indices.data_ptr(), weights.data_ptr(), self._s()), "dispatch_send")
+    @staticmethod
+    def _p(t):
+        return t.data_ptr() if t is not None else None
 
-    def dispatch_recv(self):
-        import ctypes
+    def dispatch_send(self, x, indices, weights, x_scale=None, bound_m=None):
+        """x [T, hidden] (row stride in BYTES goes over the ABI), indices i32 [T, topk], weights f32 [T, topk],
+        x_scale f32 [T, hidden_scale] or None, bound_m = device i32[1] or None"""
+        T = x.shape[0]
+        self._chk(self.lib.pegainfer_ep_dispatch_send(
+            self.h, T, x.data_ptr(), (x.stride(0) if T else self.hidden) * x.element_size(),
+            self._p(x_scale), x_scale.stride(1) if x_scale is not None else 0, x_scale.stride(0) if x_scale is not None else 0,
+            indices.data_ptr(), indices.stride(0) if T else self.topk, weights.data_ptr(), weights.stride(0) if T else self.topk,
+            self._p(bound_m), self._s()), "dispatch_send")
 
+    def dispatch_recv(self, dtype=None, with_scale=False):
+        """-> (out_x [max_recv, hidden] in the padded expert-major layout, tokens_per_expert device i32 [E / world]
+        [, out_x_scale f32 [max_recv, hidden_scale]])"""
         import torch
-        out = torch.empty((self.max_recv, self.hidden), dtype=torch.bfloat16, device="cuda")
-        n = ctypes.c_int32(0)
-        self._chk(self.lib.pegainfer_ep_dispatch_recv(self.h, ctypes.addressof(n), out.data_ptr(), self.hidden, self._s()),
-                  "dispatch_recv")
-        return out[:n.value], n.value
+        dtype = dtype or (torch.float32 if self.in_el == 4 else torch.bfloat16)
+        out = torch.zeros((self.max_recv, self.hidden), dtype=dtype, device="cuda")
+        cnt = torch.full((self.epr,), -1, dtype=torch.int32, device="cuda")
+        sc = torch.zeros((self.max_recv, self.hidden_scale), dtype=torch.float32, device="cuda") if with_scale else None
+        self._chk(self.lib.pegainfer_ep_dispatch_recv(self.h, cnt.data_ptr(), out.data_ptr(), self.hidden * out.element_size(),
+                                                      self._p(sc), 1 if with_scale else 0, self.hidden_scale if with_scale else 0,
+                                                      self._s()), "dispatch_recv")
+        return (out, cnt, sc) if with_scale else (out, cnt)
 
-    def tokens_per_expert(self, n_local):
+    def num_recv_tokens(self):
+        return self.lib.pegainfer_ep_num_recv_tokens(self.h)
+
+    def num_padded_recv_tokens(self):
+        return self.lib.pegainfer_ep_num_padded_recv_tokens(self.h)
+
+    def tokens_per_expert(self):
         """host copy of the per-local-expert row counts of the last dispatch_recv (the reference reads its device
-        counter with a D2H copy; the device pointer is pegainfer_ep_tokens_per_expert)"""
-        import ctypes
-
+        counter with a D2H copy; the device pointer is pegainfer_ep_tokens_per_expert_ptr)"""
         import numpy as np
-        buf = (ctypes.c_uint32 * n_local)()
-        self._chk(self.lib.pegainfer_ep_tokens_per_expert_host(self.h, ctypes.addressof(buf), n_local), "tokens_per_expert")
+        buf = (ctypes.c_uint32 * self.epr)()
+        self._chk(self.lib.pegainfer_ep_tokens_per_expert_host(self.h, ctypes.addressof(buf), self.epr), "tokens_per_expert")
         return np.frombuffer(buf, dtype=np.uint32).copy()
 
     def combine_send(self, expert_x):
-        self._chk(self.lib.pegainfer_ep_combine_send(self.h, expert_x.data_ptr(), expert_x.stride(0) if expert_x.shape[0] else self.hidden,
+        self._chk(self.lib.pegainfer_ep_combine_send(self.h, expert_x.data_ptr(), expert_x.stride(0) * expert_x.element_size(),
                                                      self._s()), "combine_send")
 
-    def combine_recv(self, out_tokens, indices, weights, accumulate=False):
-        self._chk(self.lib.pegainfer_ep_combine_recv(self.h, out_tokens.shape[0], out_tokens.data_ptr(),
-                                                     out_tokens.stride(0) if out_tokens.shape[0] else self.hidden, indices.data_ptr(),
-                                                     weights.data_ptr(), int(bool(accumulate)), self._s()), "combine_recv")
+    def combine_recv(self, out_tokens, indices, weights, accumulate=False, bound_m=None, in_dtype=None):
+        T = out_tokens.shape[0]
+        if in_dtype is None:
+            in_dtype = SCALAR_F32 if self.out_el == 4 else SCALAR_BF16
+        self._chk(self.lib.pegainfer_ep_combine_recv(
+            self.h, T, 0, in_dtype, out_tokens.data_ptr(), out_tokens.stride(0) if T else self.hidden, indices.data_ptr(),
+            indices.stride(0) if T else self.topk, weights.data_ptr(), weights.stride(0) if T else self.topk, self._p(bound_m),
+            int(bool(accumulate)), self._s()), "combine_recv")
         return out_tokens
 
 
