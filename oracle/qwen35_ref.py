@@ -248,11 +248,28 @@ class Qwen35Oracle:
 def synthetic_weights(cfg, seed=42, std=0.02):
     """Seeded bf16 checkpoint with the reference's tensor names and dtypes (A_log and the gated-norm weight are
     f32, weights.rs:226-241)."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
     rng = np.random.default_rng(seed)
     c = cfg
+    CH = 1 << 22
+    pool = ThreadPoolExecutor(max_workers=max(1, min(32, os.cpu_count() or 1)))
+    counter = [0]
 
     def t(*shape, scale=std, mean=0.0):
-        return bf16_round((rng.standard_normal(shape, dtype=F32) * F32(scale) + F32(mean)).astype(F32))
+        """chunk j of tensor i from default_rng([seed, i, j]): values independent of the host thread count (the
+        248 320 x 2560 embedding is 636 M draws - a minute on one thread)"""
+        idx = counter[0]
+        counter[0] += 1
+        n = int(np.prod(shape))
+        out = np.empty(n, dtype=F32)
+
+        def fill(j):
+            lo, hi = j * CH, min(n, (j + 1) * CH)
+            a = np.random.default_rng([seed, idx, j]).standard_normal(hi - lo, dtype=F32)
+            out[lo:hi] = bf16_round(a * F32(scale) + F32(mean))
+        list(pool.map(fill, range(-(-n // CH))))
+        return out.reshape(shape)
 
     w = {f"{WP}.embed_tokens.weight": t(c.vocab_size, c.hidden_size), f"{WP}.norm.weight": t(c.hidden_size, scale=0.1)}
     for i, kind in enumerate(c.layer_types):

@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -25,6 +26,18 @@ int32_t deepseek_f32_to_bf16_cuda(const float* input, Half* output, int32_t n, p
 
 namespace pc {
 
+// ---- one-shot small-message all-reduce over peer access (the regime of the DSV4 decode
+// collectives, moe-tilelang-review.md:12: ~107 f32 all-reduces of 16 KB per token, and of Qwen3 TP decode: 72 x 5 KB) ----
+constexpr int kOsMaxWorld = 8;                 // one xGMI node
+constexpr int kOsMaxBytes = 64 * 1024;         // payloads above this go to RCCL
+constexpr int kOsSeg = 16 * 1024;              // one 1024-thread workgroup moves one 16-byte vector per thread
+constexpr int kOsMaxWg = kOsMaxBytes / kOsSeg;
+constexpr size_t kOsDataBytes = (size_t)2 * kOsMaxWorld * kOsMaxBytes;   // [parity][source rank][payload]
+constexpr size_t kOsFlagStride = 64;                                      // one flag per cache line
+constexpr size_t kOsFlagBytes = (size_t)2 * kOsMaxWorld * kOsMaxWg * kOsFlagStride;
+constexpr size_t kOsSlabBytes = kOsDataBytes + kOsFlagBytes;
+struct OsPeers { unsigned char* slab[kOsMaxWorld]; };
+
 struct Comm {
   int device = 0, rank = 0, world = 1;
   ncclComm_t nccl = nullptr;
@@ -32,6 +45,14 @@ struct Comm {
   hipEvent_t ev_in = nullptr, ev_out = nullptr;
   float* scratch = nullptr;
   size_t scratch_n = 0;
+  // one-shot path: this rank's slab (fine-grained device memory, IPC-exported), the peers' slabs as mapped here,
+  // per-workgroup epoch counters and a status word (device-local)
+  unsigned char* os_slab = nullptr;
+  OsPeers os_peers{};
+  bool os_opened[kOsMaxWorld] = {};
+  uint32_t *os_epoch = nullptr, *os_status = nullptr;
+  bool os_active = false;
+  unsigned long long os_timeout_ticks = 0;
   std::string err;
 };
 
@@ -71,6 +92,132 @@ static int cast_to_bf16(Comm* c, const float* in, Half* out, int64_t n, hipStrea
     if (deepseek_f32_to_bf16_cuda(in + o, out + o, m, s)) { c->err = "f32 -> bf16 cast launch failed"; return -1; }
   }
   return 0;
+}
+
+// ---- one-shot all-reduce kernel ------------------------------------------------------------------------------------
+// Push model (xGMI writes are posted, reads are round trips): every rank stores its payload segment into EVERY rank's
+// slab (slot [parity][my rank]) with write-through system-scope stores, drains them (s_waitcnt vmcnt(0)), then stores
+// the epoch into flag [parity][my rank][segment] of every rank; a rank that has seen all `world` flags of a segment
+// reads the `world` copies from ITS OWN slab (cache-bypassing loads) and sums them in rank order in f32 - the same
+// order on every rank, so all ranks hold bit-identical results.  Epochs count up per segment index in device memory
+// (incremented by the kernel itself: hipGraph replays need no host help); parity = epoch & 1 double-buffers the slab:
+// a peer can only start epoch e + 1 after it has seen MY flag of epoch e, which I send after I finished reading e - 1.
+// Every spin is bounded; an expired wait sets the status word and the launch returns (the result is then undefined).
+typedef __attribute__((ext_vector_type(4))) uint32_t os_u4;
+__device__ __forceinline__ void os_st16(void* p, uint4 v) {
+  const os_u4 w = {v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(w) : "memory");
+}
+__device__ __forceinline__ void os_st4(void* p, uint32_t v) {
+  asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+// cache-bypassing (system-scope) loads through the compiler's own waitcnt bookkeeping: the `world` copies of a vector
+// are requested back to back and waited for once (an asm load + wait per copy would serialise 8 round trips)
+__device__ __forceinline__ uint4 os_ld16(const void* p) {
+  const unsigned long long lo = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  const unsigned long long hi = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  return make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+}
+__device__ __forceinline__ uint32_t os_ld4(const void* p) {
+  return __hip_atomic_load(reinterpret_cast<const uint32_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ size_t os_data_off(int parity, int src) { return ((size_t)parity * kOsMaxWorld + src) * kOsMaxBytes; }
+__device__ __forceinline__ size_t os_flag_off(int parity, int src, int seg) {
+  return kOsDataBytes + (((size_t)parity * kOsMaxWorld + src) * kOsMaxWg + seg) * kOsFlagStride;
+}
+__device__ __forceinline__ float os_bf_lo(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
+__device__ __forceinline__ float os_bf_hi(uint32_t w) { return __builtin_bit_cast(float, w & 0xFFFF0000u); }
+__device__ __forceinline__ uint32_t os_pack2(float lo, float hi) {
+  typedef __attribute__((ext_vector_type(2))) float f2;
+  typedef __attribute__((ext_vector_type(2))) __bf16 b2;
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f2{lo, hi}, b2));
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(1024) void oneshot_all_reduce_kernel(OsPeers peers, int rank, int world, const unsigned char* in,
+                                                                  unsigned char* out, int nbytes, uint32_t* epoch_ctr,
+                                                                  uint32_t* status, unsigned long long timeout_ticks) {
+  __shared__ uint32_t s_epoch, s_fail;
+  const int seg = blockIdx.x, tid = threadIdx.x;
+  if (tid == 0) { s_epoch = epoch_ctr[seg] + 1; epoch_ctr[seg] = s_epoch; s_fail = 0; }   // launches are stream-ordered
+  __syncthreads();
+  const uint32_t ep = s_epoch;
+  const int par = ep & 1;
+  const int seg_off = seg * kOsSeg;
+  const bool act = seg_off + tid * 16 < nbytes;
+  // 1. push my segment everywhere (own slab included), then drain the stores
+  if (act) {
+    const uint4 mine = *reinterpret_cast<const uint4*>(in + seg_off + tid * 16);
+    for (int r = 0; r < world; ++r) os_st16(peers.slab[r] + os_data_off(par, rank) + seg_off + tid * 16, mine);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  // 2. signal every rank, 3. wait for every rank's signal in my own slab
+  if (tid < world) os_st4(peers.slab[tid] + os_flag_off(par, rank, seg), ep);
+  if (tid < world) {
+    const unsigned char* f = peers.slab[rank] + os_flag_off(par, tid, seg);
+    const unsigned long long t0 = wall_clock64();
+    while ((int32_t)(os_ld4(f) - ep) < 0) {
+      if (wall_clock64() - t0 > timeout_ticks) { atomicOr(&s_fail, 1u << tid); break; }
+      __builtin_amdgcn_s_sleep(2);
+    }
+  }
+  __syncthreads();
+  if (s_fail) {
+    if (tid == 0) { status[0] = 0x100u | s_fail; status[1] = ep; status[2] = (uint32_t)seg; }
+    return;
+  }
+  // 4. reduce the `world` copies in rank order, f32 accumulation, one rounding
+  if (act) {
+    const unsigned char* base = peers.slab[rank] + seg_off + tid * 16;
+    if (BF16) {
+      float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      uint4 cp[kOsMaxWorld];
+#pragma unroll
+      for (int r = 0; r < kOsMaxWorld; ++r) cp[r] = r < world ? os_ld16(base + os_data_off(par, r)) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < kOsMaxWorld; ++r) {
+        if (r >= world) break;
+        const uint4 v = cp[r];
+        a[0] += os_bf_lo(v.x); a[1] += os_bf_hi(v.x); a[2] += os_bf_lo(v.y); a[3] += os_bf_hi(v.y);
+        a[4] += os_bf_lo(v.z); a[5] += os_bf_hi(v.z); a[6] += os_bf_lo(v.w); a[7] += os_bf_hi(v.w);
+      }
+      uint4 o;
+      o.x = os_pack2(a[0], a[1]); o.y = os_pack2(a[2], a[3]); o.z = os_pack2(a[4], a[5]); o.w = os_pack2(a[6], a[7]);
+      *reinterpret_cast<uint4*>(out + seg_off + tid * 16) = o;
+    } else {
+      float a[4] = {0.f, 0.f, 0.f, 0.f};
+      uint4 cp[kOsMaxWorld];
+#pragma unroll
+      for (int r = 0; r < kOsMaxWorld; ++r) cp[r] = r < world ? os_ld16(base + os_data_off(par, r)) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < kOsMaxWorld; ++r) {
+        if (r >= world) break;
+        const uint4 v = cp[r];
+        a[0] += __builtin_bit_cast(float, v.x); a[1] += __builtin_bit_cast(float, v.y);
+        a[2] += __builtin_bit_cast(float, v.z); a[3] += __builtin_bit_cast(float, v.w);
+      }
+      *reinterpret_cast<float4*>(out + seg_off + tid * 16) = make_float4(a[0], a[1], a[2], a[3]);
+    }
+  }
+}
+
+// 1 = taken by the one-shot path, 0 = not eligible (caller falls through to RCCL), -1 = launch error
+static int oneshot_all_reduce(Comm* c, void* data, int64_t n, int elem, hipStream_t s) {
+  const int64_t bytes = n * elem;
+  if (!c->os_active || bytes > kOsMaxBytes || (bytes & 15) || (reinterpret_cast<uintptr_t>(data) & 15)) return 0;
+  const int wgs = static_cast<int>((bytes + kOsSeg - 1) / kOsSeg);
+  if (elem == 2)
+    oneshot_all_reduce_kernel<true><<<wgs, 1024, 0, s>>>(c->os_peers, c->rank, c->world, static_cast<unsigned char*>(data),
+                                                         static_cast<unsigned char*>(data), (int)bytes, c->os_epoch,
+                                                         c->os_status, c->os_timeout_ticks);
+  else
+    oneshot_all_reduce_kernel<false><<<wgs, 1024, 0, s>>>(c->os_peers, c->rank, c->world, static_cast<unsigned char*>(data),
+                                                          static_cast<unsigned char*>(data), (int)bytes, c->os_epoch,
+                                                          c->os_status, c->os_timeout_ticks);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { c->err = std::string("one-shot all-reduce launch: ") + hipGetErrorString(e); return -1; }
+  return 1;
 }
 
 // ---- expert-parallel kernels ----------------------------------------------------------------------------------
@@ -361,15 +508,17 @@ int32_t pegainfer_comm_unique_id(void* out_128_bytes) {
   return 0;
 }
 
-pegainfer_comm_t pegainfer_comm_create(int32_t device_ordinal, int32_t rank, int32_t world, const void* unique_id_128) {
-  if (world < 1 || rank < 0 || rank >= world || (world > 1 && !unique_id_128)) return nullptr;
+static pegainfer_comm_t comm_create(int32_t device_ordinal, int32_t rank, int32_t world, const void* unique_id_128, bool rccl) {
+  if (world < 1 || rank < 0 || rank >= world || (rccl && world > 1 && !unique_id_128)) return nullptr;
   if (hipSetDevice(device_ordinal) != hipSuccess) return nullptr;
   Comm* c = new Comm();
   c->device = device_ordinal; c->rank = rank; c->world = world;
+  const char* to = getenv("PEGAINFER_ONESHOT_TIMEOUT_MS");
+  c->os_timeout_ticks = (unsigned long long)(to && *to ? atoll(to) : 10000) * 100000ull;   // wall_clock64: 100 MHz
   bool ok = hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming) == hipSuccess;
-  if (ok && world > 1) {
+  if (ok && rccl && world > 1) {
     ncclUniqueId id;
     std::memcpy(&id, unique_id_128, 128);
     ok = ncclCommInitRank(&c->nccl, world, id, rank) == ncclSuccess;
@@ -377,10 +526,112 @@ pegainfer_comm_t pegainfer_comm_create(int32_t device_ordinal, int32_t rank, int
   if (!ok) { pegainfer_comm_destroy(c); return nullptr; }
   return c;
 }
+pegainfer_comm_t pegainfer_comm_create(int32_t device_ordinal, int32_t rank, int32_t world, const void* unique_id_128) {
+  return comm_create(device_ordinal, rank, world, unique_id_128, true);
+}
+pegainfer_comm_t pegainfer_comm_create_peer_only(int32_t device_ordinal, int32_t rank, int32_t world) {
+  return world > kOsMaxWorld ? nullptr : comm_create(device_ordinal, rank, world, nullptr, false);
+}
+
+// ---- one-shot path: slab export / attach ----
+int32_t pegainfer_comm_oneshot_handle(pegainfer_comm_t h, void* out_64_bytes) {
+  Comm* c = static_cast<Comm*>(h);
+  if (!c || !out_64_bytes) return -1;
+  if (c->world > kOsMaxWorld) { c->err = "one-shot all-reduce: at most 8 ranks (one xGMI node)"; return -1; }
+  PC_HIP(c, hipSetDevice(c->device));
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+  hipIpcMemHandle_t ipc;
+  if (!c->os_slab) {
+    // fine-grained device memory: peers' stores over xGMI and this device's cache-bypassing loads meet in HBM.  If the
+    // runtime cannot allocate or export that kind, fall back to a plain hipMalloc slab (every access to it is a
+    // system-scope write-through store or cache-bypassing load anyway)
+    for (int attempt = 0; attempt < 2 && !c->os_slab; ++attempt) {
+      unsigned char* p = nullptr;
+      hipError_t e = attempt == 0 ? hipExtMallocWithFlags(reinterpret_cast<void**>(&p), kOsSlabBytes, hipDeviceMallocFinegrained)
+                                  : hipMalloc(reinterpret_cast<void**>(&p), kOsSlabBytes);
+      if (e == hipSuccess && hipIpcGetMemHandle(&ipc, p) == hipSuccess) { c->os_slab = p; break; }
+      (void)hipGetLastError();
+      if (p) (void)hipFree(p);
+    }
+    if (!c->os_slab) { c->err = "one-shot all-reduce: hipIpcGetMemHandle failed for the slab (fine-grained and plain)"; return -1; }
+    PC_HIP(c, hipMemset(c->os_slab, 0, kOsSlabBytes));
+    PC_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->os_epoch), (kOsMaxWg + 4) * sizeof(uint32_t)));
+    PC_HIP(c, hipMemset(c->os_epoch, 0, (kOsMaxWg + 4) * sizeof(uint32_t)));
+    c->os_status = c->os_epoch + kOsMaxWg;
+    PC_HIP(c, hipDeviceSynchronize());
+  }
+  PC_HIP(c, hipIpcGetMemHandle(&ipc, c->os_slab));
+  std::memcpy(out_64_bytes, &ipc, 64);
+  return 0;
+}
+int32_t pegainfer_comm_oneshot_attach(pegainfer_comm_t h, const void* handles_world_x_64) {
+  Comm* c = static_cast<Comm*>(h);
+  if (!c || !handles_world_x_64) return -1;
+  if (!c->os_slab) { c->err = "oneshot_attach before oneshot_handle"; return -1; }
+  PC_HIP(c, hipSetDevice(c->device));
+  for (int r = 0; r < c->world; ++r) {
+    if (r == c->rank) { c->os_peers.slab[r] = c->os_slab; continue; }
+    if (c->os_opened[r]) continue;
+    hipIpcMemHandle_t ipc;
+    std::memcpy(&ipc, static_cast<const unsigned char*>(handles_world_x_64) + (size_t)r * 64, 64);
+    void* p = nullptr;
+    PC_HIP(c, hipIpcOpenMemHandle(&p, ipc, hipIpcMemLazyEnablePeerAccess));
+    c->os_peers.slab[r] = static_cast<unsigned char*>(p);
+    c->os_opened[r] = true;
+  }
+  c->os_active = c->world > 1;
+  return 0;
+}
+// RCCL communicators: export, all-gather the handles over RCCL itself, attach.  Call outside graph capture.
+int32_t pegainfer_comm_oneshot_enable(pegainfer_comm_t h) {
+  Comm* c = static_cast<Comm*>(h);
+  if (!c) return -1;
+  if (c->world == 1) return 0;
+  if (!c->nccl) { c->err = "oneshot_enable needs an RCCL communicator (peer-only ones exchange handles out of band)"; return -1; }
+  unsigned char mine[64];
+  if (pegainfer_comm_oneshot_handle(h, mine)) return -1;
+  unsigned char* d = nullptr;
+  PC_HIP(c, hipMalloc(reinterpret_cast<void**>(&d), (size_t)(c->world + 1) * 64));
+  std::vector<unsigned char> all((size_t)c->world * 64);
+  int rc = 0;
+  if (hipMemcpy(d, mine, 64, hipMemcpyHostToDevice) != hipSuccess ||
+      ncclAllGather(d, d + 64, 64, ncclInt8, c->nccl, c->comm_stream) != ncclSuccess ||
+      hipStreamSynchronize(c->comm_stream) != hipSuccess ||
+      hipMemcpy(all.data(), d + 64, all.size(), hipMemcpyDeviceToHost) != hipSuccess) {
+    c->err = "oneshot_enable: handle exchange over RCCL failed";
+    rc = -1;
+  }
+  (void)hipFree(d);
+  if (rc) return rc;
+  if (pegainfer_comm_oneshot_attach(h, all.data())) return -1;
+  // nobody may push into a slab before its owner zeroed it and everyone mapped it: one barrier-like collective
+  PC_HIP(c, hipMalloc(reinterpret_cast<void**>(&d), 64));
+  ncclResult_t r = ncclAllReduce(d, d, 1, ncclInt32, ncclSum, c->nccl, c->comm_stream);
+  hipError_t e = hipStreamSynchronize(c->comm_stream);
+  (void)hipFree(d);
+  if (r != ncclSuccess || e != hipSuccess) { c->err = "oneshot_enable: closing barrier failed"; c->os_active = false; return -1; }
+  return 0;
+}
+int32_t pegainfer_comm_oneshot_active(pegainfer_comm_t h) { return h && static_cast<Comm*>(h)->os_active ? 1 : 0; }
+// 0 = every bounded wait so far completed; else 0x100 | bitmask of the ranks whose flag never arrived (synchronises)
+int32_t pegainfer_comm_oneshot_status(pegainfer_comm_t h) {
+  Comm* c = static_cast<Comm*>(h);
+  if (!c) return -1;
+  if (!c->os_status) return 0;
+  uint32_t st3[3] = {0, 0, 0};
+  if (hipMemcpy(st3, c->os_status, sizeof(st3), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  if (st3[0]) c->err = "one-shot all-reduce: wait expired, mask " + std::to_string(st3[0] & 0xff) + " epoch " +
+                      std::to_string(st3[1]) + " segment " + std::to_string(st3[2]);
+  return (int32_t)st3[0];
+}
 
 void pegainfer_comm_destroy(pegainfer_comm_t h) {
   Comm* c = static_cast<Comm*>(h);
   if (!c) return;
+  for (int r = 0; r < kOsMaxWorld; ++r)
+    if (c->os_opened[r]) (void)hipIpcCloseMemHandle(c->os_peers.slab[r]);
+  if (c->os_slab) (void)hipFree(c->os_slab);
+  if (c->os_epoch) (void)hipFree(c->os_epoch);
   if (c->nccl) ncclCommDestroy(c->nccl);
   if (c->scratch) (void)hipFree(c->scratch);
   if (c->ev_in) (void)hipEventDestroy(c->ev_in);
@@ -396,6 +647,8 @@ int32_t pegainfer_comm_all_reduce_bf16(pegainfer_comm_t h, Half* data, int64_t n
   Comm* c = static_cast<Comm*>(h);
   if (!c || !data || n < 0) return -1;
   if (c->world == 1 || n == 0) return 0;
+  if (const int r = oneshot_all_reduce(c, data, n, 2, st(stream))) return r < 0 ? -1 : 0;   // <= 64 KB: peer-access path
+  if (!c->nccl) { c->err = "peer-only communicator: payload not eligible for the one-shot path"; return -1; }
   PC_NCCL(c, ncclAllReduce(data, data, (size_t)n, ncclBfloat16, ncclSum, c->nccl, st(stream)));
   return 0;
 }
@@ -403,6 +656,8 @@ int32_t pegainfer_comm_all_reduce_f32(pegainfer_comm_t h, float* data, int64_t n
   Comm* c = static_cast<Comm*>(h);
   if (!c || !data || n < 0) return -1;
   if (c->world == 1 || n == 0) return 0;
+  if (const int r = oneshot_all_reduce(c, data, n, 4, st(stream))) return r < 0 ? -1 : 0;
+  if (!c->nccl) { c->err = "peer-only communicator: payload not eligible for the one-shot path"; return -1; }
   PC_NCCL(c, ncclAllReduce(data, data, (size_t)n, ncclFloat32, ncclSum, c->nccl, st(stream)));
   return 0;
 }
@@ -412,7 +667,7 @@ int32_t pegainfer_comm_all_reduce_bf16_to_f32(pegainfer_comm_t h, const Half* in
   if (!c || !in || !out_f32 || n < 0) return -1;
   if (n == 0) return 0;
   if (cast_to_f32(c, in, out_f32, n, st(stream))) return -1;
-  if (c->world > 1) PC_NCCL(c, ncclAllReduce(out_f32, out_f32, (size_t)n, ncclFloat32, ncclSum, c->nccl, st(stream)));
+  if (c->world > 1) return pegainfer_comm_all_reduce_f32(h, out_f32, n, stream);   // size-dispatched like the plain verb
   return 0;
 }
 int32_t pegainfer_comm_all_reduce_bf16_via_f32(pegainfer_comm_t h, Half* data, int64_t n, pegainfer_stream_t stream) {

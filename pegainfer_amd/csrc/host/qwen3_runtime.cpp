@@ -21,6 +21,7 @@
 #include "safetensors_loader.h"
 #include "pegainfer_kernels.h"
 #include "pegainfer_kernels_ext.h"
+#include "pegainfer_comm.h"
 #include "pegainfer_qwen3.h"
 
 namespace pq {
@@ -139,7 +140,7 @@ struct Model {
   Half* pf_logits = nullptr;
   int pf_logits_rows = 0;
   // tensor parallel (reference TP: weights.rs:121-291,396-405): RCCL communicator, one rank per process/GPU
-  ncclComm_t tp_comm = nullptr;
+  pegainfer_comm_t tp_comm = nullptr;   // include/pegainfer_comm.h: RCCL + the one-shot peer-access path for <= 64 KB
   int tp_rank = 0, tp_world = 1;
   // last step
   const Half* last_logits = nullptr;
@@ -296,18 +297,23 @@ struct Model {
   // stream (capturable), after O-proj and down-proj.  No-op without a communicator.
   int all_reduce_hidden(Half* buf, size_t count) {
     if (!tp_comm) return 0;
-    ncclResult_t r = ncclAllReduce(buf, buf, count, ncclBfloat16, ncclSum, tp_comm, stream);
-    if (r != ncclSuccess) { set_error(std::string("ncclAllReduce: ") + ncclGetErrorString(r)); return -1; }
+    // decode: 5 KB x bs per call, 72 calls per step - latency-bound, taken by the one-shot xGMI kernel when the peers
+    // are mapped; prefill-sized payloads go to RCCL (size dispatch inside the verb)
+    if (pegainfer_comm_all_reduce_bf16(tp_comm, buf, (int64_t)count, stream)) {
+      set_error(std::string("all_reduce_hidden: ") + pegainfer_comm_last_error(tp_comm));
+      return -1;
+    }
     return 0;
   }
   int attach_tp(int rank, int world, const void* unique_id) {
     if (world < 1 || rank < 0 || rank >= world) { set_error("bad TP rank/world"); return -1; }
     tp_rank = rank; tp_world = world;
     if (!unique_id) return world == 1 ? 0 : (set_error("TP world > 1 needs a unique id"), -1);
-    ncclUniqueId id;
-    std::memcpy(&id, unique_id, sizeof(id));
-    ncclResult_t r = ncclCommInitRank(&tp_comm, world, id, rank);
-    if (r != ncclSuccess) { set_error(std::string("ncclCommInitRank: ") + ncclGetErrorString(r)); return -1; }
+    tp_comm = pegainfer_comm_create(device, rank, world, unique_id);
+    if (!tp_comm) { set_error("pegainfer_comm_create (ncclCommInitRank) failed"); return -1; }
+    // best effort: without peer access the all-reduces stay on RCCL (PEGAINFER_TP_ONESHOT=0 forces that for A/B runs)
+    const char* os = getenv("PEGAINFER_TP_ONESHOT");
+    if (!(os && os[0] == '0')) (void)pegainfer_comm_oneshot_enable(tp_comm);
     return 0;
   }
 
@@ -1053,7 +1059,7 @@ struct Model {
 
   ~Model() {
     if (stream) hipStreamSynchronize(stream);
-    if (tp_comm) ncclCommDestroy(tp_comm);
+    if (tp_comm) pegainfer_comm_destroy(tp_comm);
     for (auto& b : graphs)
       for (auto& g : b)
         if (g) hipGraphExecDestroy(g);

@@ -228,9 +228,11 @@ class NativeComm:
     (device memory only: torch is plumbing here).  The unique id is drawn on rank 0 and broadcast over the
     torch.distributed group that launched the ranks (collectives.rs:8-287, moe.rs:1327-1461, core.rs:560-609)."""
 
-    def __init__(self, group=None, device=None):
-        import ctypes
-
+    def __init__(self, group=None, device=None, oneshot=True, peer_only=False):
+        """oneshot: enable the <= 64 KB peer-access all-reduce (handles travel over RCCL itself).
+        peer_only: NO RCCL communicator - only the one-shot path exists; the IPC handles travel over `group` (any
+        backend, e.g. gloo).  That form also runs with several ranks on ONE device (RCCL refuses duplicate GPUs), which
+        is how a single-GPU box exercises the cross-process protocol."""
         import torch
         import torch.distributed as dist
         from . import ffi
@@ -239,6 +241,23 @@ class NativeComm:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.device = torch.cuda.current_device() if device is None else int(device)
+        self.oneshot = False
+        if peer_only:
+            self.h = self.lib.pegainfer_comm_create_peer_only(self.device, self.rank, self.world)
+            if not self.h:
+                raise RuntimeError("pegainfer_comm_create_peer_only failed")
+            if self.world > 1:
+                mine = (ctypes.c_ubyte * 64)()
+                self._chk(self.lib.pegainfer_comm_oneshot_handle(self.h, ctypes.addressof(mine)), "oneshot_handle")
+                cpu = dist.get_backend(group) != "nccl"
+                dev = "cpu" if cpu else torch.device("cuda", self.device)
+                bufs = [torch.zeros(64, dtype=torch.uint8, device=dev) for _ in range(self.world)]
+                dist.all_gather(bufs, torch.tensor(list(mine), dtype=torch.uint8, device=dev), group=group)
+                allh = (ctypes.c_ubyte * (64 * self.world))(*[b for t in bufs for b in t.cpu().tolist()])
+                self._chk(self.lib.pegainfer_comm_oneshot_attach(self.h, ctypes.addressof(allh)), "oneshot_attach")
+                dist.barrier(group=group)       # every slab zeroed and mapped everywhere before the first push
+                self.oneshot = bool(self.lib.pegainfer_comm_oneshot_active(self.h))
+            return
         uid = (ctypes.c_ubyte * 128)()
         if self.world > 1:
             buf = torch.zeros(128, dtype=torch.uint8)
@@ -255,6 +274,16 @@ class NativeComm:
                                                 ctypes.addressof(uid) if self.world > 1 else None)
         if not self.h:
             raise RuntimeError("pegainfer_comm_create failed")
+        if oneshot and self.world > 1:
+            # best effort: without peer access (or IPC) the verbs simply stay on RCCL; the reason is kept
+            if self.lib.pegainfer_comm_oneshot_enable(self.h) == 0:
+                self.oneshot = bool(self.lib.pegainfer_comm_oneshot_active(self.h))
+            else:
+                self.oneshot_error = self.lib.pegainfer_comm_last_error(self.h).decode()
+
+    def oneshot_status(self):
+        """0, or 0x100 | mask of the ranks whose flag never arrived within the bound (synchronises the device)"""
+        return self.lib.pegainfer_comm_oneshot_status(self.h)
 
     def close(self):
         if self.h:
@@ -488,4 +517,18 @@ def bench_mp8_collectives(comm, hidden=4096, token_counts=(1, 8, 32, 256, 4096),
         out["reduce_scatter_f32"][str(T)] = round(timed(lambda: comm.reduce_scatter(rs)), 1)
         a2a = torch.ones((comm.world * T, hidden), dtype=torch.bfloat16, device=device)   # EP dispatch: T rows per peer
         out["all_to_all_bf16"][str(T)] = round(timed(lambda: comm.all_to_all(a2a)), 1)
+    # the small-message regime: Qwen3 TP decode 5 KB bf16 (weights.rs:396-405), DSV4 16 KB f32
+    # (moe-tilelang-review.md:12), 64 KB = the one-shot path's upper edge, and the same payloads forced onto RCCL
+    if cuda and hasattr(comm, "lib"):
+        small = {}
+        for name, n, dt in (("bf16_5KB", 2560, torch.bfloat16), ("f32_16KB", 4096, torch.float32),
+                            ("bf16_64KB", 32768, torch.bfloat16)):
+            t = torch.ones(n, dtype=dt, device=device)
+            small[name] = round(timed(lambda: comm.all_reduce_in_place(t)), 1)
+        out["all_reduce_small"] = small
+        out["oneshot_active"] = bool(getattr(comm, "oneshot", False))
+        if getattr(comm, "oneshot", False):
+            out["oneshot_status"] = comm.oneshot_status()
+        if getattr(comm, "oneshot_error", None):
+            out["oneshot_error"] = comm.oneshot_error[:200]
     return out

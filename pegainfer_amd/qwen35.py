@@ -69,6 +69,17 @@ class Qwen35Engine:
         self._chk(self.lib.pegainfer_qwen35_finalize(self.h), "finalize")
         return self
 
+    def load_state(self, tensors):
+        """tensors: {reference tensor name: np.uint16 array of bf16 bits | np.float32 array (A_log, linear_attn.norm.weight)}"""
+        for name, arr in tensors.items():
+            a = np.ascontiguousarray(arr)
+            if a.dtype not in (np.uint16, np.float32):
+                raise ValueError(f"{name}: expected uint16 bf16 bits or float32, got {a.dtype}")
+            self._chk(self.lib.pegainfer_qwen35_load_tensor(self.h, name.encode(), a.ctypes.data, a.size,
+                                                            1 if a.dtype == np.float32 else 0), name)
+        self._chk(self.lib.pegainfer_qwen35_finalize(self.h), "finalize")
+        return self
+
     def load_safetensors_native(self, path):
         import os
         self._chk(self.lib.pegainfer_qwen35_load_safetensors(self.h, os.fsencode(path)), "load_safetensors")

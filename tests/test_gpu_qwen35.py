@@ -113,7 +113,7 @@ def test_hd256_prep_and_gate(built_libs, T, prefill):
     assert bf16_ulp_diff(from_dev(ad), O.attention_gate_hd256(q_full, attn, Hq)) <= 1
 
 
-@pytest.mark.parametrize("lens", [[1], [300, 17], [1024]])
+@pytest.mark.parametrize("lens", [[1], [300, 17], [1024], [4096, 3000, 2049, 4096, 17, 1024, 4000, 4095]])   # last: bs 8 / ctx 4096
 def test_paged_decode_attention_hd256(built_libs, lens):
     import torch
     from pegainfer_amd import ffi
@@ -136,7 +136,9 @@ def test_paged_decode_attention_hd256(built_libs, lens):
     assert np.abs(from_dev(out) - ref).max() <= attn_tol(ref)
 
 
-@pytest.mark.parametrize("seq_lens,starts", [([5], [0]), ([70, 3], [0, 20]), ([130], [0])])
+@pytest.mark.parametrize("seq_lens,starts", [([5], [0]), ([70, 3], [0, 20]), ([130], [0]),
+                                             # the lengths TTFT is quoted at: 1024 / 4096 tokens, a ragged chunked batch
+                                             ([1024], [0]), ([4096], [0]), ([1500, 548], [0, 300])])
 def test_batch_prefill_paged_hd256(built_libs, seq_lens, starts):
     import torch
     from pegainfer_amd import ffi
@@ -176,7 +178,8 @@ def _gdr_inputs(rng, T, kh, vh):
     return qkv, b, a, dtb, alog, state
 
 
-@pytest.mark.parametrize("T,kh,vh", [(64, 2, 4), (150, 2, 4), (1, 1, 2), (333, 16, 32)])
+@pytest.mark.parametrize("T,kh,vh", [(64, 2, 4), (150, 2, 4), (1, 1, 2), (333, 16, 32),
+                                     (1024, 16, 32), (4096, 16, 32), (1000, 16, 32)])   # Qwen3.5-4B heads at the bench lengths; a ragged last chunk
 def test_gdr_chunkwise_prefill_stages_and_operator(built_libs, T, kh, vh):
     """The seven chunk-wise stages (ffi.rs:1041-1137) against the oracle restatement of the Triton kernels, stage by
     stage on the oracle's own inputs (so one stage's rounding noise is not amplified by the next), then the whole
