@@ -422,9 +422,17 @@ inline void gemv_launch_one(const GemvFusedArgs& a, hipStream_t s) {
   int grid = ngroups;
   // PEGAINFER_GEMV_PERSIST=0: one row group per workgroup, the hardware dispatcher balances (A/B probe knob)
   static const bool persist = [] { const char* e = getenv("PEGAINFER_GEMV_PERSIST"); return !(e && *e == '0'); }();
-  if (persist && a.K <= a.KT && ngroups > cached_cap) {
-    const int rounds = ceil_div(ngroups, cached_cap);
+  // PEGAINFER_GEMV_GRID_MULT=N: persistent grids are rounded down to a multiple of N (N = CU count: every CU hosts the
+  // same number of workgroups, so no CU carries 4/3 of its neighbour's rows - the 23 % tail of the round-2 phase trace
+  // was 811 workgroups on 256 CUs); PEGAINFER_GEMV_GRID_PER_CU caps the workgroups per CU below the occupancy
+  static const int mult = [] { const char* e = getenv("PEGAINFER_GEMV_GRID_MULT"); return e && *e ? atoi(e) : 256; }();
+  static const int per_cu_cap = [] { const char* e = getenv("PEGAINFER_GEMV_GRID_PER_CU"); return e && *e ? atoi(e) : 0; }();
+  int cap = cached_cap;
+  if (per_cu_cap > 0 && mult > 0 && per_cu_cap * mult < cap) cap = per_cu_cap * mult;
+  if (persist && a.K <= a.KT && ngroups > cap) {
+    const int rounds = ceil_div(ngroups, cap);
     grid = ceil_div(ngroups, rounds);
+    if (mult > 0 && cap / mult * mult >= mult) grid = cap / mult * mult;
   }
   GemvFusedArgs b = a;
   b.trace = g_gemv_trace;
