@@ -552,8 +552,9 @@ def main():
             fetch = {r["kernel"]: float(r["avg_value"]) for r in csv.DictReader(open(prof)) if r["counter"] == "FETCH_SIZE"}
             wprof = prof.replace("FETCH_SIZE", "WRITE_SIZE")
             wr = {r["kernel"]: float(r["avg_value"]) for r in csv.DictReader(open(wprof))} if os.path.exists(wprof) else {}
-            kname = "gemv_fused_kernel<1, 1, 1, 1>"
-            if kname in fetch:   # KiB per dispatch; gfx950 FETCH_SIZE reports 1/2 of a wide coalesced stream -> x2
+            # the gate_up site: NT 1, RPW 1, KSPLIT 1, SwiGLU epilogue (+ the in-flight depth U since round 3)
+            kname = next((k for k in fetch if k.startswith("gemv_fused_kernel<1, 1, 1, 1")), None)
+            if kname:   # KiB per dispatch; gfx950 FETCH_SIZE reports 1/2 of a wide coalesced stream -> x2
                 traffic = int(2 * fetch[kname] * 1024 + wr.get(kname, 0.0) * 1024)
                 traffic_src = ("replayed from " + os.path.relpath(prof, ROOT) + " (x2 gfx950 correction) + WRITE_SIZE, separate "
                                "rocprofv3 --pmc passes; not measured in this run")

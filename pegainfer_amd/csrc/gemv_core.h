@@ -66,11 +66,13 @@ enum { kGemvNormOffset = 1, kGemvRoundSum = 2, kGemvSiluRound = 4 };
 constexpr int kGemvProloguePrio = 64;   // launcher-only bit (PEGAINFER_GEMV_PRIO=0 clears it): see the prologue
 constexpr int kGemvNormAllWaves = 32;   // launcher-only bit (PEGAINFER_GEMV_NORM1W=0): every wave sums the squares (A/B probe)
 
-template <int NT, int RPW, int KSPLIT, int EPI>
+// U = K blocks a wave keeps in flight per row (U*NW*RPW loads of 1 KB).  The launcher picks U = 5 when that covers a
+// whole row (K = 2560: 5 blocks; K = 9728 dealt to 4 waves: 5, 5, 5, 4), so a row group needs ONE memory round trip
+// instead of "four blocks, then a dependent fifth"; the per-(row, token) block order is the same for every U.
+template <int NT, int RPW, int KSPLIT, int EPI, int U = 4>
 __global__ __launch_bounds__(256) void gemv_fused_kernel(const GemvFusedArgs a) {
   const int KT = a.KT;
   constexpr int NW = EPI == kEpiSilu ? 2 : 1;  // weight row sets streamed together
-  constexpr int U = 4;                         // K blocks in flight per wave: U*NW*RPW loads of 1 KB
   constexpr int ROWS_PER_GROUP = (KSPLIT == 1 ? 4 : 1) * RPW;
   // all LDS is dynamic and sized to the shape (guide G17: one 16-byte aligned carve, no statics): a K = 2560
   // GEMV needs 5 KB, not the 32 KB tile capacity, which is what lets 5+ workgroups share a CU.
@@ -401,13 +403,13 @@ __global__ __launch_bounds__(256) void gemv_fused_kernel(const GemvFusedArgs a) 
 // Grid sizing: every workgroup should be co-resident (no second, half-empty scheduling round) and all of them
 // should walk the same number of row groups.  capacity = occupancy(kernel, lds) x CU count; rounds =
 // ceil(ngroups / capacity); grid = ceil(ngroups / rounds).  K > KT (multi-tile x) needs one group per workgroup.
-template <int NT, int RPW, int KSPLIT, int EPI>
+template <int NT, int RPW, int KSPLIT, int EPI, int U = 4>
 inline void gemv_launch_one(const GemvFusedArgs& a, hipStream_t s) {
   constexpr int ROWS_PER_GROUP = (KSPLIT == 1 ? 4 : 1) * RPW;
   const int rows = EPI == kEpiSilu ? a.I : a.M;
   const int ngroups = ceil_div(rows, ROWS_PER_GROUP);
   const int lds = gemv_lds_bytes<NT, RPW, KSPLIT, EPI>(a.K, a.KT, a.residual != nullptr);
-  auto kern = &gemv_fused_kernel<NT, RPW, KSPLIT, EPI>;
+  auto kern = &gemv_fused_kernel<NT, RPW, KSPLIT, EPI, U>;
   static const bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
   (void)once;
@@ -426,7 +428,10 @@ inline void gemv_launch_one(const GemvFusedArgs& a, hipStream_t s) {
   // same number of workgroups, so no CU carries 4/3 of its neighbour's rows - the 23 % tail of the round-2 phase trace
   // was 811 workgroups on 256 CUs); PEGAINFER_GEMV_GRID_PER_CU caps the workgroups per CU below the occupancy
   static const int mult = [] { const char* e = getenv("PEGAINFER_GEMV_GRID_MULT"); return e && *e ? atoi(e) : 256; }();
-  static const int per_cu_cap = [] { const char* e = getenv("PEGAINFER_GEMV_GRID_PER_CU"); return e && *e ? atoi(e) : 0; }();
+  // default 2 per CU for the 1-2 column forms: 512 persistent workgroups walking their row groups beat 768-1280
+  // (x is staged by fewer workgroups, every CU carries the same row count): 2.045 -> 2.010 ms per step, same box
+  static const int per_cu_env = [] { const char* e = getenv("PEGAINFER_GEMV_GRID_PER_CU"); return e && *e ? atoi(e) : -1; }();
+  const int per_cu_cap = per_cu_env >= 0 ? per_cu_env : (NT <= 2 ? 2 : 0);
   int cap = cached_cap;
   if (per_cu_cap > 0 && mult > 0 && per_cu_cap * mult < cap) cap = per_cu_cap * mult;
   if (persist && a.K <= a.KT && ngroups > cap) {
@@ -448,8 +453,17 @@ inline void gemv_launch_nt(const GemvFusedArgs& a, hipStream_t s) {
   // rows per wave: 2 for the plain store (16 KB of loads per wave with U = 4 ... 8 KB), 1 for SwiGLU (two
   // matrices per wave); both stay <= 96 VGPRs for NT <= 2, i.e. 5 workgroups per CU.  RPW never changes results.
   constexpr int RPW = EPI == kEpiSilu ? 1 : 2;
-  if (a.K >= 4096) gemv_launch_one<NT, RPW, 4, EPI>(a, s);
-  else gemv_launch_one<NT, RPW, 1, EPI>(a, s);
+  // whole rows in flight (U = 5) for the single-request / pair forms when a wave's share of a row is exactly 5 blocks
+  // (PEGAINFER_GEMV_U5=0: the four-then-one form, for A/B runs); wider batches keep U = 4 (register budget)
+  static const bool u5 = [] { const char* e = getenv("PEGAINFER_GEMV_U5"); return !(e && *e == '0'); }();
+  const int nblk = (a.K + 511) >> 9;
+  if (a.K >= 4096) {
+    if (NT <= 2 && u5 && a.K <= a.KT && (nblk + 3) / 4 == 5) gemv_launch_one<NT, RPW, 4, EPI, (NT <= 2 ? 5 : 4)>(a, s);
+    else gemv_launch_one<NT, RPW, 4, EPI>(a, s);
+  } else {
+    if (NT <= 2 && u5 && a.K <= a.KT && nblk == 5) gemv_launch_one<NT, RPW, 1, EPI, (NT <= 2 ? 5 : 4)>(a, s);
+    else gemv_launch_one<NT, RPW, 1, EPI>(a, s);
+  }
 }
 
 // T <= 16, K % 8 == 0, 16-byte aligned W/X (and residual/norm_w/hidden_out when given)
