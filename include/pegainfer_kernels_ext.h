@@ -89,6 +89,16 @@ pegainfer_status_t pegainfer_gemm_add(const Half* W, const Half* X, Half* y_scra
  * same launch (agent-scope release/acquire around one atomic) and re-arms the counter; no merge launch.  Output
  * rows of requests that own no slot (padding columns) are then left untouched.  Same bits either way. */
 int32_t pegainfer_fused_decode_attention(const Half* qkv, Half* output, const Half* kv_data, int64_t k_offset_elems, int64_t v_offset_elems, const int32_t* page_indices, const int32_t* page_indptr, const int32_t* last_page_len_d, const int32_t* positions, const Half* q_norm_weight, const Half* k_norm_weight, const Half* cos_cache, const Half* sin_cache, float rms_eps, int32_t use_split, const int32_t* split_request_indices, const int32_t* split_kv_tile_indices, const int32_t* split_kv_chunk_size_ptr, const int32_t* split_o_indptr, const uint8_t* split_block_valid_mask, Half* tmp_v, float* tmp_s, int32_t num_qo_heads, int32_t num_kv_heads, int32_t head_dim, int32_t page_size, int32_t batch_size, int32_t split_slots, int64_t stride_page, float sm_scale, const int32_t* slot_desc, int32_t* merge_counters, pegainfer_stream_t stream);
+/* pegainfer_fused_decode_attention (partition form, merge_counters required) + the o_proj GEMV that consumes it, in ONE
+ * launch, for steps with one request: the grid is the attention's split_slots x num_kv_heads grid of 8-wave workgroups;
+ * the workgroups of the request's KV chunks (slot_desc words 6 / 7 of slot 0, read on the device: a captured launch is
+ * replayed while the request grows) run the attention, the workgroups of the padding slots - at least min_padding_slots
+ * of them by the caller's plan - request the o_proj rows into registers meanwhile, the merging workgroups publish the attention row
+ * write-through and arrive on done_counter (one device int, zero before the launch), then the o_proj workgroups finish
+ * their dot products from registers - the bits of the two stand-alone launches.  o_proj [hidden, num_qo_heads * head_dim] row-major,
+ * attn_proj_out [hidden], status (optional) receives 0x300 when the bounded wait for the attention rows expired.
+ * Returns hipErrorInvalidValue (1) when the shape does not fit; the caller then issues the two launches. */
+int32_t pegainfer_fused_decode_attention_oproj(const Half* qkv, Half* attn_out, const Half* kv_data, int64_t k_offset_elems, int64_t v_offset_elems, const int32_t* page_indices, const int32_t* page_indptr, const int32_t* last_page_len_d, const int32_t* positions, const Half* q_norm_weight, const Half* k_norm_weight, const Half* cos_cache, const Half* sin_cache, float rms_eps, const int32_t* split_request_indices, const int32_t* split_kv_tile_indices, const int32_t* split_kv_chunk_size_ptr, const int32_t* split_o_indptr, const uint8_t* split_block_valid_mask, Half* tmp_v, float* tmp_s, int32_t num_qo_heads, int32_t num_kv_heads, int32_t head_dim, int32_t page_size, int32_t batch_size, int32_t split_slots, int32_t min_padding_slots, int64_t stride_page, float sm_scale, const int32_t* slot_desc, int32_t* merge_counters, const Half* o_proj, Half* attn_proj_out, int32_t hidden, int32_t* done_counter, uint32_t* status, pegainfer_stream_t stream);
 
 /* Debug aid (not in ffi.rs): buf = device array of (workgroups per launch, <= 4096) * 8 uint64, or NULL.  Every later
  * dot2-GEMV launch stamps it with the 100 MHz wall clock per workgroup: [0] entry, [1] x staged, [2] first weight block

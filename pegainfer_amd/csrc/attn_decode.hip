@@ -85,8 +85,17 @@ __device__ __forceinline__ void decode_attn_body(const DecodeAttnArgs& a, const 
     if (sm_last) {
       for (int h = wave; h < GROUP; h += NW) {
         const int head = kvh * GROUP + h;
-        merge_one<D, true>(a.tmp_v, a.tmp_s, s0, s1, head, num_qo_heads,
-                           a.o_out + ((size_t)b * num_qo_heads + head) * D);
+        if (a.done_ctr)   // the rows are consumed inside this launch (attn_oproj_kernel): write-through
+          merge_one<D, true, true>(a.tmp_v, a.tmp_s, s0, s1, head, num_qo_heads,
+                                   a.o_out + ((size_t)b * num_qo_heads + head) * D);
+        else
+          merge_one<D, true>(a.tmp_v, a.tmp_s, s0, s1, head, num_qo_heads,
+                             a.o_out + ((size_t)b * num_qo_heads + head) * D);
+      }
+      if (a.done_ctr) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();   // workgroup-uniform branch (sm_last): every merging wave's rows are acknowledged
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(a.done_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       PK_ATTN_STAMP(a, slot, kvh, 6);
       if (a.trace && threadIdx.x == 0) a.trace[((size_t)slot * a.num_kv_heads + kvh) * 8 + 7] = 1ull;
@@ -114,9 +123,8 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(const DecodeAttnAr
 // normalises + rotates the new K row, writes K and V into the page (same bytes paged_kv_scatter_cuda would
 // write) and only then scans.  Replaces qk_norm_rope + paged_kv_scatter + decode attention: 3 launches -> 1.
 template <int GROUP, bool PARTITION, int NW>
-__global__ __launch_bounds__(NW * 64) void fused_decode_attn_kernel(const DecodeAttnArgs a) {
+__device__ __forceinline__ void fused_decode_attn_workgroup(const DecodeAttnArgs& a, int slot, int kvh) {
   constexpr int D = 128;
-  const int slot = blockIdx.x, kvh = blockIdx.y;
   ChunkInfo ci;
   int pos;
   PK_ATTN_STAMP(a, slot, kvh, 0);
@@ -159,6 +167,144 @@ __global__ __launch_bounds__(NW * 64) void fused_decode_attn_kernel(const Decode
     __syncthreads();  // workgroup-scope release/acquire: the new row is visible to the scanning waves
   }
   decode_attn_body<D, GROUP, PARTITION, NW>(a, ci, qv, slot, kvh);
+}
+
+
+template <int GROUP, bool PARTITION, int NW>
+__global__ __launch_bounds__(NW * 64) void fused_decode_attn_kernel(const DecodeAttnArgs a) {
+  fused_decode_attn_workgroup<GROUP, PARTITION, NW>(a, blockIdx.x, blockIdx.y);
+}
+
+// ---- fused decode attention + o_proj, ONE launch, single-request steps (round 3).
+// The attention launch of a bs = 1 step is a chain of dependent round trips (~9-10 us) during which HBM idles, and the
+// o_proj GEMV behind it pays a kernel boundary, an x hand-off and a cold weight burst (6.4 us for 21 MB).  Here the
+// launch grid is the attention's own slots x kv_heads grid of 8-wave workgroups (one per CU); the workgroups of the
+// plan's VALID slots run the fused attention exactly as the stand-alone kernel does, the workgroups of the padding
+// slots - idle exits in the stand-alone launch, (slots - valid) x kv_heads of them - take the o_proj: each requests
+// its share of the rows into registers (the two wave quads of a workgroup act exactly like KSPLIT = 4 GEMV workgroups:
+// K blocks dealt round-robin to the 4 waves, fixed-order LDS combine - the bits of gemv_fused_kernel), waits until the
+// merging workgroups have published the attention row write-through and arrived on `done`, takes the row with
+// cache-bypassing loads and finishes its dot products from registers.  No attention workgroup ever waits for anything
+// (the protocol needs no co-residency guarantee beyond "the attention workgroups get to run"); every wait is bounded.
+// Phase history (profiles/r3_attn_oproj_*): every workgroup holding o_proj rows THROUGH its attention slowed the
+// attention by 2.4 us (256 registers, weight bursts in front of its dependent loads) and left the merging workgroups,
+// which could only request their rows last, as a 1.5 us tail.
+struct OprojArgs {
+  const Half* W; Half* Y; int M, K;
+  int slots;                       // launch slots of the (single) request; how many carry a KV chunk is read from slot_desc
+  int done_target;                 // arrivals to wait for: num_kv_heads
+  uint32_t* status;
+  int hold_ticks;                  // 100 MHz ticks the o_proj workgroups hold their burst back (the attention's first
+                                   // dependent loads - slot record, q row, page ids, K / V tile - go first)
+};
+constexpr int kOprojMaxRows = 12;  // rows per wave quad
+
+template <int GROUP>
+__global__ __launch_bounds__(512) void attn_oproj_kernel(const DecodeAttnArgs a, const OprojArgs g) {
+  constexpr int NW = 8;
+  const int slot = (int)blockIdx.x % g.slots, kvh = (int)blockIdx.x / g.slots;   // the dim3(slots, kv_heads) order
+  // debug stamps of the o_proj workgroups (pegainfer_debug_attn_trace): 8 words per workgroup behind the attention's
+  // 64 * kv_heads records: entry, rows requested, rows of the attention seen (flag), x staged, exit
+  unsigned long long* ot = a.trace ? a.trace + ((size_t)64 * a.num_kv_heads + blockIdx.x) * 8 : nullptr;
+  // valid slots of request 0 = its partial count o_indptr[1] - o_indptr[0], words 6 / 7 of slot 0's record (a captured
+  // graph replays this launch while the request grows: the split between the two roles is decided on the device)
+  const int valid_slots = a.slot_desc[7] - a.slot_desc[6];
+  if (slot < valid_slots) {
+    fused_decode_attn_workgroup<GROUP, true, NW>(a, slot, kvh);
+    return;
+  }
+  if (ot && threadIdx.x == 0) ot[0] = wall_clock64();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, quad = wave >> 2, w4 = wave & 3;
+  const int n_gemv = (g.slots - valid_slots) * a.num_kv_heads;
+  const int gi = (slot - valid_slots) + kvh * (g.slots - valid_slots);
+  // rows per wave quad; the host's plan keeps enough padding slots that this is <= kOprojMaxRows (the launcher checks the
+  // worst case it allows); were it ever larger the surplus rows run as further, un-prefetched passes below
+  const int rows_half = (g.M + 2 * n_gemv - 1) / (2 * n_gemv);
+  const int row0 = (gi * 2 + quad) * rows_half;
+  {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < (unsigned long long)g.hold_ticks) __builtin_amdgcn_s_sleep(1);
+  }
+  u32x4 wv[kOprojMaxRows][2];
+  auto request_rows = [&](int base) {
+#pragma unroll
+    for (int r = 0; r < kOprojMaxRows; ++r) {
+      if (base + r >= rows_half) break;
+      int row = row0 + base + r;
+      row = row < g.M ? row : g.M - 1;   // clamp: loads stay in bounds, stores are masked
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        int kk = (w4 + u * 4) * 512 + lane * 8;
+        kk = kk < g.K ? kk : g.K - 8;
+        wv[r][u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(g.W + (size_t)row * g.K + kk));
+      }
+    }
+  };
+  request_rows(0);
+  if (ot && threadIdx.x == 0) ot[1] = wall_clock64();
+  __shared__ __attribute__((aligned(16))) u32x4 xs[1024];   // K <= 8192
+  __shared__ float part[2][4][kOprojMaxRows];
+  __shared__ int ok_flag;
+  if (threadIdx.x == 0) {
+    const unsigned long long t0 = wall_clock64();
+    int ok = 1;
+    while (__hip_atomic_load(a.done_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < g.done_target) {
+      if (wall_clock64() - t0 > 3000000ull) { ok = 0; break; }   // 30 ms
+      __builtin_amdgcn_s_sleep(2);
+    }
+    ok_flag = ok;
+    if (!ok && g.status) g.status[0] = 0x300u;
+  }
+  __syncthreads();
+  if (!ok_flag) return;
+  if (ot && threadIdx.x == 0) ot[2] = wall_clock64();
+  // x = the merged attention row of request 0, written through by the merging workgroups on other CUs / XCDs
+  const int nvec = g.K >> 3;
+  for (int c = threadIdx.x; c < nvec; c += 512) {
+    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(a.o_out) + (size_t)c * 2;
+    const unsigned long long lo = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long hi = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    xs[c] = u32x4{(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
+  }
+  __syncthreads();
+  if (ot && threadIdx.x == 0) ot[3] = wall_clock64();
+  for (int base = 0; base < rows_half; base += kOprojMaxRows) {
+    if (base > 0) { __syncthreads(); request_rows(base); }   // `part` is reused; only the first pass was prefetched
+    float acc[kOprojMaxRows];
+#pragma unroll
+    for (int r = 0; r < kOprojMaxRows; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int kk = (w4 + u * 4) * 512 + lane * 8;
+      const bool live = kk < g.K;
+      u32x4 xv = xs[live ? (kk >> 3) : 0];
+      if (!live) xv = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int r = 0; r < kOprojMaxRows; ++r)
+        if (base + r < rows_half) acc[r] = dot8(wv[r][u], xv, acc[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < kOprojMaxRows; ++r)
+      if (base + r < rows_half) acc[r] = wave_sum(acc[r]);
+    if (lane == 0) {
+#pragma unroll
+      for (int r = 0; r < kOprojMaxRows; ++r)
+        if (base + r < rows_half) part[quad][w4][r] = acc[r];
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * kOprojMaxRows) {
+      const int q = threadIdx.x / kOprojMaxRows, r = threadIdx.x % kOprojMaxRows;
+      const int row = (gi * 2 + q) * rows_half + base + r;
+      if (base + r < rows_half && row < g.M) {
+        float v = part[q][0][r];
+        v += part[q][1][r];
+        v += part[q][2][r];
+        v += part[q][3][r];
+        g.Y[row] = f2bf(v);
+      }
+    }
+  }
+  if (ot && threadIdx.x == 0) ot[4] = wall_clock64();
 }
 
 // merge of the partition-KV partial states: one wave per (request, q head).  Lanes first fetch all
@@ -332,6 +478,56 @@ int32_t pegainfer_fused_decode_attention(
     return launch_decode<128, true, true>(a, split_o_indptr, batch_size, split_slots, as_stream(stream));
   }
   return launch_decode<128, false, true>(a, nullptr, batch_size, batch_size, as_stream(stream));
+}
+
+// Extension: pegainfer_fused_decode_attention (partition form) + the o_proj GEMV behind it in ONE launch, for steps with
+// one request (see attn_oproj_kernel).  `o_proj` [hidden, q_dim] row-major, `attn_proj_out` [hidden]; `attn_out` still
+// receives the attention row (the o_proj phase reads it from there).  done_counter: one device int, ZERO before the
+// launch (the host runtime keeps one per layer and clears them once per step).  Returns hipErrorInvalidValue when the
+// shape does not fit the form (then the caller runs the two stand-alone launches): batch_size != 1, more attention
+// workgroups than CUs, q_dim not a multiple of 2048 or > 8192, more than 10 o_proj rows per CU.
+int32_t pegainfer_fused_decode_attention_oproj(
+    const Half* qkv, Half* attn_out, const Half* kv_data, int64_t k_offset_elems, int64_t v_offset_elems,
+    const int32_t* page_indices, const int32_t* page_indptr, const int32_t* last_page_len_d,
+    const int32_t* positions, const Half* q_norm_weight, const Half* k_norm_weight, const Half* cos_cache,
+    const Half* sin_cache, float rms_eps, const int32_t* split_request_indices,
+    const int32_t* split_kv_tile_indices, const int32_t* split_kv_chunk_size_ptr, const int32_t* split_o_indptr,
+    const uint8_t* split_block_valid_mask, Half* tmp_v, float* tmp_s, int32_t num_qo_heads, int32_t num_kv_heads,
+    int32_t head_dim, int32_t page_size, int32_t batch_size, int32_t split_slots, int32_t min_padding_slots,
+    int64_t stride_page, float sm_scale, const int32_t* slot_desc, int32_t* merge_counters, const Half* o_proj,
+    Half* attn_proj_out, int32_t hidden, int32_t* done_counter, uint32_t* status, pegainfer_stream_t stream) {
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+    return n;
+  }();
+  const int q_dim = num_qo_heads * head_dim;
+  const int grid = split_slots * num_kv_heads;
+  const int n_gemv = min_padding_slots * num_kv_heads;   // the caller's plan never leaves fewer padding slots than this
+  const int group = num_kv_heads > 0 ? num_qo_heads / num_kv_heads : 0;
+  if (head_dim != 128 || batch_size != 1 || !merge_counters || !done_counter || !o_proj || !attn_proj_out || !slot_desc ||
+      split_slots < 1 || min_padding_slots < 1 || min_padding_slots >= split_slots || grid > cus || (q_dim % 2048) != 0 ||
+      q_dim / 2048 > 2 /* 2 K blocks per wave */ || hidden < 1 || (group != 1 && group != 2 && group != 4) ||
+      !host_aligned16(qkv) || !host_aligned16(kv_data) || !host_aligned16(slot_desc) || !host_aligned16(o_proj) ||
+      !host_aligned16(attn_out))
+    return static_cast<int32_t>(hipErrorInvalidValue);
+  if (n_gemv < 1 || ceil_div(hidden, 2 * n_gemv) > kOprojMaxRows) return static_cast<int32_t>(hipErrorInvalidValue);
+  DecodeAttnArgs a;
+  fill_args(a, nullptr, attn_out, kv_data, k_offset_elems, v_offset_elems, page_indices, page_indptr, last_page_len_d,
+            split_request_indices, split_kv_tile_indices, split_kv_chunk_size_ptr, split_block_valid_mask, tmp_v, tmp_s,
+            num_qo_heads, num_kv_heads, page_size, stride_page, sm_scale);
+  a.qkv = qkv; a.q_norm_w = q_norm_weight; a.k_norm_w = k_norm_weight; a.cos_cache = cos_cache;
+  a.sin_cache = sin_cache; a.positions = positions; a.eps = rms_eps; a.slot_desc = slot_desc;
+  a.merge_counters = merge_counters; a.o_indptr = split_o_indptr; a.done_ctr = done_counter;
+  static const int hold = [] { const char* e = getenv("PEGAINFER_ATTN_OPROJ_HOLD"); return e && *e ? atoi(e) : 0; }();
+  OprojArgs g{o_proj, attn_proj_out, hidden, q_dim, split_slots, num_kv_heads, status, hold};
+  hipStream_t s = as_stream(stream);
+  switch (group) {
+    case 1: attn_oproj_kernel<1><<<grid, 512, 0, s>>>(a, g); break;
+    case 2: attn_oproj_kernel<2><<<grid, 512, 0, s>>>(a, g); break;
+    default: attn_oproj_kernel<4><<<grid, 512, 0, s>>>(a, g); break;
+  }
+  return static_cast<int32_t>(hipGetLastError());
 }
 
 }  // extern "C"

@@ -38,6 +38,9 @@ struct DecodeAttnArgs {
   // The counters are kMergeCtrStride ints apart (a cache line each): at bs 1 the 8 kv heads' counters shared ONE
   // line and their 8 x 17 arrivals serialised on it (the 1.0-1.1 us "ticket" phase of the in-kernel stamps).
   int* merge_counters; const int* o_indptr;
+  // fused attention + o_proj launch only (attn_oproj_kernel): the merging workgroup writes its head group's rows
+  // write-through and then adds 1 here - the o_proj phase of every workgroup waits for num_kv_heads arrivals per request
+  int* done_ctr;
   // debug: 8 wall-clock stamps (100 MHz) per (slot, kv head) written by thread 0 (pegainfer_debug_attn_trace)
   unsigned long long* trace;
 };

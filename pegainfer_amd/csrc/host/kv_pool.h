@@ -106,6 +106,12 @@ struct SplitPlan {
 // workgroups towards >= 256 (256 CUs): chunks/request = clamp(ceil(256/(bs*kv_heads)), 1, 64),
 // chunk = max(64, round_up16(ceil(L/chunks))); 64 tokens = one 16-token tile per wave, i.e. a workgroup's
 // whole K/V fetch is a single round trip.
+constexpr int kOprojFusedMaxSeq = 18 * 128;
+// chunks a single request of up to kOprojFusedMaxSeq tokens is cut into (PEGAINFER_OPROJ_CHUNKS, A/B knob)
+inline int oproj_fused_max_chunks() {
+  static const int c = [] { const char* e = getenv("PEGAINFER_OPROJ_CHUNKS"); const int v = e && *e ? atoi(e) : 18; return v < 2 ? 2 : (v > 30 ? 30 : v); }();
+  return c;
+}
 inline SplitPlan make_split_plan(int policy, const std::vector<int>& seq_lens, int padded_bs, int num_kv_heads) {
   SplitPlan p;
   int max_seq = 0;
@@ -125,6 +131,11 @@ inline SplitPlan make_split_plan(int policy, const std::vector<int>& seq_lens, i
     const int target_wgs = target_env > 0 ? target_env : (pairs >= 32 && pairs < 256 ? 512 : 256);
     int want = pairs >= 256 && target_env <= 0 ? 1 : (target_wgs + pairs - 1) / pairs;
     want = std::min(std::max(want, 1), kSplitMaxChunksPerRequest);
+    // single request, up to kOprojFusedMaxSeq tokens: at most kOprojFusedMaxChunks chunks (an 8-wave workgroup scans 128
+    // tokens in one tile per wave) - the other slots of the launch grid stay
+    // padding, and the fused attention + o_proj launch gives their workgroups the o_proj rows (attn_oproj_kernel)
+    const int grid_slots = want;   // the launch grid keeps its one-workgroup-per-CU size
+    if (pairs <= num_kv_heads && max_seq <= kOprojFusedMaxSeq && target_env <= 0) want = std::min(want, oproj_fused_max_chunks());
     int chunk = (max_seq + want - 1) / want;
     chunk = std::max(64, (chunk + 15) / 16 * 16);
     p.chunk = chunk;
@@ -132,7 +143,7 @@ inline SplitPlan make_split_plan(int policy, const std::vector<int>& seq_lens, i
     // a request never gets more than `want` chunks, and `want` depends on the bucket only: the launch grid (fixed
     // at graph capture) needs padded_bs * want slots, not the reference's padded_bs * 64 - at bs 16 that is 512
     // workgroups instead of 8192 of which 7680 exited at once (SQ_WAVES per launch 32768 -> 2048)
-    slots_per_request = want;
+    slots_per_request = grid_slots;
   }
   p.slots = padded_bs * slots_per_request;
   p.o_indptr.push_back(0);

@@ -106,6 +106,15 @@ struct Model {
   // PEGAINFER_MID_BATCH_FUSED=0: decode batches of 17..64 keep the reference op sequence (A/B + bit-equality probe)
   bool mid_batch_fused = [] { const char* e = getenv("PEGAINFER_MID_BATCH_FUSED"); return !(e && e[0] == '0'); }();
   int32_t* merge_ctr = nullptr;  // per (request, kv head) arrival counters of the in-kernel split-KV merge
+  // single-request steps: attention + o_proj in ONE launch (pegainfer_fused_decode_attention_oproj): the o_proj rows are
+  // requested into registers while the attention's chain of round trips runs.  One arrival counter per layer (a cache
+  // line each), cleared once per step; PEGAINFER_ATTN_OPROJ=0 keeps the two launches (A/B, bit-identical).
+  bool attn_oproj = [] { const char* e = getenv("PEGAINFER_ATTN_OPROJ"); return !(e && e[0] == '0'); }();
+  int32_t* attn_done = nullptr;
+  uint32_t *attn_status = nullptr, *attn_status_host = nullptr;
+  bool oproj_step = false;   // the step being recorded / run uses the fused launch
+  bool oproj_plan = false;   // this step's split plan keeps the padding slots the fused launch needs (single request, <= 2304 tokens)
+  int oproj_fallbacks = 0;
   // decode_mode 2: the persistent decode-step engine (csrc/decode_engine.hip) for a single request; larger batches and
   // unsupported shapes run the decode_mode 1 kernels.  PEGAINFER_ENGINE_WGS overrides the workgroup count (probe knob).
   pegainfer_engine_layer_t* eng_layers_d = nullptr;
@@ -126,8 +135,8 @@ struct Model {
   uint8_t* meta_host = nullptr;  // pinned
   uint8_t* meta_dev = nullptr;
   int32_t* tokens_out_host = nullptr;  // pinned
-  hipGraphExec_t graphs[kNumBuckets][2];
-  bool graph_engine[kNumBuckets][2] = {};   // the captured step runs on the decode_mode 2 engine
+  hipGraphExec_t graphs[kNumBuckets][3];   // [bucket][0 = non-partition | 1 = split-KV | 2 = split-KV with the fused attention + o_proj launch]
+  bool graph_engine[kNumBuckets][3] = {};   // the captured step runs on the decode_mode 2 engine
   // prefill workspace (grow-only)
   size_t pf_cap_tokens = 0;
   Half *pf_hidden = nullptr, *pf_hidden_out = nullptr, *pf_normed = nullptr, *pf_q = nullptr, *pf_k = nullptr,
@@ -153,7 +162,7 @@ struct Model {
       : device(dev), H(h), L(l), Hq(hq), Hkv(hkv), D(d), I(inter), V(vocab), tie(tie_), max_pos(mp),
         num_pages(pages), max_bs(mbs), enable_graph(graph), decode_mode(mode), split_policy(pol), eps(e),
         theta(th), q_dim(hq * d), kv_dim(hkv * d), layout(l, hkv, d, 16), pool(pages) {
-    for (auto& b : graphs) b[0] = b[1] = nullptr;
+    for (auto& b : graphs) b[0] = b[1] = b[2] = nullptr;
   }
 
   void set_error(const std::string& s) { err = s; }
@@ -229,6 +238,13 @@ struct Model {
     std::memset(meta_host, 0, ml.total);
     if (dalloc(&meta_dev, ml.total)) return -1;
     PQ_HIP(hipHostMalloc(reinterpret_cast<void**>(&tokens_out_host), bs * 4, hipHostMallocDefault));
+    if (attn_oproj) {
+      if (dalloc(&attn_done, (size_t)L * 32) || dalloc(&attn_status, 4)) return -1;
+      PQ_HIP(hipMemsetAsync(attn_done, 0, (size_t)L * 32 * sizeof(int32_t), stream));
+      PQ_HIP(hipMemsetAsync(attn_status, 0, 16, stream));
+      PQ_HIP(hipHostMalloc(reinterpret_cast<void**>(&attn_status_host), 16, hipHostMallocDefault));
+      attn_status_host[0] = 0;
+    }
     if (decode_mode == 2) {
       int cus = 0;
       PQ_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
@@ -593,6 +609,8 @@ struct Model {
   // logits are bit-identical to decode_mode 0 (tests/test_gpu_fused.py).
   int decode_kernels_fused(int bs, bool split, int split_slots) {
     if (fused_merge && split) PQ_HIP(hipMemsetAsync(merge_ctr, 0, (size_t)max_bs * Hkv * 32 * sizeof(int32_t), stream));
+    oproj_step = attn_oproj && attn_done && fused_merge && split && bs == 1 && !tp_comm && D == 128 && oproj_plan;
+    if (oproj_step) PQ_HIP(hipMemsetAsync(attn_done, 0, (size_t)L * 32 * sizeof(int32_t), stream));
     if (embedding_batched_cuda(embed, md<uint32_t>(ml.token_ids), hidden, H, bs, S())) {
       set_error("embedding_batched_cuda failed");
       return -1;
@@ -605,7 +623,21 @@ struct Model {
       int rc = pegainfer_gemv_fused(ly.qkv, cur, qkv_out, q_dim + 2 * kv_dim, bs, H, resid, ly.ln1,
                                     resid ? nxt : nullptr, eps, 0, S());
       if (resid) std::swap(cur, nxt);
-      if (!rc)
+      bool fused_o = false;
+      if (!rc && oproj_step) {
+        const int r2 = pegainfer_fused_decode_attention_oproj(
+            qkv_out, attn_out, kv_buffer, layout.k_offset(li), layout.v_offset(li), md<int32_t>(ml.page_indices),
+            md<int32_t>(ml.page_indptr), md<int32_t>(ml.last_page_len), md<int32_t>(ml.positions), ly.q_norm,
+            ly.k_norm, cos, sin, eps, md<int32_t>(ml.split_request_indices), md<int32_t>(ml.split_kv_tile_indices),
+            md<int32_t>(ml.split_kv_chunk_size), md<int32_t>(ml.split_o_indptr), md<uint8_t>(ml.split_valid),
+            split_tmp_v, split_tmp_s, Hq, Hkv, D, layout.page_size, bs, split_slots,
+            split_slots - pq::oproj_fused_max_chunks(), layout.page_stride, sm, md<int32_t>(ml.slot_desc), merge_ctr, ly.o,
+            attn_proj, H, attn_done + (size_t)li * 32, attn_status, S());
+        if (r2 == 0) fused_o = true;
+        else if (r2 != (int)hipErrorInvalidValue) rc = r2;
+        else oproj_step = false;   // the shape does not fit the form: two launches for this and the later layers
+      }
+      if (!rc && !fused_o)
         rc = pegainfer_fused_decode_attention(
             qkv_out, attn_out, kv_buffer, layout.k_offset(li), layout.v_offset(li), md<int32_t>(ml.page_indices),
             md<int32_t>(ml.page_indptr), md<int32_t>(ml.last_page_len), md<int32_t>(ml.positions), ly.q_norm,
@@ -614,7 +646,7 @@ struct Model {
             md<int32_t>(ml.split_o_indptr), md<uint8_t>(ml.split_valid), split_tmp_v, split_tmp_s, Hq, Hkv, D,
             layout.page_size, bs, split_slots, layout.page_stride, sm, md<int32_t>(ml.slot_desc),
             fused_merge ? merge_ctr : nullptr, S());
-      if (!rc) rc = pegainfer_gemv_fused(ly.o, attn_out, attn_proj, H, bs, q_dim, nullptr, nullptr, nullptr, 0.f, 0, S());
+      if (!rc && !fused_o) rc = pegainfer_gemv_fused(ly.o, attn_out, attn_proj, H, bs, q_dim, nullptr, nullptr, nullptr, 0.f, 0, S());
       if (!rc) rc = all_reduce_hidden(attn_proj, (size_t)bs * H);
       if (!rc) {
         rc = pegainfer_gemv_fused(ly.gate_up, cur, mlp_act, 2 * I, bs, H, attn_proj, ly.ln2, nxt, eps, I, S());
@@ -726,6 +758,8 @@ struct Model {
       kti[i] = 0;
     }
     const SplitPlan plan = make_split_plan(split_policy, seq_lens, padded, Hkv);
+    oproj_plan = split_policy == 1 && padded == 1 && plan.use_split && seq_lens[0] <= pq::kOprojFusedMaxSeq &&
+                 plan.slots > pq::oproj_fused_max_chunks();
     std::memcpy(mh<int32_t>(ml.split_request_indices), plan.request_indices.data(), plan.slots * 4);
     std::memcpy(mh<int32_t>(ml.split_kv_tile_indices), plan.kv_tile_indices.data(), plan.slots * 4);
     mh<int32_t>(ml.split_kv_chunk_size)[0] = plan.chunk;
@@ -766,7 +800,8 @@ struct Model {
       PQ_HIP(hipEventRecord(ev0, stream));
       if (enable_graph) {
         const int bi = bucket_index(padded);
-        hipGraphExec_t& exec = graphs[bi][split ? 1 : 0];
+        const int gv = !split ? 0 : (oproj_plan && attn_oproj && padded == 1 && !tp_comm && decode_mode >= 1 ? 2 : 1);
+        hipGraphExec_t& exec = graphs[bi][gv];
         if (!exec) {  // capture once (cuda_graph.rs:36-55), thread-local mode
           hipGraph_t graph = nullptr;
           PQ_HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
@@ -775,9 +810,9 @@ struct Model {
           if (rc || e != hipSuccess) { set_error("graph capture failed: " + err); return -1; }
           PQ_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
           PQ_HIP(hipGraphDestroy(graph));
-          graph_engine[bi][split ? 1 : 0] = eng_used;   // decode_kernels() recorded which path it captured
+          graph_engine[bi][gv] = eng_used;   // decode_kernels() recorded which path it captured
         }
-        engine_step = graph_engine[bi][split ? 1 : 0];
+        engine_step = graph_engine[bi][gv];
         PQ_HIP(hipGraphLaunch(exec, stream));
       } else {
         if (decode_kernels(padded, split, plan.slots)) return -1;
@@ -787,15 +822,33 @@ struct Model {
       PQ_HIP(hipEventRecord(ev1, stream));
       PQ_HIP(hipMemcpyAsync(tokens_out_host, tokens_out_d, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
       if (engine_step) PQ_HIP(hipMemcpyAsync(eng_status_host, eng_status, 16, hipMemcpyDeviceToHost, stream));
+      const bool oproj_check = attn_status && attn_oproj && oproj_plan && padded == 1 && split && !engine_step && decode_mode >= 1;
+      if (oproj_check) PQ_HIP(hipMemcpyAsync(attn_status_host, attn_status, 4, hipMemcpyDeviceToHost, stream));
       PQ_HIP(hipStreamSynchronize(stream));
       hipEventElapsedTime(&last_step_ms, ev0, ev1);
+      if (oproj_check && attn_status_host[0] != 0) {
+        // the o_proj phase of the fused launch never saw the attention rows (workgroups not co-resident): this attempt's
+        // outputs are invalid.  Disable the form, drop the graphs that captured it and take the second attempt on the
+        // two stand-alone launches (same metadata, same KV slots: the request state stays consistent).
+        attn_oproj = false;
+        oproj_fallbacks += 1;
+        PQ_HIP(hipMemsetAsync(attn_status, 0, 4, stream));
+        for (int b = 0; b < kNumBuckets; ++b)
+          for (int q = 0; q < 3; ++q)
+            if (graphs[b][q]) { hipGraphExecDestroy(graphs[b][q]); graphs[b][q] = nullptr; graph_engine[b][q] = false; }
+        err = "fused attention + o_proj launch: the bounded wait for the attention rows expired (code " +
+              std::to_string(attn_status_host[0]) + "); step re-run on two launches, form disabled";
+        attn_status_host[0] = 0;
+        if (attempt == 1) { set_error("fused attention + o_proj reported a failure after it was disabled"); return -4; }
+        continue;
+      }
       if (!(engine_step && eng_status_host[0] != 0)) break;
       // a bounded spin expired (the grid was not co-resident, or a hand-off never completed): this attempt's outputs
       // are invalid.  Disable the engine for good, drop the graphs that captured it and take the second attempt.
       eng_disabled = true;
       eng_fallbacks += 1;
       for (int b = 0; b < kNumBuckets; ++b)
-        for (int q = 0; q < 2; ++q)
+        for (int q = 0; q < 3; ++q)
           if (graphs[b][q]) { hipGraphExecDestroy(graphs[b][q]); graphs[b][q] = nullptr; graph_engine[b][q] = false; }
       err = "decode engine gave up: code " + std::to_string(eng_status_host[0] & 0xff) + " at " +
             std::to_string(eng_status_host[1]) + " (step re-run on the decode_mode 1 kernels; engine disabled)";
@@ -1073,6 +1126,7 @@ struct Model {
     if (meta_host) hipHostFree(meta_host);
     if (tokens_out_host) hipHostFree(tokens_out_host);
     if (eng_status_host) hipHostFree(eng_status_host);
+    if (attn_status_host) hipHostFree(attn_status_host);
     if (ev0) hipEventDestroy(ev0);
     if (ev1) hipEventDestroy(ev1);
     if (stream) hipStreamDestroy(stream);

@@ -33,13 +33,14 @@ def main():
     rids = [eng.new_request() for _ in range(args.batch)]
     toks = [int(eng.prefill([r], [prompt])[0]) for r in rids]
     nslots, hkv = 64 * max(args.batch, 1), cfg["num_key_value_heads"]
-    buf = torch.zeros(nslots * hkv * 8, dtype=torch.int64, device="cuda")
+    buf = torch.zeros((nslots * hkv + 256) * 8, dtype=torch.int64, device="cuda")   # + the o_proj phase of the fused launch
     ffi.lib().pegainfer_debug_attn_trace(buf.data_ptr())
     for _ in range(args.steps):
         buf.zero_()
         toks = [int(t) for t in eng.decode(rids, toks)]
     torch.cuda.synchronize()
-    t = buf.cpu().numpy().reshape(nslots * hkv, 8).astype(np.float64)
+    raw = buf.cpu().numpy().reshape(nslots * hkv + 256, 8).astype(np.float64)
+    t, op = raw[:nslots * hkv], raw[64 * hkv:64 * hkv + 256]
     ffi.lib().pegainfer_debug_attn_trace(None)
     live = t[:, 0] > 0
     t = t[live]
@@ -55,6 +56,14 @@ def main():
     last = np.where(t[:, 7] > 0, t[:, 6], np.where(t[:, 5] > 0, t[:, 5], t[:, 3]))
     print(f"  first entry -> last exit: {(last.max() - t[:, 0].min()) * ns / 1e3:.2f} us;"
           f" entry spread {(t[:, 0].max() - t[:, 0].min()) * ns / 1e3:.2f} us")
+    if args.batch == 1 and (op[:, 4] > 0).any():   # fused attention + o_proj launch: the o_proj workgroups (padding slots)
+        op = op[op[:, 4] > 0]
+        t0 = min(op[:, 0].min(), t[:, 0].min())
+        us = lambda a: (a - t0) * ns / 1e3
+        print(f"  fused launch: {len(t)} attention + {len(op)} o_proj workgroups; attention's last exit at {us(last.max()):.2f} | o_proj rows "
+              f"requested at {us(op[:, 1]).mean():.2f} | attention row seen at {us(op[:, 2]).mean():.2f} (min {us(op[:, 2]).min():.2f} max "
+              f"{us(op[:, 2]).max():.2f}) | x staged at {us(op[:, 3]).mean():.2f} (max {us(op[:, 3]).max():.2f}) | exit {us(op[:, 4]).mean():.2f} "
+              f"(max {us(op[:, 4]).max():.2f})")
     eng.close()
 
 

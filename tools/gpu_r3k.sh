@@ -1,0 +1,21 @@
+#!/bin/bash
+# round 3, call K: attention + o_proj in one launch: A/B, kernel stats, bit-identity tests
+repo=${GRAFT_REPO_ROOT:-/root/repo}
+cd $repo
+mkdir -p gpurun_out
+ab() {  # label, args, env...
+  label=$1; shift; args=$1; shift
+  env "$@" timeout 200 python bench.py $args --steps 64 --cpu-steps 0 --ttft-iters 1 --profile-iters 0 --ttft10k-iters 0 2>/dev/null | tail -1 | \
+    python -c "import sys,json;d=json.loads(sys.stdin.read());print('$label','tok/s',d['value'],'device_ms',d['tpot_ms']['device_p50'])"
+}
+for i in 1 2; do
+  ab "attn_oproj=0 bs1" "" PEGAINFER_ATTN_OPROJ=0
+  ab "attn_oproj=1 bs1" "" PEGAINFER_ATTN_OPROJ=1
+done 2>&1 | tee gpurun_out/r3k_attn_oproj_ab.txt
+ab "attn_oproj=1 ctx 4096" "--ctx 4096" PEGAINFER_ATTN_OPROJ=1 | tee -a gpurun_out/r3k_attn_oproj_ab.txt
+ab "attn_oproj=0 ctx 4096" "--ctx 4096" PEGAINFER_ATTN_OPROJ=0 | tee -a gpurun_out/r3k_attn_oproj_ab.txt
+ab "attn_oproj=1 ctx 128" "--ctx 128" PEGAINFER_ATTN_OPROJ=1 | tee -a gpurun_out/r3k_attn_oproj_ab.txt
+ab "attn_oproj=0 ctx 128" "--ctx 128" PEGAINFER_ATTN_OPROJ=0 | tee -a gpurun_out/r3k_attn_oproj_ab.txt
+timeout 900 python -m pytest tests/test_gpu_fused.py tests/test_gpu_real_dims.py tests/test_gpu_model.py -m gpu -q -x --tb=short > gpurun_out/pytest_r3k.log 2>&1
+tail -5 gpurun_out/pytest_r3k.log
+bash tools/gpu_kt.sh r3k_decode --steps 48 --cpu-steps 0 --ttft-iters 1 --profile-iters 0 --ttft10k-iters 0 2>&1 | head -9

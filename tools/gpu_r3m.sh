@@ -1,0 +1,16 @@
+#!/bin/bash
+repo=${GRAFT_REPO_ROOT:-/root/repo}
+cd $repo
+mkdir -p gpurun_out
+ab() {  # label, args, env...
+  label=$1; shift; args=$1; shift
+  env "$@" timeout 200 python bench.py $args --steps 64 --cpu-steps 0 --ttft-iters 1 --profile-iters 0 --ttft10k-iters 0 2>/dev/null | tail -1 | \
+    python -c "import sys,json;d=json.loads(sys.stdin.read());print('$label','tok/s',d['value'],'device_ms',d['tpot_ms']['device_p50'])"
+}
+for i in 1 2; do
+  ab "attn_oproj=0      " "" PEGAINFER_ATTN_OPROJ=0
+  ab "attn_oproj=1 h160 " "" PEGAINFER_ATTN_OPROJ=1
+  ab "attn_oproj=1 h0   " "" PEGAINFER_ATTN_OPROJ=1 PEGAINFER_ATTN_OPROJ_HOLD=0
+  ab "attn_oproj=1 h400 " "" PEGAINFER_ATTN_OPROJ=1 PEGAINFER_ATTN_OPROJ_HOLD=400
+done 2>&1 | tee gpurun_out/r3m_attn_oproj_ab.txt
+timeout 200 python tools/attn_probe.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r3m_attn_oproj_trace.txt
