@@ -1,7 +1,7 @@
 #!/bin/bash
 # Run on the GPU box (via gpurun): regenerate the files under profiles/ for round $1 (default r2) into
 # gpurun_out/profiles_new/.  part = a | b | all (two calls keep each under ~8 minutes of box time).
-R=${1:-r2}; part=${2:-all}
+R=${1:-r3}; part=${2:-all}
 repo=${GRAFT_REPO_ROOT:-/root/repo}
 out=$repo/gpurun_out/profiles_new
 mkdir -p $out
@@ -21,8 +21,8 @@ pmc() {  # out name, counters, bench args...
 }
 SQ="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"
 if [ $part = a ] || [ $part = all ]; then
-  kt ${R}_fused_decode_mode1 --steps 64 --cpu-steps 0
-  kt ${R}_baseline_decode_mode0 --steps 64 --cpu-steps 0 --decode-mode 0
+  kt ${R}_fused_decode_mode1 --steps 64 --cpu-steps 0 --ttft-iters 5 --profile-iters 0 --ttft10k-iters 0
+  kt ${R}_baseline_decode_mode0 --steps 64 --cpu-steps 0 --decode-mode 0 --ttft-iters 1 --profile-iters 0 --ttft10k-iters 0
   kt ${R}_ctx10000 --ctx 10000 --steps 8 --cpu-steps 0 --ttft-iters 2 --profile-iters 0 --ttft10k-iters 0
   pmc ${R}_fused_pmc_FETCH_SIZE FETCH_SIZE --steps 8 --ttft-iters 1 --profile-iters 0 --ttft10k-iters 0
   pmc ${R}_fused_pmc_WRITE_SIZE WRITE_SIZE --steps 8 --ttft-iters 1 --profile-iters 0 --ttft10k-iters 0
@@ -45,7 +45,7 @@ if [ $part = b ] || [ $part = all ]; then
   for c in 128 512 2048 4096 8192 10000; do
     timeout 250 python bench.py --ctx $c --steps 32 --cpu-steps 0 --ttft-iters 2 --profile-iters 0 --ttft10k-iters 0 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('ctx', d['config']['ctx'], 'tok/s', d['value'], 'device_ms', d['tpot_ms']['device_p50'], 'ttft_ms', d['ttft_ms']['p50'])"
   done > $out/${R}_context_sweep.txt
-  timeout 250 python bench.py --model qwen3-8b --steps 64 --cpu-steps 0 2>/dev/null | tail -1 > $out/${R}_qwen3_8b_greedy.json
+  timeout 250 python bench.py --model qwen3-8b --steps 64 --cpu-steps 0 --profile-iters 0 --ttft10k-iters 0 2>/dev/null | tail -1 > $out/${R}_qwen3_8b_greedy.json
   timeout 250 python bench.py --model qwen3-8b --sampling topk_topp --steps 64 --cpu-steps 0 --ttft-iters 1 --profile-iters 0 --ttft10k-iters 0 2>/dev/null | tail -1 > $out/${R}_qwen3_8b_topk_topp.json
   timeout 250 python bench.py --model qwen3.5-4b 2>/dev/null | tail -1 > $out/${R}_qwen35_4b_bench.json
   cd /tmp
