@@ -428,16 +428,26 @@ inline void gemv_launch_one(const GemvFusedArgs& a, hipStream_t s) {
   // same number of workgroups, so no CU carries 4/3 of its neighbour's rows - the 23 % tail of the round-2 phase trace
   // was 811 workgroups on 256 CUs); PEGAINFER_GEMV_GRID_PER_CU caps the workgroups per CU below the occupancy
   static const int mult = [] { const char* e = getenv("PEGAINFER_GEMV_GRID_MULT"); return e && *e ? atoi(e) : 256; }();
-  // default 2 per CU for the 1-2 column forms: 512 persistent workgroups walking their row groups beat 768-1280
-  // (x is staged by fewer workgroups, every CU carries the same row count): 2.045 -> 2.010 ms per step, same box
+  // default for the 1-2 column forms: 2 persistent workgroups per CU when a workgroup keeps >= kGemvCapMinKB of weight
+  // loads in flight (K = 2560 rows whole: 40 KB; K = 9728 dealt to 4 waves: 40 KB) - 512 workgroups walking their row
+  // groups beat 768-1280 there (x is staged by fewer workgroups, every CU carries the same row count): 2.045 -> 2.010 ms
+  // per Qwen3-4B step, same box.  Workgroups with little in flight (K = 4096 dealt to 4 waves: 16 KB; the Qwen3-8B
+  // family: 3.166 capped vs 3.066 ms uncapped) need the occupancy to cover the latency and keep it.
   static const int per_cu_env = [] { const char* e = getenv("PEGAINFER_GEMV_GRID_PER_CU"); return e && *e ? atoi(e) : -1; }();
-  const int per_cu_cap = per_cu_env >= 0 ? per_cu_env : (NT <= 2 ? 2 : 0);
+  static const int cap_min_kb = [] { const char* e = getenv("PEGAINFER_GEMV_CAP_MIN_KB"); return e && *e ? atoi(e) : 40; }();
+  const int blocks_per_wave = KSPLIT == 1 ? ceil_div(a.K, 512) : ceil_div(ceil_div(a.K, 512), KSPLIT);
+  constexpr int NW_ = EPI == kEpiSilu ? 2 : 1;
+  const int inflight_kb = 4 * (blocks_per_wave < U ? blocks_per_wave : U) * NW_ * RPW;
+  const int per_cu_cap = per_cu_env >= 0 ? per_cu_env : (NT <= 2 && inflight_kb >= cap_min_kb ? 2 : 0);
   int cap = cached_cap;
   if (per_cu_cap > 0 && mult > 0 && per_cu_cap * mult < cap) cap = per_cu_cap * mult;
   if (persist && a.K <= a.KT && ngroups > cap) {
     const int rounds = ceil_div(ngroups, cap);
     grid = ceil_div(ngroups, rounds);
-    if (mult > 0 && cap / mult * mult >= mult) grid = cap / mult * mult;
+    // the CU-count multiple matters when a workgroup walks only a few groups (gate_up: 3); a grid that walks dozens of
+    // rounds (an uncapped lm_head: 60) balances by count, and there the even split measured better (Qwen3-8B lm_head
+    // 177 vs 185 us)
+    if (mult > 0 && cap / mult * mult >= mult && (rounds <= 8 || per_cu_cap > 0)) grid = cap / mult * mult;
   }
   GemvFusedArgs b = a;
   b.trace = g_gemv_trace;
