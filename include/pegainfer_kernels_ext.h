@@ -74,6 +74,14 @@ pegainfer_status_t pegainfer_gemm_add_rms_norm(const Half* W, const Half* X, Hal
  * (prefill.rs:176-185).  On a split-K shape the slice sum and the add are one launch over the fp32 partials
  * (y_scratch [T, M] is then left untouched).  out may alias a.  Same bits either way. */
 pegainfer_status_t pegainfer_gemm_add(const Half* W, const Half* X, Half* y_scratch, const Half* a, Half* out, int32_t M, int32_t T, int32_t K, pegainfer_stream_t stream);
+/* down_proj + residual add + the NEXT layer's input RMSNorm (prefill): gemm_cuda + add_cuda + rms_norm_batched_cuda in
+ * at most two launches, same bits (the norm sees the bf16-rounded sum: prefill.rs:183 then prefill.rs:89). */
+pegainfer_status_t pegainfer_gemm_add_then_rms_norm(const Half* W, const Half* X, Half* y_scratch, const Half* a, Half* out, const Half* norm_weight, Half* normed_out, int32_t M, int32_t T, int32_t K, float eps, pegainfer_stream_t stream);
+/* prefill_qk_norm_rope_only_cuda / qk_norm_rope_batched_decode_cuda + paged_kv_scatter_cuda in ONE launch (head_dim 128):
+ * q and k are normalised + rotated in place exactly as the reference kernel does, and the rotated k row and the v row
+ * of every token go to cache slot page_indices[page_indptr[batch_indices[i]] + positions[i] / page_size] - the same
+ * bytes the two calls leave in q, k and the cache. */
+int32_t pegainfer_qk_norm_rope_scatter(Half* q, Half* k, const Half* v, const Half* q_norm_weight, const Half* k_norm_weight, const Half* cos_cache, const Half* sin_cache, const int32_t* positions, const int32_t* batch_indices, Half* kv_data, int64_t k_offset_elems, int64_t v_offset_elems, const int32_t* page_indices, const int32_t* page_indptr, int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim, int32_t page_size, int64_t stride_page, int32_t tokens, float rms_eps, pegainfer_stream_t stream);
 
 /* Decode attention with the per-head q/k RMSNorm + RoPE and the KV append folded in (head_dim 128):
  * reads the raw fused-QKV GEMV output qkv[bs, (Hq + 2 Hkv) * 128], writes the new K (normalised, rotated)

@@ -968,9 +968,16 @@ struct Model {
     if (embedding_batched_cuda(embed, tok_d, pf_hidden, H, Ti, S())) { set_error("embedding failed"); return -1; }
     Half *hid = pf_hidden, *hid_out = pf_hidden_out;
     const float sm = 1.0f / std::sqrt((float)D);
+    // prefill launch fusions (bit-identical to the reference op sequence; PEGAINFER_PREFILL_FUSE=0 runs it 1:1):
+    //   qk_norm_rope + paged_kv_scatter -> one launch; down_proj's slice sum + residual add + the NEXT layer's input
+    //   RMSNorm -> one launch (the norm sees the bf16-rounded sum exactly as add_cuda -> rms_norm does)
+    const char* pf_env = getenv("PEGAINFER_PREFILL_FUSE");   // read per call: tests flip it between two engines
+    const bool pf_fuse = !(pf_env && pf_env[0] == '0');
+    bool normed_ready = false;   // pf_normed already holds rms_norm(hid, this layer's ln1)
     for (int li = 0; li < L; ++li) {
       const Layer& ly = layers[li];
-      rms_norm_batched_cuda(hid, ly.ln1, pf_normed, H, Ti, eps, S());
+      if (!normed_ready) rms_norm_batched_cuda(hid, ly.ln1, pf_normed, H, Ti, eps, S());
+      normed_ready = false;
       auto G = [&](const Half* w, const Half* x, Half* y, int M, int K) {
         if (Ti == 1) gemm_graphsafe_cuda(w, x, y, M, 1, K, S());
         else gemm_cuda(w, x, y, M, Ti, K, S());
@@ -984,13 +991,21 @@ struct Model {
         G(ly.qkv + (size_t)q_dim * H, pf_normed, pf_k, kv_dim, H);
         G(ly.qkv + (size_t)(q_dim + kv_dim) * H, pf_normed, pf_v, kv_dim, H);
       }
-      if (n == 1 && n_decode_tail == 0)
-        prefill_qk_norm_rope_only_cuda(pf_q, pf_k, ly.q_norm, ly.k_norm, cos, sin, Hq, Hkv, D, Ti, starts[0], eps, S());
-      else
-        qk_norm_rope_batched_decode_cuda(pf_q, pf_k, ly.q_norm, ly.k_norm, cos, sin, D32(5), Hq, Hkv, D, Ti, eps, S());
-      int rc = paged_kv_scatter_cuda(kv_buffer, layout.k_offset(li), layout.v_offset(li), D32(1), D32(2), D32(3), pf_k,
-                                     pf_v, D32(4), D32(5), Ti, Hkv, D, layout.page_size, layout.page_stride, kv_dim, D, S());
-      if (rc) { set_error("paged_kv_scatter_cuda failed"); return -1; }
+      int rc = 0;
+      if (pf_fuse && D == 128) {
+        rc = pegainfer_qk_norm_rope_scatter(pf_q, pf_k, pf_v, ly.q_norm, ly.k_norm, cos, sin, D32(5), D32(4), kv_buffer,
+                                            layout.k_offset(li), layout.v_offset(li), D32(1), D32(2), Hq, Hkv, D,
+                                            layout.page_size, layout.page_stride, Ti, eps, S());
+        if (rc) { set_error("pegainfer_qk_norm_rope_scatter failed"); return -1; }
+      } else {
+        if (n == 1 && n_decode_tail == 0)
+          prefill_qk_norm_rope_only_cuda(pf_q, pf_k, ly.q_norm, ly.k_norm, cos, sin, Hq, Hkv, D, Ti, starts[0], eps, S());
+        else
+          qk_norm_rope_batched_decode_cuda(pf_q, pf_k, ly.q_norm, ly.k_norm, cos, sin, D32(5), Hq, Hkv, D, Ti, eps, S());
+        rc = paged_kv_scatter_cuda(kv_buffer, layout.k_offset(li), layout.v_offset(li), D32(1), D32(2), D32(3), pf_k,
+                                   pf_v, D32(4), D32(5), Ti, Hkv, D, layout.page_size, layout.page_stride, kv_dim, D, S());
+        if (rc) { set_error("paged_kv_scatter_cuda failed"); return -1; }
+      }
       rc = batch_prefill_paged_cuda_with_cta_tile_q(
           pf_q, pf_attn, kv_buffer, layout.k_offset(li), layout.v_offset(li), D32(1), D32(2), D32(3), D32(6), D32(7),
           D32(8), D32(9), D32(10), reinterpret_cast<uint32_t*>(pf_meta_dev + offs[11]), Hq, Hkv, D, layout.page_size,
@@ -1020,6 +1035,12 @@ struct Model {
         G(ly.down, pf_act, pf_o, H, I);
         if (all_reduce_hidden(pf_o, (size_t)Ti * H)) return -1;   // prefill.rs:180
         if (add_cuda(hid, pf_o, hid_out, Ti * H, S())) { set_error("add_cuda failed"); return -1; }
+      } else if (pf_fuse && li + 1 < L) {
+        if (pegainfer_gemm_add_then_rms_norm(ly.down, pf_act, pf_o, hid, hid_out, layers[li + 1].ln1, pf_normed, H, Ti, I,
+                                             eps, S())) {
+          set_error("pegainfer_gemm_add_then_rms_norm (prefill down_proj) failed"); return -1;
+        }
+        normed_ready = true;
       } else if (pegainfer_gemm_add(ly.down, pf_act, pf_o, hid, hid_out, H, Ti, I, S())) {
         set_error("pegainfer_gemm_add (prefill down_proj) failed"); return -1;
       }

@@ -388,10 +388,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 //   r = bf16(sum_z part[z][t][:])  (what the reduce kernel would have stored),  hidden = bf16(hidden + r),
 //   out = bf16((hidden + r)_fp32 * inv_rms * w).  All 512 threads build r in LDS; wave 0 then takes the row's sum of
 // squares in the canonical one-wave order of norm_core.h, so the result is bit-identical to the two-kernel sequence.
+// round_sum = false: FlashInfer's fused add + norm (the norm sees the un-rounded fp32 sum; hidden_in == hidden_out).
+// round_sum = true:  add_cuda, then rms_norm on its bf16 output (prefill.rs:183 + the next layer's prefill.rs:89):
+//                    hidden_out = bf16(hidden_in + r), out = norm(hidden_out) - the norm sees the ROUNDED sum.
 __global__ __launch_bounds__(512) void splitk_reduce_add_norm_kernel(const float* __restrict__ part,
+                                                                     const Half* __restrict__ hidden_in,
                                                                      Half* __restrict__ hidden,
                                                                      const Half* __restrict__ w, Half* __restrict__ out,
-                                                                     int d, int T, int ksplit, float eps) {
+                                                                     int d, int T, int ksplit, float eps, bool round_sum) {
   extern __shared__ __attribute__((aligned(16))) unsigned char rn_smem[];
   u32x4* rrow = reinterpret_cast<u32x4*>(rn_smem);              // [d / 8] bf16x8
   float* sm_inv = reinterpret_cast<float*>(rn_smem + (size_t)d * 2);
@@ -415,9 +419,10 @@ __global__ __launch_bounds__(512) void splitk_reduce_add_norm_kernel(const float
     rrow[i] = r;
   }
   __syncthreads();
+  const Half* hin = hidden_in + (size_t)t * d;
   Half* hr = hidden + (size_t)t * d;
   if (threadIdx.x < 64) {
-    const float inv = wave_row_inv_rms(hr, reinterpret_cast<const Half*>(rrow), d, eps);
+    const float inv = wave_row_inv_rms(hin, reinterpret_cast<const Half*>(rrow), d, eps, round_sum);
     if (threadIdx.x == 0) *sm_inv = inv;
   }
   __syncthreads();
@@ -426,8 +431,8 @@ __global__ __launch_bounds__(512) void splitk_reduce_add_norm_kernel(const float
   for (int i = threadIdx.x; i < nvec; i += 512) {
     const u32x4 r = rrow[i];
     u32x4 nh;
-    const u32x4 o = norm_scale8(reinterpret_cast<const u32x4*>(hr)[i], &r, reinterpret_cast<const u32x4*>(w)[i], inv,
-                                0.f, &nh);
+    const u32x4 o = norm_scale8(reinterpret_cast<const u32x4*>(hin)[i], &r, reinterpret_cast<const u32x4*>(w)[i], inv,
+                                0.f, &nh, round_sum);
     reinterpret_cast<u32x4*>(hr)[i] = nh;
     reinterpret_cast<u32x4*>(orow)[i] = o;
   }
@@ -866,8 +871,8 @@ pegainfer_status_t pegainfer_gemm_add_rms_norm(const Half* W, const Half* X, Hal
   if (vec && split) {
     const SplitKPlan pl = splitk_plan(M, T, K);
     glds_splitk_launch(W, X, y_scratch, M, T, K, SplitOut{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0}, pl, s, false);
-    splitk_reduce_add_norm_kernel<<<T, 512, (size_t)M * 2 + 16, s>>>(g_splitk_ws, hidden, norm_weight, normed_out, M, T,
-                                                                    pl.ksplit, eps);
+    splitk_reduce_add_norm_kernel<<<T, 512, (size_t)M * 2 + 16, s>>>(g_splitk_ws, hidden, hidden, norm_weight, normed_out,
+                                                                    M, T, pl.ksplit, eps, false);
     return (pegainfer_status_t)hipGetLastError();
   }
   gemm_dispatch(W, X, y_scratch, M, T, K, s);
@@ -894,6 +899,35 @@ pegainfer_status_t pegainfer_gemm_add(const Half* W, const Half* X, Half* y_scra
   }
   gemm_dispatch(W, X, y_scratch, M, T, K, s);
   return add_cuda(a, y_scratch, out, M * T, stream);
+}
+
+// down_proj + residual add + the NEXT layer's input RMSNorm (extension, prefill): exactly gemm_cuda(W, X, y_scratch),
+// add_cuda(a, y_scratch, out) and rms_norm_batched_cuda(out, norm_weight, normed_out) (prefill.rs:176-185 and the next
+// layer's prefill.rs:89) - the norm sees the bf16-ROUNDED sum, unlike the fused add + norm above.  On a split-K shape the
+// slice sum, the add and the norm are one launch over the fp32 partials; every other shape runs the three calls.  out may
+// alias a.  Same bits either way.
+pegainfer_status_t pegainfer_gemm_add_then_rms_norm(const Half* W, const Half* X, Half* y_scratch, const Half* a, Half* out,
+                                                    const Half* norm_weight, Half* normed_out, int32_t M, int32_t T,
+                                                    int32_t K, float eps, pegainfer_stream_t stream) {
+  using namespace pk;
+  if (M <= 0 || T <= 0 || K <= 0 || !y_scratch || !a || !out || !norm_weight || !normed_out)
+    return (pegainfer_status_t)hipErrorInvalidValue;
+  hipStream_t s = as_stream(stream);
+  const bool vec = (M & 7) == 0 && host_aligned16(a) && host_aligned16(out) && host_aligned16(norm_weight) &&
+                   host_aligned16(normed_out) && (size_t)M * 2 + 16 <= 64 * 1024;
+  const bool split = glds_gemm_ok(W, X, y_scratch, M, K) &&
+                     (T > 64 ? splitk_plan(M, T, K).nk_slice > 0 : mid_batch_route(W, X, y_scratch, M, T, K) == 2);
+  if (vec && split) {
+    const SplitKPlan pl = splitk_plan(M, T, K);
+    glds_splitk_launch(W, X, y_scratch, M, T, K, SplitOut{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0}, pl, s, false);
+    splitk_reduce_add_norm_kernel<<<T, 512, (size_t)M * 2 + 16, s>>>(g_splitk_ws, a, out, norm_weight, normed_out, M, T,
+                                                                    pl.ksplit, eps, true);
+    return (pegainfer_status_t)hipGetLastError();
+  }
+  const pegainfer_status_t rc = pegainfer_gemm_add(W, X, y_scratch, a, out, M, T, K, stream);
+  if (rc) return rc;
+  rms_norm_batched_cuda(out, norm_weight, normed_out, M, T, eps, stream);
+  return (pegainfer_status_t)hipGetLastError();
 }
 
 }  // extern "C"

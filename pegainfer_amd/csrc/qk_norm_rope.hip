@@ -8,6 +8,7 @@
 //   out[d+half] = bf16(m[d]*s + m[d+half]*c)          c,s = bf16 table[pos*head_dim + d]
 #include "common.h"
 #include "rope_core.h"
+#include "pegainfer_kernels_ext.h"
 
 namespace pk {
 
@@ -82,6 +83,44 @@ __global__ __launch_bounds__(256) void qk_norm_rope128_kernel(
   *reinterpret_cast<u32x4*>(data + sub * 8) = r;
 }
 
+// qk_norm_rope128_kernel + paged_kv_scatter_kernel in one launch: 16-lane rows over (token, q heads | k heads | v heads).
+// A k row is normalised + rotated, written back in place AND into its cache slot; a v row is copied into its slot.
+__global__ __launch_bounds__(256) void qk_norm_rope128_scatter_kernel(
+    Half* __restrict__ q, Half* __restrict__ k, const Half* __restrict__ v, const Half* __restrict__ q_w,
+    const Half* __restrict__ k_w, const Half* __restrict__ cos_cache, const Half* __restrict__ sin_cache,
+    const int* __restrict__ positions, const int* __restrict__ batch_indices, Half* __restrict__ kv, long k_off, long v_off,
+    const int* __restrict__ page_indices, const int* __restrict__ page_indptr, int num_q_heads, int num_kv_heads,
+    int page_size, long stride_page, int tokens, float eps) {
+  const int heads = num_q_heads + 2 * num_kv_heads;
+  const long unit = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+  if (unit >= (long)tokens * heads) return;  // whole 16-lane rows drop out together (DPP stays inside a row)
+  const int token = (int)(unit / heads);
+  const int hg = (int)(unit - (long)token * heads);
+  const int sub = threadIdx.x & 15;
+  const int pos = positions[token];
+  if (hg < num_q_heads) {
+    Half* data = q + ((size_t)token * num_q_heads + hg) * 128;
+    const u32x4 x = *reinterpret_cast<const u32x4*>(data + sub * 8);
+    *reinterpret_cast<u32x4*>(data + sub * 8) =
+        head_norm_rope16(x, q_w, cos_cache + (size_t)pos * 128, sin_cache + (size_t)pos * 128, sub, eps);
+    return;
+  }
+  const bool is_v = hg >= num_q_heads + num_kv_heads;
+  const int h = hg - num_q_heads - (is_v ? num_kv_heads : 0);
+  const int page = page_indices[page_indptr[batch_indices[token]] + pos / page_size];
+  const long dst = (long)page * stride_page + (is_v ? v_off : k_off) + ((long)(pos % page_size) * num_kv_heads + h) * 128;
+  u32x4 r;
+  if (is_v) {
+    r = *reinterpret_cast<const u32x4*>(v + ((size_t)token * num_kv_heads + h) * 128 + sub * 8);
+  } else {
+    Half* data = k + ((size_t)token * num_kv_heads + h) * 128;
+    const u32x4 x = *reinterpret_cast<const u32x4*>(data + sub * 8);
+    r = head_norm_rope16(x, k_w, cos_cache + (size_t)pos * 128, sin_cache + (size_t)pos * 128, sub, eps);
+    *reinterpret_cast<u32x4*>(data + sub * 8) = r;
+  }
+  *reinterpret_cast<u32x4*>(kv + dst + sub * 8) = r;
+}
+
 static void launch(Half* q, Half* k, const Half* qw, const Half* kw, const Half* c, const Half* s, int hq,
                    int hkv, int hd, int tokens, int start_pos, const int* positions, float eps,
                    hipStream_t stream) {
@@ -118,6 +157,28 @@ void qk_norm_rope_batched_decode_cuda(Half* q, Half* k, const Half* q_norm_weigh
                                       int32_t batch_size, float rms_eps, pegainfer_stream_t stream) {
   pk::launch(q, k, q_norm_weight, k_norm_weight, cos_cache, sin_cache, num_q_heads, num_kv_heads, head_dim,
              batch_size, 0, positions, rms_eps, pk::as_stream(stream));
+}
+
+// extension (include/pegainfer_kernels_ext.h): the two reference calls above + paged_kv_scatter_cuda in one launch
+int32_t pegainfer_qk_norm_rope_scatter(Half* q, Half* k, const Half* v, const Half* q_norm_weight,
+                                       const Half* k_norm_weight, const Half* cos_cache, const Half* sin_cache,
+                                       const int32_t* positions, const int32_t* batch_indices, Half* kv_data,
+                                       int64_t k_offset_elems, int64_t v_offset_elems, const int32_t* page_indices,
+                                       const int32_t* page_indptr, int32_t num_q_heads, int32_t num_kv_heads,
+                                       int32_t head_dim, int32_t page_size, int64_t stride_page, int32_t tokens,
+                                       float rms_eps, pegainfer_stream_t stream) {
+  using namespace pk;
+  if (tokens <= 0) return 0;
+  if (head_dim != 128 || num_q_heads < 0 || num_kv_heads <= 0 || page_size <= 0 || !positions || !batch_indices ||
+      !host_aligned16(q) || !host_aligned16(k) || !host_aligned16(v) || !host_aligned16(kv_data) ||
+      !host_aligned16(q_norm_weight) || !host_aligned16(k_norm_weight) || !host_aligned16(cos_cache) ||
+      !host_aligned16(sin_cache) || (stride_page & 7) || (k_offset_elems & 7) || (v_offset_elems & 7))
+    return static_cast<int32_t>(hipErrorInvalidValue);
+  const long units = (long)tokens * (num_q_heads + 2 * num_kv_heads);
+  qk_norm_rope128_scatter_kernel<<<ceil_div(units, 16), 256, 0, as_stream(stream)>>>(
+      q, k, v, q_norm_weight, k_norm_weight, cos_cache, sin_cache, positions, batch_indices, kv_data, k_offset_elems,
+      v_offset_elems, page_indices, page_indptr, num_q_heads, num_kv_heads, page_size, stride_page, tokens, rms_eps);
+  return static_cast<int32_t>(hipGetLastError());
 }
 
 }  // extern "C"

@@ -238,3 +238,102 @@ def test_model_mid_batch_fused_layer_bitwise_equals_reference_sequence(built_lib
         else:
             os.environ["PEGAINFER_MID_BATCH_FUSED"] = old
     assert np.array_equal(outs[0], outs[1])
+
+
+# ------------------------------------------------------------------ prefill launch fusions (round 3)
+@pytest.mark.parametrize("T", [1024, 333, 40, 5])
+def test_gemm_add_then_rms_norm_matches_the_three_calls(built_libs, T):
+    """pegainfer_gemm_add_then_rms_norm (down_proj + residual add + the next layer's input RMSNorm; on split-K shapes
+    the slice sum, the add and the norm are one launch) == gemm_cuda -> add_cuda -> rms_norm_batched_cuda, every bit of
+    the new hidden state and of the normalised output (the norm sees the bf16-ROUNDED sum, prefill.rs:183 + :89)."""
+    import torch
+    import pegainfer_amd.ops as P
+    from pegainfer_amd import ffi
+    M, K = 2560, 9728
+    rng = np.random.default_rng(T)
+    W, X, A = rnd(rng, M, K, scale=0.03), rnd(rng, T, K, scale=1.0), rnd(rng, T, M, scale=2.0)
+    g = bf16_round(1 + rnd(rng, M, scale=0.2))
+    L, s = ffi.lib(), torch.cuda.current_stream().cuda_stream
+    Wd, Xd, Ad, gd = to_dev(W), to_dev(X), to_dev(A), to_dev(g)
+    # the three reference-named calls
+    y = P.gemm(Wd, Xd)
+    out_ref = torch.empty_like(Ad)
+    assert L.add_cuda(Ad.data_ptr(), y.data_ptr(), out_ref.data_ptr(), T * M, s) == 0
+    n_ref = torch.empty_like(Ad)
+    P.rms_norm_batch_into(out_ref, gd, 1e-6, n_ref)
+    # the fused entry point
+    scratch, out, normed = torch.empty_like(Ad), torch.empty_like(Ad), torch.empty_like(Ad)
+    assert L.pegainfer_gemm_add_then_rms_norm(Wd.data_ptr(), Xd.data_ptr(), scratch.data_ptr(), Ad.data_ptr(), out.data_ptr(),
+                                              gd.data_ptr(), normed.data_ptr(), M, T, K, 1e-6, s) == 0
+    assert np.array_equal(bf16_bits(from_dev(out)), bf16_bits(from_dev(out_ref)))
+    assert np.array_equal(bf16_bits(from_dev(normed)), bf16_bits(from_dev(n_ref)))
+    # and against the oracle's op sequence (tolerance of the GEMM summation order)
+    ref = O.rms_norm(O.add(A, O.gemm(W, X)), g, 1e-6)
+    assert np.abs(from_dev(normed) - ref).max() <= 2.0 ** -5 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("lens,starts", [([300], [0]), ([70, 3, 129], [5, 40, 0])])
+def test_qk_norm_rope_scatter_matches_the_two_calls(built_libs, lens, starts):
+    """pegainfer_qk_norm_rope_scatter == qk_norm_rope_batched_decode_cuda + paged_kv_scatter_cuda: q and k in place and
+    every byte of the cache (32 / 8 heads x 128, ragged multi-request batch with chunked continuations)."""
+    import torch
+    from pegainfer_amd import ffi
+    from test_gpu_ops import make_paged
+    rng = np.random.default_rng(sum(lens))
+    Hq, Hkv, D = 32, 8, 128
+    tot = [s + n for s, n in zip(starts, lens)]
+    lay, kv, pages, indptr, last = make_paged(rng, len(lens), tot, Hkv=Hkv, D=D)
+    T = sum(lens)
+    q, k, v = rnd(rng, T, Hq * D), rnd(rng, T, Hkv * D), rnd(rng, T, Hkv * D)
+    qw, kw = bf16_round(1 + rnd(rng, D, scale=0.1)), bf16_round(1 + rnd(rng, D, scale=0.1))
+    cos, sin = O.precompute_rope(D, 512, 1e6)
+    bidx = np.concatenate([np.full(n, i) for i, n in enumerate(lens)]).astype(np.int32)
+    pos = np.concatenate([np.arange(s, s + n) for s, n in zip(starts, lens)]).astype(np.int32)
+    i32 = lambda a: torch.tensor(np.asarray(a), dtype=torch.int32, device="cuda")
+    L, s = ffi.lib(), torch.cuda.current_stream().cuda_stream
+    keep = [to_dev(qw), to_dev(kw), to_dev(cos), to_dev(sin), i32(pos), i32(bidx), i32(pages), i32(indptr), i32(last), to_dev(v)]
+    outs = []
+    for fused in (False, True):
+        qd, kd, kvd = to_dev(q), to_dev(k), to_dev(kv)
+        if fused:
+            assert L.pegainfer_qk_norm_rope_scatter(qd.data_ptr(), kd.data_ptr(), keep[9].data_ptr(), keep[0].data_ptr(),
+                                                    keep[1].data_ptr(), keep[2].data_ptr(), keep[3].data_ptr(), keep[4].data_ptr(),
+                                                    keep[5].data_ptr(), kvd.data_ptr(), lay.layer_stride, lay.layer_stride + lay.kv_block_len,
+                                                    keep[6].data_ptr(), keep[7].data_ptr(), Hq, Hkv, D, 16, lay.page_stride, T,
+                                                    1e-6, s) == 0
+        else:
+            L.qk_norm_rope_batched_decode_cuda(qd.data_ptr(), kd.data_ptr(), keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr(),
+                                               keep[3].data_ptr(), keep[4].data_ptr(), Hq, Hkv, D, T, 1e-6, s)
+            assert L.paged_kv_scatter_cuda(kvd.data_ptr(), lay.layer_stride, lay.layer_stride + lay.kv_block_len, keep[6].data_ptr(),
+                                           keep[7].data_ptr(), keep[8].data_ptr(), kd.data_ptr(), keep[9].data_ptr(),
+                                           keep[5].data_ptr(), keep[4].data_ptr(), T, Hkv, D, 16, lay.page_stride, Hkv * D, D, s) == 0
+        outs.append((bf16_bits(from_dev(qd)), bf16_bits(from_dev(kd)), bf16_bits(from_dev(kvd))))
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+
+
+def test_model_prefill_fusions_bitwise_equal_reference_sequence(built_libs, monkeypatch):
+    """Whole model: prefill logits and the KV the following decode steps read are bit-identical with the prefill launch
+    fusions on (default) and off (PEGAINFER_PREFILL_FUSE=0 = the reference op sequence 1:1); single prompt, ragged batch
+    and a chunked continuation."""
+    from pegainfer_amd.qwen3 import Qwen3Engine
+    meta = json.load(open(os.path.join(G, "qwen3_tiny_golden.json")))
+    prompts = [c["prompt_tokens"] for c in meta["cases"][:3]]
+    runs = []
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("PEGAINFER_PREFILL_FUSE", fuse)
+        eng = Qwen3Engine(meta["config"], num_kv_pages=96, max_batch_size=4).load_safetensors(os.path.join(G, "qwen3_tiny.safetensors"))
+        rids = [eng.new_request() for _ in prompts]
+        tok, lg = eng.prefill(rids, prompts, return_logits=True)
+        rows = [lg.copy()]
+        for _ in range(3):
+            tok, lg = eng.decode(rids, tok, return_logits=True)
+            rows.append(lg.copy())
+        r = eng.new_request()                                   # chunked: 20 tokens, then the rest
+        eng.prefill([r], [prompts[2][:20]])
+        _, lg2 = eng.prefill([r], [prompts[2][20:]], return_logits=True)
+        rows.append(lg2.copy())
+        eng.close()
+        runs.append(rows)
+    for a, b in zip(*runs):
+        assert np.array_equal(a, b)
