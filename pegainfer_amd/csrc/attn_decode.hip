@@ -226,6 +226,8 @@ __global__ __launch_bounds__(512) void attn_oproj_kernel(const DecodeAttnArgs a,
     while (wall_clock64() - t0 < (unsigned long long)g.hold_ticks) __builtin_amdgcn_s_sleep(1);
   }
   u32x4 wv[kOprojMaxRows][2];
+#pragma unroll
+  for (int r = 0; r < kOprojMaxRows; ++r) wv[r][0] = wv[r][1] = u32x4{0u, 0u, 0u, 0u};
   auto request_rows = [&](int base) {
 #pragma unroll
     for (int r = 0; r < kOprojMaxRows; ++r) {
@@ -243,14 +245,16 @@ __global__ __launch_bounds__(512) void attn_oproj_kernel(const DecodeAttnArgs a,
   request_rows(0);
   if (ot && threadIdx.x == 0) ot[1] = wall_clock64();
   __shared__ __attribute__((aligned(16))) u32x4 xs[1024];   // K <= 8192
-  __shared__ float part[2][4][kOprojMaxRows];
+  // per-lane partial dot products, one 64-float line (+4 pad) per (wave quad, row, K-split wave)
+  constexpr int kRedStride = 68;
+  __shared__ __attribute__((aligned(16))) float red[2 * kOprojMaxRows * 4][kRedStride];
   __shared__ int ok_flag;
   if (threadIdx.x == 0) {
     const unsigned long long t0 = wall_clock64();
     int ok = 1;
     while (__hip_atomic_load(a.done_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < g.done_target) {
       if (wall_clock64() - t0 > 3000000ull) { ok = 0; break; }   // 30 ms
-      __builtin_amdgcn_s_sleep(2);
+      __builtin_amdgcn_s_sleep(1);
     }
     ok_flag = ok;
     if (!ok && g.status) g.status[0] = 0x300u;
@@ -269,7 +273,8 @@ __global__ __launch_bounds__(512) void attn_oproj_kernel(const DecodeAttnArgs a,
   __syncthreads();
   if (ot && threadIdx.x == 0) ot[3] = wall_clock64();
   for (int base = 0; base < rows_half; base += kOprojMaxRows) {
-    if (base > 0) { __syncthreads(); request_rows(base); }   // `part` is reused; only the first pass was prefetched
+    if (base > 0) { __syncthreads(); request_rows(base); }   // `red` is reused; only the first pass was prefetched
+    // all kOprojMaxRows rows are computed, branch-free (rows past rows_half hold zeros / a previous pass: masked below)
     float acc[kOprojMaxRows];
 #pragma unroll
     for (int r = 0; r < kOprojMaxRows; ++r) acc[r] = 0.f;
@@ -280,29 +285,39 @@ __global__ __launch_bounds__(512) void attn_oproj_kernel(const DecodeAttnArgs a,
       u32x4 xv = xs[live ? (kk >> 3) : 0];
       if (!live) xv = u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
-      for (int r = 0; r < kOprojMaxRows; ++r)
-        if (base + r < rows_half) acc[r] = dot8(wv[r][u], xv, acc[r]);
+      for (int r = 0; r < kOprojMaxRows; ++r) acc[r] = dot8(wv[r][u], xv, acc[r]);
     }
+    if (ot && threadIdx.x == 0 && base == 0) ot[5] = wall_clock64();
+    // The 64-lane sums through LDS instead of kOprojMaxRows dependent wave butterflies (1.0 us of the 2.2 us this phase
+    // took): every lane parks its partials, then 4 threads per (quad, row, K-split wave) line rebuild wave_sum's own
+    // addition tree - lane pairs, quads, 8, 16 inside a thread, the 16-lane rows across the 4 threads - and the four
+    // K-split waves are added in order: the bits of gemv_fused_kernel<.., KSPLIT = 4>.
 #pragma unroll
-    for (int r = 0; r < kOprojMaxRows; ++r)
-      if (base + r < rows_half) acc[r] = wave_sum(acc[r]);
-    if (lane == 0) {
-#pragma unroll
-      for (int r = 0; r < kOprojMaxRows; ++r)
-        if (base + r < rows_half) part[quad][w4][r] = acc[r];
-    }
+    for (int r = 0; r < kOprojMaxRows; ++r) red[(quad * kOprojMaxRows + r) * 4 + w4][lane] = acc[r];
     __syncthreads();
-    if (threadIdx.x < 2 * kOprojMaxRows) {
-      const int q = threadIdx.x / kOprojMaxRows, r = threadIdx.x % kOprojMaxRows;
+    if (threadIdx.x < 2 * kOprojMaxRows * 16) {
+      const int line = threadIdx.x >> 2, t = threadIdx.x & 3;
+      const float4* p = reinterpret_cast<const float4*>(&red[line][t * 16]);
+      const float4 c0 = p[0], c1 = p[1], c2 = p[2], c3 = p[3];
+      const float s0 = (c0.x + c0.y) + (c0.z + c0.w), s1 = (c1.x + c1.y) + (c1.z + c1.w);
+      const float s2 = (c2.x + c2.y) + (c2.z + c2.w), s3 = (c3.x + c3.y) + (c3.z + c3.w);
+      float v = (s0 + s1) + (s2 + s3);          // one 16-lane row of the wave
+      v += dpp_mov<kDppQuadXor1>(v);            // rows 16 apart
+      v += dpp_mov<kDppQuadXor2>(v);            // rows 32 apart: the wave's sum, in all 4 threads of the line
+      const int rowbase = lane & ~15;           // 16 threads = the 4 K-split lines of one (quad, row)
+      const float p0 = __shfl(v, rowbase, kWave), p1 = __shfl(v, rowbase + 4, kWave);
+      const float p2 = __shfl(v, rowbase + 8, kWave), p3 = __shfl(v, rowbase + 12, kWave);
+      const int qr = threadIdx.x >> 4, q = qr / kOprojMaxRows, r = qr % kOprojMaxRows;
       const int row = (gi * 2 + q) * rows_half + base + r;
-      if (base + r < rows_half && row < g.M) {
-        float v = part[q][0][r];
-        v += part[q][1][r];
-        v += part[q][2][r];
-        v += part[q][3][r];
-        g.Y[row] = f2bf(v);
+      if ((threadIdx.x & 15) == 0 && base + r < rows_half && row < g.M) {
+        float y = p0;
+        y += p1;
+        y += p2;
+        y += p3;
+        g.Y[row] = f2bf(y);
       }
     }
+    if (ot && threadIdx.x == 0 && base == 0) ot[6] = wall_clock64();
   }
   if (ot && threadIdx.x == 0) ot[4] = wall_clock64();
 }

@@ -63,7 +63,7 @@ def main():
         print(f"  fused launch: {len(t)} attention + {len(op)} o_proj workgroups; attention's last exit at {us(last.max()):.2f} | o_proj rows "
               f"requested at {us(op[:, 1]).mean():.2f} | attention row seen at {us(op[:, 2]).mean():.2f} (min {us(op[:, 2]).min():.2f} max "
               f"{us(op[:, 2]).max():.2f}) | x staged at {us(op[:, 3]).mean():.2f} (max {us(op[:, 3]).max():.2f}) | exit {us(op[:, 4]).mean():.2f} "
-              f"(max {us(op[:, 4]).max():.2f})")
+              f"(max {us(op[:, 4]).max():.2f}) | dot products done {us(op[:, 5]).mean():.2f}, wave sums done {us(op[:, 6]).mean():.2f}")
     eng.close()
 
 
