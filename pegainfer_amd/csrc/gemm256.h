@@ -307,4 +307,211 @@ inline void gemm256_splitk_launch(const Half* W, const Half* X, int M, int T, in
       W, X, nullptr, M, T, K, m_tiles, t_tiles, SplitOut{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0}, part, nk_slice);
 }
 
+// ---- 128 x 256 tiles: the same machinery for matrices with too few 256-row tiles to fill the chip (qkv / o_proj /
+// down_proj at ~0.5-2 k tokens: 2560 rows are 10 tiles of 256 but 20 of 128).  8 waves as 2 x 4, wave (wr, wc) owns
+// 64 W rows x 64 token rows = 4 x 4 MFMA tiles (64 accumulator VGPRs).  A K tile is THREE 16 KiB half-tiles - A (all 128
+// rows), B_lo / B_hi (token rows of n-tiles 0-1 / 2-3 of every wave column) - and two phases:
+//     phase 1: read A + B_lo, quadrant lo (16 MFMAs)        phase 2: read B_hi, quadrant hi (16 MFMAs)
+// LDS holds a ring of three K tiles (144 KiB): the three half-tiles of K tile kt + 2 are staged during K tile kt into the
+// slots K tile kt - 1 was read from, one counted vmcnt(6) per K tile (tile kt + 2 stays in flight across the barrier,
+// tile kt + 1 has landed), wave row 1 runs one barrier behind wave row 0 as above.  Per-element K order unchanged: same
+// bits as the other tiled kernels.
+// Measured (profiles/r3_gemm128x256_ab.txt, 1024 tokens, cold weights): qkv 57 -> 43 us, down_proj 84 -> 67 us, o_proj
+// 45 -> 41 us; per-CU efficiency ~40-45 % (the 256 x 256 kernel: 57 %): a 128 x 256 tile moves 48 KiB into LDS per 32
+// MFMAs per wave, ~3/4 of a CU's L1 fill rate at the MFMA-bound pace.  A variant with double-buffered fragment registers
+// and ONE barrier per K tile (every read a quadrant ahead of its MFMAs, no wave-row skew) was 25 % SLOWER (qkv 55 us):
+// without the skew both waves of a SIMD sit in the same segment and nothing feeds the matrix pipe across the barrier.
+constexpr int G128_BM = 128;
+constexpr int kG128LdsBytes = 9 * kG256HalfBytes;
+enum { kG128A = 0, kG128Blo = 1, kG128Bhi = 2 };
+
+__global__ __launch_bounds__(512) void mfma_gemm128x256_kernel(const Half* __restrict__ W, const Half* __restrict__ X,
+                                                               Half* __restrict__ Y, int M, int T, int K, int m_tiles,
+                                                               int t_tiles, SplitOut so, float* __restrict__ part,
+                                                               int nk_slice) {
+  extern __shared__ __attribute__((aligned(16))) u32x4 g256_smem[];
+  const int ntiles = m_tiles * t_tiles;
+  int tile = blockIdx.x;
+  {
+    const int q = ntiles / 8, r = ntiles % 8, xcd = tile % 8, idx = tile / 8;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int mt = tile / t_tiles, tt = tile - mt * t_tiles;
+  const int m0 = mt * G128_BM, t0 = tt * G256_BT;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int l15 = lane & 15, g = lane >> 4;
+
+  const Half* src[3][2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int p = (j * 8 + wave) * 64 + lane, hrow = p >> 3, cs = (p & 7) ^ (hrow & 7);
+    int row = m0 + hrow;
+    row = row < M ? row : M - 1;
+    src[kG128A][j] = W + (size_t)row * K + cs * 8;
+    const int wc_ = hrow >> 5, r = hrow & 31;
+#pragma unroll
+    for (int hi = 0; hi < 2; ++hi) {
+      int tr = t0 + wc_ * 64 + hi * 32 + r;
+      tr = tr < T ? tr : T - 1;
+      src[hi ? kG128Bhi : kG128Blo][j] = X + (size_t)tr * K + cs * 8;
+    }
+  }
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)&g256_smem[0];
+  const int kt_begin = part ? (int)blockIdx.y * nk_slice : 0;
+  const int nk_total = K / G256_BK;
+  const int nk = part ? (nk_total - kt_begin < nk_slice ? nk_total - kt_begin : nk_slice) : nk_total;
+#pragma unroll
+  for (int w = 0; w < 3; ++w)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) src[w][j] += (size_t)kt_begin * G256_BK;
+  // stage half-tile `which` of K tile kt into ring slot `ring` (clamped past the end: a dead slot, the load only keeps
+  // vmcnt uniform)
+  auto stage = [&](int which, int kt, int ring) {
+    const int ktc = kt < nk ? kt : nk - 1;
+    const uint32_t slot = lds0 + (uint32_t)((ring * 3 + which) * kG256HalfBytes);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const uint32_t dst = __builtin_amdgcn_readfirstlane(slot + (uint32_t)(j * 8 + wave) * 1024u);
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                   :: "v"(src[which][j] + (size_t)ktc * G256_BK), "s"(dst) : "memory", "m0");
+    }
+  };
+  auto half_ptr = [&](int ring, int which) { return g256_smem + (size_t)(ring * 3 + which) * (kG256HalfBytes / 16); };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8_t a[4][2], b[2][2];
+  auto read_a = [&](int ring) {
+    const u32x4* h = half_ptr(ring, kG128A);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        a[i][ks] = __builtin_bit_cast(bf16x8_t, h[lds_slot(wr * 64 + i * 16 + l15, ks * 4 + g)]);
+  };
+  auto read_b = [&](int ring, int which) {
+    const u32x4* h = half_ptr(ring, which);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        b[j][ks] = __builtin_bit_cast(bf16x8_t, h[lds_slot(wc * 32 + j * 16 + l15, ks * 4 + g)]);
+  };
+  auto quad = [&](int jh) {   // 16 MFMAs: all 4 m-tiles, n-tiles jh*2..
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][jh * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][ks], b[j][ks], acc[i][jh * 2 + j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // ---- prologue: K tiles 0 and 1 requested, tile 0 landed ----
+  stage(kG128A, 0, 0); stage(kG128Blo, 0, 0); stage(kG128Bhi, 0, 0);
+  stage(kG128A, 1, 1); stage(kG128Blo, 1, 1); stage(kG128Bhi, 1, 1);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();   // the second wave row runs one barrier behind the first
+
+  // one K tile = two phases (fragment reads + DMA issue | barrier | 16 MFMAs | barrier); the counted wait sits in front
+  // of the first barrier of the last phase, so it covers both wave rows (see the 256 x 256 kernel)
+  auto ktile = [&](int kt, int ring) {
+    const int ring2 = (ring + 2) % 3;
+    read_b(ring, kG128Blo);
+    __builtin_amdgcn_sched_barrier(0);
+    read_a(ring);
+    stage(kG128A, kt + 2, ring2);
+    stage(kG128Blo, kt + 2, ring2);
+    __builtin_amdgcn_s_barrier();
+    quad(0);
+    __builtin_amdgcn_s_barrier();
+    read_b(ring, kG128Bhi);
+    stage(kG128Bhi, kt + 2, ring2);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    quad(1);
+    __builtin_amdgcn_s_barrier();
+  };
+  for (int kt = 0; kt < nk; kt += 3) {
+    ktile(kt, 0);
+    if (kt + 1 < nk) ktile(kt + 1, 1);
+    if (kt + 2 < nk) ktile(kt + 2, 2);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail loads must not outlive the workgroup's LDS
+  if (wr == 0) __builtin_amdgcn_s_barrier();
+
+  if (part) {
+    float* pz = part + (size_t)blockIdx.y * T * M;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int t = t0 + wc * 64 + j * 16 + l15;
+      if (t >= T) continue;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wr * 64 + i * 16 + g * 4;
+        if (m + 3 < M) {
+          *reinterpret_cast<f32x4*>(pz + (size_t)t * M + m) = acc[i][j];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (m + e < M) pz[(size_t)t * M + m + e] = acc[i][j][e];
+        }
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int t = t0 + wc * 64 + j * 16 + l15;
+    if (t >= T) continue;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + wr * 64 + i * 16 + g * 4;
+      Half* dst = Y;
+      int ld = M, mm = m, mlim = M;
+      if (so.Y1) {
+        const int b1 = so.M0 + so.M1, b2 = b1 + so.M2;
+        if (m < so.M0) { ld = mlim = so.M0; }
+        else if (m < b1) { dst = so.Y1; ld = mlim = so.M1; mm = m - so.M0; }
+        else if (m < b2) { dst = so.Y2; ld = mlim = so.M2; mm = m - b1; }
+        else { dst = so.Y3; ld = mlim = M - b2; mm = m - b2; }
+      }
+      if (mm + 3 < mlim) {
+        u32x2 o;
+        o.x = pack_bf2(acc[i][j][0], acc[i][j][1]);
+        o.y = pack_bf2(acc[i][j][2], acc[i][j][3]);
+        *reinterpret_cast<u32x2*>(dst + (size_t)t * ld + mm) = o;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (mm + e < mlim) dst[(size_t)t * ld + mm + e] = f2bf(acc[i][j][e]);
+      }
+    }
+  }
+}
+
+inline bool gemm128x256_ok(int M, int T, int K) { return (K % G256_BK) == 0 && K >= 128 && M >= 128 && T > 64; }
+
+// plain (part == nullptr, ksplit == 1) or split-K (fp32 partials into part[ksplit][T][M]; the caller sums the slices)
+inline void gemm128x256_launch(const Half* W, const Half* X, Half* Y, int M, int T, int K, SplitOut so, float* part,
+                               int ksplit, int nk_slice, hipStream_t s) {
+  static const bool once = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_gemm128x256_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kG128LdsBytes);
+    return true;
+  }();
+  (void)once;
+  const int m_tiles = ceil_div(M, G128_BM), t_tiles = ceil_div(T, G256_BT);
+  mfma_gemm128x256_kernel<<<dim3(m_tiles * t_tiles, part ? ksplit : 1), 512, kG128LdsBytes, s>>>(
+      W, X, Y, M, T, K, m_tiles, t_tiles, so, part, nk_slice);
+}
+
 }  // namespace pk

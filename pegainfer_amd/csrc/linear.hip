@@ -489,6 +489,10 @@ static void glds_gemm_launch_t(const Half* W, const Half* X, Half* Y, int M, int
 //    resident.  o_proj / down_proj at 1024 tokens (160 tiles): 3 slices, 45 -> 40 and 100 -> 78 us (2 slices leave a
 //    quarter of the CUs with two workgroups: the makespan does not move); at 128 tokens qkv / o / down have 48 / 20 / 20
 //    tiles of 128x128 and ran at 95-150 TFLOP/s un-split.
+static bool gemm128x256_on() {
+  static const bool v = [] { const char* e = getenv("PEGAINFER_GEMM128X256"); return !(e && e[0] == '0'); }();
+  return v;
+}
 constexpr int kSplitKMaxRows = 16384;   // below this (< 128 row tiles) the 17..64-column GEMM splits K
 struct SplitKPlan { int ksplit, nk_slice, tt; };
 static SplitKPlan splitk_plan(int M, int T, int K) {
@@ -511,6 +515,19 @@ static SplitKPlan splitk_plan(int M, int T, int K) {
         nk_slice = nk_slice < 16 ? 16 : nk_slice;
         const int ksplit = ceil_div(nk_all, nk_slice);
         if (ksplit >= 2 && (size_t)ksplit * T * M * 4 <= kSplitKWorkspaceBytes) return {ksplit, nk_slice, 256};
+      }
+    }
+    // 128 x 256 tiles on the 2-phase schedule (gemm256.h), one workgroup per CU: up to 128 tiles, floor(256 / tiles)
+    // K slices (tt == 129 marks this plan; PEGAINFER_GEMM128X256=0 switches it off)
+    if (gemm128x256_on() && gemm128x256_ok(M, T, K) && T >= 512) {
+      const long tiles = (long)ceil_div(M, G128_BM) * ceil_div(T, G256_BT);
+      if (tiles <= 128) {
+        int want = (int)(256 / tiles);
+        want = want > 8 ? 8 : want;
+        int nk_slice = ceil_div(nk_all, want);
+        nk_slice = nk_slice < 8 ? 8 : nk_slice;
+        const int ksplit = ceil_div(nk_all, nk_slice);
+        if (ksplit >= 2 && (size_t)ksplit * T * M * 4 <= kSplitKWorkspaceBytes) return {ksplit, nk_slice, 129};
       }
     }
     const int tt = T <= 256 ? 64 : 128;
@@ -541,6 +558,8 @@ static void glds_splitk_launch(const Half* W, const Half* X, Half* Y, int M, int
   const int m_tiles = ceil_div(M, BM);
   if (pl.tt == 256) {
     gemm256_splitk_launch(W, X, M, T, K, g_splitk_ws, pl.ksplit, pl.nk_slice, s);
+  } else if (pl.tt == 129) {
+    gemm128x256_launch(W, X, Y, M, T, K, so, g_splitk_ws, pl.ksplit, pl.nk_slice, s);
   } else if (pl.tt == 64) {
     constexpr int kLds = 3 * (BM + 64) * 8 * 16;
     static const bool once = [] {
@@ -595,6 +614,14 @@ static void glds_gemm_launch(const Half* W, const Half* X, Half* Y, int M, int T
           return;
         }
         gemm256_launch(W, X, Y, M, T, K, so, s);
+        return;
+      }
+    }
+    // 129..256 tiles of 128 x 256: one un-split round of the 2-phase kernel (qkv at 1024 tokens: 192 tiles)
+    if (so.silu_I == 0 && gemm128x256_on() && gemm128x256_ok(M, T, K) && T >= 512) {
+      const long tiles = (long)ceil_div(M, G128_BM) * ceil_div(T, G256_BT);
+      if (tiles > 128 && tiles <= 256) {
+        gemm128x256_launch(W, X, Y, M, T, K, so, nullptr, 1, 0, s);
         return;
       }
     }
