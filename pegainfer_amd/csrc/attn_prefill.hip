@@ -67,7 +67,7 @@ __device__ __forceinline__ float max3_raw(float a, float b, float c) {
   return r;
 }
 
-template <int QBLK, int D, int NW, typename Addr>
+template <int QBLK, int D, int NW, typename Addr, bool DMA = false>
 __device__ __forceinline__ void prefill_tile(const Half* __restrict__ q_base, Half* __restrict__ o_base,
                                              const Half* __restrict__ kbuf, const Half* __restrict__ vbuf,
                                              Addr& addr, int qo_len, int kv_len, int tile_row0,
@@ -209,25 +209,8 @@ __device__ __forceinline__ void prefill_tile(const Half* __restrict__ q_base, Ha
     }
   };
 
-  if (cta_kv_end > 0) {
-    __syncthreads();  // page-id window staged
-    load_tile(0);
-  }
-  for (int kv0 = 0; kv0 < cta_kv_end; kv0 += TKV) {
-    __syncthreads();  // previous tile fully consumed
-    store_tile();
-    __syncthreads();
-    if (kv0 + TKV < cta_kv_end) {
-      const int next_end = kv0 + 2 * TKV < kv_len ? kv0 + 2 * TKV : kv_len;
-      if (!addr.covers(next_end)) {  // workgroup-uniform, once per kPgLdsMax pages
-        __syncthreads();
-        addr.load_window(kv0 + TKV);
-        __syncthreads();
-      }
-      load_tile(kv0 + TKV);  // prefetch under the MFMAs
-    }
-    if (!wave_active || kv0 >= wave_kv_end) continue;
-
+  // one KV tile's arithmetic for this wave: kt = the staged K tile, load_vf(db, kb) = the V^T fragment (16 dims x 32 tokens)
+  auto compute_tile = [&](int kv0, const u32x4* kt, auto&& load_vf) {
     // ---- S^T = K . Q^T ----  (raised issue priority around the MFMA clusters: the other resident wave of the SIMD is
     //      in its softmax / staging VALU segment and should not delay these)
     __builtin_amdgcn_s_setprio(1);
@@ -241,7 +224,7 @@ __device__ __forceinline__ void prefill_tile(const Half* __restrict__ q_base, Ha
       const int row = tb * 16 + l15;
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
-        const bf16x8_t kf = __builtin_bit_cast(bf16x8_t, ks[row * KCH + ((s * 4 + g) ^ (row & 15))]);
+        const bf16x8_t kf = __builtin_bit_cast(bf16x8_t, kt[row * KCH + ((s * 4 + g) ^ (row & 15))]);
 #pragma unroll
         for (int qb = 0; qb < QBLK; ++qb)
           sacc[qb][tb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qb][s], sacc[qb][tb], 0, 0, 0);
@@ -312,17 +295,110 @@ __device__ __forceinline__ void prefill_tile(const Half* __restrict__ q_base, Ha
     for (int db = 0; db < DB; ++db) {
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
-        const Half* vrow = vt + (db * 16 + l15) * VT_PITCH;
-        const int rot = 4 * (db >> 1);  // column rotation of this 32-row group (see store_tile)
-        u32x2 a0 = *reinterpret_cast<const u32x2*>(vrow + ((kb * 8 + g + rot) & 15) * 4);
-        u32x2 a1 = *reinterpret_cast<const u32x2*>(vrow + ((kb * 8 + g + 4 + rot) & 15) * 4);
-        const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, u32x4{a0.x, a0.y, a1.x, a1.y});
+        const bf16x8_t vf = load_vf(db, kb);
 #pragma unroll
         for (int qb = 0; qb < QBLK; ++qb)
           acc_o[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qb][kb], acc_o[qb][db], 0, 0, 0);
       }
     }
     __builtin_amdgcn_s_setprio(0);
+  };
+  if constexpr (DMA) {
+    // ---- LDS-DMA staging (head_dim 128): K and V tiles go global -> LDS with global_load_lds_dwordx4, no staging
+    //      registers, no ds_write pass, no software transpose.  Two-deep ring per operand; one barrier per KV tile.
+    //      K image: [64 tok][16 chunks of 16 B], chunk ^= row & 15 (as above).  V image: ROW-major [64 tok][128 dims],
+    //      32-byte chunk index ^= tok & 7, and the V^T fragments are gathered by ds_read_b64_tr_b16: inside a 16-lane
+    //      group lane 4 j + c supplies the address of 4 consecutive dims (chunk c) of token row j and lane i receives
+    //      dim i of the four rows (measured semantics, tools/probes/tr16_probe.hip) - exactly the (4 tokens of lane
+    //      group g) x (dim l15) block the swapped product's P^T fragment pairs with.  Both swizzles are applied through
+    //      the per-lane SOURCE address, the DMA writes LDS lane-linearly.
+    static_assert(!DMA || (D == 128 && TKV == 64), "LDS-DMA staging is laid out for head_dim 128");
+    typedef short v4s_t __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) void* lds_vptr_t;
+    u32x4* kring = ks;                                   // 2 x 1024 chunks
+    u32x4* vring = reinterpret_cast<u32x4*>(vt);         // 2 x 1024 chunks
+    const uint32_t k_lds = (uint32_t)(uintptr_t)(lds_vptr_t)kring, v_lds = (uint32_t)(uintptr_t)(lds_vptr_t)vring;
+    constexpr int PPW = 16 / NW;                         // 1-KiB pieces (4 token rows) per wave, operand and tile
+    const int t_last = kv_len - 1;
+    auto issue_tile = [&](int kv0, int buf) {
+#pragma unroll
+      for (int j = 0; j < PPW; ++j) {
+        const int piece = wave * PPW + j;
+        const int r = piece * 4 + (lane >> 4), c = lane & 15;
+        int t = kv0 + r;
+        t = t < t_last ? t : t_last;
+        const long ro = addr.row(t);
+        const Half* ksrc = kbuf + ro + ((c ^ (r & 15)) << 3);
+        const Half* vsrc = vbuf + ro + ((c ^ ((r & 7) << 1)) << 3);
+        const uint32_t kd = __builtin_amdgcn_readfirstlane(k_lds + (uint32_t)(buf * 16384 + piece * 1024));
+        const uint32_t vd = __builtin_amdgcn_readfirstlane(v_lds + (uint32_t)(buf * 16384 + piece * 1024));
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(ksrc), "s"(kd) : "memory", "m0");
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(vsrc), "s"(vd) : "memory", "m0");
+      }
+    };
+    // per-lane byte offsets of the V^T gathers inside a V tile: token row 4 g + (l15 >> 2) of a 16-token block, chunk l15 & 3
+    const int jq = l15 >> 2, cq = l15 & 3, xs = (4 * g + jq) & 7;
+    uint32_t voff[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+      voff[db] = (uint32_t)((4 * g + jq) * 256 + ((((db ^ xs) << 1) | (cq >> 1)) << 4) + (cq & 1) * 8);
+    const __attribute__((address_space(3))) char* vbase = (const __attribute__((address_space(3))) char*)vring;
+    if (cta_kv_end > 0) {
+      __syncthreads();  // page-id window staged
+      issue_tile(0, 0);
+    }
+    int it = 0;
+    for (int kv0 = 0; kv0 < cta_kv_end; kv0 += TKV, ++it) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile `it` have landed
+      __syncthreads();                                   // everyone's have; everyone is done with tile it - 1's buffers
+      if (kv0 + TKV < cta_kv_end) {
+        const int next_end = kv0 + 2 * TKV < kv_len ? kv0 + 2 * TKV : kv_len;
+        if (!addr.covers(next_end)) {  // workgroup-uniform, once per kPgLdsMax pages
+          addr.load_window(kv0 + TKV);
+          __syncthreads();
+        }
+        issue_tile(kv0 + TKV, (it + 1) & 1);  // lands under this tile's MFMAs
+      }
+      if (!wave_active || kv0 >= wave_kv_end) continue;
+      const int buf = it & 1;
+      const __attribute__((address_space(3))) char* vb = vbase + buf * 16384;
+      compute_tile(kv0, kring + buf * 1024, [&](int db, int kb) {
+        const v4s_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (v4s_t __attribute__((address_space(3)))*)(vb + voff[db] + (2 * kb) * 4096));
+        const v4s_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (v4s_t __attribute__((address_space(3)))*)(vb + voff[db] + (2 * kb + 1) * 4096));
+        const u32x2 w0 = __builtin_bit_cast(u32x2, a0), w1 = __builtin_bit_cast(u32x2, a1);
+        return __builtin_bit_cast(bf16x8_t, u32x4{w0.x, w0.y, w1.x, w1.y});
+      });
+    }
+  } else {
+    if (cta_kv_end > 0) {
+      __syncthreads();  // page-id window staged
+      load_tile(0);
+    }
+    for (int kv0 = 0; kv0 < cta_kv_end; kv0 += TKV) {
+      __syncthreads();  // previous tile fully consumed
+      store_tile();
+      __syncthreads();
+      if (kv0 + TKV < cta_kv_end) {
+        const int next_end = kv0 + 2 * TKV < kv_len ? kv0 + 2 * TKV : kv_len;
+        if (!addr.covers(next_end)) {  // workgroup-uniform, once per kPgLdsMax pages
+          __syncthreads();
+          addr.load_window(kv0 + TKV);
+          __syncthreads();
+        }
+        load_tile(kv0 + TKV);  // prefetch under the MFMAs
+      }
+      if (!wave_active || kv0 >= wave_kv_end) continue;
+
+      compute_tile(kv0, ks, [&](int db, int kb) {
+        const Half* vrow = vt + (db * 16 + l15) * VT_PITCH;
+        const int rot = 4 * (db >> 1);  // column rotation of this 32-row group (see store_tile)
+        u32x2 a0 = *reinterpret_cast<const u32x2*>(vrow + ((kb * 8 + g + rot) & 15) * 4);
+        u32x2 a1 = *reinterpret_cast<const u32x2*>(vrow + ((kb * 8 + g + 4 + rot) & 15) * 4);
+        return __builtin_bit_cast(bf16x8_t, u32x4{a0.x, a0.y, a1.x, a1.y});
+      });
+    }
   }
   // ---- epilogue: O = acc / l ; lane (row l15, g) holds dims db*16 + g*4 .. +3 ----
 #pragma unroll
@@ -347,7 +423,8 @@ __device__ __forceinline__ void prefill_tile(const Half* __restrict__ q_base, Ha
 // and a staged KV tile is shared by only 64 rows.  With GROUPED = 2 a workgroup takes plan tiles 2i and 2i + 1; when
 // they are adjacent rows of the same request (all but the seams between requests) they run as ONE 2 x cta_tile_q
 // tile, 32 rows per wave; otherwise one after the other.  Per-row arithmetic does not depend on the grouping.
-template <int QBLK, int D, bool POW2, int GROUPED = 1, int NW = 4>
+constexpr int kPrefillDmaLdsBytes = 4 * 16384 + kPgLdsMax * 4;   // K ring, V ring (2 x 16 KiB each), page-id window
+template <int QBLK, int D, bool POW2, int GROUPED = 1, int NW = 4, bool DMA = false>
 __global__ __launch_bounds__(NW * 64, D == 128 ? 2 : 1) void batch_prefill_paged_kernel(
     const Half* __restrict__ q, Half* __restrict__ out, const Half* __restrict__ kv, long k_off, long v_off,
     const int* __restrict__ page_indices, const int* __restrict__ page_indptr,
@@ -355,9 +432,20 @@ __global__ __launch_bounds__(NW * 64, D == 128 ? 2 : 1) void batch_prefill_paged
     const int* __restrict__ request_indices, const int* __restrict__ qo_tile_indices, int num_qo_heads,
     int num_kv_heads, int page_size, long stride_page, float scale_log2, int cta_tile_q, int page_shift,
     int num_plan_tiles, int xcd_heads) {
-  __shared__ __attribute__((aligned(16))) u32x4 ks[TKV * D / 8];
-  __shared__ __attribute__((aligned(16))) Half vt[D * VT_PITCH];
-  __shared__ int lds_pg[kPgLdsMax];
+  u32x4* ks;
+  Half* vt;
+  int* lds_pg;
+  if constexpr (DMA) {   // LDS-DMA staging: two-deep K / V rings in dynamic LDS (kPrefillDmaLdsBytes)
+    extern __shared__ __attribute__((aligned(16))) u32x4 prefill_dyn_lds[];
+    ks = prefill_dyn_lds;
+    vt = reinterpret_cast<Half*>(prefill_dyn_lds + 2048);
+    lds_pg = reinterpret_cast<int*>(prefill_dyn_lds + 4096);
+  } else {
+    __shared__ __attribute__((aligned(16))) u32x4 ks_s[TKV * D / 8];
+    __shared__ __attribute__((aligned(16))) Half vt_s[D * VT_PITCH];
+    __shared__ int lds_pg_s[kPgLdsMax];
+    ks = ks_s; vt = vt_s; lds_pg = lds_pg_s;
+  }
   // longest tiles first: within a request the plan lists tiles by ascending row, i.e. ascending causal KV length;
   // dispatching them in reverse keeps the tail of the launch made of short tiles
   // 1-D grid, kv head fastest: workgroup b runs on XCD b % 8, so with 8 kv heads every XCD keeps ONE head's K / V in its
@@ -391,8 +479,9 @@ __global__ __launch_bounds__(NW * 64, D == 128 ? 2 : 1) void batch_prefill_paged
     const long q_stride_n = (long)num_qo_heads * D;
     const long qo_base = (long)q0 * q_stride_n + (long)kvh * group * D;
     const Half* kvh_base = kv + (long)kvh * D;
-    prefill_tile<QBLK, D, NW>(q + qo_base, out + qo_base, kvh_base + k_off, kvh_base + v_off, addr, qo_len, kv_len, row0[k],
-                              fuse ? 2 * cta_tile_q : cta_tile_q, group, q_stride_n, scale_log2, ks, vt);
+    prefill_tile<QBLK, D, NW, PagedAddr<POW2>, DMA>(q + qo_base, out + qo_base, kvh_base + k_off, kvh_base + v_off, addr,
+                                                    qo_len, kv_len, row0[k], fuse ? 2 * cta_tile_q : cta_tile_q, group,
+                                                    q_stride_n, scale_log2, ks, vt);
   }
 }
 
@@ -490,7 +579,27 @@ int32_t batch_prefill_paged_cuda_with_cta_tile_q(
       q, output, kv_data, k_offset_elems, v_offset_elems, page_indices, page_indptr, last_page_len_d, q_indptr, \
       request_indices, qo_tile_indices, num_qo_heads, num_kv_heads, page_size, stride_page, scale_log2, CTA, shift, \
       padded_batch_size, xcd_heads)
-  if (cta == 128) {
+  // LDS-DMA staging + ds_read_b64_tr_b16 form of the 32-rows-per-wave tiles (power-of-two page sizes;
+  // PEGAINFER_PREFILL_DMA=0 keeps the register-staged form; per-row arithmetic is identical)
+  static const bool dma_on = [] { const char* e = getenv("PEGAINFER_PREFILL_DMA"); return !(e && *e == '0'); }();
+#define PK_PREFILL_DMA(G, CTA)                                                                                  \
+  do {                                                                                                          \
+    static const bool once = [] {                                                                               \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&batch_prefill_paged_kernel<2, 128, true, G, 4, true>), \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kPrefillDmaLdsBytes);              \
+      return true;                                                                                              \
+    }();                                                                                                        \
+    (void)once;                                                                                                 \
+    batch_prefill_paged_kernel<2, 128, true, G, 4, true>                                                        \
+        <<<((padded_batch_size + G - 1) / G) * num_kv_heads, 256, kPrefillDmaLdsBytes, s>>>(                    \
+            q, output, kv_data, k_offset_elems, v_offset_elems, page_indices, page_indptr, last_page_len_d, q_indptr, \
+            request_indices, qo_tile_indices, num_qo_heads, num_kv_heads, page_size, stride_page, scale_log2, CTA, shift, \
+            padded_batch_size, xcd_heads);                                                                      \
+  } while (0)
+  if (dma_on && shift >= 0 && (cta == 128 || pair)) {
+    if (cta == 128) PK_PREFILL_DMA(1, 128);
+    else PK_PREFILL_DMA(2, 64);
+  } else if (cta == 128) {
     if (shift >= 0) PK_PREFILL(2, true, 1, 128);
     else PK_PREFILL(2, false, 1, 128);
   } else if (pair) {
@@ -501,6 +610,7 @@ int32_t batch_prefill_paged_cuda_with_cta_tile_q(
     else PK_PREFILL(1, false, 1, (int)cta);
   }
 #undef PK_PREFILL
+#undef PK_PREFILL_DMA
   return (int32_t)hipGetLastError();
 }
 
