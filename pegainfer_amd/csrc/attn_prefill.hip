@@ -81,7 +81,7 @@ __device__ __forceinline__ void prefill_tile(const Half* __restrict__ q_base, Ha
   // 19.8 / 195.1 - occupancy, not LDS reads, is what the 64-row tile is short of.
   constexpr int NT = NW * 64;
   constexpr int KPT = TKV * KCH / NT;      // K chunks staged per thread
-  constexpr int VPT = 16 * KCH / NT;       // V (4-token x 8-dim) units staged per thread
+  constexpr int VPT = 16 * KCH / NT > 0 ? 16 * KCH / NT : 1;   // V (4-token x 8-dim) units staged per thread (register-staged form: NT <= 256)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int l15 = lane & 15, g = lane >> 4;
   const int packed_len = qo_len * group;
@@ -109,6 +109,10 @@ __device__ __forceinline__ void prefill_tile(const Half* __restrict__ q_base, Ha
     for (int s = 0; s < KS; ++s)
       qf[qb][s] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(q_base + off + s * 32 + g * 8));
   }
+  // LDS-DMA form: retire the q loads with a wait the COMPILER sees.  The DMAs below are inline asm, invisible to hipcc's
+  // wait-count bookkeeping; it would otherwise carry "q fragments still pending" around the loop and put an
+  // s_waitcnt vmcnt(0) in front of the first MFMAs of every KV tile - which in hardware waits for the NEXT tile's DMAs.
+  if constexpr (DMA) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched
   // wave-uniform bounds on the KV positions this wave attends to: [0, wave_kv_end) is visible to its last row,
   // [0, wave_kv_full) to every one of its rows (tiles below that line need no causal mask)
   int wave_last_row = tile_row0 + (wave * QBLK + QBLK) * 16 - 1;
@@ -219,21 +223,33 @@ __device__ __forceinline__ void prefill_tile(const Half* __restrict__ q_base, Ha
     for (int qb = 0; qb < QBLK; ++qb)
 #pragma unroll
       for (int tb = 0; tb < 4; ++tb) sacc[qb][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // K fragments through a 4-deep register ring: the read for step i + 4 is issued right behind the MFMAs of step i
+    // (hipcc otherwise reuses one register quad for every fragment and each MFMA pair waits out a full LDS round trip)
+    auto load_kf = [&](int i) {
+      const int row = (i / KS) * 16 + l15, sl = i % KS;
+      return __builtin_bit_cast(bf16x8_t, kt[row * KCH + ((sl * 4 + g) ^ (row & 15))]);
+    };
+    {
+      bf16x8_t kr[4];
 #pragma unroll
-    for (int tb = 0; tb < 4; ++tb) {
-      const int row = tb * 16 + l15;
+      for (int i = 0; i < 4; ++i) kr[i] = load_kf(i);
 #pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        const bf16x8_t kf = __builtin_bit_cast(bf16x8_t, kt[row * KCH + ((s * 4 + g) ^ (row & 15))]);
+      for (int i = 0; i < 4 * KS; ++i) {
 #pragma unroll
         for (int qb = 0; qb < QBLK; ++qb)
-          sacc[qb][tb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qb][s], sacc[qb][tb], 0, 0, 0);
+          sacc[qb][i / KS] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kr[i & 3], qf[qb][i % KS], sacc[qb][i / KS], 0, 0, 0);
+        if (i + 4 < 4 * KS) kr[i & 3] = load_kf(i + 4);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     __builtin_amdgcn_s_setprio(0);
     // ---- online softmax per query row (= per lane column), exp2 domain with the scale folded into one fma.
     //      The causal / length mask is applied only on the tiles that cross this wave's diagonal or the end of
     //      the sequence (wave-uniform test); interior tiles - nearly all of a long prompt - take no compare at all.
+    // the first V^T fragments are requested here: their LDS round trip runs under the softmax arithmetic
+    bf16x8_t vr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) vr[i] = load_vf(i >> 1, i & 1);
     const bool need_mask = kv0 + TKV > wave_kv_full;
     bf16x8_t pf[QBLK][2];
 #pragma unroll
@@ -257,8 +273,14 @@ __device__ __forceinline__ void prefill_tile(const Half* __restrict__ q_base, Ha
       mx = max3_raw(mx, sacc[qb][2][3], sacc[qb][3][0]);
       mx = max3_raw(mx, sacc[qb][3][1], sacc[qb][3][2]);
       mx = max3_raw(mx, sacc[qb][3][3], mx);
-      mx = fmaxf(mx, __shfl_xor(mx, 16, kWave));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, kWave));
+      {  // max over the row's 4 lane groups: v_permlane16/32_swap (gfx950; VALU speed, no LDS round trips as with
+         // ds_bpermute; the two operands must be distinct registers): rows [m0 m1 m2 m3] -> [m01 m01 m23 m23] -> all
+        float a = mx, b = mx;
+        asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+        a = fmaxf(a, b); b = a;
+        asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+        mx = fmaxf(a, b);
+      }
       const float mn = fmaxf(m_run[qb], mx * scale_log2);   // scale_log2 > 0: the max commutes with the scaling
       const float msafe = mn == -INFINITY ? 0.f : mn;
       // rescale only when some row's running max grew (alpha == 1 exactly otherwise): wave-uniform branch
@@ -292,14 +314,12 @@ __device__ __forceinline__ void prefill_tile(const Half* __restrict__ q_base, Ha
     // ---- O^T += V^T . P^T ----
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int db = 0; db < DB; ++db) {
+    for (int i = 0; i < 2 * DB; ++i) {   // step i = (db = i / 2, kb = i % 2), fragments through the 4-deep ring
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        const bf16x8_t vf = load_vf(db, kb);
-#pragma unroll
-        for (int qb = 0; qb < QBLK; ++qb)
-          acc_o[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qb][kb], acc_o[qb][db], 0, 0, 0);
-      }
+      for (int qb = 0; qb < QBLK; ++qb)
+        acc_o[qb][i >> 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vr[i & 3], pf[qb][i & 1], acc_o[qb][i >> 1], 0, 0, 0);
+      if (i + 4 < 2 * DB) vr[i & 3] = load_vf((i + 4) >> 1, (i + 4) & 1);
+      __builtin_amdgcn_sched_barrier(0);
     }
     __builtin_amdgcn_s_setprio(0);
   };
@@ -320,18 +340,43 @@ __device__ __forceinline__ void prefill_tile(const Half* __restrict__ q_base, Ha
     const uint32_t k_lds = (uint32_t)(uintptr_t)(lds_vptr_t)kring, v_lds = (uint32_t)(uintptr_t)(lds_vptr_t)vring;
     constexpr int PPW = 16 / NW;                         // 1-KiB pieces (4 token rows) per wave, operand and tile
     const int t_last = kv_len - 1;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    // A piece = 4 consecutive token rows x 256 B.  For full tiles every row address is (page id) x stride + a per-lane
+    // constant: kv0 is a multiple of 64 and the page size a power of two <= 64 (else the general path), so a row's
+    // position inside its page and its page's distance from the tile's first page do not depend on the tile.  That
+    // leaves one page-id read (LDS) and three 64-bit adds per piece instead of ~15 integer instructions per row.
+    const bool fast_pages = addr.page_size <= TKV;
+    int pg_step[PPW], k_lane[PPW], v_lane[PPW];
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+      const int r = (wave_s * PPW + j) * 4 + (lane >> 4), c = lane & 15;
+      const int in_page = r & (addr.page_size - 1);
+      pg_step[j] = r >> addr.shift;
+      k_lane[j] = in_page * addr.row_stride + ((c ^ (r & 15)) << 3);
+      v_lane[j] = in_page * addr.row_stride + ((c ^ ((r & 7) << 1)) << 3);
+    }
     auto issue_tile = [&](int kv0, int buf) {
+      const bool fast = fast_pages && kv0 + TKV <= kv_len;   // workgroup-uniform
+      const int pi0 = (kv0 >> addr.shift) - addr.win0;
 #pragma unroll
       for (int j = 0; j < PPW; ++j) {
-        const int piece = wave * PPW + j;
-        const int r = piece * 4 + (lane >> 4), c = lane & 15;
-        int t = kv0 + r;
-        t = t < t_last ? t : t_last;
-        const long ro = addr.row(t);
-        const Half* ksrc = kbuf + ro + ((c ^ (r & 15)) << 3);
-        const Half* vsrc = vbuf + ro + ((c ^ ((r & 7) << 1)) << 3);
-        const uint32_t kd = __builtin_amdgcn_readfirstlane(k_lds + (uint32_t)(buf * 16384 + piece * 1024));
-        const uint32_t vd = __builtin_amdgcn_readfirstlane(v_lds + (uint32_t)(buf * 16384 + piece * 1024));
+        const int piece = wave_s * PPW + j;
+        const Half* ksrc;
+        const Half* vsrc;
+        if (fast) {
+          const long pbase = (long)addr.pg[pi0 + pg_step[j]] * (long)addr.stride_page;
+          ksrc = kbuf + pbase + k_lane[j];
+          vsrc = vbuf + pbase + v_lane[j];
+        } else {
+          const int r = piece * 4 + (lane >> 4), c = lane & 15;
+          int t = kv0 + r;
+          t = t < t_last ? t : t_last;
+          const long ro = addr.row(t);
+          ksrc = kbuf + ro + ((c ^ (r & 15)) << 3);
+          vsrc = vbuf + ro + ((c ^ ((r & 7) << 1)) << 3);
+        }
+        const uint32_t kd = k_lds + (uint32_t)(buf * 16384 + piece * 1024);
+        const uint32_t vd = v_lds + (uint32_t)(buf * 16384 + piece * 1024);
         asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(ksrc), "s"(kd) : "memory", "m0");
         asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(vsrc), "s"(vd) : "memory", "m0");
       }
@@ -362,14 +407,15 @@ __device__ __forceinline__ void prefill_tile(const Half* __restrict__ q_base, Ha
       if (!wave_active || kv0 >= wave_kv_end) continue;
       const int buf = it & 1;
       const __attribute__((address_space(3))) char* vb = vbase + buf * 16384;
-      compute_tile(kv0, kring + buf * 1024, [&](int db, int kb) {
+      auto vf_dma = [&](int db, int kb) {
         const v4s_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
             (v4s_t __attribute__((address_space(3)))*)(vb + voff[db] + (2 * kb) * 4096));
         const v4s_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
             (v4s_t __attribute__((address_space(3)))*)(vb + voff[db] + (2 * kb + 1) * 4096));
         const u32x2 w0 = __builtin_bit_cast(u32x2, a0), w1 = __builtin_bit_cast(u32x2, a1);
         return __builtin_bit_cast(bf16x8_t, u32x4{w0.x, w0.y, w1.x, w1.y});
-      });
+      };
+      compute_tile(kv0, kring + buf * 1024, vf_dma);
     }
   } else {
     if (cta_kv_end > 0) {
@@ -463,9 +509,10 @@ __global__ __launch_bounds__(NW * 64, D == 128 ? 2 : 1) void batch_prefill_paged
     req[k] = tile < num_plan_tiles ? request_indices[tile] : -1;
     row0[k] = tile < num_plan_tiles ? qo_tile_indices[tile] * cta_tile_q : 0;
   }
-  const bool fuse = GROUPED == 2 && req[0] >= 0 && req[GROUPED - 1] == req[0] && row0[GROUPED - 1] == row0[0] + cta_tile_q;
-  for (int k = 0; k < GROUPED; ++k) {
-    if (fuse && k > 0) break;
+  // runs of adjacent plan tiles of one request are taken as ONE tile of n x cta_tile_q rows
+  for (int k = 0, n = 1; k < GROUPED; k += n) {
+    n = 1;
+    while (k + n < GROUPED && req[k] >= 0 && req[k + n] == req[k] && row0[k + n] == row0[k] + n * cta_tile_q) ++n;
     const int r = req[k];
     if (r < 0) continue;
     const int q0 = q_indptr[r];
@@ -480,7 +527,7 @@ __global__ __launch_bounds__(NW * 64, D == 128 ? 2 : 1) void batch_prefill_paged
     const long qo_base = (long)q0 * q_stride_n + (long)kvh * group * D;
     const Half* kvh_base = kv + (long)kvh * D;
     prefill_tile<QBLK, D, NW, PagedAddr<POW2>, DMA>(q + qo_base, out + qo_base, kvh_base + k_off, kvh_base + v_off, addr,
-                                                    qo_len, kv_len, row0[k], fuse ? 2 * cta_tile_q : cta_tile_q, group,
+                                                    qo_len, kv_len, row0[k], n * cta_tile_q, group,
                                                     q_stride_n, scale_log2, ks, vt);
   }
 }

@@ -85,9 +85,9 @@ def test_attention_kernels_keep_their_occupancy():
     check(md, r"decode_attn_kernel<(128|256), [124], (true|false), [48]>", 256, at_least=24)
     md = kernel_metadata("attn_prefill.hip")
     # head dim 128: two workgroups per CU (the __launch_bounds__(256, 2) budget), no AGPR shuffling, no spills
-    check(md, r"batch_prefill_paged_kernel<\d, 128, (true|false), \d, 4>", 256, at_least=6)
+    check(md, r"batch_prefill_paged_kernel<\d, 128, (true|false), \d, 4, (true|false)>", 256, at_least=6)
     for k, v in md.items():
-        if re.fullmatch(r"batch_prefill_paged_kernel<\d, 128, (true|false), \d, 4>", k):
+        if re.fullmatch(r"batch_prefill_paged_kernel<\d, 128, (true|false), \d, 4, (true|false)>", k):
             assert v["agpr"] == 0, f"{k} keeps accumulators in AGPRs: {v}"
     # head dim 256 (Qwen3.5): one workgroup per CU is accepted, spills are not
-    check(md, r"batch_prefill_paged_kernel<\d, 256, (true|false), \d, 4>", 512, at_least=2)
+    check(md, r"batch_prefill_paged_kernel<\d, 256, (true|false), \d, 4, false>", 512, at_least=2)
