@@ -464,254 +464,13 @@ __device__ __forceinline__ void prefill_tile(const Half* __restrict__ q_base, Ha
   }
 }
 
-// ---- 32 x 32 x 16 form of the LDS-DMA tile (head_dim 128, power-of-two pages, 32 packed rows per wave).
-// Why: with v_mfma_f32_16x16x32_bf16 (~17 cycles per SIMD) an MFMA hides about ONE other instruction in its shadow, with
-// v_mfma_f32_32x32x16_bf16 (32 cycles, twice the FLOPs) about FIVE (guide, issue-slot table) - and the online softmax is
-// ~250-300 VALU instructions per 64-token tile next to 64 (16x16x32) resp. 32 (32x32x16) MFMAs.  Counters and knock-outs
-// of the 16 x 16 form at 10 k tokens (profiles/r3_prefill_attn_knockouts.txt): matrix pipe busy 38 %, a wave issuing 36 %
-// of its time, every removed MFMA / exp / DMA shortens the kernel by about its own issue time - the segments run one
-// after the other, whatever the tile shape, occupancy or in-wave interleaving.
-// Layouts (wave64; l31 = lane % 32, h = lane / 32):
-//   S^T (32 kv x 32 q) = K (A: row l31 of the 32-token block, dims 16 s + 8 h ..+7 - one swizzled 16-byte chunk)
-//                      . Q^T (B: query row l31, the same dims; 8 fragments held in registers)
-//   C: lane (q = l31, h) holds kv = 8 b + 4 h + r (b, r = 0..3): ONE query row per lane, its row max / sum need a single
-//      exchange with lane ^ 32 (v_permlane32_swap), and bf16(P^T) of a 16-token slice - {b = 2 e, r}, {b = 2 e + 1, r} - is the
-//      B operand of O^T += V^T . P^T as it stands; the same token order is applied to the V^T fragment:
-//   V^T (A: dim 32 d + l31, tokens 16 e + 4 h + r and 16 e + 8 + 4 h + r) = two ds_read_b64_tr_b16 gathers from the
-//      row-major V image (16-lane group -> 4 token rows x 16 dims).  V image swizzle: 16-byte chunk ^= (tok & 3) << 2.
-//   O^T C: lane (q, h) holds dims 32 d + 8 b + 4 h + r.
-template <int NW, typename Addr>
-__device__ __forceinline__ void prefill_tile32(const Half* __restrict__ q_base, Half* __restrict__ o_base,
-                                               const Half* __restrict__ kbuf, const Half* __restrict__ vbuf,
-                                               Addr& addr, int qo_len, int kv_len, int tile_row0, int tile_rows,
-                                               int group, long q_stride_n, float scale_log2, u32x4* kring, u32x4* vring) {
-  constexpr int D = 128;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int l31 = lane & 31, h = lane >> 5;
-  const int packed_len = qo_len * group;
-  const int tile_end = (tile_row0 + tile_rows) < packed_len ? (tile_row0 + tile_rows) : packed_len;
-  const int causal_off = kv_len - qo_len;
-  const int cta_kv_end_raw = (tile_end - 1) / group + causal_off + 1;
-  const int cta_kv_end = cta_kv_end_raw < kv_len ? cta_kv_end_raw : kv_len;
-
-  addr.load_window(0);
-
-  const int r_row = tile_row0 + wave * 32 + l31;
-  const bool qok = r_row < tile_end;
-  const int rc = qok ? r_row : tile_row0;
-  const int qtok = rc / group;
-  const long o_off = (long)qtok * q_stride_n + (long)(rc % group) * D;
-  bf16x8_t qf[8];
-#pragma unroll
-  for (int s = 0; s < 8; ++s)
-    qf[s] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(q_base + o_off + s * 16 + h * 8));
-  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), seen by the compiler (the DMAs below are not: see prefill_tile)
-
-  int wave_last_row = tile_row0 + wave * 32 + 31;
-  if (wave_last_row >= tile_end) wave_last_row = tile_end - 1;
-  const bool wave_active = tile_row0 + wave * 32 < tile_end;
-  const int wave_kv_end = wave_active ? wave_last_row / group + causal_off + 1 : 0;
-  const int wave_kv_full_raw = (tile_row0 + wave * 32) / group + causal_off + 1;
-  const int wave_kv_full = wave_kv_full_raw < kv_len ? wave_kv_full_raw : kv_len;
-
-  f32x16 acc_o[4];
-#pragma unroll
-  for (int d = 0; d < 4; ++d)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc_o[d][i] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
-
-  typedef short v4s_t __attribute__((ext_vector_type(4)));
-  typedef __attribute__((address_space(3))) void* lds_vptr_t;
-  const uint32_t k_lds = (uint32_t)(uintptr_t)(lds_vptr_t)kring, v_lds = (uint32_t)(uintptr_t)(lds_vptr_t)vring;
-  constexpr int PPW = 16 / NW;
-  const int t_last = kv_len - 1;
-  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
-  const bool fast_pages = addr.page_size <= TKV;
-  int pg_step[PPW], k_lane[PPW], v_lane[PPW];
-#pragma unroll
-  for (int j = 0; j < PPW; ++j) {
-    const int r = (wave_s * PPW + j) * 4 + (lane >> 4), c = lane & 15;
-    const int in_page = r & (addr.page_size - 1);
-    pg_step[j] = r >> addr.shift;
-    k_lane[j] = in_page * addr.row_stride + ((c ^ (r & 15)) << 3);
-    v_lane[j] = in_page * addr.row_stride + ((c ^ ((r & 3) << 2)) << 3);
-  }
-  auto issue_tile = [&](int kv0, int buf) {
-    const bool fast = fast_pages && kv0 + TKV <= kv_len;   // workgroup-uniform
-    const int pi0 = (kv0 >> addr.shift) - addr.win0;
-#pragma unroll
-    for (int j = 0; j < PPW; ++j) {
-      const int piece = wave_s * PPW + j;
-      const Half* ksrc;
-      const Half* vsrc;
-      if (fast) {
-        const long pbase = (long)addr.pg[pi0 + pg_step[j]] * (long)addr.stride_page;
-        ksrc = kbuf + pbase + k_lane[j];
-        vsrc = vbuf + pbase + v_lane[j];
-      } else {
-        const int r = piece * 4 + (lane >> 4), c = lane & 15;
-        int t = kv0 + r;
-        t = t < t_last ? t : t_last;
-        const long ro = addr.row(t);
-        ksrc = kbuf + ro + ((c ^ (r & 15)) << 3);
-        vsrc = vbuf + ro + ((c ^ ((r & 3) << 2)) << 3);
-      }
-      const uint32_t kd = k_lds + (uint32_t)(buf * 16384 + piece * 1024);
-      const uint32_t vd = v_lds + (uint32_t)(buf * 16384 + piece * 1024);
-      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(ksrc), "s"(kd) : "memory", "m0");
-      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(vsrc), "s"(vd) : "memory", "m0");
-    }
-  };
-  // V^T gathers: 16-lane group G = lane >> 4 covers dims 16 (G & 1) .. + 15 of a 32-dim block and the token rows 4 h + j;
-  // lane i16 = lane & 15 supplies the address of token row i16 >> 2, 4-dim chunk i16 & 3, and receives dim i16 of 4 rows
-  const int i16 = lane & 15, G1 = (lane >> 4) & 1, jq = i16 >> 2, cq = i16 & 3;
-  // byte offset inside a V tile, without the 32-dim block d (chunk16 = 4 d + 2 G1 + (cq >> 1), ^ ((tok & 3) << 2) = ^ (jq << 2)
-  // acts on the d bits only) and without the slice / half base (multiples of 8 tokens: tok & 3 = jq)
-  uint32_t voff[4];
-#pragma unroll
-  for (int d = 0; d < 4; ++d)
-    voff[d] = (uint32_t)((4 * h + jq) * 256 + ((((4 * d) ^ (jq << 2)) + 2 * G1 + (cq >> 1)) << 4) + (cq & 1) * 8);
-  const __attribute__((address_space(3))) char* vbase = (const __attribute__((address_space(3))) char*)vring;
-
-  if (cta_kv_end > 0) {
-    __syncthreads();
-    issue_tile(0, 0);
-  }
-  int it = 0;
-  for (int kv0 = 0; kv0 < cta_kv_end; kv0 += TKV, ++it) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (kv0 + TKV < cta_kv_end) {
-      const int next_end = kv0 + 2 * TKV < kv_len ? kv0 + 2 * TKV : kv_len;
-      if (!addr.covers(next_end)) {
-        addr.load_window(kv0 + TKV);
-        __syncthreads();
-      }
-      issue_tile(kv0 + TKV, (it + 1) & 1);
-    }
-    if (!wave_active || kv0 >= wave_kv_end) continue;
-    const int buf = it & 1;
-    const u32x4* kt = kring + buf * 1024;
-    const __attribute__((address_space(3))) char* vb = vbase + buf * 16384;
-    // K fragment of step i = (32-token block i >> 3, dim slice i & 7); V^T fragment of step i = (dim block i >> 2, slice i & 3)
-    auto load_kf = [&](int i) {
-      const int row = (i >> 3) * 32 + l31;
-      return __builtin_bit_cast(bf16x8_t, kt[row * 16 + ((((i & 7) << 1) | h) ^ (row & 15))]);
-    };
-    auto load_vf = [&](int i) {
-      const int d = i >> 2, e = i & 3;
-      const v4s_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-          (v4s_t __attribute__((address_space(3)))*)(vb + voff[d] + e * 4096));
-      const v4s_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-          (v4s_t __attribute__((address_space(3)))*)(vb + voff[d] + e * 4096 + 2048));
-      const u32x2 w0 = __builtin_bit_cast(u32x2, a0), w1 = __builtin_bit_cast(u32x2, a1);
-      return __builtin_bit_cast(bf16x8_t, u32x4{w0.x, w0.y, w1.x, w1.y});
-    };
-    // ---- S^T = K . Q^T: 2 token blocks x 8 dim slices, fragments through a 4-deep register ring
-    f32x16 sacc[2];
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) sacc[b][i] = 0.f;
-    {
-      bf16x8_t kr[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) kr[i] = load_kf(i);
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        sacc[i >> 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[i & 3], qf[i & 7], sacc[i >> 3], 0, 0, 0);
-        if (i + 4 < 16) kr[i & 3] = load_kf(i + 4);
-      }
-    }
-    bf16x8_t vr[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) vr[i] = load_vf(i);
-    // ---- online softmax: one query row per lane, 32 of its 64 scores
-    if (kv0 + TKV > wave_kv_full) {   // the tile crosses this wave's diagonal or the end of the sequence
-      const int lim_c = qok ? qtok + causal_off : -1;
-      const int limit = lim_c < kv_len - 1 ? lim_c : kv_len - 1;
-#pragma unroll
-      for (int b2 = 0; b2 < 2; ++b2)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int kvt = kv0 + b2 * 32 + 8 * (i >> 2) + 4 * h + (i & 3);
-          sacc[b2][i] = kvt <= limit ? sacc[b2][i] : -INFINITY;
-        }
-    }
-    float mx = max3_raw(sacc[0][0], sacc[0][1], sacc[0][2]);
-#pragma unroll
-    for (int i = 3; i < 15; i += 2) mx = max3_raw(mx, sacc[0][i], sacc[0][i + 1]);
-    mx = max3_raw(mx, sacc[0][15], sacc[1][0]);
-#pragma unroll
-    for (int i = 1; i < 15; i += 2) mx = max3_raw(mx, sacc[1][i], sacc[1][i + 1]);
-    mx = max3_raw(mx, sacc[1][15], mx);
-    {
-      float a = mx, b = mx;
-      asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
-      mx = fmaxf(a, b);
-    }
-    const float mn = fmaxf(m_run, mx * scale_log2);
-    const float msafe = mn == -INFINITY ? 0.f : mn;
-    if (__builtin_amdgcn_ballot_w64(mn > m_run) != 0ull) {
-      const float alpha = exp2_raw(m_run - msafe);
-      l_run *= alpha;
-#pragma unroll
-      for (int d = 0; d < 4; ++d)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc_o[d][i] *= alpha;
-      m_run = mn;
-    }
-    bf16x8_t pf[4];
-    float ps0 = 0.f, ps1 = 0.f;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {   // 16-token slice e = token block e >> 1, C row blocks b = 2 (e & 1), 2 (e & 1) + 1
-      float p[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) p[i] = exp2_raw(fmaf(sacc[e >> 1][8 * (e & 1) + i], scale_log2, -msafe));
-      ps0 += (p[0] + p[1]) + (p[2] + p[3]);
-      ps1 += (p[4] + p[5]) + (p[6] + p[7]);
-      u32x4 pk4;
-      pk4.x = pack_bf2(p[0], p[1]);
-      pk4.y = pack_bf2(p[2], p[3]);
-      pk4.z = pack_bf2(p[4], p[5]);
-      pk4.w = pack_bf2(p[6], p[7]);
-      pf[e] = __builtin_bit_cast(bf16x8_t, pk4);
-    }
-    l_run += ps0 + ps1;
-    // ---- O^T += V^T . P^T: 4 dim blocks x 4 token slices
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      acc_o[i >> 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vr[i & 3], pf[i & 3], acc_o[i >> 2], 0, 0, 0);
-      if (i + 4 < 16) vr[i & 3] = load_vf(i + 4);
-    }
-  }
-  // ---- epilogue: lane (q, h) holds dims 32 d + 8 b + 4 h + r
-  {
-    float a = l_run, b = l_run;
-    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
-    l_run = a + b;
-  }
-  if (!qok) return;
-  const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
-#pragma unroll
-  for (int d = 0; d < 4; ++d)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      u32x2 o;
-      o.x = pack_bf2(acc_o[d][4 * b] * inv, acc_o[d][4 * b + 1] * inv);
-      o.y = pack_bf2(acc_o[d][4 * b + 2] * inv, acc_o[d][4 * b + 3] * inv);
-      *reinterpret_cast<u32x2*>(o_base + o_off + 32 * d + 8 * b + 4 * h) = o;
-    }
-}
-
 // GROUPED = number of consecutive plan tiles one workgroup takes (1 or 2).  The reference model crates plan with
 // 64-row tiles (config.rs:5), i.e. 16 packed rows per wave: every K / V^T fragment read from LDS then feeds ONE MFMA
 // and a staged KV tile is shared by only 64 rows.  With GROUPED = 2 a workgroup takes plan tiles 2i and 2i + 1; when
 // they are adjacent rows of the same request (all but the seams between requests) they run as ONE 2 x cta_tile_q
 // tile, 32 rows per wave; otherwise one after the other.  Per-row arithmetic does not depend on the grouping.
 constexpr int kPrefillDmaLdsBytes = 4 * 16384 + kPgLdsMax * 4;   // K ring, V ring (2 x 16 KiB each), page-id window
-template <int QBLK, int D, bool POW2, int GROUPED = 1, int NW = 4, bool DMA = false, bool M32 = false>
+template <int QBLK, int D, bool POW2, int GROUPED = 1, int NW = 4, bool DMA = false>
 __global__ __launch_bounds__(NW * 64, D == 128 ? 2 : 1) void batch_prefill_paged_kernel(
     const Half* __restrict__ q, Half* __restrict__ out, const Half* __restrict__ kv, long k_off, long v_off,
     const int* __restrict__ page_indices, const int* __restrict__ page_indptr,
@@ -767,13 +526,9 @@ __global__ __launch_bounds__(NW * 64, D == 128 ? 2 : 1) void batch_prefill_paged
     const long q_stride_n = (long)num_qo_heads * D;
     const long qo_base = (long)q0 * q_stride_n + (long)kvh * group * D;
     const Half* kvh_base = kv + (long)kvh * D;
-    if constexpr (M32)
-      prefill_tile32<NW>(q + qo_base, out + qo_base, kvh_base + k_off, kvh_base + v_off, addr, qo_len, kv_len, row0[k],
-                         n * cta_tile_q, group, q_stride_n, scale_log2, ks, reinterpret_cast<u32x4*>(vt));
-    else
-      prefill_tile<QBLK, D, NW, PagedAddr<POW2>, DMA>(q + qo_base, out + qo_base, kvh_base + k_off, kvh_base + v_off, addr,
-                                                      qo_len, kv_len, row0[k], n * cta_tile_q, group,
-                                                      q_stride_n, scale_log2, ks, vt);
+    prefill_tile<QBLK, D, NW, PagedAddr<POW2>, DMA>(q + qo_base, out + qo_base, kvh_base + k_off, kvh_base + v_off, addr,
+                                                    qo_len, kv_len, row0[k], n * cta_tile_q, group,
+                                                    q_stride_n, scale_log2, ks, vt);
   }
 }
 
@@ -873,42 +628,27 @@ int32_t batch_prefill_paged_cuda_with_cta_tile_q(
       padded_batch_size, xcd_heads)
   // LDS-DMA staging + ds_read_b64_tr_b16 form of the 32-rows-per-wave tiles (power-of-two page sizes;
   // PEGAINFER_PREFILL_DMA=0 keeps the register-staged form; per-row arithmetic is identical)
+  static const bool dma64_on = [] { const char* e = getenv("PEGAINFER_PREFILL_DMA64"); return !(e && *e == '0'); }();
   static const bool dma_on = [] { const char* e = getenv("PEGAINFER_PREFILL_DMA"); return !(e && *e == '0'); }();
-  static const bool m32_on = [] { const char* e = getenv("PEGAINFER_PREFILL_M32"); return e && *e == '1'; }();
-#define PK_PREFILL_M32(G, CTA)                                                                                  \
+#define PK_PREFILL_DMA(QB, G, CTA)                                                                                 \
   do {                                                                                                          \
     static const bool once = [] {                                                                               \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&batch_prefill_paged_kernel<2, 128, true, G, 4, true, true>), \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&batch_prefill_paged_kernel<QB, 128, true, G, 4, true>), \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, kPrefillDmaLdsBytes);              \
       return true;                                                                                              \
     }();                                                                                                        \
     (void)once;                                                                                                 \
-    batch_prefill_paged_kernel<2, 128, true, G, 4, true, true>                                                  \
+    batch_prefill_paged_kernel<QB, 128, true, G, 4, true>                                                       \
         <<<((padded_batch_size + G - 1) / G) * num_kv_heads, 256, kPrefillDmaLdsBytes, s>>>(                    \
             q, output, kv_data, k_offset_elems, v_offset_elems, page_indices, page_indptr, last_page_len_d, q_indptr, \
             request_indices, qo_tile_indices, num_qo_heads, num_kv_heads, page_size, stride_page, scale_log2, CTA, shift, \
             padded_batch_size, xcd_heads);                                                                      \
   } while (0)
-#define PK_PREFILL_DMA(G, CTA)                                                                                  \
-  do {                                                                                                          \
-    static const bool once = [] {                                                                               \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&batch_prefill_paged_kernel<2, 128, true, G, 4, true>), \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, kPrefillDmaLdsBytes);              \
-      return true;                                                                                              \
-    }();                                                                                                        \
-    (void)once;                                                                                                 \
-    batch_prefill_paged_kernel<2, 128, true, G, 4, true>                                                        \
-        <<<((padded_batch_size + G - 1) / G) * num_kv_heads, 256, kPrefillDmaLdsBytes, s>>>(                    \
-            q, output, kv_data, k_offset_elems, v_offset_elems, page_indices, page_indptr, last_page_len_d, q_indptr, \
-            request_indices, qo_tile_indices, num_qo_heads, num_kv_heads, page_size, stride_page, scale_log2, CTA, shift, \
-            padded_batch_size, xcd_heads);                                                                      \
-  } while (0)
-  if (dma_on && m32_on && shift >= 0 && (cta == 128 || pair)) {
-    if (cta == 128) PK_PREFILL_M32(1, 128);
-    else PK_PREFILL_M32(2, 64);
-  } else if (dma_on && shift >= 0 && (cta == 128 || pair)) {
-    if (cta == 128) PK_PREFILL_DMA(1, 128);
-    else PK_PREFILL_DMA(2, 64);
+  if (dma_on && shift >= 0 && (cta == 128 || pair)) {
+    if (cta == 128) PK_PREFILL_DMA(2, 1, 128);
+    else PK_PREFILL_DMA(2, 2, 64);
+  } else if (dma_on && dma64_on && shift >= 0 && cta == 64) {
+    PK_PREFILL_DMA(1, 1, 64);   // 64-row tiles, 16 rows per wave (prompts of ~1 k tokens: too few tiles to pair)
   } else if (cta == 128) {
     if (shift >= 0) PK_PREFILL(2, true, 1, 128);
     else PK_PREFILL(2, false, 1, 128);
@@ -921,7 +661,6 @@ int32_t batch_prefill_paged_cuda_with_cta_tile_q(
   }
 #undef PK_PREFILL
 #undef PK_PREFILL_DMA
-#undef PK_PREFILL_M32
   return (int32_t)hipGetLastError();
 }
 
