@@ -168,7 +168,11 @@ def test_batch_prefill_paged_long(P, seq_lens, starts):
 @pytest.mark.parametrize("ps,seq_lens,starts", [(16, [300, 77], [0, 41]),      # 16-token pages: the full-tile fast path
                                                  (32, [300, 77], [0, 41]),      # other power of two: shift / mask path
                                                  (12, [300, 77], [0, 41]),      # not a power of two: division path
-                                                 (2, [4700], [0])])             # 2350 pages: the 2048-entry LDS window reloads
+                                                 (2, [4700], [0]),              # 2350 pages: the 2048-entry LDS window reloads
+                                                 (64, [300, 77], [0, 41]),      # page == KV tile: LDS-DMA pieces, per-tile page id
+                                                 (128, [300, 77], [0, 41]),     # page > KV tile: the DMA form's general addressing
+                                                 (128, [4700], [0]),            # ... on paired 128-row tiles
+                                                 (4, [4700], [0])])             # a DMA piece (4 rows) = one page, paired tiles
 def test_batch_prefill_paged_page_sizes(P, ps, seq_lens, starts):
     """The prefill kernel's three page-addressing forms and the page-id window in LDS (a request with more than 2048
     pages - 32 k tokens at the usual page size, here 4700 tokens on 2-token pages) against the oracle."""
