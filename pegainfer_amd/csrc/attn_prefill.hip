@@ -223,22 +223,34 @@ __device__ __forceinline__ void prefill_tile(const Half* __restrict__ q_base, Ha
     for (int qb = 0; qb < QBLK; ++qb)
 #pragma unroll
       for (int tb = 0; tb < 4; ++tb) sacc[qb][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // K fragments through a 4-deep register ring: the read for step i + 4 is issued right behind the MFMAs of step i
-    // (hipcc otherwise reuses one register quad for every fragment and each MFMA pair waits out a full LDS round trip)
-    auto load_kf = [&](int i) {
-      const int row = (i / KS) * 16 + l15, sl = i % KS;
+    // K fragments in PAIRS through a two-pair register ring.  The kernel is instruction-issue-bound and every fragment
+    // hipcc sees for the first time costs one s_waitcnt: the pair's YOUNGER read is used first, so one wait covers both.
+    // Pair p = dim slice p % KS of the token blocks 2 (p / KS) and 2 (p / KS) + 1: different accumulators, so every
+    // accumulator still sees its slices in ascending order (same bits).  Pair p + 2 is requested behind pair p's MFMAs.
+    auto load_kf = [&](int tb, int sl) {
+      const int row = tb * 16 + l15;
       return __builtin_bit_cast(bf16x8_t, kt[row * KCH + ((sl * 4 + g) ^ (row & 15))]);
     };
     {
-      bf16x8_t kr[4];
+      bf16x8_t kr[2][2];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) kr[i] = load_kf(i);
+      for (int p = 0; p < 2; ++p) {
+        kr[p][0] = load_kf(2 * (p / KS), p % KS);
+        kr[p][1] = load_kf(2 * (p / KS) + 1, p % KS);
+      }
 #pragma unroll
-      for (int i = 0; i < 4 * KS; ++i) {
+      for (int p = 0; p < 2 * KS; ++p) {
+        const int tb0 = 2 * (p / KS), sl = p % KS;
 #pragma unroll
         for (int qb = 0; qb < QBLK; ++qb)
-          sacc[qb][i / KS] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kr[i & 3], qf[qb][i % KS], sacc[qb][i / KS], 0, 0, 0);
-        if (i + 4 < 4 * KS) kr[i & 3] = load_kf(i + 4);
+          sacc[qb][tb0 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kr[p & 1][1], qf[qb][sl], sacc[qb][tb0 + 1], 0, 0, 0);
+#pragma unroll
+        for (int qb = 0; qb < QBLK; ++qb)
+          sacc[qb][tb0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kr[p & 1][0], qf[qb][sl], sacc[qb][tb0], 0, 0, 0);
+        if (p + 2 < 2 * KS) {
+          kr[p & 1][0] = load_kf(2 * ((p + 2) / KS), (p + 2) % KS);
+          kr[p & 1][1] = load_kf(2 * ((p + 2) / KS) + 1, (p + 2) % KS);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -247,9 +259,13 @@ __device__ __forceinline__ void prefill_tile(const Half* __restrict__ q_base, Ha
     //      The causal / length mask is applied only on the tiles that cross this wave's diagonal or the end of
     //      the sequence (wave-uniform test); interior tiles - nearly all of a long prompt - take no compare at all.
     // the first V^T fragments are requested here: their LDS round trip runs under the softmax arithmetic
-    bf16x8_t vr[4];
+    // pair p = token half p % 2 of the dim blocks 2 (p / 2) and 2 (p / 2) + 1
+    bf16x8_t vr[2][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) vr[i] = load_vf(i >> 1, i & 1);
+    for (int p = 0; p < 2; ++p) {
+      vr[p][0] = load_vf(2 * (p >> 1), p & 1);
+      vr[p][1] = load_vf(2 * (p >> 1) + 1, p & 1);
+    }
     const bool need_mask = kv0 + TKV > wave_kv_full;
     bf16x8_t pf[QBLK][2];
 #pragma unroll
@@ -265,20 +281,25 @@ __device__ __forceinline__ void prefill_tile(const Half* __restrict__ q_base, Ha
             sacc[qb][tb][i] = kvt <= limit ? sacc[qb][tb][i] : -INFINITY;
           }
       }
-      float mx = max3_raw(sacc[qb][0][0], sacc[qb][0][1], sacc[qb][0][2]);
-      mx = max3_raw(mx, sacc[qb][0][3], sacc[qb][1][0]);
-      mx = max3_raw(mx, sacc[qb][1][1], sacc[qb][1][2]);
-      mx = max3_raw(mx, sacc[qb][1][3], sacc[qb][2][0]);
-      mx = max3_raw(mx, sacc[qb][2][1], sacc[qb][2][2]);
-      mx = max3_raw(mx, sacc[qb][2][3], sacc[qb][3][0]);
-      mx = max3_raw(mx, sacc[qb][3][1], sacc[qb][3][2]);
-      mx = max3_raw(mx, sacc[qb][3][3], mx);
+      // two interleaved max3 chains (a dependent inline-asm pair costs a hazard s_nop each, and issue slots are what
+      // this kernel is short of); the maximum does not depend on the order
+      float mxa = max3_raw(sacc[qb][0][0], sacc[qb][0][1], sacc[qb][0][2]);
+      float mxb = max3_raw(sacc[qb][2][0], sacc[qb][2][1], sacc[qb][2][2]);
+      mxa = max3_raw(mxa, sacc[qb][0][3], sacc[qb][1][0]);
+      mxb = max3_raw(mxb, sacc[qb][2][3], sacc[qb][3][0]);
+      mxa = max3_raw(mxa, sacc[qb][1][1], sacc[qb][1][2]);
+      mxb = max3_raw(mxb, sacc[qb][3][1], sacc[qb][3][2]);
+      float mx = max3_raw(mxa, sacc[qb][1][3], sacc[qb][3][3]);
+      mx = fmaxf(mx, mxb);
       {  // max over the row's 4 lane groups: v_permlane16/32_swap (gfx950; VALU speed, no LDS round trips as with
-         // ds_bpermute; the two operands must be distinct registers): rows [m0 m1 m2 m3] -> [m01 m01 m23 m23] -> all
+         // ds_bpermute): rows [m0 m1 m2 m3] -> [m01 m01 m23 m23] -> all.  Inline asm on purpose: the swap needs two
+         // REGISTERS, and __builtin_amdgcn_permlane16_swap with one value for both operands (also behind an opaque
+         // copy) makes hipcc drop the max that follows (checked in the ISA; results then differ).  s_nop 1 = the two
+         // wait states hipcc itself puts between a VALU write and the swap.
         float a = mx, b = mx;
-        asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+        asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
         a = fmaxf(a, b); b = a;
-        asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+        asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
         mx = fmaxf(a, b);
       }
       const float mn = fmaxf(m_run[qb], mx * scale_log2);   // scale_log2 > 0: the max commutes with the scaling
@@ -314,11 +335,18 @@ __device__ __forceinline__ void prefill_tile(const Half* __restrict__ q_base, Ha
     // ---- O^T += V^T . P^T ----
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int i = 0; i < 2 * DB; ++i) {   // step i = (db = i / 2, kb = i % 2), fragments through the 4-deep ring
+    for (int p = 0; p < DB; ++p) {   // fragment pairs as above: an accumulator still sees token half 0 before half 1
+      const int db0 = 2 * (p >> 1), kb = p & 1;
 #pragma unroll
       for (int qb = 0; qb < QBLK; ++qb)
-        acc_o[qb][i >> 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vr[i & 3], pf[qb][i & 1], acc_o[qb][i >> 1], 0, 0, 0);
-      if (i + 4 < 2 * DB) vr[i & 3] = load_vf((i + 4) >> 1, (i + 4) & 1);
+        acc_o[qb][db0 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vr[p & 1][1], pf[qb][kb], acc_o[qb][db0 + 1], 0, 0, 0);
+#pragma unroll
+      for (int qb = 0; qb < QBLK; ++qb)
+        acc_o[qb][db0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vr[p & 1][0], pf[qb][kb], acc_o[qb][db0], 0, 0, 0);
+      if (p + 2 < DB) {
+        vr[p & 1][0] = load_vf(2 * ((p + 2) >> 1), (p + 2) & 1);
+        vr[p & 1][1] = load_vf(2 * ((p + 2) >> 1) + 1, (p + 2) & 1);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     __builtin_amdgcn_s_setprio(0);
