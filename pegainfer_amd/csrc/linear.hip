@@ -592,7 +592,10 @@ static void glds_gemm_launch(const Half* W, const Half* X, Half* Y, int M, int T
   if (variant == 0) {
     // long prompts: 256 x 256 tiles on the 8-phase schedule once they give every CU work (PEGAINFER_GEMM256 = 0 never,
     // 1 whenever the shape allows, N = from N tiles on; A/B probe knob)
-    static const int g256_min = [] { const char* e = getenv("PEGAINFER_GEMM256"); return e && *e ? atoi(e) : 224; }();
+    // from 128 tiles on (half the CUs): one partly filled round of 256 x 256 tiles still beats the smaller tilings -
+    // gate_up at 512 tokens (152 tiles) 100 -> 70 us, qkv at 1536 tokens (144 tiles) 80 -> 64 us, same bits
+    // (profiles/r3_gemm256_threshold_ab.txt); at 96 tiles (qkv at 1024 tokens) the 128 x 256 kernel wins (43 vs ~71 us)
+    static const int g256_min = [] { const char* e = getenv("PEGAINFER_GEMM256"); return e && *e ? atoi(e) : 128; }();
     if (g256_min > 0 && gemm256_ok(M, T, K)) {
       const int mt256 = so.silu_I > 0 ? ceil_div(so.silu_I, 128) : ceil_div(M, G256_BM), tt256 = ceil_div(T, G256_BT);
       const long tiles256 = (long)mt256 * tt256;
