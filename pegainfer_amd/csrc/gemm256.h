@@ -325,6 +325,7 @@ constexpr int G128_BM = 128;
 constexpr int kG128LdsBytes = 9 * kG256HalfBytes;
 enum { kG128A = 0, kG128Blo = 1, kG128Bhi = 2 };
 
+template <bool SILU>
 __global__ __launch_bounds__(512) void mfma_gemm128x256_kernel(const Half* __restrict__ W, const Half* __restrict__ X,
                                                                Half* __restrict__ Y, int M, int T, int K, int m_tiles,
                                                                int t_tiles, SplitOut so, float* __restrict__ part,
@@ -346,8 +347,15 @@ __global__ __launch_bounds__(512) void mfma_gemm128x256_kernel(const Half* __res
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int p = (j * 8 + wave) * 64 + lane, hrow = p >> 3, cs = (p & 7) ^ (hrow & 7);
-    int row = m0 + hrow;
-    row = row < M ? row : M - 1;
+    int row;
+    if (SILU) {   // a wave row's m-tiles 0, 1 are 32 gate rows, 2, 3 their 32 up rows: gate and up of an element meet in one lane
+      int gr = so.silu_c0 + mt * 64 + (hrow >> 6) * 32 + ((hrow >> 4) & 1) * 16 + (hrow & 15);
+      gr = gr < silu_cols_end(so) ? gr : silu_cols_end(so) - 1;
+      row = gr + (((hrow >> 4) & 2) ? so.silu_I : 0);
+    } else {
+      row = m0 + hrow;
+      row = row < M ? row : M - 1;
+    }
     src[kG128A][j] = W + (size_t)row * K + cs * 8;
     const int wc_ = hrow >> 5, r = hrow & 31;
 #pragma unroll
@@ -448,6 +456,34 @@ __global__ __launch_bounds__(512) void mfma_gemm128x256_kernel(const Half* __res
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail loads must not outlive the workgroup's LDS
   if (wr == 0) __builtin_amdgcn_s_barrier();
 
+  if (SILU) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int t = t0 + wc * 64 + j * 16 + l15;
+      if (t >= T) continue;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int m = so.silu_c0 + mt * 64 + wr * 32 + i * 16 + g * 4;
+        float r[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {  // the GEMM output is bf16 before SwiGLU (fused_proj.cu:57-62)
+          const float sg = silu_f(bf16_round_f(acc[i][j][e]));
+          r[e] = (so.silu_round ? bf16_round_f(sg) : sg) * bf16_round_f(acc[i + 2][j][e]);
+        }
+        if (m + 3 < silu_cols_end(so)) {
+          u32x2 o;
+          o.x = pack_bf2(r[0], r[1]);
+          o.y = pack_bf2(r[2], r[3]);
+          *reinterpret_cast<u32x2*>(Y + (size_t)t * so.silu_I + m) = o;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (m + e < silu_cols_end(so)) Y[(size_t)t * so.silu_I + m + e] = f2bf(r[e]);
+        }
+      }
+    }
+    return;
+  }
   if (part) {
     float* pz = part + (size_t)blockIdx.y * T * M;
 #pragma unroll
@@ -503,14 +539,27 @@ inline bool gemm128x256_ok(int M, int T, int K) { return (K % G256_BK) == 0 && K
 // plain (part == nullptr, ksplit == 1) or split-K (fp32 partials into part[ksplit][T][M]; the caller sums the slices)
 inline void gemm128x256_launch(const Half* W, const Half* X, Half* Y, int M, int T, int K, SplitOut so, float* part,
                                int ksplit, int nk_slice, hipStream_t s) {
+  const int t_tiles = ceil_div(T, G256_BT);
+  if (so.silu_I > 0) {   // SwiGLU form (un-split only): a tile = 64 gate rows + their 64 up rows
+    static const bool once = [] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_gemm128x256_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kG128LdsBytes);
+      return true;
+    }();
+    (void)once;
+    const int m_tiles = ceil_div(silu_cols_end(so) - so.silu_c0, 64);
+    mfma_gemm128x256_kernel<true><<<m_tiles * t_tiles, 512, kG128LdsBytes, s>>>(W, X, Y, M, T, K, m_tiles, t_tiles, so,
+                                                                                nullptr, 0);
+    return;
+  }
   static const bool once = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_gemm128x256_kernel),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_gemm128x256_kernel<false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, kG128LdsBytes);
     return true;
   }();
   (void)once;
-  const int m_tiles = ceil_div(M, G128_BM), t_tiles = ceil_div(T, G256_BT);
-  mfma_gemm128x256_kernel<<<dim3(m_tiles * t_tiles, part ? ksplit : 1), 512, kG128LdsBytes, s>>>(
+  const int m_tiles = ceil_div(M, G128_BM);
+  mfma_gemm128x256_kernel<false><<<dim3(m_tiles * t_tiles, part ? ksplit : 1), 512, kG128LdsBytes, s>>>(
       W, X, Y, M, T, K, m_tiles, t_tiles, so, part, nk_slice);
 }
 

@@ -620,6 +620,17 @@ static void glds_gemm_launch(const Half* W, const Half* X, Half* Y, int M, int T
         return;
       }
     }
+    // SwiGLU GEMM on short prompts (65..256 tokens: 152 tiles of (64 + 64) x 256 for Qwen3-4B, one round) - the 128 x 128
+    // kernel runs these at one 4-wave workgroup per CU.  Same per-element K order: bit-identical to gemm + silu_mul
+    // (tested).  TTFT(128) 4.85 -> 4.63 ms, TTFT(256) 5.79 -> 5.27 ms same-box (PEGAINFER_GEMM128X256_SILU=0 for the A/B)
+    static const bool silu128_on = [] { const char* e = getenv("PEGAINFER_GEMM128X256_SILU"); return !(e && e[0] == '0'); }();
+    if (so.silu_I > 0 && so.silu_c1 == 0 && silu128_on && gemm128x256_on() && gemm128x256_ok(M, T, K) && T <= 256) {
+      const long tiles = (long)ceil_div(so.silu_I, 64) * ceil_div(T, G256_BT);
+      if (tiles > 128 && tiles <= 256) {
+        gemm128x256_launch(W, X, Y, M, T, K, so, nullptr, 1, 0, s);
+        return;
+      }
+    }
     // 129..256 tiles of 128 x 256: one un-split round of the 2-phase kernel (qkv at 1024 tokens: 192 tiles)
     if (so.silu_I == 0 && gemm128x256_on() && gemm128x256_ok(M, T, K) && T >= 512) {
       const long tiles = (long)ceil_div(M, G128_BM) * ceil_div(T, G256_BT);

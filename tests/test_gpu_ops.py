@@ -261,7 +261,7 @@ def test_gemm_split3_equals_three_gemms(P, T, K, ms):
 
 
 @pytest.mark.parametrize("T,I,K", [(1024, 9728, 2560), (130, 512, 256), (40, 9728, 2560), (40, 512, 256), (100, 1000, 128),
-                                   (7, 9728, 2560)])
+                                   (7, 9728, 2560), (256, 9728, 2560), (200, 9730 - 2, 2560), (100, 8200, 1024)])
 def test_gemm_silu_epilogue_equals_gemm_then_silu_mul_fused(P, T, I, K):
     """SwiGLU in the tiled GEMM's epilogue (64 gate rows + their 64 up rows per workgroup) == gemm_cuda +
     silu_mul_fused_cuda, bit for bit, incl. partial row tiles, the mid-batch (17..64) family and the small-shape
