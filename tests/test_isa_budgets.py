@@ -74,6 +74,8 @@ def test_decode_gemv_and_gemm_kernels_keep_their_occupancy():
     check(md, r"skinny_resident_kernel<\d, \d>", 256, at_least=4)
     # prefill: 8-wave 256 x 256 tiles need two waves per SIMD; the 128-tile LDS-DMA kernels two workgroups per CU
     check(md, r"mfma_gemm256_kernel<(true|false)>", 256, at_least=2)
+    # round 3: 128 x 256 tiles (plain / split-K and SwiGLU forms), 8 waves = two per SIMD, 64 accumulators
+    check(md, r"mfma_gemm128x256_kernel<(true|false)>", 256, at_least=2)
     check(md, r"mfma_gemm_glds_kernel<\d+, \d, (true|false)>", 256, at_least=6)
     check(md, r"splitk_reduce\w*kernel", 256, at_least=3)
 
@@ -86,6 +88,8 @@ def test_attention_kernels_keep_their_occupancy():
     md = kernel_metadata("attn_prefill.hip")
     # head dim 128: two workgroups per CU (the __launch_bounds__(256, 2) budget), no AGPR shuffling, no spills
     check(md, r"batch_prefill_paged_kernel<\d, 128, (true|false), \d, 4, (true|false)>", 256, at_least=6)
+    # round 3: the LDS-DMA forms the launcher takes for power-of-two pages (128-row, paired 64-row and single 64-row tiles)
+    check(md, r"batch_prefill_paged_kernel<[12], 128, true, [12], 4, true>", 256, at_least=3)
     for k, v in md.items():
         if re.fullmatch(r"batch_prefill_paged_kernel<\d, 128, (true|false), \d, 4, (true|false)>", k):
             assert v["agpr"] == 0, f"{k} keeps accumulators in AGPRs: {v}"
