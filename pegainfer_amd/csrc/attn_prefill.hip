@@ -16,6 +16,12 @@
 //     transpose; row pitch 136 B) so V^T fragments are two ds_read_b64 each.
 //   * global->register prefetch of the next KV tile overlaps the MFMAs of the current one.
 //   * online softmax in the exp2 domain (sm_scale*log2e folded), fp32 accumulation, bf16 output.
+// Round 3 adds the LDS-DMA form (template flag DMA; head_dim 128, power-of-two pages, 64- / 128-row tiles - what the model
+// path runs): K and V tiles go global -> LDS by global_load_lds_dwordx4 into two-deep rings with ONE barrier per tile, V
+// stays row-major and the V^T fragments are gathered by ds_read_b64_tr_b16, the row max crosses lane groups by
+// v_permlane16/32_swap.  Both forms share compute_tile(): identical per-row arithmetic (sha-checked,
+// tools/bench_prefill_attn.py).  The kernel is instruction-issue-bound (DESIGN.md "Prefill attention"), so the loop is
+// written to spend few instructions: fragment reads in pairs (one s_waitcnt each), interleaved max chains.
 // kv_len comes from the page table; the causal rule is kv_idx <= q_idx + (kv_len - qo_len).
 #include <type_traits>
 
