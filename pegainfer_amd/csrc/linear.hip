@@ -495,9 +495,9 @@ static bool gemm128x256_on() {
 }
 constexpr int kSplitKMaxRows = 16384;   // below this (< 128 row tiles) the 17..64-column GEMM splits K
 struct SplitKPlan { int ksplit, nk_slice, tt; };
-static SplitKPlan splitk_plan(int M, int T, int K) {
+static SplitKPlan splitk_plan(int M, int T, int K, bool assume_ws = false) {
   static const bool enabled = [] { const char* e = getenv("PEGAINFER_SPLITK"); return !(e && e[0] == '0'); }();
-  if (!enabled || !g_splitk_ws || T <= 16) return {0, 0, 0};
+  if (!enabled || (!g_splitk_ws && !assume_ws) || T <= 16) return {0, 0, 0};
   const int m_tiles = ceil_div(M, BM), nk_all = K / BK;
   if (T > 64) {
     // long-K matrices at ~1.3-3 k tokens (down_proj: 50-128 tiles of 256 x 256): the 8-phase kernel over 2-5 K
@@ -586,66 +586,74 @@ static void glds_splitk_launch(const Half* W, const Half* X, Half* Y, int M, int
   if (reduce) splitk_reduce_kernel<<<ceil_div((long)T * (M >> 2), 256), 256, 0, s>>>(g_splitk_ws, Y, M, T, pl.ksplit, so);
 }
 
+// Which tiled kernel a prefill-shaped GEMM (T > 64, not K-split) takes - by shape only.  kind: 12 / 13 / 22 / 23 = the
+// 128-row LDS-DMA kernel with 128- / 64-token tiles and that ring depth, 256 = the 256 x 256 8-phase kernel, 257 = its
+// SwiGLU form with the thin last round handed to the 128-row kernel (m_head = activation-column tiles of the head), 1280 /
+// 1281 = the 128 x 256 kernel, plain / SwiGLU.  One function for the launcher and for pegainfer_debug_gemm_route (the
+// routing table is pinned by a CPU test: a threshold edit must not silently change what the GPU tests exercise).
+struct TiledRoute { int kind, m_head; };
+static TiledRoute tiled_route(int M, int T, int K, const SplitOut& so) {
+  // long prompts: 256 x 256 tiles on the 8-phase schedule once they give every CU work (PEGAINFER_GEMM256 = 0 never,
+  // 1 whenever the shape allows, N = from N tiles on; A/B probe knob)
+  // from 128 tiles on (half the CUs): one partly filled round of 256 x 256 tiles still beats the smaller tilings -
+  // gate_up at 512 tokens (152 tiles) 100 -> 70 us, qkv at 1536 tokens (144 tiles) 80 -> 64 us, same bits
+  // (profiles/r3_gemm256_threshold_ab.txt); at 96 tiles (qkv at 1024 tokens) the 128 x 256 kernel wins (43 vs ~71 us)
+  static const int g256_min = [] { const char* e = getenv("PEGAINFER_GEMM256"); return e && *e ? atoi(e) : 128; }();
+  if (g256_min > 0 && gemm256_ok(M, T, K)) {
+    const int mt256 = so.silu_I > 0 ? ceil_div(so.silu_I, 128) : ceil_div(M, G256_BM), tt256 = ceil_div(T, G256_BT);
+    const long tiles256 = (long)mt256 * tt256;
+    if (tiles256 >= g256_min) {
+      // A thin last round: 304 tiles (gate_up at 1024 tokens) are one full round of the 256 CUs plus 48 tiles that
+      // cost a second full tile time (127 us for 102 GFLOP).  The SwiGLU form can hand the activation columns of
+      // that remainder to the 128-row kernel (192 quarter-size tiles: one short round) - both kernels keep the same
+      // per-element K order, so the result does not depend on the cut.  PEGAINFER_GEMM256_TAIL=0 switches it off.
+      static const bool tail_on = [] { const char* e = getenv("PEGAINFER_GEMM256_TAIL"); return !(e && *e == '0'); }();
+      constexpr int kCus = 256;
+      const int rem = (int)(tiles256 % kCus);
+      const int m_head = (int)((tiles256 / kCus) * kCus / tt256);   // whole activation-column tiles in full rounds
+      if (tail_on && so.silu_I > 0 && so.silu_c1 == 0 && rem > 0 && rem * 2 <= kCus && m_head > 0 && m_head < mt256)
+        return {257, m_head};
+      return {256, 0};
+    }
+  }
+  // SwiGLU GEMM on short prompts (65..256 tokens: 152 tiles of (64 + 64) x 256 for Qwen3-4B, one round) - the 128 x 128
+  // kernel runs these at one 4-wave workgroup per CU.  Same per-element K order: bit-identical to gemm + silu_mul
+  // (tested).  TTFT(128) 4.85 -> 4.63 ms, TTFT(256) 5.79 -> 5.27 ms same-box (PEGAINFER_GEMM128X256_SILU=0 for the A/B)
+  static const bool silu128_on = [] { const char* e = getenv("PEGAINFER_GEMM128X256_SILU"); return !(e && e[0] == '0'); }();
+  if (so.silu_I > 0 && so.silu_c1 == 0 && silu128_on && gemm128x256_on() && gemm128x256_ok(M, T, K) && T <= 256) {
+    const long tiles = (long)ceil_div(so.silu_I, 64) * ceil_div(T, G256_BT);
+    if (tiles > 128 && tiles <= 256) return {1281, 0};
+  }
+  // 129..256 tiles of 128 x 256: one un-split round of the 2-phase kernel (qkv at 1024 tokens: 192 tiles)
+  if (so.silu_I == 0 && gemm128x256_on() && gemm128x256_ok(M, T, K) && T >= 512) {
+    const long tiles = (long)ceil_div(M, G128_BM) * ceil_div(T, G256_BT);
+    if (tiles > 128 && tiles <= 256) return {1280, 0};
+  }
+  // Measured on MI355X (tools/bench_prefill_gemm.py, T = 1024): co-resident workgroups hide DMA latency better
+  // than a deeper ring, so the ring only goes to 3 when every 64-token tile is resident at once (<= 2 per CU);
+  // 128-token tiles (half the LDS reads per MFMA) once they give each CU >= 1.5 workgroups.
+  const long m_tiles = ceil_div(M, BM), wide = m_tiles * ceil_div(T, 128), narrow = m_tiles * ceil_div(T, 64);
+  // With cold (HBM) weights, long-K small matrices (down_proj: 160 wide tiles, K = 9728) do best as one 128-token
+  // tile per CU with the 3-deep ring (102 vs 115 us); measured with tools/bench_prefill_gemm.py 1024 12.
+  return {narrow <= 512 ? (K >= 8192 && wide <= 256 ? 13 : 23) : wide >= 384 ? 12 : 22, 0};
+}
+
 // variant: 0 = by shape; else 10*tile + stages with tile 1 = 128-token, 2 = 64-token (A/B probe only)
 static void glds_gemm_launch(const Half* W, const Half* X, Half* Y, int M, int T, int K, SplitOut so, int variant,
                              hipStream_t s) {
   if (variant == 0) {
-    // long prompts: 256 x 256 tiles on the 8-phase schedule once they give every CU work (PEGAINFER_GEMM256 = 0 never,
-    // 1 whenever the shape allows, N = from N tiles on; A/B probe knob)
-    // from 128 tiles on (half the CUs): one partly filled round of 256 x 256 tiles still beats the smaller tilings -
-    // gate_up at 512 tokens (152 tiles) 100 -> 70 us, qkv at 1536 tokens (144 tiles) 80 -> 64 us, same bits
-    // (profiles/r3_gemm256_threshold_ab.txt); at 96 tiles (qkv at 1024 tokens) the 128 x 256 kernel wins (43 vs ~71 us)
-    static const int g256_min = [] { const char* e = getenv("PEGAINFER_GEMM256"); return e && *e ? atoi(e) : 128; }();
-    if (g256_min > 0 && gemm256_ok(M, T, K)) {
-      const int mt256 = so.silu_I > 0 ? ceil_div(so.silu_I, 128) : ceil_div(M, G256_BM), tt256 = ceil_div(T, G256_BT);
-      const long tiles256 = (long)mt256 * tt256;
-      if (tiles256 >= g256_min) {
-        // A thin last round: 304 tiles (gate_up at 1024 tokens) are one full round of the 256 CUs plus 48 tiles that
-        // cost a second full tile time (127 us for 102 GFLOP).  The SwiGLU form can hand the activation columns of
-        // that remainder to the 128-row kernel (192 quarter-size tiles: one short round) - both kernels keep the same
-        // per-element K order, so the result does not depend on the cut.  PEGAINFER_GEMM256_TAIL=0 switches it off.
-        static const bool tail_on = [] { const char* e = getenv("PEGAINFER_GEMM256_TAIL"); return !(e && *e == '0'); }();
-        constexpr int kCus = 256;
-        const int rem = (int)(tiles256 % kCus);
-        const int m_head = (int)((tiles256 / kCus) * kCus / tt256);   // whole activation-column tiles in full rounds
-        if (tail_on && so.silu_I > 0 && so.silu_c1 == 0 && rem > 0 && rem * 2 <= kCus && m_head > 0 && m_head < mt256) {
-          SplitOut head = so, tail = so;
-          head.silu_c0 = 0; head.silu_c1 = m_head * 128;
-          tail.silu_c0 = m_head * 128; tail.silu_c1 = so.silu_I;
-          gemm256_launch(W, X, Y, M, T, K, head, s);
-          glds_gemm_launch_t<128, 2>(W, X, Y, M, T, K, tail, s);
-          return;
-        }
-        gemm256_launch(W, X, Y, M, T, K, so, s);
-        return;
-      }
+    const TiledRoute r = tiled_route(M, T, K, so);
+    if (r.kind == 257) {
+      SplitOut head = so, tail = so;
+      head.silu_c0 = 0; head.silu_c1 = r.m_head * 128;
+      tail.silu_c0 = r.m_head * 128; tail.silu_c1 = so.silu_I;
+      gemm256_launch(W, X, Y, M, T, K, head, s);
+      glds_gemm_launch_t<128, 2>(W, X, Y, M, T, K, tail, s);
+      return;
     }
-    // SwiGLU GEMM on short prompts (65..256 tokens: 152 tiles of (64 + 64) x 256 for Qwen3-4B, one round) - the 128 x 128
-    // kernel runs these at one 4-wave workgroup per CU.  Same per-element K order: bit-identical to gemm + silu_mul
-    // (tested).  TTFT(128) 4.85 -> 4.63 ms, TTFT(256) 5.79 -> 5.27 ms same-box (PEGAINFER_GEMM128X256_SILU=0 for the A/B)
-    static const bool silu128_on = [] { const char* e = getenv("PEGAINFER_GEMM128X256_SILU"); return !(e && e[0] == '0'); }();
-    if (so.silu_I > 0 && so.silu_c1 == 0 && silu128_on && gemm128x256_on() && gemm128x256_ok(M, T, K) && T <= 256) {
-      const long tiles = (long)ceil_div(so.silu_I, 64) * ceil_div(T, G256_BT);
-      if (tiles > 128 && tiles <= 256) {
-        gemm128x256_launch(W, X, Y, M, T, K, so, nullptr, 1, 0, s);
-        return;
-      }
-    }
-    // 129..256 tiles of 128 x 256: one un-split round of the 2-phase kernel (qkv at 1024 tokens: 192 tiles)
-    if (so.silu_I == 0 && gemm128x256_on() && gemm128x256_ok(M, T, K) && T >= 512) {
-      const long tiles = (long)ceil_div(M, G128_BM) * ceil_div(T, G256_BT);
-      if (tiles > 128 && tiles <= 256) {
-        gemm128x256_launch(W, X, Y, M, T, K, so, nullptr, 1, 0, s);
-        return;
-      }
-    }
-    // Measured on MI355X (tools/bench_prefill_gemm.py, T = 1024): co-resident workgroups hide DMA latency better
-    // than a deeper ring, so the ring only goes to 3 when every 64-token tile is resident at once (<= 2 per CU);
-    // 128-token tiles (half the LDS reads per MFMA) once they give each CU >= 1.5 workgroups.
-    const long m_tiles = ceil_div(M, BM), wide = m_tiles * ceil_div(T, 128), narrow = m_tiles * ceil_div(T, 64);
-    // With cold (HBM) weights, long-K small matrices (down_proj: 160 wide tiles, K = 9728) do best as one 128-token
-    // tile per CU with the 3-deep ring (102 vs 115 us); measured with tools/bench_prefill_gemm.py 1024 12.
-    variant = narrow <= 512 ? (K >= 8192 && wide <= 256 ? 13 : 23) : wide >= 384 ? 12 : 22;
+    if (r.kind == 256) { gemm256_launch(W, X, Y, M, T, K, so, s); return; }
+    if (r.kind == 1280 || r.kind == 1281) { gemm128x256_launch(W, X, Y, M, T, K, so, nullptr, 1, 0, s); return; }
+    variant = r.kind;
   }
   switch (variant) {
     case 12: glds_gemm_launch_t<128, 2>(W, X, Y, M, T, K, so, s); break;
@@ -885,6 +893,27 @@ pegainfer_status_t pegainfer_gemm_silu(const Half* W, const Half* X, Half* Y, Ha
 pegainfer_status_t pegainfer_gemm_silu_rounded(const Half* W, const Half* X, Half* Y, Half* gate_up_scratch, int32_t I,
                                                int32_t T, int32_t K, pegainfer_stream_t stream) {
   return gemm_silu_impl(W, X, Y, gate_up_scratch, I, T, K, 1, stream);
+}
+
+// Debug / test hook (no device work, callable without a GPU): which kernel a prefill-shaped GEMM of this shape takes.
+// silu_I > 0 asks for the SwiGLU form (M is then ignored, the matrix has 2 * silu_I rows).  out[0] = kind, out[1] = K
+// slices (1 = un-split), out[2] = K tiles per slice or, for kind 257, the activation-column tiles of the 256 x 256 head.
+// kind: 0 = decode family (T <= 64: GEMV / skinny / mid-batch routing, not detailed here); the TiledRoute kinds (12, 13,
+// 22, 23, 256, 257, 1280, 1281); 1000 + tt for the K-split plans (tt = 64 / 128: 128-row kernel, 129: 128 x 256 kernel,
+// 256: 256 x 256 kernel).  Assumes the split-K workspace of cublas_init() exists.
+pegainfer_status_t pegainfer_debug_gemm_route(int32_t M, int32_t T, int32_t K, int32_t silu_I, int32_t* out) {
+  using namespace pk;
+  if (!out || T <= 0 || K <= 0 || (silu_I <= 0 && M <= 0)) return (pegainfer_status_t)hipErrorInvalidValue;
+  out[0] = 0; out[1] = 1; out[2] = 0;
+  if (T <= 64) return 0;
+  if (silu_I <= 0) {
+    const SplitKPlan pl = splitk_plan(M, T, K, true);
+    if (pl.nk_slice > 0) { out[0] = 1000 + pl.tt; out[1] = pl.ksplit; out[2] = pl.nk_slice; return 0; }
+  }
+  SplitOut so{nullptr, nullptr, nullptr, 0, 0, 0, silu_I > 0 ? silu_I : 0, 0, 0, 0};
+  const TiledRoute r = tiled_route(silu_I > 0 ? 2 * silu_I : M, T, K, so);
+  out[0] = r.kind; out[2] = r.m_head;
+  return 0;
 }
 
 pegainfer_status_t pegainfer_gemm_split3(const Half* W, const Half* X, Half* Y0, int32_t M0, Half* Y1, int32_t M1,

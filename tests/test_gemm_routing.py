@@ -1,0 +1,60 @@
+"""Host logic of the prefill GEMM launcher (linear.hip: splitk_plan + tiled_route), pinned on CPU through
+pegainfer_debug_gemm_route: which kernel each Qwen3-4B projection takes at the prompt lengths the bench and the GPU
+parity tests run.  A threshold edit that silently moved a shape to another kernel would otherwise only show up as a
+different (still correct) number - and as GPU tests that no longer exercise the kernel they were written for
+(tests/test_gpu_ops.py::test_gemm_shapes, test_gpu_real_dims.py)."""
+import ctypes
+
+import pytest
+
+QKV, O, DOWN, I = (6144, 2560), (2560, 4096), (2560, 9728), 9728
+
+
+@pytest.fixture(scope="module")
+def route():
+    from pegainfer_amd import ffi
+    lib = ffi.lib()
+
+    def f(M, T, K, silu_I=0):
+        out = (ctypes.c_int32 * 3)()
+        assert lib.pegainfer_debug_gemm_route(M, T, K, silu_I, out) == 0
+        return tuple(out)
+    return f
+
+
+def test_decode_family_is_not_routed_here(route):
+    assert route(2560, 64, 4096)[0] == 0 and route(2560, 1, 4096)[0] == 0
+
+
+@pytest.mark.parametrize("T,qkv,o,down,gate_up", [
+    # kind 1000 + tt = K-split plan on tt-token tiles (129: 128 x 256 kernel, 256: 256 x 256 kernel), (slices, K tiles per slice)
+    (128, (1064, 5, 8), (1064, 8, 8), (1064, 8, 19), (1281, 1, 0)),
+    (256, (23, 1, 0), (1064, 6, 11), (1064, 6, 26), (1281, 1, 0)),      # gate_up: SwiGLU form of the 128 x 256 kernel
+    (512, (1129, 2, 20), (1129, 6, 11), (1129, 6, 26), (256, 1, 0)),    # gate_up: 152 tiles of 256 x 256, one round
+    (1024, (1280, 1, 0), (1129, 3, 22), (1129, 3, 51), (257, 1, 64)),   # the headline TTFT shape
+    (2048, (256, 1, 0), (1256, 3, 22), (1256, 3, 52), (257, 1, 64)),
+    (4096, (256, 1, 0), (256, 1, 0), (256, 1, 0), (256, 1, 0)),
+    (10000, (256, 1, 0), (256, 1, 0), (256, 1, 0), (256, 1, 0)),
+])
+def test_qwen3_4b_projection_routes(route, T, qkv, o, down, gate_up):
+    assert route(*QKV[:1], T, QKV[1]) == qkv
+    assert route(O[0], T, O[1]) == o
+    assert route(DOWN[0], T, DOWN[1]) == down
+    assert route(0, T, 2560, I) == gate_up
+
+
+def test_split_plans_cover_k_exactly(route):
+    """every K-split plan walks all K tiles: (slices - 1) * per_slice < K / 64 <= slices * per_slice"""
+    for (M, K) in (QKV, O, DOWN, (4096, 4096), (4096, 12288), (1024, 2560)):
+        for T in (65, 128, 200, 256, 512, 777, 1024, 1536, 2048, 3000):
+            kind, ks, per = route(M, T, K)
+            if kind in (1064, 1128, 1129, 1256):   # the K-split plans
+                nk = K // 64
+                assert ks >= 2 and (ks - 1) * per < nk <= ks * per, (M, K, T, kind, ks, per)
+
+
+def test_invalid_arguments(route):
+    from pegainfer_amd import ffi
+    out = (ctypes.c_int32 * 3)()
+    assert ffi.lib().pegainfer_debug_gemm_route(0, 128, 2560, 0, out) != 0
+    assert ffi.lib().pegainfer_debug_gemm_route(2560, 128, 2560, 0, None) != 0
