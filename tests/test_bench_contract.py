@@ -80,3 +80,31 @@ def test_world_size_mismatch_and_missing_gpu_are_loud(monkeypatch):
     with pytest.raises(SystemExit) as e:
         bench.main()
     assert "needs a GPU" in str(e.value)       # no silent CPU path behind the bench line
+
+
+def test_committed_bench_line_carries_the_contract_fields():
+    """The bench line kept under profiles/ for the current round (the same command the driver runs) has every field of
+    the driver's contract plus the roofline / cpu_baseline objects, and its numbers are self-consistent."""
+    import glob
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    paths = sorted(glob.glob(os.path.join(root, "profiles", "r*_bench_default_run.json")))
+    assert paths, "no committed bench line under profiles/"
+    d = json.load(open(paths[-1]))
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] * d["ms_per_step"] / 1000.0 - 1.0) < 0.02          # tokens/s x s/step == 1 at batch 1
+    r = d["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in r, key
+    assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert abs(r["achieved"] - r["bytes_per_launch"] / r["avg_launch_us"] * 1e-3) / r["achieved"] < 0.01   # GB/s
+    assert r["traffic"] is None or 0.95 < r["traffic"] / r["bytes_per_launch"] < 1.10
+    c = d["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in c, key
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0
