@@ -301,8 +301,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="requests decoded together per rank")
     ap.add_argument("--model", default="qwen3-4b", choices=["qwen3-4b", "qwen3-8b", "qwen3.5-4b"])
     ap.add_argument("--decode-mode", type=int, default=int(os.environ.get("PEGAINFER_DECODE_MODE", "1")),
-                    help="0 = reference op sequence 1:1, 1 = fused MI355X decode kernels, 2 = persistent decode-step engine "
-                         "for bs 1 (all bit-identical)")
+                    help="0 = reference op sequence 1:1, 1 = fused MI355X decode kernels (bit-identical)")
     ap.add_argument("--split-policy", type=int, default=1)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=12, help="decode steps for the CPU baseline (0 = skip)")

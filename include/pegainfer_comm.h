@@ -48,14 +48,19 @@ const char* pegainfer_comm_last_error(pegainfer_comm_t c);
  * The decode collectives are latency-bound: DSV4 issues ~107 f32 all-reduces of 16 KB per token
  * (docs/models/deepseek-v4/moe-tilelang-review.md:12), Qwen3 TP 72 bf16 all-reduces of 5 KB (weights.rs:396-405).
  * Once enabled, pegainfer_comm_all_reduce_{bf16,f32} (and the cast-fused forms built on them) take payloads of at
- * most 64 KB whose byte count and address are multiples of 16 through ONE kernel launch: every rank pushes its payload
+ * most 64 KB (decided by the byte count alone, so every rank takes the same route; an address or size that is not a
+ * multiple of 16 is staged through a 64 KB buffer of the handle) through ONE kernel launch: every rank pushes its payload
  * into every rank's slab over xGMI (write-through stores), signals with an epoch flag, waits for the world's flags and
  * sums the copies in rank order in f32 - bit-identical results on all ranks, graph-capturable (epochs live in device
  * memory), every wait bounded (PEGAINFER_ONESHOT_TIMEOUT_MS, default 10 000; expiry -> pegainfer_comm_oneshot_status).
- * Larger or unaligned payloads go to RCCL as before.  At most 8 ranks (one node).
+ * Larger payloads go to RCCL as before; a peer-only communicator (no RCCL behind it) cuts them into 64 KB pieces, one
+ * launch each.  At most 8 ranks (one node).  All one-shot all-reduces of a communicator must be ordered with respect to
+ * each other (one stream, or streams joined by events): the epochs advance in launch order.
+ * pegainfer_comm_oneshot_enable is COLLECTIVE and never strands a peer: a rank whose export / mapping failed still takes
+ * part in both exchanges, and the path is switched on only if every rank succeeded (otherwise off on every rank).
  *   RCCL communicators:   pegainfer_comm_oneshot_enable(c)            (handles travel over RCCL itself)
  *   peer-only (no RCCL):  create_peer_only -> oneshot_handle -> exchange the 64-byte handles out of band, rank-major ->
- *                         oneshot_attach -> caller barrier.  Only the eligible all-reduces work on such a communicator;
+ *                         oneshot_attach -> caller barrier.  Only the all-reduces work on such a communicator;
  *                         this is also how two processes sharing ONE GPU exercise the protocol on a single-GPU box. */
 pegainfer_comm_t pegainfer_comm_create_peer_only(int32_t device_ordinal, int32_t rank, int32_t world);
 int32_t pegainfer_comm_oneshot_handle(pegainfer_comm_t c, void* out_64_bytes);
@@ -63,6 +68,10 @@ int32_t pegainfer_comm_oneshot_attach(pegainfer_comm_t c, const void* handles_wo
 int32_t pegainfer_comm_oneshot_enable(pegainfer_comm_t c);
 int32_t pegainfer_comm_oneshot_active(pegainfer_comm_t c);
 int32_t pegainfer_comm_oneshot_status(pegainfer_comm_t c);
+/* device address of the status block behind oneshot_status ({0x100 | mask of missing ranks, epoch, segment}, uint32 x 3;
+ * NULL before the slab exists): a runtime whose captured step contains one-shot all-reduces copies it back with the
+ * step's results instead of paying a synchronising call (csrc/host/qwen3_runtime.cpp does) */
+const uint32_t* pegainfer_comm_oneshot_status_ptr(pegainfer_comm_t c);
 int32_t pegainfer_comm_rank(pegainfer_comm_t c);
 int32_t pegainfer_comm_world(pegainfer_comm_t c);
 

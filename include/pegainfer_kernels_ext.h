@@ -132,39 +132,6 @@ pegainfer_status_t pegainfer_debug_gemm_route(int32_t M, int32_t T, int32_t K, i
  * result within bf16 rounding of the partials. */
 int32_t pegainfer_paged_attention_decode_split_kv_hd256(const Half* q, Half* output, const Half* kv_data, int64_t k_offset_elems, int64_t v_offset_elems, const int32_t* page_indices, const int32_t* page_indptr, const int32_t* last_page_len_d, const int32_t* request_indices, const int32_t* kv_tile_indices, const int32_t* kv_chunk_size_ptr, const int32_t* o_indptr, const uint8_t* block_valid_mask, Half* tmp_v, float* tmp_s, int32_t num_qo_heads, int32_t num_kv_heads, int32_t head_dim, int32_t page_size, int32_t batch_size, int32_t padded_batch_size, int64_t stride_page, float sm_scale, int32_t* merge_counters, pegainfer_stream_t stream);
 
-/* ---- persistent decode-step engine (csrc/decode_engine.hip): every layer of ONE Qwen3 decode step (bs = 1) in one
- * launch.  Per CU one workgroup = 1 loader wave streaming this workgroup's row slices of all matrices through an LDS
- * ring with LDS-DMA + 3 consumer waves; op outputs are handed to all workgroups by write-through stores and arrival
- * counters (no kernel boundary, no fence).  Replaces, per layer, the five launches of the fused path
- * (pegainfer_gemv_fused x4 + pegainfer_fused_decode_attention) and produces the same bits.  The caller runs the final
- * norm + lm_head + sampling as before, on hidden_a (residual stream) and mlp_out (last residual).
- *   layer_table: device array [layers]; sync: layers*5*8*32 uint32 (one cache line per shard counter), status: 4 uint32 - both ZERO before every launch
- *   (memset nodes); status[0] != 0 after the launch = the engine gave up (a bounded spin expired: the grid was not
- *   co-resident) and every output of the step is invalid.
- *   slot_desc records {b, lo, hi, page_indptr[b], position, kv_len, o_indptr[b], o_indptr[b+1]} as for
- *   pegainfer_fused_decode_attention; num_slots / use_split = that call's split_slots (or batch_size) / use_split. */
-typedef struct {
-  const Half *qkv, *o, *gate_up, *down, *ln1, *ln2, *q_norm, *k_norm;
-} pegainfer_engine_layer_t;
-typedef struct {
-  int32_t hidden, layers, num_qo_heads, num_kv_heads, head_dim, intermediate;
-  float rms_eps, sm_scale;
-  const pegainfer_engine_layer_t* layer_table;
-  const Half* embed; const Half* cos_cache; const Half* sin_cache;
-  Half* hidden_a; Half* hidden_b;
-  Half* qkv_out; Half* attn_out; Half* attn_proj; Half* act; Half* mlp_out;
-  Half* kv_data; int64_t page_stride; int64_t layer_stride; int64_t kv_block_len; int32_t page_size;
-  const uint32_t* token_id; const int32_t* page_indices; const int32_t* slot_desc;
-  int32_t num_slots; int32_t use_split;
-  Half* tmp_v; float* tmp_s; int32_t* merge_counters;
-  uint32_t* sync; uint32_t* status;
-  uint64_t* trace;   /* optional: num_workgroups * 32 uint64 - per-workgroup phase cycle sums (tools/engine_trace.py) */
-} pegainfer_engine_args_t;
-int32_t pegainfer_decode_engine_lds_bytes(void);
-/* 0 when the shape can run with num_workgroups workgroups (rows of every matrix divisible by it, ...) */
-int32_t pegainfer_decode_engine_supported(const pegainfer_engine_args_t* args, int32_t num_workgroups);
-int32_t pegainfer_decode_engine_step(const pegainfer_engine_args_t* args, int32_t num_workgroups, pegainfer_stream_t stream);
-
 #ifdef __cplusplus
 }
 #endif

@@ -30,9 +30,6 @@ typedef void* pegainfer_qwen3_t;
 
 /* decode_mode: 0 = replay the reference's op sequence 1:1 through the reference-named symbols
  *              1 = MI355X fused decode kernels (bit-identical results, fewer launches)
- *              2 = persistent decode-step engine for single-request steps (one launch for all layers, weights
- *                  streamed through an LDS-DMA ring across op boundaries; bit-identical results); batches > 1,
- *                  tensor parallel and shapes the engine does not take run the decode_mode 1 kernels
  * split_policy: 0 = reference gate (bs<=2 && L>=1024, chunk max(256, ceil(L/64)))
  *               1 = MI355X policy (fill >=256 workgroups) */
 pegainfer_qwen3_t pegainfer_qwen3_create(int32_t device_ordinal, int32_t hidden_size, int32_t num_layers,
@@ -50,6 +47,9 @@ int32_t pegainfer_qwen3_load_tensor(pegainfer_qwen3_t m, const char* name, const
 /* seeded N(mean, std) bf16 checkpoint generated on the device (BASELINE.md §3 synthetic weights) */
 int32_t pegainfer_qwen3_fill_synthetic(pegainfer_qwen3_t m, uint64_t seed, float std);
 int32_t pegainfer_qwen3_finalize(pegainfer_qwen3_t m);
+/* the bf16 bits of one tensor (HF name, full logical shape; q/k/v and gate/up are rows of the stacked device matrices)
+ * copied back to the host: hands the checkpoint the engine computes with - loaded or synthetic - to a checker */
+int32_t pegainfer_qwen3_export_tensor(pegainfer_qwen3_t m, const char* name, void* host_bf16, int64_t numel);
 /* Native checkpoint load (weight_loader.rs:18-206 + weights.rs:121-291): `path` is a
  * .safetensors file or an HF model directory (model.safetensors, or model.safetensors.index.json + shards), mmap'ed;
  * with tp_world > 1 the rank's slices are cut on the fly (q/k/v/gate/up rows, o/down columns) into a model created
@@ -67,6 +67,15 @@ pegainfer_qwen3_t pegainfer_qwen3_from_pretrained(const char* model_dir, int32_t
  * (sum, bf16, in place, on the model stream) after O-proj and after down-proj.  world == 1 is a no-op. */
 int32_t pegainfer_qwen3_rccl_unique_id(void* out_128_bytes);
 int32_t pegainfer_qwen3_attach_tp(pegainfer_qwen3_t m, int32_t rank, int32_t world, const void* unique_id_128_bytes);
+/* Same, over a communicator the caller built (pegainfer_comm_t of include/pegainfer_comm.h; the caller keeps ownership
+ * and keeps it alive until the model is destroyed).  An RCCL communicator behaves like attach_tp.  A PEER-ONLY one
+ * (pegainfer_comm_create_peer_only: no RCCL, slabs mapped over hipIpc) carries every all-reduce on the one-shot
+ * peer-access kernel - prefill-sized payloads in 64 KB pieces - so the sharded runtime also runs with several ranks on
+ * ONE device, which is how a single-GPU box executes the TP data path (tests/test_gpu_tp_one_gpu.py).
+ * A step whose one-shot all-reduce hit its bounded wait (a peer late or gone) fails with -5; nothing is returned. */
+int32_t pegainfer_qwen3_attach_comm(pegainfer_qwen3_t m, void* comm);
+/* 1 when the attached communicator's <= 64 KB all-reduces take the one-shot peer-access kernel */
+int32_t pegainfer_qwen3_tp_oneshot_active(pegainfer_qwen3_t m);
 
 /* requests = KvState handles (kv_pool.rs:147-260) */
 int32_t pegainfer_qwen3_new_request(pegainfer_qwen3_t m);
@@ -104,18 +113,19 @@ int32_t pegainfer_qwen3_decode(pegainfer_qwen3_t m, int32_t n_requests, const in
 int32_t pegainfer_qwen3_sample(pegainfer_qwen3_t m, int32_t column, float temperature, int32_t top_k, float top_p,
                                float random_val, int32_t* out_token);
 
+/* Per-token log-probabilities (executor.rs:400-434 compute_logprobs_from_cpu, :807-816 extract_logprobs): the logits
+ * row of request `column` of the LAST prefill / decode step is copied to the host as f32; out_logprob = logit[token] -
+ * log_sum_exp, and the top_k largest entries (value descending, index ascending on ties - the reference's ordered
+ * insertion) go to out_top_ids / out_top_logprobs.  Returns the number of top entries (min(top_k, vocab)) or < 0. */
+int32_t pegainfer_qwen3_logprobs(pegainfer_qwen3_t m, int32_t column, uint32_t token, int32_t top_k, float* out_logprob,
+                                 uint32_t* out_top_ids, float* out_top_logprobs);
+/* the same arithmetic on a host f32 row (pure host: CPU-testable against oracle/ops.py:compute_logprobs) */
+int32_t pegainfer_logprobs_from_logits(const float* logits_f32, int32_t n, uint32_t token, int32_t top_k,
+                                       float* out_logprob, uint32_t* out_top_ids, float* out_top_logprobs);
+
 /* device-side timing of the last decode step's graph (hipEvent pair on the model stream), ms */
 float pegainfer_qwen3_last_step_ms(pegainfer_qwen3_t m);
 int32_t pegainfer_qwen3_last_attention_path(pegainfer_qwen3_t m);
-/* decode_mode 2 diagnostics: 1 when the last decode step ran on the persistent engine; with PEGAINFER_ENGINE_TRACE=1 in
- * the environment at creation, engine_trace copies 32 uint64 per workgroup (phase cycle sums of the last engine step:
- * [0..17] consumer wave 0 {wait, stage, gemv, store} x {qkv, attention, o, gate|up, down}, [18] its wait for landed
- * fills, [20] loader wait for free slots, [21] loader total, [22] consumer total) and returns the word count */
-int32_t pegainfer_qwen3_engine_active(pegainfer_qwen3_t m);
-/* steps on which the engine gave up (a bounded spin expired) and the SAME decode call re-ran on the decode_mode 1
- * kernels; the engine stays disabled afterwards.  PEGAINFER_ENGINE_INJECT_FAIL=1 forces that path (tests). */
-int32_t pegainfer_qwen3_engine_fallbacks(pegainfer_qwen3_t m);
-int32_t pegainfer_qwen3_engine_trace(pegainfer_qwen3_t m, uint64_t* out, int32_t max_words); /* 0 non-partition, 1 split-KV */
 /* average ms per launch of one GEMM call site over the layers' real weights, hipEvents on the model
  * stream (bench.py roofline).  which: 0 fused qkv, 1 o, 2 gate_up, 3 down, 4 lm_head (plain GEMM call sites);
  * 5 gate_up with add+RMSNorm prologue and SwiGLU epilogue, 6 qkv with add+RMSNorm prologue, 7 lm_head with

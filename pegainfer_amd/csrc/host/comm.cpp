@@ -51,6 +51,7 @@ struct Comm {
   OsPeers os_peers{};
   bool os_opened[kOsMaxWorld] = {};
   uint32_t *os_epoch = nullptr, *os_status = nullptr;
+  unsigned char* os_stage = nullptr;   // 64 KB: unaligned / ragged payloads are staged through it
   bool os_active = false;
   unsigned long long os_timeout_ticks = 0;
   std::string err;
@@ -202,21 +203,47 @@ __global__ __launch_bounds__(1024) void oneshot_all_reduce_kernel(OsPeers peers,
   }
 }
 
-// 1 = taken by the one-shot path, 0 = not eligible (caller falls through to RCCL), -1 = launch error
-static int oneshot_all_reduce(Comm* c, void* data, int64_t n, int elem, hipStream_t s) {
-  const int64_t bytes = n * elem;
-  if (!c->os_active || bytes > kOsMaxBytes || (bytes & 15) || (reinterpret_cast<uintptr_t>(data) & 15)) return 0;
-  const int wgs = static_cast<int>((bytes + kOsSeg - 1) / kOsSeg);
+// One launch over an aligned, 16-byte-sized payload of at most 64 KB.
+static int oneshot_launch(Comm* c, unsigned char* data, int bytes, int elem, hipStream_t s) {
+  const int wgs = (bytes + kOsSeg - 1) / kOsSeg;
   if (elem == 2)
-    oneshot_all_reduce_kernel<true><<<wgs, 1024, 0, s>>>(c->os_peers, c->rank, c->world, static_cast<unsigned char*>(data),
-                                                         static_cast<unsigned char*>(data), (int)bytes, c->os_epoch,
+    oneshot_all_reduce_kernel<true><<<wgs, 1024, 0, s>>>(c->os_peers, c->rank, c->world, data, data, bytes, c->os_epoch,
                                                          c->os_status, c->os_timeout_ticks);
   else
-    oneshot_all_reduce_kernel<false><<<wgs, 1024, 0, s>>>(c->os_peers, c->rank, c->world, static_cast<unsigned char*>(data),
-                                                          static_cast<unsigned char*>(data), (int)bytes, c->os_epoch,
+    oneshot_all_reduce_kernel<false><<<wgs, 1024, 0, s>>>(c->os_peers, c->rank, c->world, data, data, bytes, c->os_epoch,
                                                           c->os_status, c->os_timeout_ticks);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { c->err = std::string("one-shot all-reduce launch: ") + hipGetErrorString(e); return -1; }
+  return 0;
+}
+// 1 = taken by the one-shot path, 0 = not eligible (caller falls through to RCCL), -1 = launch error.
+// Whether a payload is eligible depends on its BYTE COUNT only (every rank passes the same count, so every rank takes
+// the same route - an address-dependent rule could send one rank to RCCL while its peers spin on flags): <= 64 KB on an
+// RCCL communicator, any size on a peer-only one (64 KB pieces, launch after launch on the caller's stream; the
+// parity double-buffer argument holds across launches because a peer starts epoch e + 1 only after it saw my flag of
+// e).  A payload whose address or size is not a multiple of 16 travels through the handle's 64 KB staging buffer
+// (device-to-device copies on the same stream, zero-padded tail - graph-capturable).
+// SINGLE-STREAM CONTRACT: the epochs are plain per-segment counters advanced by the launches in stream order; all
+// one-shot all-reduces of a communicator must be ordered with respect to each other (one stream, or streams joined by
+// events / host synchronisation between calls).  The comm stream of this handle is for the RCCL verbs of the
+// overlapped MoE exchange (all-gather / reduce-scatter), never for all-reduces issued next to the compute stream's.
+static int oneshot_all_reduce(Comm* c, void* data, int64_t n, int elem, hipStream_t s) {
+  const int64_t bytes = n * elem;
+  if (!c->os_active || (c->nccl && bytes > kOsMaxBytes)) return 0;
+  unsigned char* p = static_cast<unsigned char*>(data);
+  for (int64_t off = 0; off < bytes; off += kOsMaxBytes) {
+    const int piece = (int)std::min<int64_t>(kOsMaxBytes, bytes - off);
+    const int padded = (piece + 15) & ~15;
+    if (padded != piece || (reinterpret_cast<uintptr_t>(p + off) & 15)) {
+      if (!c->os_stage) { c->err = "one-shot all-reduce: no staging buffer"; return -1; }
+      if (padded != piece && hipMemsetAsync(c->os_stage + piece, 0, (size_t)(padded - piece), s) != hipSuccess) return -1;
+      if (hipMemcpyAsync(c->os_stage, p + off, (size_t)piece, hipMemcpyDeviceToDevice, s) != hipSuccess) return -1;
+      if (oneshot_launch(c, c->os_stage, padded, elem, s)) return -1;
+      if (hipMemcpyAsync(p + off, c->os_stage, (size_t)piece, hipMemcpyDeviceToDevice, s) != hipSuccess) return -1;
+    } else if (oneshot_launch(c, p + off, piece, elem, s)) {
+      return -1;
+    }
+  }
   return 1;
 }
 
@@ -558,6 +585,7 @@ int32_t pegainfer_comm_oneshot_handle(pegainfer_comm_t h, void* out_64_bytes) {
     PC_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->os_epoch), (kOsMaxWg + 4) * sizeof(uint32_t)));
     PC_HIP(c, hipMemset(c->os_epoch, 0, (kOsMaxWg + 4) * sizeof(uint32_t)));
     c->os_status = c->os_epoch + kOsMaxWg;
+    PC_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->os_stage), kOsMaxBytes));
     PC_HIP(c, hipDeviceSynchronize());
   }
   PC_HIP(c, hipIpcGetMemHandle(&ipc, c->os_slab));
@@ -583,33 +611,54 @@ int32_t pegainfer_comm_oneshot_attach(pegainfer_comm_t h, const void* handles_wo
   return 0;
 }
 // RCCL communicators: export, all-gather the handles over RCCL itself, attach.  Call outside graph capture.
+// COLLECTIVE: every rank of the communicator must call it, and every rank takes part in both RCCL exchanges whatever
+// happened locally - a rank whose export or mapping failed sends a zero handle / a zero success flag instead of
+// returning early (its peers would otherwise block in the all-gather forever).  The path is switched on only when the
+// min over the ranks' success flags is 1; otherwise it stays off on EVERY rank and the all-reduces keep using RCCL.
+// PEGAINFER_TP_ONESHOT / any other opt-out must therefore be decided identically on all ranks BEFORE calling this.
 int32_t pegainfer_comm_oneshot_enable(pegainfer_comm_t h) {
   Comm* c = static_cast<Comm*>(h);
   if (!c) return -1;
   if (c->world == 1) return 0;
   if (!c->nccl) { c->err = "oneshot_enable needs an RCCL communicator (peer-only ones exchange handles out of band)"; return -1; }
-  unsigned char mine[64];
-  if (pegainfer_comm_oneshot_handle(h, mine)) return -1;
+  unsigned char mine[64] = {};
+  int32_t ok = pegainfer_comm_oneshot_handle(h, mine) == 0 ? 1 : 0;
+  std::string local_err = ok ? std::string() : c->err;
+  if (!ok) std::memset(mine, 0, sizeof(mine));
   unsigned char* d = nullptr;
-  PC_HIP(c, hipMalloc(reinterpret_cast<void**>(&d), (size_t)(c->world + 1) * 64));
   std::vector<unsigned char> all((size_t)c->world * 64);
-  int rc = 0;
-  if (hipMemcpy(d, mine, 64, hipMemcpyHostToDevice) != hipSuccess ||
-      ncclAllGather(d, d + 64, 64, ncclInt8, c->nccl, c->comm_stream) != ncclSuccess ||
-      hipStreamSynchronize(c->comm_stream) != hipSuccess ||
-      hipMemcpy(all.data(), d + 64, all.size(), hipMemcpyDeviceToHost) != hipSuccess) {
-    c->err = "oneshot_enable: handle exchange over RCCL failed";
-    rc = -1;
+  // exchange 1: the handles (a rank that cannot even allocate the exchange buffer cannot take part in RCCL at all)
+  if (hipMalloc(reinterpret_cast<void**>(&d), (size_t)(c->world + 1) * 64 + 64) != hipSuccess) {
+    c->err = "oneshot_enable: hipMalloc of the exchange buffer failed";
+    return -1;
   }
+  bool xfer = hipMemcpy(d, mine, 64, hipMemcpyHostToDevice) == hipSuccess;
+  xfer = (ncclAllGather(d, d + 64, 64, ncclInt8, c->nccl, c->comm_stream) == ncclSuccess) && xfer;
+  xfer = (hipStreamSynchronize(c->comm_stream) == hipSuccess) && xfer;
+  xfer = xfer && hipMemcpy(all.data(), d + 64, all.size(), hipMemcpyDeviceToHost) == hipSuccess;
+  if (!xfer) { ok = 0; if (local_err.empty()) local_err = "oneshot_enable: handle exchange over RCCL failed"; }
+  if (ok) {
+    static const unsigned char zero[64] = {};
+    for (int r = 0; r < c->world && ok; ++r)
+      if (std::memcmp(all.data() + (size_t)r * 64, zero, 64) == 0) { ok = 0; local_err = "oneshot_enable: rank " + std::to_string(r) + " could not export its slab"; }
+  }
+  if (ok && pegainfer_comm_oneshot_attach(h, all.data())) { ok = 0; local_err = c->err; }
+  c->os_active = false;   // attach switched it on locally; the world decides below
+  // exchange 2: min over the success flags.  It is also the barrier the protocol needs: nobody may push into a slab
+  // before its owner zeroed it and everyone mapped it
+  int32_t* flag = reinterpret_cast<int32_t*>(d + (size_t)(c->world + 1) * 64);
+  bool red = hipMemcpy(flag, &ok, 4, hipMemcpyHostToDevice) == hipSuccess;
+  red = (ncclAllReduce(flag, flag, 1, ncclInt32, ncclMin, c->nccl, c->comm_stream) == ncclSuccess) && red;
+  red = (hipStreamSynchronize(c->comm_stream) == hipSuccess) && red;
+  int32_t all_ok = 0;
+  red = red && hipMemcpy(&all_ok, flag, 4, hipMemcpyDeviceToHost) == hipSuccess;
   (void)hipFree(d);
-  if (rc) return rc;
-  if (pegainfer_comm_oneshot_attach(h, all.data())) return -1;
-  // nobody may push into a slab before its owner zeroed it and everyone mapped it: one barrier-like collective
-  PC_HIP(c, hipMalloc(reinterpret_cast<void**>(&d), 64));
-  ncclResult_t r = ncclAllReduce(d, d, 1, ncclInt32, ncclSum, c->nccl, c->comm_stream);
-  hipError_t e = hipStreamSynchronize(c->comm_stream);
-  (void)hipFree(d);
-  if (r != ncclSuccess || e != hipSuccess) { c->err = "oneshot_enable: closing barrier failed"; c->os_active = false; return -1; }
+  if (!red) { c->err = "oneshot_enable: closing all-reduce failed"; return -1; }
+  if (all_ok != 1) {
+    c->err = local_err.empty() ? "oneshot_enable: a peer could not export or map the slabs; all ranks stay on RCCL" : local_err;
+    return -1;
+  }
+  c->os_active = true;
   return 0;
 }
 int32_t pegainfer_comm_oneshot_active(pegainfer_comm_t h) { return h && static_cast<Comm*>(h)->os_active ? 1 : 0; }
@@ -625,6 +674,10 @@ int32_t pegainfer_comm_oneshot_status(pegainfer_comm_t h) {
   return (int32_t)st3[0];
 }
 
+// device address of the 3-word status block {0x100 | mask, epoch, segment} (NULL before the slab exists): a runtime that
+// issues one-shot all-reduces inside its own captured step copies it back together with the step's results
+const uint32_t* pegainfer_comm_oneshot_status_ptr(pegainfer_comm_t h) { return h ? static_cast<Comm*>(h)->os_status : nullptr; }
+
 void pegainfer_comm_destroy(pegainfer_comm_t h) {
   Comm* c = static_cast<Comm*>(h);
   if (!c) return;
@@ -632,6 +685,7 @@ void pegainfer_comm_destroy(pegainfer_comm_t h) {
     if (c->os_opened[r]) (void)hipIpcCloseMemHandle(c->os_peers.slab[r]);
   if (c->os_slab) (void)hipFree(c->os_slab);
   if (c->os_epoch) (void)hipFree(c->os_epoch);
+  if (c->os_stage) (void)hipFree(c->os_stage);
   if (c->nccl) ncclCommDestroy(c->nccl);
   if (c->scratch) (void)hipFree(c->scratch);
   if (c->ev_in) (void)hipEventDestroy(c->ev_in);
@@ -648,7 +702,7 @@ int32_t pegainfer_comm_all_reduce_bf16(pegainfer_comm_t h, Half* data, int64_t n
   if (!c || !data || n < 0) return -1;
   if (c->world == 1 || n == 0) return 0;
   if (const int r = oneshot_all_reduce(c, data, n, 2, st(stream))) return r < 0 ? -1 : 0;   // <= 64 KB: peer-access path
-  if (!c->nccl) { c->err = "peer-only communicator: payload not eligible for the one-shot path"; return -1; }
+  if (!c->nccl) { c->err = "peer-only communicator: the one-shot path is not attached (oneshot_handle / oneshot_attach first)"; return -1; }
   PC_NCCL(c, ncclAllReduce(data, data, (size_t)n, ncclBfloat16, ncclSum, c->nccl, st(stream)));
   return 0;
 }
@@ -657,7 +711,7 @@ int32_t pegainfer_comm_all_reduce_f32(pegainfer_comm_t h, float* data, int64_t n
   if (!c || !data || n < 0) return -1;
   if (c->world == 1 || n == 0) return 0;
   if (const int r = oneshot_all_reduce(c, data, n, 4, st(stream))) return r < 0 ? -1 : 0;
-  if (!c->nccl) { c->err = "peer-only communicator: payload not eligible for the one-shot path"; return -1; }
+  if (!c->nccl) { c->err = "peer-only communicator: the one-shot path is not attached (oneshot_handle / oneshot_attach first)"; return -1; }
   PC_NCCL(c, ncclAllReduce(data, data, (size_t)n, ncclFloat32, ncclSum, c->nccl, st(stream)));
   return 0;
 }

@@ -115,15 +115,6 @@ struct Model {
   bool oproj_step = false;   // the step being recorded / run uses the fused launch
   bool oproj_plan = false;   // this step's split plan keeps the padding slots the fused launch needs (single request, <= 2304 tokens)
   int oproj_fallbacks = 0;
-  // decode_mode 2: the persistent decode-step engine (csrc/decode_engine.hip) for a single request; larger batches and
-  // unsupported shapes run the decode_mode 1 kernels.  PEGAINFER_ENGINE_WGS overrides the workgroup count (probe knob).
-  pegainfer_engine_layer_t* eng_layers_d = nullptr;
-  uint32_t *eng_sync = nullptr, *eng_status = nullptr, *eng_status_host = nullptr;
-  Half *eng_act = nullptr;
-  uint64_t* eng_trace = nullptr;   // PEGAINFER_ENGINE_TRACE=1: per-workgroup phase cycle sums of the last engine step
-  int eng_wgs = 0;
-  bool eng_disabled = false, eng_used = false;
-  int eng_fallbacks = 0;   // steps the engine gave up on and the decode_mode 1 kernels re-ran
   // sampling scratch (ops/sampling.rs)
   float* probs_scratch = nullptr;
   Half* top1_value = nullptr;
@@ -136,7 +127,6 @@ struct Model {
   uint8_t* meta_dev = nullptr;
   int32_t* tokens_out_host = nullptr;  // pinned
   hipGraphExec_t graphs[kNumBuckets][3];   // [bucket][0 = non-partition | 1 = split-KV | 2 = split-KV with the fused attention + o_proj launch]
-  bool graph_engine[kNumBuckets][3] = {};   // the captured step runs on the decode_mode 2 engine
   // prefill workspace (grow-only)
   size_t pf_cap_tokens = 0;
   Half *pf_hidden = nullptr, *pf_hidden_out = nullptr, *pf_normed = nullptr, *pf_q = nullptr, *pf_k = nullptr,
@@ -151,6 +141,8 @@ struct Model {
   // tensor parallel (reference TP: weights.rs:121-291,396-405): RCCL communicator, one rank per process/GPU
   pegainfer_comm_t tp_comm = nullptr;   // include/pegainfer_comm.h: RCCL + the one-shot peer-access path for <= 64 KB
   int tp_rank = 0, tp_world = 1;
+  bool tp_comm_owned = false;
+  uint32_t* tp_status_host = nullptr;   // pinned: the one-shot status block of the step, copied back with the tokens
   // last step
   const Half* last_logits = nullptr;
   int last_rows = 0;
@@ -245,67 +237,7 @@ struct Model {
       PQ_HIP(hipHostMalloc(reinterpret_cast<void**>(&attn_status_host), 16, hipHostMallocDefault));
       attn_status_host[0] = 0;
     }
-    if (decode_mode == 2) {
-      int cus = 0;
-      PQ_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
-      const char* e = getenv("PEGAINFER_ENGINE_WGS");
-      eng_wgs = e && *e ? atoi(e) : cus;
-      if (eng_wgs > cus) eng_wgs = cus;   // one workgroup per CU, all co-resident: the engine's hand-offs spin
-      if (dalloc(&eng_layers_d, (size_t)L) || dalloc(&eng_sync, (size_t)L * 5 * 8 * 32) || dalloc(&eng_status, 4) ||
-          dalloc(&eng_act, (size_t)I))
-        return -1;
-      PQ_HIP(hipHostMalloc(reinterpret_cast<void**>(&eng_status_host), 16, hipHostMallocDefault));
-      if (const char* t = getenv("PEGAINFER_ENGINE_TRACE"); t && t[0] == '1')
-        if (dalloc(&eng_trace, (size_t)eng_wgs * 32)) return -1;
-      std::vector<pegainfer_engine_layer_t> tab(L);
-      for (int i = 0; i < L; ++i)
-        tab[i] = pegainfer_engine_layer_t{layers[i].qkv, layers[i].o, layers[i].gate_up, layers[i].down,
-                                          layers[i].ln1, layers[i].ln2, layers[i].q_norm, layers[i].k_norm};
-      PQ_HIP(hipMemcpy(eng_layers_d, tab.data(), tab.size() * sizeof(tab[0]), hipMemcpyHostToDevice));
-    }
     PQ_HIP(hipStreamSynchronize(stream));
-    return 0;
-  }
-
-  // ---- decode_mode 2: one persistent launch for all layers (bs = 1), then lm_head + top-1 as in the fused path ----
-  void engine_args(pegainfer_engine_args_t* a, bool split, int split_slots) {
-    *a = pegainfer_engine_args_t{};
-    a->hidden = H; a->layers = L; a->num_qo_heads = Hq; a->num_kv_heads = Hkv; a->head_dim = D; a->intermediate = I;
-    a->rms_eps = eps; a->sm_scale = 1.0f / std::sqrt((float)D);
-    a->layer_table = eng_layers_d; a->embed = embed; a->cos_cache = cos; a->sin_cache = sin;
-    a->hidden_a = hidden; a->hidden_b = hidden2; a->qkv_out = qkv_out; a->attn_out = attn_out; a->attn_proj = attn_proj;
-    a->act = eng_act; a->mlp_out = mlp_out;
-    a->kv_data = kv_buffer; a->page_stride = layout.page_stride; a->layer_stride = layout.layer_stride;
-    a->kv_block_len = layout.kv_block_len; a->page_size = layout.page_size;
-    a->token_id = md<uint32_t>(ml.token_ids); a->page_indices = md<int32_t>(ml.page_indices);
-    a->slot_desc = md<int32_t>(ml.slot_desc); a->num_slots = split ? split_slots : 1; a->use_split = split ? 1 : 0;
-    a->tmp_v = split_tmp_v; a->tmp_s = split_tmp_s; a->merge_counters = merge_ctr;
-    a->sync = eng_sync; a->status = eng_status; a->trace = eng_trace;
-  }
-  bool engine_ok(int bs) {
-    if (decode_mode != 2 || eng_disabled || bs != 1 || tp_comm || !eng_layers_d) return false;
-    pegainfer_engine_args_t a;
-    engine_args(&a, false, 1);
-    return pegainfer_decode_engine_supported(&a, eng_wgs) == 0;
-  }
-  int decode_kernels_engine(bool split, int split_slots) {
-    PQ_HIP(hipMemsetAsync(eng_sync, 0, (size_t)L * 5 * 8 * 32 * sizeof(uint32_t), stream));
-    PQ_HIP(hipMemsetAsync(eng_status, 0, 16, stream));
-    if (split) PQ_HIP(hipMemsetAsync(merge_ctr, 0, (size_t)max_bs * Hkv * 32 * sizeof(int32_t), stream));
-    pegainfer_engine_args_t a;
-    engine_args(&a, split, split_slots);
-    if (pegainfer_decode_engine_step(&a, eng_wgs, S())) { set_error("pegainfer_decode_engine_step failed"); return -1; }
-    // fault injection for the fallback test: the status word reads as "a bounded spin expired"
-    if (const char* f = getenv("PEGAINFER_ENGINE_INJECT_FAIL"); f && f[0] == '1')
-      PQ_HIP(hipMemsetAsync(eng_status, 0x01, 4, stream));
-    if (pegainfer_gemv_fused(lm_head, hidden, logits, V, 1, H, mlp_out, final_norm, hidden2, eps, 0, S())) {
-      set_error("fused lm_head failed");
-      return -1;
-    }
-    if (pegainfer_batched_top1(logits, V, 1, V, top1_state, tokens_out_d, S())) {
-      set_error("pegainfer_batched_top1 failed");
-      return -1;
-    }
     return 0;
   }
 
@@ -323,13 +255,41 @@ struct Model {
   }
   int attach_tp(int rank, int world, const void* unique_id) {
     if (world < 1 || rank < 0 || rank >= world) { set_error("bad TP rank/world"); return -1; }
+    if (tp_comm) { set_error("a TP communicator is already attached"); return -1; }
     tp_rank = rank; tp_world = world;
     if (!unique_id) return world == 1 ? 0 : (set_error("TP world > 1 needs a unique id"), -1);
     tp_comm = pegainfer_comm_create(device, rank, world, unique_id);
     if (!tp_comm) { set_error("pegainfer_comm_create (ncclCommInitRank) failed"); return -1; }
-    // best effort: without peer access the all-reduces stay on RCCL (PEGAINFER_TP_ONESHOT=0 forces that for A/B runs)
+    tp_comm_owned = true;
+    // best effort, and collective-safe: a rank whose export / mapping failed still takes part in the exchanges and the
+    // path is switched on only when EVERY rank succeeded, so a failure leaves all ranks on RCCL.  PEGAINFER_TP_ONESHOT=0
+    // (A/B runs) must be set on every rank or on none: it decides whether the rank enters the collective at all.
     const char* os = getenv("PEGAINFER_TP_ONESHOT");
     if (!(os && os[0] == '0')) (void)pegainfer_comm_oneshot_enable(tp_comm);
+    return tp_after_attach();
+  }
+  // An already-built communicator (include/pegainfer_comm.h) drives the runtime's all-reduces: RCCL ones behave like
+  // attach_tp; PEER-ONLY ones (no RCCL, slabs mapped over hipIpc) carry every all-reduce on the one-shot kernel, 64 KB
+  // pieces for prefill-sized payloads - which is how the sharded runtime runs with several ranks on ONE GPU.
+  // The caller keeps ownership of the communicator and must keep it alive until the model is destroyed.
+  int attach_comm(pegainfer_comm_t comm) {
+    if (!comm) { set_error("attach_comm: null communicator"); return -1; }
+    if (tp_comm) { set_error("a TP communicator is already attached"); return -1; }
+    const int world = pegainfer_comm_world(comm), rank = pegainfer_comm_rank(comm);
+    if (world < 1 || rank < 0 || rank >= world) { set_error("attach_comm: bad communicator"); return -1; }
+    tp_rank = rank; tp_world = world;
+    if (world == 1) return 0;
+    tp_comm = comm;
+    tp_comm_owned = false;
+    return tp_after_attach();
+  }
+  int tp_after_attach() {
+    // every graph captured so far has no all-reduce nodes
+    for (auto& b : graphs)
+      for (auto& g : b)
+        if (g) { hipGraphExecDestroy(g); g = nullptr; }
+    if (!tp_status_host) PQ_HIP(hipHostMalloc(reinterpret_cast<void**>(&tp_status_host), 16, hipHostMallocDefault));
+    tp_status_host[0] = tp_status_host[1] = tp_status_host[2] = 0;
     return 0;
   }
 
@@ -337,14 +297,15 @@ struct Model {
   // expected tensors: 3 globals (embed, lm_head unless tied, final norm) + 11 per layer; `loaded` is checked by finalize()
   enum { kSlotEmbed = 0, kSlotLmHead = 1, kSlotNorm = 2, kSlotLayer0 = 3, kSlotsPerLayer = 11 };
   std::vector<uint8_t> loaded;
-  int load_tensor(const char* name_c, const void* host, int64_t numel, const int64_t* shape = nullptr, int ndim = 0) {
-    const std::string name(name_c);
+  // HF tensor name -> device address, logical shape and bookkeeping slot (weights.rs:102-296).  0 ok, 1 = a tensor this
+  // model ignores (lm_head of a tied checkpoint), -1 = error
+  int resolve_tensor(const std::string& name, Half** dst_out, int64_t* rows_out, int64_t* cols_out, int* slot_out) {
     Half* dst = nullptr;
     int64_t rows = 0, cols = 0;
     int slot = -1;
     auto set = [&](Half* p, int64_t r, int64_t c, int sl) { dst = p; rows = r; cols = c; slot = sl; };
     if (name == "model.embed_tokens.weight") set(embed, V, H, kSlotEmbed);
-    else if (name == "lm_head.weight") { if (tie) return 0; set(lm_head, V, H, kSlotLmHead); }
+    else if (name == "lm_head.weight") { if (tie) return 1; set(lm_head, V, H, kSlotLmHead); }
     else if (name == "model.norm.weight") set(final_norm, H, 1, kSlotNorm);
     else if (name.rfind("model.layers.", 0) == 0) {
       const size_t p0 = 13, p1 = name.find('.', p0);
@@ -371,6 +332,29 @@ struct Model {
       else if (rest == "post_attention_layernorm.weight") set(ly.ln2, H, 1, base + 10);
     }
     if (!dst) { set_error("unknown tensor name: " + name); return -1; }
+    *dst_out = dst; *rows_out = rows; *cols_out = cols; *slot_out = slot;
+    return 0;
+  }
+  // the bf16 bits of a loaded (or synthetic) tensor back on the host: the checkpoint the engine computes with can be
+  // handed to a checker as it is (bench.py's parity leg, tests)
+  int export_tensor(const char* name_c, void* host, int64_t numel) {
+    Half* src = nullptr;
+    int64_t rows = 0, cols = 0;
+    int slot = -1;
+    const std::string name(name_c);
+    if (name == "lm_head.weight" && tie) { src = embed; rows = V; cols = H; }
+    else if (resolve_tensor(name, &src, &rows, &cols, &slot)) return -1;
+    if (numel != rows * cols) { set_error("shape mismatch for " + name); return -1; }
+    PQ_HIP(hipStreamSynchronize(stream));
+    PQ_HIP(hipMemcpy(host, src, (size_t)numel * 2, hipMemcpyDeviceToHost));
+    return 0;
+  }
+  int load_tensor(const char* name_c, const void* host, int64_t numel, const int64_t* shape = nullptr, int ndim = 0) {
+    const std::string name(name_c);
+    Half* dst = nullptr;
+    int64_t rows = 0, cols = 0;
+    int slot = -1;
+    if (const int r = resolve_tensor(name, &dst, &rows, &cols, &slot)) return r == 1 ? 0 : -1;
     if (numel != rows * cols) { set_error("shape mismatch for " + name); return -1; }
     if (shape) {  // a transposed or re-shaped tensor with the right element count is still wrong
       const bool ok = cols == 1 ? (ndim == 1 && shape[0] == rows) : (ndim == 2 && shape[0] == rows && shape[1] == cols);
@@ -672,8 +656,6 @@ struct Model {
   bool stacked_qkv(int bs) const { return decode_mode >= 1 && bs > 16; }
 
   int decode_kernels(int bs, bool split, int split_slots) {
-    eng_used = engine_ok(bs);
-    if (eng_used) return decode_kernels_engine(split, split_slots);
     if (fused_ok(bs)) return decode_kernels_fused(bs, split, split_slots);
     if (embedding_batched_cuda(embed, md<uint32_t>(ml.token_ids), hidden, H, bs, S())) {
       set_error("embedding_batched_cuda failed");
@@ -783,7 +765,7 @@ struct Model {
           b = sl; lo = 0; hi = kcs[b];
         }
         r[0] = b; r[1] = lo; r[2] = hi; r[3] = indptr[b]; r[4] = pos[b]; r[5] = kcs[b];
-        r[6] = plan.o_indptr[b]; r[7] = plan.o_indptr[b + 1];   // partial slots of this request (engine merge)
+        r[6] = plan.o_indptr[b]; r[7] = plan.o_indptr[b + 1];   // partial slots of this request (in-launch merge)
       }
     }
     const size_t upload = ml.page_indices + (size_t)np * 4;
@@ -791,12 +773,12 @@ struct Model {
     const bool split = plan.use_split;
     last_path = split ? 1 : 0;
 
-    // one attempt = graph replay (or eager launches) + token D2H + sync.  A decode_mode 2 step whose bounded spins
-    // expired is re-run in the SAME call on the decode_mode 1 kernels: the metadata block is already on the device,
-    // the step recomputes everything from the embedding and the KV append rewrites the same slots with the same
-    // bits, so the request state the caller sees (seq_len advanced, pages held) matches the tokens it gets back.
-    for (int attempt = 0; attempt < 2; ++attempt) {
-      bool engine_step = false;
+    // one attempt = graph replay (or eager launches) + token D2H + sync.  A step whose fused attention + o_proj launch
+    // reported an expired bounded wait is re-run in the SAME call on the two stand-alone launches: the metadata block is
+    // already on the device, the step recomputes everything from the embedding and the KV append rewrites the same slots
+    // with the same bits, so the request state the caller sees (seq_len advanced, pages held) matches the tokens it gets
+    // back.  The loop runs until an attempt took no fallback (every fallback disables its cause for good), capped at 3.
+    for (int attempt = 0;; ++attempt) {
       PQ_HIP(hipEventRecord(ev0, stream));
       if (enable_graph) {
         const int bi = bucket_index(padded);
@@ -810,49 +792,43 @@ struct Model {
           if (rc || e != hipSuccess) { set_error("graph capture failed: " + err); return -1; }
           PQ_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
           PQ_HIP(hipGraphDestroy(graph));
-          graph_engine[bi][gv] = eng_used;   // decode_kernels() recorded which path it captured
         }
-        engine_step = graph_engine[bi][gv];
         PQ_HIP(hipGraphLaunch(exec, stream));
       } else {
         if (decode_kernels(padded, split, plan.slots)) return -1;
-        engine_step = eng_used;
       }
-      eng_used = engine_step;   // what THIS step ran on (pegainfer_qwen3_engine_active), replayed graphs included
       PQ_HIP(hipEventRecord(ev1, stream));
       PQ_HIP(hipMemcpyAsync(tokens_out_host, tokens_out_d, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
-      if (engine_step) PQ_HIP(hipMemcpyAsync(eng_status_host, eng_status, 16, hipMemcpyDeviceToHost, stream));
-      const bool oproj_check = attn_status && attn_oproj && oproj_plan && padded == 1 && split && !engine_step && decode_mode >= 1;
+      const bool oproj_check = attn_status && attn_oproj && oproj_plan && padded == 1 && split && decode_mode >= 1;
       if (oproj_check) PQ_HIP(hipMemcpyAsync(attn_status_host, attn_status, 4, hipMemcpyDeviceToHost, stream));
+      // tensor parallel: the 72 one-shot all-reduces of the step share one status block; it travels back with the tokens
+      const uint32_t* os_status_d = tp_comm && tp_status_host && pegainfer_comm_oneshot_active(tp_comm)
+                                        ? pegainfer_comm_oneshot_status_ptr(tp_comm) : nullptr;
+      if (os_status_d) PQ_HIP(hipMemcpyAsync(tp_status_host, os_status_d, 12, hipMemcpyDeviceToHost, stream));
       PQ_HIP(hipStreamSynchronize(stream));
       hipEventElapsedTime(&last_step_ms, ev0, ev1);
-      if (oproj_check && attn_status_host[0] != 0) {
-        // the o_proj phase of the fused launch never saw the attention rows (workgroups not co-resident): this attempt's
-        // outputs are invalid.  Disable the form, drop the graphs that captured it and take the second attempt on the
-        // two stand-alone launches (same metadata, same KV slots: the request state stays consistent).
-        attn_oproj = false;
-        oproj_fallbacks += 1;
-        PQ_HIP(hipMemsetAsync(attn_status, 0, 4, stream));
-        for (int b = 0; b < kNumBuckets; ++b)
-          for (int q = 0; q < 3; ++q)
-            if (graphs[b][q]) { hipGraphExecDestroy(graphs[b][q]); graphs[b][q] = nullptr; graph_engine[b][q] = false; }
-        err = "fused attention + o_proj launch: the bounded wait for the attention rows expired (code " +
-              std::to_string(attn_status_host[0]) + "); step re-run on two launches, form disabled";
-        attn_status_host[0] = 0;
-        if (attempt == 1) { set_error("fused attention + o_proj reported a failure after it was disabled"); return -4; }
-        continue;
+      if (os_status_d && tp_status_host[0] != 0) {
+        // a peer's flag never arrived within the bound: the sums of this step are undefined on this rank and the peer is
+        // late or gone - RCCL would block on it too.  Fail the step loudly; the caller drops the request(s).
+        set_error("tensor-parallel one-shot all-reduce: bounded wait expired (missing-rank mask " +
+                  std::to_string(tp_status_host[0] & 0xff) + ", epoch " + std::to_string(tp_status_host[1]) +
+                  ", segment " + std::to_string(tp_status_host[2]) + "); step failed");
+        return -5;
       }
-      if (!(engine_step && eng_status_host[0] != 0)) break;
-      // a bounded spin expired (the grid was not co-resident, or a hand-off never completed): this attempt's outputs
-      // are invalid.  Disable the engine for good, drop the graphs that captured it and take the second attempt.
-      eng_disabled = true;
-      eng_fallbacks += 1;
+      if (!(oproj_check && attn_status_host[0] != 0)) break;
+      // the o_proj phase of the fused launch never saw the attention rows (workgroups not co-resident): this attempt's
+      // outputs are invalid.  Disable the form, drop the graphs that captured it and take another attempt on the two
+      // stand-alone launches (same metadata, same KV slots: the request state stays consistent).
+      attn_oproj = false;
+      oproj_fallbacks += 1;
+      PQ_HIP(hipMemsetAsync(attn_status, 0, 4, stream));
       for (int b = 0; b < kNumBuckets; ++b)
         for (int q = 0; q < 3; ++q)
-          if (graphs[b][q]) { hipGraphExecDestroy(graphs[b][q]); graphs[b][q] = nullptr; graph_engine[b][q] = false; }
-      err = "decode engine gave up: code " + std::to_string(eng_status_host[0] & 0xff) + " at " +
-            std::to_string(eng_status_host[1]) + " (step re-run on the decode_mode 1 kernels; engine disabled)";
-      if (attempt == 1) { set_error("decode engine reported a failure after it was disabled"); return -3; }
+          if (graphs[b][q]) { hipGraphExecDestroy(graphs[b][q]); graphs[b][q] = nullptr; }
+      err = "fused attention + o_proj launch: the bounded wait for the attention rows expired (code " +
+            std::to_string(attn_status_host[0]) + "); step re-run on two launches, form disabled";
+      attn_status_host[0] = 0;
+      if (attempt >= 2) { set_error("decode step still reported a fallback after every fused form was disabled"); return -4; }
     }
     for (int i = 0; i < n; ++i) out_tokens[i] = tokens_out_host[i];
     last_logits = logits;
@@ -1073,7 +1049,15 @@ struct Model {
     }
     if (pegainfer_batched_top1(pf_logits, V, n, V, top1_state, tokens_out_d, S())) { set_error("top1 failed"); return -1; }
     PQ_HIP(hipMemcpyAsync(tokens_out_host, tokens_out_d, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
+    const uint32_t* os_status_d = tp_comm && tp_status_host && pegainfer_comm_oneshot_active(tp_comm)
+                                      ? pegainfer_comm_oneshot_status_ptr(tp_comm) : nullptr;
+    if (os_status_d) PQ_HIP(hipMemcpyAsync(tp_status_host, os_status_d, 12, hipMemcpyDeviceToHost, stream));
     PQ_HIP(hipStreamSynchronize(stream));
+    if (os_status_d && tp_status_host[0] != 0) {
+      set_error("tensor-parallel one-shot all-reduce: bounded wait expired during prefill (missing-rank mask " +
+                std::to_string(tp_status_host[0] & 0xff) + "); step failed");
+      return -5;
+    }
     for (int i = 0; i < n; ++i) out_tokens[i] = tokens_out_host[i];
     last_logits = pf_logits;
     last_rows = n;
@@ -1131,9 +1115,28 @@ struct Model {
     return 0;
   }
 
+  // executor.rs:807-816 extract_logprobs: the logits row of request `column` of the last step goes to the host as f32 and
+  // compute_logprobs_from_cpu (executor.rs:400-434) runs on it
+  std::vector<uint16_t> lp_row_bits;
+  std::vector<float> lp_row;
+  int logprobs(int column, uint32_t token, int top_k, float* out_lp, uint32_t* top_ids, float* top_lps) {
+    if (!last_logits || column < 0 || column >= last_rows) { set_error("no logits for that column"); return -1; }
+    if (token >= (uint32_t)V) { set_error("logprobs: token outside the vocabulary"); return -1; }
+    lp_row_bits.resize(V);
+    lp_row.resize(V);
+    PQ_HIP(hipStreamSynchronize(stream));
+    PQ_HIP(hipMemcpy(lp_row_bits.data(), last_logits + (size_t)column * V, (size_t)V * 2, hipMemcpyDeviceToHost));
+    for (int i = 0; i < V; ++i) {
+      const uint32_t u = (uint32_t)lp_row_bits[i] << 16;
+      std::memcpy(&lp_row[i], &u, 4);
+    }
+    return pegainfer_logprobs_from_logits(lp_row.data(), V, token, top_k, out_lp, top_ids, top_lps);
+  }
+
   ~Model() {
     if (stream) hipStreamSynchronize(stream);
-    if (tp_comm) pegainfer_comm_destroy(tp_comm);
+    if (tp_comm && tp_comm_owned) pegainfer_comm_destroy(tp_comm);
+    if (tp_status_host) hipHostFree(tp_status_host);
     for (auto& b : graphs)
       for (auto& g : b)
         if (g) hipGraphExecDestroy(g);
@@ -1146,7 +1149,6 @@ struct Model {
     if (pf_meta_host) hipHostFree(pf_meta_host);
     if (meta_host) hipHostFree(meta_host);
     if (tokens_out_host) hipHostFree(tokens_out_host);
-    if (eng_status_host) hipHostFree(eng_status_host);
     if (attn_status_host) hipHostFree(attn_status_host);
     if (ev0) hipEventDestroy(ev0);
     if (ev1) hipEventDestroy(ev1);
@@ -1280,6 +1282,47 @@ int32_t pegainfer_qwen3_sample(pegainfer_qwen3_t m, int32_t column, float temper
                                float random_val, int32_t* out_token) {
   return M(m)->sample(column, temperature, top_k, top_p, random_val, out_token);
 }
+int32_t pegainfer_qwen3_export_tensor(pegainfer_qwen3_t m, const char* name, void* host_bf16, int64_t numel) {
+  return M(m)->export_tensor(name, host_bf16, numel);
+}
+int32_t pegainfer_qwen3_logprobs(pegainfer_qwen3_t m, int32_t column, uint32_t token, int32_t top_k, float* out_logprob,
+                                 uint32_t* out_top_ids, float* out_top_logprobs) {
+  return M(m)->logprobs(column, token, top_k, out_logprob, out_top_ids, out_top_logprobs);
+}
+// compute_logprobs_from_cpu (executor.rs:400-434), statement for statement: f32 max fold, f32 sequential sum of
+// exp(x - max), log_sum_exp = max + ln(sum); the top list is built by ordered insertion (a later equal value never
+// displaces an earlier one), so it is sorted by (value descending, index ascending).  Returns the number of top
+// entries written (min(top_k, n)), or -1 (empty row / token out of range: the reference returns None)
+int32_t pegainfer_logprobs_from_logits(const float* logits_f32, int32_t n, uint32_t token, int32_t top_k,
+                                       float* out_logprob, uint32_t* out_top_ids, float* out_top_logprobs) {
+  if (!logits_f32 || n <= 0 || token >= (uint32_t)n) return -1;
+  float max_val = -INFINITY;
+  for (int i = 0; i < n; ++i) max_val = std::fmax(max_val, logits_f32[i]);   // f32::max: NaN-ignoring like fmaxf
+  float sum_exp = 0.f;
+  for (int i = 0; i < n; ++i) sum_exp += std::exp(logits_f32[i] - max_val);
+  const float lse = max_val + std::log(sum_exp);
+  if (out_logprob) *out_logprob = logits_f32[token] - lse;
+  const int k = std::min(std::max(top_k, 0), n);
+  if (k == 0) return 0;
+  std::vector<std::pair<uint32_t, float>> best;
+  best.reserve((size_t)k + 1);
+  for (int i = 0; i < n; ++i) {
+    const float val = logits_f32[i];
+    if ((int)best.size() < k || val > best.back().second) {
+      size_t pos = 0;   // partition_point(|v| v > val)
+      size_t lo = 0, hi = best.size();
+      while (lo < hi) { const size_t mid = (lo + hi) / 2; if (best[mid].second > val) lo = mid + 1; else hi = mid; }
+      pos = lo;
+      best.insert(best.begin() + pos, {(uint32_t)i, val});
+      if ((int)best.size() > k) best.pop_back();
+    }
+  }
+  for (size_t i = 0; i < best.size(); ++i) {
+    if (out_top_ids) out_top_ids[i] = best[i].first;
+    if (out_top_logprobs) out_top_logprobs[i] = best[i].second - lse;
+  }
+  return (int32_t)best.size();
+}
 int32_t pegainfer_qwen3_rccl_unique_id(void* out_128_bytes) {
   ncclUniqueId id;
   if (ncclGetUniqueId(&id) != ncclSuccess) return -1;
@@ -1289,20 +1332,15 @@ int32_t pegainfer_qwen3_rccl_unique_id(void* out_128_bytes) {
 int32_t pegainfer_qwen3_attach_tp(pegainfer_qwen3_t m, int32_t rank, int32_t world, const void* unique_id_128_bytes) {
   return M(m)->attach_tp(rank, world, unique_id_128_bytes);
 }
+int32_t pegainfer_qwen3_attach_comm(pegainfer_qwen3_t m, void* comm) { return M(m)->attach_comm(comm); }
+int32_t pegainfer_qwen3_tp_oneshot_active(pegainfer_qwen3_t m) {
+  return M(m)->tp_comm ? pegainfer_comm_oneshot_active(M(m)->tp_comm) : 0;
+}
 float pegainfer_qwen3_last_step_ms(pegainfer_qwen3_t m) { return M(m)->last_step_ms; }
 float pegainfer_qwen3_bench_gemv(pegainfer_qwen3_t m, int32_t which, int32_t iters, int32_t bs) {
   return M(m)->bench_gemv(which, iters, bs);
 }
 int32_t pegainfer_qwen3_last_attention_path(pegainfer_qwen3_t m) { return M(m)->last_path; }
-int32_t pegainfer_qwen3_engine_trace(pegainfer_qwen3_t m, uint64_t* out, int32_t max_words) {
-  pq::Model* md = M(m);
-  if (!md->eng_trace) return 0;
-  const int n = std::min(max_words, md->eng_wgs * 32);
-  if (hipMemcpy(out, md->eng_trace, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-  return n;
-}
-int32_t pegainfer_qwen3_engine_active(pegainfer_qwen3_t m) { return M(m)->eng_used ? 1 : 0; }
-int32_t pegainfer_qwen3_engine_fallbacks(pegainfer_qwen3_t m) { return M(m)->eng_fallbacks; }
 int64_t pegainfer_qwen3_weight_bytes(pegainfer_qwen3_t m) { return M(m)->weight_bytes; }
 void* pegainfer_qwen3_stream(pegainfer_qwen3_t m) { return M(m)->S(); }
 

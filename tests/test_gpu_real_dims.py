@@ -328,101 +328,3 @@ def test_real_dims_fused_path_bit_identical_to_reference_sequence(built_libs, re
             eng.close()
             outs.append(bf16_bits(dec))
         assert np.array_equal(outs[0], outs[1]), name
-
-
-# ------------------------------------------------------------------ decode_mode 2: the persistent decode-step engine
-def _decode_bits(eng, prompt, n_steps, feed=None):
-    """prefill + n greedy decode steps; returns (tokens fed, logits bits per step)."""
-    rid = eng.new_request()
-    tok, _ = eng.prefill([rid], [prompt], return_logits=True)
-    toks, rows = [int(tok[0])], []
-    for step in range(n_steps):
-        t = toks[-1] if feed is None else feed[step]
-        out, lg = eng.decode([rid], [t], return_logits=True)
-        rows.append(lg[0].copy())
-        toks.append(int(out[0]))
-    eng.drop_request(rid)
-    return toks, np.stack(rows)
-
-
-@pytest.mark.parametrize("ctx,policy,graph", [(1024, 1, True), (1024, 0, True), (1024, 1, False), (20, 1, True), (3000, 1, True)])
-def test_engine_bit_identical_to_fused_decode_path(built_libs, real2, ctx, policy, graph):
-    """decode_mode 2 (ONE persistent launch for all layers: LDS-DMA weight ring, in-launch hand-offs) == decode_mode 1
-    (five launches per layer) in every logit bit and every greedy token, at Qwen3-4B widths: ctx 1024 (partition-KV,
-    64-token chunks), ctx 20 (non-partition attention), ctx 3000 (longer chunks: more than four scan waves per chunk),
-    both split policies, captured graph and eager.  decode_mode 1 is itself pinned to the oracle above."""
-    _, state, _ = real2
-    rng = np.random.default_rng(ctx)
-    prompt = rng.integers(0, CFG2["vocab_size"], ctx).tolist()
-    e1 = _engine(state, decode_mode=1, split_policy=policy, enable_graph=graph, max_batch_size=4)
-    toks1, bits1 = _decode_bits(e1, prompt, 12)
-    e2 = _engine(state, decode_mode=2, split_policy=policy, enable_graph=graph, max_batch_size=4)
-    toks2, bits2 = _decode_bits(e2, prompt, 12, feed=toks1[:-1])
-    # the comparison is vacuous if engine_ok() silently routed the steps to the decode_mode 1 kernels
-    assert e2.lib.pegainfer_qwen3_engine_active(e2.h) == 1 and e2.lib.pegainfer_qwen3_engine_fallbacks(e2.h) == 0
-    assert e1.lib.pegainfer_qwen3_engine_active(e1.h) == 0
-    e1.close()
-    e2.close()
-    assert np.array_equal(bits1, bits2), int((bits1 != bits2).sum())
-    assert toks1 == toks2
-
-
-def test_engine_many_steps_and_interleaved_requests(built_libs, real2):
-    """200 engine steps over two alternating requests (hand-off counters, ring epochs and KV appends are re-armed
-    every launch) == the fused path, token for token and bit for bit on every 10th step; then a batch of two falls
-    back to the decode_mode 1 kernels on the same engine object and still matches."""
-    _, state, _ = real2
-    rng = np.random.default_rng(5)
-    prompts = [rng.integers(0, CFG2["vocab_size"], n).tolist() for n in (700, 90)]
-    outs = {}
-    for mode in (1, 2):
-        eng = _engine(state, decode_mode=mode, max_batch_size=4)
-        rids = [eng.new_request() for _ in prompts]
-        last = [int(eng.prefill([r], [p])[0]) for r, p in zip(rids, prompts)]
-        toks, bits = [], []
-        for step in range(200):
-            i = step & 1
-            feed = last[i] if mode == 1 else outs[1]["feed"][step]
-            o, lg = eng.decode([rids[i]], [feed], return_logits=True)
-            toks.append(int(o[0]))
-            outs.setdefault(mode, {}).setdefault("feed", []).append(feed)
-            last[i] = int(o[0])
-            if step % 10 == 0:
-                bits.append(lg[0].copy())
-            # replayed graphs included: the flag says what THIS step ran on
-            assert eng.lib.pegainfer_qwen3_engine_active(eng.h) == (1 if mode == 2 else 0)
-        o, lg = eng.decode(rids, last, return_logits=True)        # bs 2: not an engine step
-        assert eng.lib.pegainfer_qwen3_engine_active(eng.h) == 0
-        outs[mode].update(toks=toks, bits=np.stack(bits), pair=lg.copy())
-        eng.close()
-    assert outs[1]["toks"] == outs[2]["toks"]
-    assert np.array_equal(outs[1]["bits"], outs[2]["bits"])
-    assert np.array_equal(outs[1]["pair"], outs[2]["pair"])
-
-
-@pytest.mark.parametrize("graph", [True, False])
-def test_engine_failure_reruns_the_step_on_the_fused_kernels(built_libs, real2, graph, monkeypatch):
-    """A decode_mode 2 step whose bounded spins expire (injected: the status word is overwritten after the launch) must
-    not cost the caller the step: the SAME decode call re-runs on the decode_mode 1 kernels, returns 0 with the right
-    token and logits, leaves seq_len advanced exactly once, and every later step stays off the engine."""
-    _, state, _ = real2
-    rng = np.random.default_rng(77)
-    prompt = rng.integers(0, CFG2["vocab_size"], 300).tolist()
-    e1 = _engine(state, decode_mode=1, enable_graph=graph, max_batch_size=4)
-    toks1, bits1 = _decode_bits(e1, prompt, 6)
-    e1.close()
-    monkeypatch.setenv("PEGAINFER_ENGINE_INJECT_FAIL", "1")
-    e2 = _engine(state, decode_mode=2, enable_graph=graph, max_batch_size=4)
-    rid = e2.new_request()
-    tok, _ = e2.prefill([rid], [prompt], return_logits=True)
-    assert int(tok[0]) == toks1[0]
-    rows = []
-    for step in range(6):
-        out, lg = e2.decode([rid], [toks1[step]], return_logits=True)   # rc != 0 would raise
-        rows.append(lg[0].copy())
-        assert int(out[0]) == toks1[step + 1]
-        assert e2.seq_len(rid) == len(prompt) + step + 1
-        assert e2.lib.pegainfer_qwen3_engine_active(e2.h) == 0
-        assert e2.lib.pegainfer_qwen3_engine_fallbacks(e2.h) == 1
-    e2.close()
-    assert np.array_equal(np.stack(rows), bits1)
