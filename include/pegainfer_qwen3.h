@@ -86,6 +86,7 @@ int32_t pegainfer_qwen3_available_pages(pegainfer_qwen3_t m);
 int32_t pegainfer_qwen3_capacity_pages(pegainfer_qwen3_t m);
 /* the max_batch_size the model was created with (rows of the decode buffers) */
 int32_t pegainfer_qwen3_max_batch_size(pegainfer_qwen3_t m);
+int32_t pegainfer_qwen3_vocab_size(pegainfer_qwen3_t m);
 
 /* batch_prefill (prefill.rs:220-285): greedy first token per request; optional last-position
  * logits copied to host as bf16 bits [n_requests, vocab]. */
@@ -115,8 +116,9 @@ int32_t pegainfer_qwen3_sample(pegainfer_qwen3_t m, int32_t column, float temper
 
 /* Per-token log-probabilities (executor.rs:400-434 compute_logprobs_from_cpu, :807-816 extract_logprobs): the logits
  * row of request `column` of the LAST prefill / decode step is copied to the host as f32; out_logprob = logit[token] -
- * log_sum_exp, and the top_k largest entries (value descending, index ascending on ties - the reference's ordered
- * insertion) go to out_top_ids / out_top_logprobs.  Returns the number of top entries (min(top_k, vocab)) or < 0. */
+ * log_sum_exp, and the top_k largest entries (value descending; the reference's ordered insertion, literally: among equal
+ * values the later index comes first, and a value equal to the last entry of a full list does not enter) go to
+ * out_top_ids / out_top_logprobs.  Returns the number of top entries (min(top_k, vocab)) or < 0. */
 int32_t pegainfer_qwen3_logprobs(pegainfer_qwen3_t m, int32_t column, uint32_t token, int32_t top_k, float* out_logprob,
                                  uint32_t* out_top_ids, float* out_top_logprobs);
 /* the same arithmetic on a host f32 row (pure host: CPU-testable against oracle/ops.py:compute_logprobs) */

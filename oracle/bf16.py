@@ -31,3 +31,10 @@ def bf16_from_bits(u):
     """uint16 image -> float32."""
     u = np.ascontiguousarray(u, dtype=np.uint16)
     return (u.astype(np.uint32) << np.uint32(16)).view(np.float32).reshape(u.shape)
+
+
+def bf16_bits_exact(x):
+    """uint16 image of a float32 array whose values are ALREADY bf16-representable (weights out of synthetic_weights,
+    oracle activations): a shift, no rounding pass - 4 G elements in seconds instead of minutes."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    return (x.view(np.uint32) >> np.uint32(16)).astype(np.uint16).reshape(x.shape)

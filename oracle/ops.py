@@ -503,6 +503,36 @@ def argmax(x):
     return int(np.flatnonzero(x == x.max())[0])
 
 
+def compute_logprobs(logits_f32, sampled_token, top_k):
+    """compute_logprobs_from_cpu (pegainfer-qwen3-4b/src/executor.rs:400-434), statement for statement: f32 max fold, f32
+    SEQUENTIAL sum of exp(x - max) (Rust's Iterator::sum is a left fold - np.cumsum keeps that order, np.sum would
+    not), log_sum_exp = max + ln(sum).  The top list is the reference's ordered insertion, literally: a value enters
+    when the list is short or it beats the last entry STRICTLY, at partition_point(v > val) - i.e. in FRONT of entries
+    equal to it - so the list is value-descending and, among equal values that made it in, the LATER index comes first;
+    a value equal to the last entry of a full list does not enter.
+    Returns (logprob, [(token id, logprob), ...]) or None for an empty row."""
+    x = np.asarray(logits_f32, dtype=F32)
+    if x.size == 0:
+        return None
+    max_val = F32(x.max())
+    e = np.exp(x - max_val, dtype=F32)
+    sum_exp = F32(np.cumsum(e, dtype=F32)[-1])
+    lse = F32(max_val + np.log(sum_exp, dtype=F32))
+    k = min(int(top_k), x.size)
+    best = []                                   # (index, value), value descending
+    if k > 0:
+        for idx, val in enumerate(x.tolist()):
+            if len(best) < k or val > best[-1][1]:
+                pos = 0
+                while pos < len(best) and best[pos][1] > val:      # partition_point(|v| v > val)
+                    pos += 1
+                best.insert(pos, (idx, val))
+                if len(best) > k:
+                    best.pop()
+    top = [(int(i), float(F32(F32(v) - lse))) for i, v in best]
+    return float(F32(x[int(sampled_token)] - lse)), top
+
+
 def logits_to_probs(logits, inv_temperature):
     """fp32 softmax of logits*inv_T (csrc/flashinfer_sampling.cu:13-70)."""
     v = logits.astype(F32) * F32(inv_temperature)

@@ -203,48 +203,60 @@ class Qwen3Oracle:
         return out, all_logits
 
 
-def synthetic_weights(cfg, seed=42, std=0.02, dtype_round=True):
+def synthetic_weights(cfg, seed=42, std=0.02, dtype_round=True, with_bits=False):
     """Seeded N(0, std) bf16 checkpoint of the given shape (used when no
     real weights are on disk; throughput is data-independent).  Every tensor is drawn in fixed
     4 Mi-element chunks, chunk j of tensor i from default_rng([seed, i, j]), so the values do not
-    depend on how many host threads fill them (a Qwen3-4B-width embedding table is 389 M draws)."""
+    depend on how many host threads fill them (a Qwen3-4B-width embedding table is 389 M draws).
+    with_bits=True returns (weights, bits): the uint16 bf16 images are produced in the same threaded pass
+    (a separate conversion of 4 G parameters costs minutes)."""
     import os
     from concurrent.futures import ThreadPoolExecutor
     CH = 1 << 22
     pool = ThreadPoolExecutor(max_workers=max(1, min(32, os.cpu_count() or 1)))
     counter = [0]
+    bits = {}
 
-    def t(*shape, scale=std, mean=0.0):
+    def t(name, *shape, scale=std, mean=0.0):
         idx = counter[0]
         counter[0] += 1
         n = int(np.prod(shape))
         out = np.empty(n, dtype=F32)
+        ob = np.empty(n, dtype=np.uint16) if with_bits else None
 
         def fill(j):
             lo, hi = j * CH, min(n, (j + 1) * CH)
             a = np.random.default_rng([seed, idx, j]).standard_normal(hi - lo, dtype=F32)
             a = a * F32(scale) + F32(mean)
-            out[lo:hi] = bf16_round(a) if dtype_round else a
+            a = bf16_round(a) if dtype_round else a
+            out[lo:hi] = a
+            if ob is not None:
+                ob[lo:hi] = bf16_round(a).view(np.uint32) >> np.uint32(16)
         list(pool.map(fill, range(-(-n // CH))))
+        if ob is not None:
+            bits[name] = ob.reshape(shape)
         return out.reshape(shape)
 
     c = cfg
-    w = {"model.embed_tokens.weight": t(c.vocab_size, c.hidden_size),
-         "model.norm.weight": t(c.hidden_size, scale=0.1, mean=1.0)}
+    names = ["model.embed_tokens.weight", "model.norm.weight"]
+    w = {"model.embed_tokens.weight": t(names[0], c.vocab_size, c.hidden_size),
+         "model.norm.weight": t(names[1], c.hidden_size, scale=0.1, mean=1.0)}
     if not c.tie_word_embeddings:
-        w["lm_head.weight"] = t(c.vocab_size, c.hidden_size)
+        w["lm_head.weight"] = t("lm_head.weight", c.vocab_size, c.hidden_size)
     for i in range(c.num_hidden_layers):
         p = f"model.layers.{i}."
-        w[p + "self_attn.q_proj.weight"] = t(c.q_dim, c.hidden_size)
-        w[p + "self_attn.k_proj.weight"] = t(c.kv_dim, c.hidden_size)
-        w[p + "self_attn.v_proj.weight"] = t(c.kv_dim, c.hidden_size)
-        w[p + "self_attn.o_proj.weight"] = t(c.hidden_size, c.q_dim)
-        w[p + "self_attn.q_norm.weight"] = t(c.head_dim, scale=0.1, mean=1.0)
-        w[p + "self_attn.k_norm.weight"] = t(c.head_dim, scale=0.1, mean=1.0)
-        w[p + "mlp.gate_proj.weight"] = t(c.intermediate_size, c.hidden_size)
-        w[p + "mlp.up_proj.weight"] = t(c.intermediate_size, c.hidden_size)
-        w[p + "mlp.down_proj.weight"] = t(c.hidden_size, c.intermediate_size)
-        w[p + "input_layernorm.weight"] = t(c.hidden_size, scale=0.1, mean=1.0)
-        w[p + "post_attention_layernorm.weight"] = t(c.hidden_size, scale=0.1, mean=1.0)
+        for suffix, shape, kw in (
+                ("self_attn.q_proj.weight", (c.q_dim, c.hidden_size), {}),
+                ("self_attn.k_proj.weight", (c.kv_dim, c.hidden_size), {}),
+                ("self_attn.v_proj.weight", (c.kv_dim, c.hidden_size), {}),
+                ("self_attn.o_proj.weight", (c.hidden_size, c.q_dim), {}),
+                ("self_attn.q_norm.weight", (c.head_dim,), dict(scale=0.1, mean=1.0)),
+                ("self_attn.k_norm.weight", (c.head_dim,), dict(scale=0.1, mean=1.0)),
+                ("mlp.gate_proj.weight", (c.intermediate_size, c.hidden_size), {}),
+                ("mlp.up_proj.weight", (c.intermediate_size, c.hidden_size), {}),
+                ("mlp.down_proj.weight", (c.hidden_size, c.intermediate_size), {}),
+                ("input_layernorm.weight", (c.hidden_size,), dict(scale=0.1, mean=1.0)),
+                ("post_attention_layernorm.weight", (c.hidden_size,), dict(scale=0.1, mean=1.0))):
+            w[p + suffix] = t(p + suffix, *shape, **kw)
     pool.shutdown()
-    return w
+    return (w, bits) if with_bits else w

@@ -4,14 +4,18 @@ Follows pegainfer-qwen3-4b/src/scheduler.rs:97-327 (loop, admission by KV-page b
 scheduler/plan.rs:31-117 (Prefill / Decode / Unified plan, one random_val per request per step, prompts first),
 scheduler/resolve.rs:9-132 (stop token / length rules) and scheduler/effects.rs:67-217 (event order, swap_remove
 retirement, dropped-receiver cleanup).  One call of ``step()`` = one iteration of ``scheduler_loop``; channels
-become per-scheduler event lists.  echo / logprobs are not modelled (out of scope for the forward-pass path).
+become per-scheduler event lists.  logprobs / echo (executor.rs:211-284, resolve.rs:40-49,66,86,118,126,
+effects.rs:75-82) are modelled since round 4: events carry an 8th element, None or (logprob, [(id, logprob), ...]).
 
 Executor protocol (duck-typed, mirrors executor.rs:502-512): page_size(), max_request_pages(), available_pages(),
 is_stop_token(tok), drop_request(id), execute(prefill_items, decode_items) -> (prefill_tokens, decode_tokens) or raises.
 prefill_items: [(id, prompt, params, random_val)], decode_items: [(id, last_token, params, random_val)].
+Optional, for logprobs / echo: logprobs(row, token, top_k) and prompt_logprobs(position, target, top_k) ->
+(logprob, [(id, logprob), ...]) for the LAST execute (rows = requests, prompts first); execute(..., echo=True) is the
+pure-Prefill plan with any_echo (plan.rs:62-66).
 """
 
-TOKEN, FINISHED, ERROR, REJECTED = 1, 2, 3, 4
+TOKEN, FINISHED, ERROR, REJECTED, PROMPT_TOKEN = 1, 2, 3, 4, 5
 STOP, LENGTH = 0, 1
 PLAN_NONE, PLAN_PREFILL, PLAN_DECODE, PLAN_UNIFIED, STEP_FAILED = 0, 1, 2, 3, -1
 
@@ -34,20 +38,26 @@ class SchedulerOracle:
         self.closed = set()
 
     # ---- EngineHandle::submit + receiver drop ----
-    def submit(self, prompt, max_tokens, params=(0.0, -1, 1.0, False)):
+    def submit(self, prompt, max_tokens, params=(0.0, -1, 1.0, False), logprobs=0, echo=False):
         rid = self.next_id
         self.next_id += 1
-        self.deferred.append(dict(id=rid, prompt=list(prompt), params=tuple(params), max_tokens=int(max_tokens)))
+        self.deferred.append(dict(id=rid, prompt=list(prompt), params=tuple(params), max_tokens=int(max_tokens),
+                                  logprobs=max(int(logprobs), 0), echo=bool(echo)))
         return rid
 
     def cancel(self, rid):
         self.closed.add(rid)
 
-    def _send(self, rid, kind, token=0, reason=0, prompt_tokens=0, completion_tokens=0, message=""):
+    def _send(self, rid, kind, token=0, reason=0, prompt_tokens=0, completion_tokens=0, message="", logprob=None):
         if rid in self.closed:
             return False
-        self.events.append((rid, kind, token, reason, prompt_tokens, completion_tokens, message))
+        self.events.append((rid, kind, token, reason, prompt_tokens, completion_tokens, message, logprob))
         return True
+
+    def _row_logprob(self, row, token, top_k):
+        """Some(extract_logprobs(..)) when the request asked for logprobs (executor.rs:222-226, 273-277)"""
+        fn = getattr(self.ex, "logprobs", None)
+        return fn(row, token, top_k) if (top_k > 0 and fn) else None
 
     # ---- scheduler.rs:175-261 ----
     def _admit(self):
@@ -100,17 +110,43 @@ class SchedulerOracle:
             if plan != PLAN_DECODE else []
         dec_items = [(a["id"], a["last_token"], a["params"], self.rng.next_f32()) for a in self.active] \
             if plan != PLAN_PREFILL else []
+        any_echo = plan == PLAN_PREFILL and any(p["echo"] for p in pending)
+        echo_step = any_echo and hasattr(self.ex, "prompt_logprobs")
         try:
-            pf_tokens, dec_tokens = self.ex.execute(pf_items, dec_items)
+            if echo_step:
+                pf_tokens, dec_tokens = self.ex.execute(pf_items, dec_items, echo=True)
+            else:
+                pf_tokens, dec_tokens = self.ex.execute(pf_items, dec_items)
+            # build_prefill_request_results / build_decode_request_results (executor.rs:211-284): part of the step
+            pf_lps = [self._row_logprob(i, tok, p["logprobs"]) for i, (p, tok) in enumerate(zip(pending, pf_tokens))] \
+                if plan != PLAN_DECODE else []
+            echo_lps, off = [], 0
+            for p in (pending if plan != PLAN_DECODE else []):
+                row = None
+                if p["echo"]:
+                    row = [None] * len(p["prompt"])
+                    if echo_step:
+                        for j in range(1, len(p["prompt"])):
+                            row[j] = self.ex.prompt_logprobs(off + j - 1, p["prompt"][j], p["logprobs"])
+                echo_lps.append(row)
+                off += len(p["prompt"])
+            dec_lps = [self._row_logprob(len(pf_items) + j, tok, a["logprobs"])
+                       for j, (a, tok) in enumerate(zip(self.active, dec_tokens))] if plan != PLAN_PREFILL else []
         except Exception as e:  # scheduler.rs:307-327
             for rid, pt, ct in targets:
                 self._send(rid, ERROR, prompt_tokens=pt, completion_tokens=ct, message=str(e))
                 self.ex.drop_request(rid)
             self.active = []
             return STEP_FAILED
+        # ---- prompt echoes first (resolve.rs:40-49, effects.rs:75-82) ----
+        for p, row in zip(pending if plan != PLAN_DECODE else [], echo_lps):
+            if row is not None:
+                for j, t in enumerate(p["prompt"]):
+                    self._send(p["id"], PROMPT_TOKEN, token=t, prompt_tokens=j, completion_tokens=len(p["prompt"]),
+                               logprob=row[j])
         # ---- resolve decode (resolve.rs:96-132) + apply (effects.rs:84-159) ----
         retire = []
-        for (rid, _, _, _), tok in zip(dec_items, dec_tokens):
+        for ((rid, _, _, _), tok), lp in zip(zip(dec_items, dec_tokens), dec_lps):
             idx = next((i for i, a in enumerate(self.active) if a["id"] == rid), None)
             if idx is None:
                 continue
@@ -122,13 +158,13 @@ class SchedulerOracle:
                 self.ex.drop_request(rid)
                 retire.append(idx)
             elif completion >= a["max_tokens"]:
-                if self._send(rid, TOKEN, token=tok):
+                if self._send(rid, TOKEN, token=tok, logprob=lp):
                     self._send(rid, FINISHED, reason=LENGTH, prompt_tokens=a["prompt_len"],
                                completion_tokens=completion)
                 self.ex.drop_request(rid)
                 retire.append(idx)
             else:
-                if not self._send(rid, TOKEN, token=tok):
+                if not self._send(rid, TOKEN, token=tok, logprob=lp):
                     self.ex.drop_request(rid)
                     retire.append(idx)
                 else:
@@ -138,19 +174,19 @@ class SchedulerOracle:
             self.active[i] = self.active[-1]
             self.active.pop()
         # ---- resolve prefill (resolve.rs:31-94) + apply (effects.rs:164-216) ----
-        for p, tok in zip(pending if plan != PLAN_DECODE else [], pf_tokens):
+        for (p, tok), lp in zip(zip(pending if plan != PLAN_DECODE else [], pf_tokens), pf_lps):
             rid, plen, ignore_eos = p["id"], len(p["prompt"]), p["params"][3]
             if (not ignore_eos) and self.ex.is_stop_token(tok):
                 self._send(rid, FINISHED, reason=STOP, prompt_tokens=plen, completion_tokens=0)
                 self.ex.drop_request(rid)
             elif p["max_tokens"] <= 1:
-                if self._send(rid, TOKEN, token=tok):
+                if self._send(rid, TOKEN, token=tok, logprob=lp):
                     self._send(rid, FINISHED, reason=LENGTH, prompt_tokens=plen, completion_tokens=1)
                 self.ex.drop_request(rid)
             else:
-                if self._send(rid, TOKEN, token=tok):
+                if self._send(rid, TOKEN, token=tok, logprob=lp):
                     self.active.append(dict(id=rid, last_token=tok, generated=1, max_tokens=p["max_tokens"],
-                                            prompt_len=plen, params=p["params"]))
+                                            prompt_len=plen, params=p["params"], logprobs=p["logprobs"]))
                 else:
                     self.ex.drop_request(rid)
         return plan
@@ -197,8 +233,16 @@ class FakeExecutor:
         self.avail -= max(grow, 0)
         self.held[rid] = tokens
 
-    def execute(self, pf_items, dec_items):
+    # deterministic fake TokenLogprobs: a function of (row, token) resp. (position, target) only
+    def logprobs(self, row, token, top_k):
+        return (-0.5 - 0.001 * token - 0.25 * row, [(token + i, -1.0 - i - 0.125 * row) for i in range(top_k)])
+
+    def prompt_logprobs(self, position, target, top_k):
+        return (-0.25 * (position + 1), [(target + i, -2.0 - i) for i in range(top_k)])
+
+    def execute(self, pf_items, dec_items, echo=False):
         self.calls.append((len(pf_items), len(dec_items)))
+        self.echo_calls = getattr(self, "echo_calls", []) + [bool(echo)]
         if dec_items and not pf_items and self.fail_decode_once:
             self.fail_decode_once = False
             raise RuntimeError("fake decode KV capacity exhausted")

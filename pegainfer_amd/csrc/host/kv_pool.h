@@ -112,7 +112,11 @@ inline int oproj_fused_max_chunks() {
   static const int c = [] { const char* e = getenv("PEGAINFER_OPROJ_CHUNKS"); const int v = e && *e ? atoi(e) : 18; return v < 2 ? 2 : (v > 30 ? 30 : v); }();
   return c;
 }
-inline SplitPlan make_split_plan(int policy, const std::vector<int>& seq_lens, int padded_bs, int num_kv_heads) {
+// fused_oproj_usable: the caller can run the fused attention + o_proj launch on this step (single GPU, form enabled, shape
+// fits) - only then is a short single request capped at oproj_fused_max_chunks() chunks; otherwise the cap would cost
+// attention workgroups and buy nothing
+inline SplitPlan make_split_plan(int policy, const std::vector<int>& seq_lens, int padded_bs, int num_kv_heads,
+                                 bool fused_oproj_usable = true) {
   SplitPlan p;
   int max_seq = 0;
   for (int n : seq_lens) max_seq = std::max(max_seq, n);
@@ -135,7 +139,8 @@ inline SplitPlan make_split_plan(int policy, const std::vector<int>& seq_lens, i
     // tokens in one tile per wave) - the other slots of the launch grid stay
     // padding, and the fused attention + o_proj launch gives their workgroups the o_proj rows (attn_oproj_kernel)
     const int grid_slots = want;   // the launch grid keeps its one-workgroup-per-CU size
-    if (pairs <= num_kv_heads && max_seq <= kOprojFusedMaxSeq && target_env <= 0) want = std::min(want, oproj_fused_max_chunks());
+    if (fused_oproj_usable && pairs <= num_kv_heads && max_seq <= kOprojFusedMaxSeq && target_env <= 0)
+      want = std::min(want, oproj_fused_max_chunks());
     int chunk = (max_seq + want - 1) / want;
     chunk = std::max(64, (chunk + 15) / 16 * 16);
     p.chunk = chunk;

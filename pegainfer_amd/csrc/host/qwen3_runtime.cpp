@@ -113,6 +113,7 @@ struct Model {
   int32_t* attn_done = nullptr;
   uint32_t *attn_status = nullptr, *attn_status_host = nullptr;
   bool oproj_step = false;   // the step being recorded / run uses the fused launch
+  bool oproj_shape_ok = true;   // cleared the first time the fused launcher refuses the model's shape (e.g. hidden 4096)
   bool oproj_plan = false;   // this step's split plan keeps the padding slots the fused launch needs (single request, <= 2304 tokens)
   int oproj_fallbacks = 0;
   // sampling scratch (ops/sampling.rs)
@@ -619,7 +620,7 @@ struct Model {
             attn_proj, H, attn_done + (size_t)li * 32, attn_status, S());
         if (r2 == 0) fused_o = true;
         else if (r2 != (int)hipErrorInvalidValue) rc = r2;
-        else oproj_step = false;   // the shape does not fit the form: two launches for this and the later layers
+        else { oproj_step = false; oproj_shape_ok = false; }   // the shape does not fit the form: two launches from here on, and no chunk cap in later plans
       }
       if (!rc && !fused_o)
         rc = pegainfer_fused_decode_attention(
@@ -739,8 +740,9 @@ struct Model {
       ri[i] = i;
       kti[i] = 0;
     }
-    const SplitPlan plan = make_split_plan(split_policy, seq_lens, padded, Hkv);
-    oproj_plan = split_policy == 1 && padded == 1 && plan.use_split && seq_lens[0] <= pq::kOprojFusedMaxSeq &&
+    const bool oproj_usable = attn_oproj && attn_done && fused_merge && !tp_comm && decode_mode >= 1 && D == 128 && oproj_shape_ok;
+    const SplitPlan plan = make_split_plan(split_policy, seq_lens, padded, Hkv, oproj_usable);
+    oproj_plan = oproj_usable && split_policy == 1 && padded == 1 && plan.use_split && seq_lens[0] <= pq::kOprojFusedMaxSeq &&
                  plan.slots > pq::oproj_fused_max_chunks();
     std::memcpy(mh<int32_t>(ml.split_request_indices), plan.request_indices.data(), plan.slots * 4);
     std::memcpy(mh<int32_t>(ml.split_kv_tile_indices), plan.kv_tile_indices.data(), plan.slots * 4);
@@ -1260,6 +1262,7 @@ pegainfer_qwen3_t pegainfer_qwen3_from_pretrained(const char* model_dir, int32_t
 int32_t pegainfer_qwen3_available_pages(pegainfer_qwen3_t m) { return M(m)->pool.available(); }
 int32_t pegainfer_qwen3_capacity_pages(pegainfer_qwen3_t m) { return M(m)->pool.capacity(); }
 int32_t pegainfer_qwen3_max_batch_size(pegainfer_qwen3_t m) { return M(m)->max_bs; }
+int32_t pegainfer_qwen3_vocab_size(pegainfer_qwen3_t m) { return M(m)->V; }
 int32_t pegainfer_qwen3_prefill(pegainfer_qwen3_t m, int32_t n, const int32_t* ids, const int32_t* lens,
                                 const uint32_t* tokens, int32_t* out_tokens, void* out_logits_host) {
   return M(m)->prefill(n, ids, lens, tokens, out_tokens, out_logits_host);
@@ -1290,8 +1293,9 @@ int32_t pegainfer_qwen3_logprobs(pegainfer_qwen3_t m, int32_t column, uint32_t t
   return M(m)->logprobs(column, token, top_k, out_logprob, out_top_ids, out_top_logprobs);
 }
 // compute_logprobs_from_cpu (executor.rs:400-434), statement for statement: f32 max fold, f32 sequential sum of
-// exp(x - max), log_sum_exp = max + ln(sum); the top list is built by ordered insertion (a later equal value never
-// displaces an earlier one), so it is sorted by (value descending, index ascending).  Returns the number of top
+// exp(x - max), log_sum_exp = max + ln(sum); the top list is built by the reference's ordered insertion (strictly-greater
+// test against the last entry, insertion at partition_point(v > val): value descending, a later equal value in FRONT of
+// an earlier one, none displaced from a full list by an equal value).  Returns the number of top
 // entries written (min(top_k, n)), or -1 (empty row / token out of range: the reference returns None)
 int32_t pegainfer_logprobs_from_logits(const float* logits_f32, int32_t n, uint32_t token, int32_t top_k,
                                        float* out_logprob, uint32_t* out_top_ids, float* out_top_logprobs) {

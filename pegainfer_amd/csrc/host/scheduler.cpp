@@ -18,11 +18,15 @@ namespace psched {
 struct Sampling { float temperature; int32_t top_k; float top_p; bool ignore_eos; };
 
 struct Active {   // ActiveRequestState (scheduler.rs:31-41)
-  uint64_t id; uint32_t last_token; int generated, max_tokens, prompt_len; Sampling p;
+  uint64_t id; uint32_t last_token; int generated, max_tokens, prompt_len; Sampling p; int logprobs = 0;
 };
 struct Pending {  // PendingRequest (scheduler.rs:43-51)
-  uint64_t id; std::vector<uint32_t> prompt; Sampling p; int max_tokens;
+  uint64_t id; std::vector<uint32_t> prompt; Sampling p; int max_tokens; int logprobs = 0; bool echo = false;
 };
+struct TokenLogprob {   // Option<TokenLogprob> (engine.rs:34-38)
+  bool some = false; float logprob = 0.f; std::vector<uint32_t> ids; std::vector<float> vals;
+};
+struct Event { pegainfer_token_event e; std::vector<uint32_t> ids; std::vector<float> vals; };
 
 static inline int pages_needed(long tokens, int page_size) { return (int)((tokens + page_size - 1) / page_size); }
 
@@ -87,6 +91,11 @@ struct Qwen3Exec {
   std::unordered_set<uint32_t> stop;
   std::unordered_map<uint64_t, int32_t> slot;  // RequestId -> model request id
   std::string err;
+  // echo = true prefill (prefill.rs:196-212): logits of every prompt position, bf16 bits [total_tokens, vocab], on the host
+  bool echo_request = false;
+  std::vector<uint16_t> echo_logits;
+  std::vector<float> row_f32;
+  int64_t echo_vocab = 0;
   static int32_t page_size(void*) { return 16; }
   static int32_t max_request_pages(void* u) { return pegainfer_qwen3_capacity_pages(((Qwen3Exec*)u)->model) - 1; }
   static int32_t available_pages(void* u) { return pegainfer_qwen3_available_pages(((Qwen3Exec*)u)->model); }
@@ -120,7 +129,13 @@ struct Qwen3Exec {
       }
     }
     int32_t rc;
-    if (n_dec == 0) rc = pegainfer_qwen3_prefill(e->model, n_pf, mids.data(), lens, tokens, out_i.data(), nullptr);
+    if (n_dec == 0 && e->echo_request) {
+      int64_t T = 0;
+      for (int i = 0; i < n_pf; ++i) T += lens[i];
+      e->echo_vocab = pegainfer_qwen3_vocab_size(e->model);
+      e->echo_logits.resize((size_t)T * (size_t)e->echo_vocab);
+      rc = pegainfer_qwen3_prefill_echo(e->model, n_pf, mids.data(), lens, tokens, out_i.data(), nullptr, e->echo_logits.data());
+    } else if (n_dec == 0) rc = pegainfer_qwen3_prefill(e->model, n_pf, mids.data(), lens, tokens, out_i.data(), nullptr);
     else if (n_pf == 0) rc = pegainfer_qwen3_decode(e->model, n_dec, mids.data(), tokens, out_i.data(), nullptr);
     else rc = pegainfer_qwen3_unified_step(e->model, n_pf, n_dec, mids.data(), lens, tokens, out_i.data(), nullptr);
     if (rc) { const char* m = pegainfer_qwen3_last_error(e->model); e->err = m ? m : "model step failed"; return rc; }
@@ -135,6 +150,33 @@ struct Qwen3Exec {
       out[i] = (uint32_t)out_i[i];
     }
     return 0;
+  }
+};
+
+// logprobs / echo callbacks of the Qwen3 executor (executor.rs:211-284, 807-831)
+struct Qwen3ExecLp {
+  static int32_t logprobs(void* u, int32_t row, uint32_t token, int32_t top_k, float* lp, uint32_t* ids, float* vals) {
+    auto* e = (Qwen3Exec*)u;
+    const int32_t rc = pegainfer_qwen3_logprobs(e->model, row, token, top_k, lp, ids, vals);
+    if (rc < 0) { const char* m = pegainfer_qwen3_last_error(e->model); e->err = m ? m : "logprobs failed"; }
+    return rc;
+  }
+  static int32_t execute_echo(void* u, int32_t n_pf, const uint64_t* ids, const int32_t* lens, const uint32_t* tokens,
+                              const float* temp, const int32_t* top_k, const float* top_p, const float* rv, uint32_t* out) {
+    auto* e = (Qwen3Exec*)u;
+    e->echo_request = true;
+    const int32_t rc = Qwen3Exec::execute(u, n_pf, 0, ids, lens, tokens, temp, top_k, top_p, rv, out);
+    e->echo_request = false;
+    return rc;
+  }
+  static int32_t prompt_logprobs(void* u, int32_t pos, uint32_t target, int32_t top_k, float* lp, uint32_t* ids, float* vals) {
+    auto* e = (Qwen3Exec*)u;
+    const int64_t V = e->echo_vocab;
+    if (V <= 0 || pos < 0 || (int64_t)(pos + 1) * V > (int64_t)e->echo_logits.size()) { e->err = "no echo logits for that position"; return -1; }
+    e->row_f32.resize((size_t)V);
+    const uint16_t* src = e->echo_logits.data() + (size_t)pos * V;
+    for (int64_t i = 0; i < V; ++i) { const uint32_t w = (uint32_t)src[i] << 16; std::memcpy(&e->row_f32[i], &w, 4); }
+    return pegainfer_logprobs_from_logits(e->row_f32.data(), (int32_t)V, target, top_k, lp, ids, vals);
   }
 };
 
@@ -204,14 +246,33 @@ struct Scheduler {
   std::vector<Active> active;
   std::vector<Pending> deferred;
   std::unordered_set<uint64_t> closed;
-  std::deque<pegainfer_token_event> events;
+  std::deque<Event> events;
+  std::vector<uint32_t> poll_ids;    // top_logprobs of the events handed out by the last poll
+  std::vector<float> poll_vals;
   uint64_t next_id = 0;
   std::string last_message;
 
-  bool send(uint64_t id, int kind, uint32_t token, int reason, int prompt_tokens, int completion_tokens) {
+  bool send(uint64_t id, int kind, uint32_t token, int reason, int prompt_tokens, int completion_tokens,
+            const TokenLogprob* lp = nullptr) {
     if (closed.count(id)) return false;
-    events.push_back(pegainfer_token_event{id, kind, token, reason, prompt_tokens, completion_tokens});
+    Event ev{pegainfer_token_event{id, kind, token, reason, prompt_tokens, completion_tokens, 0, 0.f, 0, 0}, {}, {}};
+    if (lp && lp->some) {
+      ev.e.has_logprob = 1; ev.e.logprob = lp->logprob; ev.e.n_top = (int32_t)lp->ids.size();
+      ev.ids = lp->ids; ev.vals = lp->vals;
+    }
+    events.push_back(std::move(ev));
     return true;
+  }
+  // Some(extract_logprobs(..)) when the request asked for logprobs (executor.rs:222-226,273-277) and the executor can
+  TokenLogprob row_logprob(int row, uint32_t token, int top_k, bool* failed) {
+    TokenLogprob lp;
+    if (top_k <= 0 || !ex.logprobs) return lp;
+    lp.ids.resize((size_t)top_k); lp.vals.resize((size_t)top_k);
+    const int32_t n = ex.logprobs(ex.user, row, token, top_k, &lp.logprob, lp.ids.data(), lp.vals.data());
+    if (n < 0) { *failed = true; return TokenLogprob(); }
+    lp.ids.resize((size_t)n); lp.vals.resize((size_t)n);
+    lp.some = true;
+    return lp;
   }
   static int max_tokens_of(int prompt_len, int max_tokens) { return prompt_len + std::max(max_tokens - 1, 0); }
 
@@ -272,8 +333,43 @@ struct Scheduler {
       temp[i] = a.p.temperature; top_k[i] = a.p.top_k; top_p[i] = a.p.top_p; rv[i] = rng.next_f32();
       tokens.push_back(a.last_token);
     }
-    const int rc = ex.execute(ex.user, n_pf, n_dec, ids.data(), lens.data(), tokens.data(), temp.data(), top_k.data(),
-                              top_p.data(), rv.data(), out.data());
+    bool any_echo = false;   // plan.rs:62-66: only a pure Prefill plan computes the all-position logits
+    if (plan == PEGAINFER_PLAN_PREFILL)
+      for (const Pending& r : pending) any_echo = any_echo || r.echo;
+    const bool echo_step = any_echo && ex.execute_echo && ex.prompt_logprobs;
+    int rc = echo_step ? ex.execute_echo(ex.user, n_pf, ids.data(), lens.data(), tokens.data(), temp.data(), top_k.data(),
+                                         top_p.data(), rv.data(), out.data())
+                       : ex.execute(ex.user, n_pf, n_dec, ids.data(), lens.data(), tokens.data(), temp.data(), top_k.data(),
+                                    top_p.data(), rv.data(), out.data());
+    // logprobs of the emitted tokens + prompt logprobs: part of the executor's result (build_*_request_results,
+    // executor.rs:211-284) - a failure here fails the step like any other executor error
+    std::vector<TokenLogprob> lps(n);
+    std::vector<std::vector<TokenLogprob>> echo_lps(n_pf);
+    if (!rc) {
+      bool failed = false;
+      size_t off = 0;
+      for (int i = 0; i < n_pf && !failed; ++i) {
+        const Pending& r = pending[i];
+        lps[i] = row_logprob(i, out[i], r.logprobs, &failed);
+        if (r.echo) {
+          echo_lps[i].resize(r.prompt.size());          // [None, lp(1), ..., lp(n - 1)] or all None (executor.rs:227-252)
+          if (echo_step)
+            for (size_t j = 1; j < r.prompt.size() && !failed; ++j) {
+              TokenLogprob& lp = echo_lps[i][j];
+              const int k = std::max(r.logprobs, 0);
+              lp.ids.resize((size_t)k); lp.vals.resize((size_t)k);
+              const int32_t nt = ex.prompt_logprobs(ex.user, (int32_t)(off + j - 1), r.prompt[j], k, &lp.logprob,
+                                                    lp.ids.data(), lp.vals.data());
+              if (nt < 0) { lp = TokenLogprob(); continue; }   // extract_prompt_logprobs -> None on failure (.ok())
+              lp.ids.resize((size_t)nt); lp.vals.resize((size_t)nt);
+              lp.some = true;
+            }
+        }
+        off += r.prompt.size();
+      }
+      for (int j = 0; j < n_dec && !failed; ++j) lps[n_pf + j] = row_logprob(n_pf + j, out[n_pf + j], active[j].logprobs, &failed);
+      if (failed) rc = -1;
+    }
     if (rc) {  // fail_touched_requests (scheduler.rs:307-327): active targets first, then the pending ones
       const char* m = ex.last_error ? ex.last_error(ex.user) : nullptr;
       last_message = m ? m : "execution step failed";
@@ -287,6 +383,13 @@ struct Scheduler {
       }
       active.clear();
       return -1;
+    }
+    // ---- prompt echoes first (resolve.rs:40-49, effects.rs:75-82) ----
+    for (int i = 0; i < n_pf; ++i) {
+      const Pending& r = pending[i];
+      if (!r.echo) continue;
+      for (size_t j = 0; j < r.prompt.size(); ++j)
+        send(r.id, PEGAINFER_EVENT_PROMPT_TOKEN, r.prompt[j], 0, (int)j, (int)r.prompt.size(), &echo_lps[i][j]);
     }
     // ---- decode results: resolve.rs:96-132 + effects.rs:84-159 ----
     std::vector<size_t> retire;
@@ -304,11 +407,11 @@ struct Scheduler {
         ex.drop_request(ex.user, id);
         retire.push_back(idx);
       } else if (completion >= a.max_tokens) {
-        if (send(id, PEGAINFER_EVENT_TOKEN, tok, 0, 0, 0))
+        if (send(id, PEGAINFER_EVENT_TOKEN, tok, 0, 0, 0, &lps[n_pf + j]))
           send(id, PEGAINFER_EVENT_FINISHED, 0, PEGAINFER_FINISH_LENGTH, a.prompt_len, completion);
         ex.drop_request(ex.user, id);
         retire.push_back(idx);
-      } else if (!send(id, PEGAINFER_EVENT_TOKEN, tok, 0, 0, 0)) {
+      } else if (!send(id, PEGAINFER_EVENT_TOKEN, tok, 0, 0, 0, &lps[n_pf + j])) {
         ex.drop_request(ex.user, id);
         retire.push_back(idx);
       } else {
@@ -329,11 +432,11 @@ struct Scheduler {
         send(r.id, PEGAINFER_EVENT_FINISHED, 0, PEGAINFER_FINISH_STOP, plen, 0);
         ex.drop_request(ex.user, r.id);
       } else if (r.max_tokens <= 1) {
-        if (send(r.id, PEGAINFER_EVENT_TOKEN, tok, 0, 0, 0))
+        if (send(r.id, PEGAINFER_EVENT_TOKEN, tok, 0, 0, 0, &lps[i]))
           send(r.id, PEGAINFER_EVENT_FINISHED, 0, PEGAINFER_FINISH_LENGTH, plen, 1);
         ex.drop_request(ex.user, r.id);
-      } else if (send(r.id, PEGAINFER_EVENT_TOKEN, tok, 0, 0, 0)) {
-        active.push_back(Active{r.id, tok, 1, r.max_tokens, plen, r.p});
+      } else if (send(r.id, PEGAINFER_EVENT_TOKEN, tok, 0, 0, 0, &lps[i])) {
+        active.push_back(Active{r.id, tok, 1, r.max_tokens, plen, r.p, r.logprobs});
       } else {
         ex.drop_request(ex.user, r.id);
       }
@@ -372,7 +475,8 @@ pegainfer_sched_t pegainfer_sched_create_qwen3(void* model, uint64_t seed, const
   pegainfer_executor_vtbl v{sizeof(pegainfer_executor_vtbl), e, &psched::Qwen3Exec::page_size, &psched::Qwen3Exec::max_request_pages,
                             &psched::Qwen3Exec::available_pages, &psched::Qwen3Exec::is_stop_token,
                             &psched::Qwen3Exec::drop_request, &psched::Qwen3Exec::execute, &psched::Qwen3Exec::last_error,
-                            &psched::Qwen3Exec::max_batch_size};
+                            &psched::Qwen3Exec::max_batch_size, &psched::Qwen3ExecLp::logprobs,
+                            &psched::Qwen3ExecLp::execute_echo, &psched::Qwen3ExecLp::prompt_logprobs};
   Scheduler* s = static_cast<Scheduler*>(pegainfer_sched_create(&v, seed));
   s->owned = e;
   return s;
@@ -385,7 +489,7 @@ pegainfer_sched_t pegainfer_sched_create_qwen35(void* model, uint64_t seed, cons
   pegainfer_executor_vtbl v{sizeof(pegainfer_executor_vtbl), e, &psched::Qwen35Exec::page_size, &psched::Qwen35Exec::max_request_pages,
                             &psched::Qwen35Exec::available_pages, &psched::Qwen35Exec::is_stop_token,
                             &psched::Qwen35Exec::drop_request, &psched::Qwen35Exec::execute, &psched::Qwen35Exec::last_error,
-                            &psched::Qwen35Exec::max_batch_size};
+                            &psched::Qwen35Exec::max_batch_size, nullptr, nullptr, nullptr};
   Scheduler* s = static_cast<Scheduler*>(pegainfer_sched_create(&v, seed));
   s->owned35 = e;
   return s;
@@ -396,16 +500,23 @@ void pegainfer_sched_destroy(pegainfer_sched_t s) {
   delete SC(s)->owned35;
   delete SC(s);
 }
-uint64_t pegainfer_sched_submit(pegainfer_sched_t s, const uint32_t* prompt_tokens, int32_t n_tokens, int32_t max_tokens,
-                                float temperature, int32_t top_k, float top_p, int32_t ignore_eos) {
+uint64_t pegainfer_sched_submit_ex(pegainfer_sched_t s, const uint32_t* prompt_tokens, int32_t n_tokens, int32_t max_tokens,
+                                   float temperature, int32_t top_k, float top_p, int32_t ignore_eos, int32_t logprobs,
+                                   int32_t echo) {
   Scheduler* sc = SC(s);
   psched::Pending p;
   p.id = sc->next_id++;
   p.prompt.assign(prompt_tokens, prompt_tokens + (n_tokens > 0 ? n_tokens : 0));
   p.p = psched::Sampling{temperature, top_k, top_p, ignore_eos != 0};
   p.max_tokens = max_tokens;
+  p.logprobs = logprobs > 0 ? logprobs : 0;
+  p.echo = echo != 0;
   sc->deferred.push_back(std::move(p));
   return sc->deferred.back().id;
+}
+uint64_t pegainfer_sched_submit(pegainfer_sched_t s, const uint32_t* prompt_tokens, int32_t n_tokens, int32_t max_tokens,
+                                float temperature, int32_t top_k, float top_p, int32_t ignore_eos) {
+  return pegainfer_sched_submit_ex(s, prompt_tokens, n_tokens, max_tokens, temperature, top_k, top_p, ignore_eos, 0, 0);
 }
 int32_t pegainfer_sched_cancel(pegainfer_sched_t s, uint64_t request_id) {
   SC(s)->closed.insert(request_id);
@@ -415,10 +526,24 @@ int32_t pegainfer_sched_step(pegainfer_sched_t s) { return SC(s)->step(); }
 int32_t pegainfer_sched_poll(pegainfer_sched_t s, pegainfer_token_event* out, int32_t max_events) {
   Scheduler* sc = SC(s);
   int n = 0;
+  sc->poll_ids.clear();
+  sc->poll_vals.clear();
   while (n < max_events && !sc->events.empty()) {
-    out[n++] = sc->events.front();
+    psched::Event& ev = sc->events.front();
+    ev.e.top_index = (int32_t)sc->poll_ids.size();
+    sc->poll_ids.insert(sc->poll_ids.end(), ev.ids.begin(), ev.ids.end());
+    sc->poll_vals.insert(sc->poll_vals.end(), ev.vals.begin(), ev.vals.end());
+    out[n++] = ev.e;
     sc->events.pop_front();
   }
+  return n;
+}
+int32_t pegainfer_sched_poll_tops(pegainfer_sched_t s, uint32_t* out_ids, float* out_logprobs, int32_t max_pairs) {
+  Scheduler* sc = SC(s);
+  const int32_t n = (int32_t)sc->poll_ids.size();
+  const int32_t m = std::min(n, std::max(max_pairs, 0));
+  if (out_ids && m > 0) std::memcpy(out_ids, sc->poll_ids.data(), (size_t)m * 4);
+  if (out_logprobs && m > 0) std::memcpy(out_logprobs, sc->poll_vals.data(), (size_t)m * 4);
   return n;
 }
 int32_t pegainfer_sched_num_active(pegainfer_sched_t s) { return (int32_t)SC(s)->active.size(); }

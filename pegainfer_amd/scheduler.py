@@ -10,13 +10,14 @@ import numpy as np
 
 from . import ffi
 
-TOKEN, FINISHED, ERROR, REJECTED = 1, 2, 3, 4
+TOKEN, FINISHED, ERROR, REJECTED, PROMPT_TOKEN = 1, 2, 3, 4, 5
 
 
 class TokenEvent(ctypes.Structure):
     _fields_ = [("request_id", ctypes.c_uint64), ("kind", ctypes.c_int32), ("token", ctypes.c_uint32),
                 ("finish_reason", ctypes.c_int32), ("prompt_tokens", ctypes.c_int32),
-                ("completion_tokens", ctypes.c_int32)]
+                ("completion_tokens", ctypes.c_int32), ("has_logprob", ctypes.c_int32), ("logprob", ctypes.c_float),
+                ("n_top", ctypes.c_int32), ("top_index", ctypes.c_int32)]
 
 
 _I32_V = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p)
@@ -28,12 +29,20 @@ _EXEC = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes
                          ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_float),
                          ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_uint32))
 _ERR = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_void_p)   # const char*: a pointer into a buffer we keep alive
+_LP = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint32, ctypes.c_int32,
+                       ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_float))
+_EXEC_ECHO = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_uint64),
+                              ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_uint32),
+                              ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int32),
+                              ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float),
+                              ctypes.POINTER(ctypes.c_uint32))
 
 
 class ExecutorVtbl(ctypes.Structure):
     _fields_ = [("struct_size", ctypes.c_size_t), ("user", ctypes.c_void_p), ("page_size", _I32_V), ("max_request_pages", _I32_V),
                 ("available_pages", _I32_V), ("is_stop_token", _STOP), ("drop_request", _DROP), ("execute", _EXEC),
-                ("last_error", _ERR), ("max_batch_size", _I32_V)]
+                ("last_error", _ERR), ("max_batch_size", _I32_V), ("logprobs", _LP), ("execute_echo", _EXEC_ECHO),
+                ("prompt_logprobs", _LP)]
 
 
 class Scheduler:
@@ -54,11 +63,11 @@ class Scheduler:
         return cls(h, keep=engine)
 
     @classmethod
-    def over_callbacks(cls, ex, seed=42):
+    def over_callbacks(cls, ex, seed=42, logprobs=True):
         lib = ffi.host_lib()
         state = {"buf": ctypes.create_string_buffer(512)}
 
-        def execute(_u, n_pf, n_dec, ids, lens, tokens, temp, top_k, top_p, rv, out):
+        def execute(_u, n_pf, n_dec, ids, lens, tokens, temp, top_k, top_p, rv, out, echo=False):
             pf, dec, off = [], [], 0
             for i in range(n_pf + n_dec):
                 params = (temp[i], top_k[i], top_p[i])
@@ -68,7 +77,7 @@ class Scheduler:
                     dec.append((ids[i], tokens[off], params, rv[i]))
                 off += lens[i]
             try:
-                pt, dt = ex.execute(pf, dec)
+                pt, dt = ex.execute(pf, dec, echo=True) if echo else ex.execute(pf, dec)
             except Exception as e:  # noqa: BLE001 - surfaced as the step's error message
                 state["buf"].value = str(e).encode()[:511]
                 return -1
@@ -83,20 +92,44 @@ class Scheduler:
                    last_error=_ERR(lambda _u: ctypes.addressof(state["buf"])))
         keys = ["page_size", "max_request_pages", "available_pages", "is_stop_token", "drop_request", "execute",
                 "last_error"]
+        size = ExecutorVtbl.max_batch_size.offset
         if hasattr(ex, "max_batch_size"):   # optional callback: NULL = unlimited
             cbs["max_batch_size"] = _I32_V(lambda _u: ex.max_batch_size())
             keys.append("max_batch_size")
-        # struct_size = the bytes this caller fills: without the optional trailing callback the table ends at last_error,
-        # exactly what a caller built against the older header would pass
-        size = ctypes.sizeof(ExecutorVtbl) if "max_batch_size" in cbs else ExecutorVtbl.max_batch_size.offset
+            size = ExecutorVtbl.logprobs.offset
+        if logprobs and hasattr(ex, "logprobs") and hasattr(ex, "prompt_logprobs"):   # optional trailing block (round 4)
+            def lp_cb(fn):
+                def cb(_u, a, tok, k, out_lp, out_ids, out_vals):
+                    try:
+                        lp, top = fn(int(a), int(tok), int(k))
+                    except Exception as e:  # noqa: BLE001
+                        state["buf"].value = str(e).encode()[:511]
+                        return -1
+                    out_lp[0] = lp
+                    for i, (t, v) in enumerate(top[:k]):
+                        out_ids[i], out_vals[i] = int(t), float(v)
+                    return min(len(top), k)
+                return _LP(cb)
+            if "max_batch_size" not in cbs:
+                cbs["max_batch_size"] = _I32_V()      # NULL
+                keys.append("max_batch_size")
+            cbs["logprobs"] = lp_cb(ex.logprobs)
+            cbs["execute_echo"] = _EXEC_ECHO(lambda _u, n_pf, ids, lens, tokens, temp, top_k, top_p, rv, out:
+                                             execute(_u, n_pf, 0, ids, lens, tokens, temp, top_k, top_p, rv, out, echo=True))
+            cbs["prompt_logprobs"] = lp_cb(ex.prompt_logprobs)
+            keys += ["logprobs", "execute_echo", "prompt_logprobs"]
+            size = ctypes.sizeof(ExecutorVtbl)
+        # struct_size = the bytes this caller fills: without the optional trailing callbacks the table ends earlier,
+        # exactly what a caller built against an older header would pass
         vt = ExecutorVtbl(size, None, *[cbs[k] for k in keys])
         h = lib.pegainfer_sched_create(ctypes.addressof(vt), seed)
         return cls(h, keep=(vt, cbs, state, ex))
 
-    def submit(self, prompt, max_tokens, params=(0.0, -1, 1.0, False)):
+    def submit(self, prompt, max_tokens, params=(0.0, -1, 1.0, False), logprobs=0, echo=False):
         p = np.ascontiguousarray(prompt, dtype=np.uint32)
-        return int(self.lib.pegainfer_sched_submit(self.h, p.ctypes.data, int(p.size), int(max_tokens), float(params[0]),
-                                                   int(params[1]), float(params[2]), int(bool(params[3]))))
+        return int(self.lib.pegainfer_sched_submit_ex(self.h, p.ctypes.data, int(p.size), int(max_tokens), float(params[0]),
+                                                      int(params[1]), float(params[2]), int(bool(params[3])),
+                                                      int(logprobs), int(bool(echo))))
 
     def cancel(self, rid):
         self.lib.pegainfer_sched_cancel(self.h, int(rid))
@@ -107,8 +140,17 @@ class Scheduler:
     def poll(self, max_events=4096):
         buf = (TokenEvent * max_events)()
         n = self.lib.pegainfer_sched_poll(self.h, ctypes.addressof(buf), max_events)
-        return [(e.request_id, e.kind, e.token, e.finish_reason, e.prompt_tokens, e.completion_tokens)
-                for e in buf[:n]]
+        n_top = self.lib.pegainfer_sched_poll_tops(self.h, None, None, 0)
+        ids, vals = np.zeros(max(n_top, 1), np.uint32), np.zeros(max(n_top, 1), np.float32)
+        if n_top:
+            self.lib.pegainfer_sched_poll_tops(self.h, ids.ctypes.data, vals.ctypes.data, n_top)
+        out = []
+        for e in buf[:n]:   # same 8-tuple as oracle/scheduler_ref.py: (..., message, None | (logprob, [(id, logprob)]))
+            lp = None
+            if e.has_logprob:
+                lp = (float(e.logprob), [(int(ids[e.top_index + i]), float(vals[e.top_index + i])) for i in range(e.n_top)])
+            out.append((e.request_id, e.kind, e.token, e.finish_reason, e.prompt_tokens, e.completion_tokens, "", lp))
+        return out
 
     def num_active(self):
         return int(self.lib.pegainfer_sched_num_active(self.h))

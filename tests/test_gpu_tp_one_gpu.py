@@ -1,0 +1,152 @@
+"""The tensor-parallel C++ runtime at world size 2 (and 4) ON ONE GPU.
+
+RCCL refuses two ranks on one device, and the pool's boxes have one GPU - so in three rounds the sharded runtime
+(weights.rs:121-291 sharding, the two sum all-reduces per layer of batch_decode.rs:266,292 / prefill.rs:154,180, issued by
+csrc/host/qwen3_runtime.cpp on the model stream and captured into the decode graph) had never executed with world > 1.
+`pegainfer_qwen3_attach_comm` takes a communicator the caller built; a PEER-ONLY one (pegainfer_comm_create_peer_only:
+no RCCL, the peers' slabs mapped over hipIpc) carries every all-reduce on the one-shot peer-access kernel, so N processes
+sharing device 0 run the real TP data path: sharded weights, local KV heads, 72-per-step in-graph all-reduces (here
+2 layers x 2), prefill-sized payloads in 64 KB pieces, the bounded-wait failure path.
+
+Checked: sharded engine == unsharded engine within the bar of tests/test_parallel_gloo.py (partial sums are rounded to
+bf16 before the reduce), decode_mode 0 and 1, hipGraph capture + many replays, all ranks bit-identical to each other, a
+300-token prompt (150 KB payload = three pieces), and a peer that stops participating makes the step FAIL with the
+one-shot status in the message instead of returning garbage tokens.
+The physical link is the device's own memory instead of xGMI; everything above it is the code a multi-GPU node runs.
+"""
+import os
+import tempfile
+import traceback
+
+import numpy as np
+import pytest
+
+from test_gpu_comm_multi import _spawn
+from test_gpu_tp2 import _bf16_bits
+
+pytestmark = pytest.mark.gpu
+
+# 8 / 4 heads so that world 2 and 4 both divide the kv heads (local: 4 / 2 and 2 / 1 heads, I 512 and 256)
+CFG = dict(hidden_size=256, num_hidden_layers=2, num_attention_heads=8, num_key_value_heads=4, head_dim=128,
+           intermediate_size=1024, vocab_size=1024, rms_norm_eps=1e-6, rope_theta=1e6, tie_word_embeddings=True,
+           max_position_embeddings=4096)
+
+
+def _state(seed=23):
+    rng = np.random.default_rng(seed)
+    c, hd = CFG, CFG["head_dim"]
+    H, I, V = c["hidden_size"], c["intermediate_size"], c["vocab_size"]
+    t = {"model.embed_tokens.weight": rng.standard_normal((V, H)) * 0.05, "model.norm.weight": 1 + 0.1 * rng.standard_normal(H)}
+    for l in range(c["num_hidden_layers"]):
+        p = f"model.layers.{l}."
+        t[p + "self_attn.q_proj.weight"] = rng.standard_normal((c["num_attention_heads"] * hd, H)) * 0.05
+        t[p + "self_attn.k_proj.weight"] = rng.standard_normal((c["num_key_value_heads"] * hd, H)) * 0.05
+        t[p + "self_attn.v_proj.weight"] = rng.standard_normal((c["num_key_value_heads"] * hd, H)) * 0.05
+        t[p + "self_attn.o_proj.weight"] = rng.standard_normal((H, c["num_attention_heads"] * hd)) * 0.03
+        t[p + "self_attn.q_norm.weight"] = 1 + 0.1 * rng.standard_normal(hd)
+        t[p + "self_attn.k_norm.weight"] = 1 + 0.1 * rng.standard_normal(hd)
+        t[p + "mlp.gate_proj.weight"] = rng.standard_normal((I, H)) * 0.05
+        t[p + "mlp.up_proj.weight"] = rng.standard_normal((I, H)) * 0.05
+        t[p + "mlp.down_proj.weight"] = rng.standard_normal((H, I)) * 0.03
+        t[p + "input_layernorm.weight"] = 1 + 0.1 * rng.standard_normal(H)
+        t[p + "post_attention_layernorm.weight"] = 1 + 0.1 * rng.standard_normal(H)
+    return {k: _bf16_bits(v) for k, v in t.items()}
+
+
+PROMPTS = {"short": [3 + (7 * i) % 1000 for i in range(90)], "long": [5 + (11 * i) % 1000 for i in range(300)]}
+N_DECODE = 24       # replays of the captured step
+
+
+def _run(eng, prompt, n_decode=N_DECODE, feed=None):
+    rid = eng.new_request()
+    tok, lg = eng.prefill([rid], [prompt], return_logits=True)
+    rows, toks = [lg[0].copy()], [int(tok[0])]
+    for i in range(n_decode):
+        t = toks[-1] if feed is None else feed[i]
+        tok, lg = eng.decode([rid], [t], return_logits=True)
+        rows.append(lg[0].copy())
+        toks.append(int(tok[0]))
+    eng.drop_request(rid)
+    return toks, np.stack(rows)
+
+
+def _reference(d):
+    """unsharded engine, decode_mode 1, on the parent's device: tokens + logits bits per prompt"""
+    from pegainfer_amd.qwen3 import Qwen3Engine
+    eng = Qwen3Engine(CFG, num_kv_pages=96, max_batch_size=2, decode_mode=1).load_state(_state())
+    for name, p in PROMPTS.items():
+        toks, rows = _run(eng, p)
+        np.save(os.path.join(d, f"ref_{name}_rows.npy"), rows)
+        np.save(os.path.join(d, f"ref_{name}_toks.npy"), np.asarray(toks))
+    eng.close()
+
+
+def _tp_worker(rank, world, port, out_dir):
+    err = None
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                          PEGAINFER_ONESHOT_TIMEOUT_MS="2000")
+        import torch
+        import torch.distributed as dist
+        from pegainfer_amd import parallel
+        from pegainfer_amd.qwen3 import Qwen3Engine
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        ref_dir = os.environ["PEGAINFER_TP_REF_DIR"]
+        try:
+            comm = parallel.NativeComm(device=0, peer_only=True)
+            assert comm.oneshot
+            state = parallel.shard_qwen3_state(_state(), CFG, rank, world)
+            for mode in (0, 1):
+                eng = Qwen3Engine(parallel.tp_local_config(CFG, world), num_kv_pages=96, max_batch_size=2,
+                                  decode_mode=mode, device=0).load_state(state)
+                eng._chk(eng.lib.pegainfer_qwen3_attach_comm(eng.h, comm.h), "attach_comm")
+                assert eng.lib.pegainfer_qwen3_tp_oneshot_active(eng.h) == 1
+                for name, p in PROMPTS.items():
+                    feed = np.load(os.path.join(ref_dir, f"ref_{name}_toks.npy")).tolist()
+                    dist.barrier()
+                    toks, rows = _run(eng, p, feed=feed)        # teacher-forced on the unsharded engine's tokens
+                    np.save(os.path.join(ref_dir, f"tp_{name}_mode{mode}_rank{rank}.npy"), rows)   # outlives _spawn's directory
+                assert comm.oneshot_status() == 0
+                if mode == 1:
+                    # failure path: the last rank sits this step out; everyone else must get an ERROR naming the
+                    # one-shot wait, never tokens
+                    rid = eng.new_request()
+                    tok = eng.prefill([rid], [PROMPTS["short"]])
+                    dist.barrier()
+                    if rank != world - 1:
+                        with pytest.raises(RuntimeError, match="bounded wait expired"):
+                            eng.decode([rid], tok)
+                    dist.barrier()
+                eng.close()
+            comm.close()
+        finally:
+            dist.destroy_process_group()
+    except BaseException:  # noqa: BLE001 - reported to the parent through the file
+        err = traceback.format_exc()
+    with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as f:
+        f.write(err or "OK")
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_tp_runtime_on_one_gpu_matches_unsharded_engine(built_libs, world, monkeypatch):
+    from oracle.bf16 import bf16_from_bits
+    with tempfile.TemporaryDirectory() as d:
+        _reference(d)
+        monkeypatch.setenv("PEGAINFER_TP_REF_DIR", d)
+        out = _spawn(_tp_worker, world, 420)
+        if any("hipIpc" in o and "OK" != o for o in out):
+            pytest.skip("this box cannot map device memory across processes (hipIpc*): " + out[0][-300:])
+        assert out == ["OK"] * world, "\n".join(o[-1500:] for o in out)
+        for name in PROMPTS:
+            ref = bf16_from_bits(np.load(os.path.join(d, f"ref_{name}_rows.npy")))
+            for mode in (0, 1):
+                ranks = [np.load(os.path.join(d, f"tp_{name}_mode{mode}_rank{r}.npy")) for r in range(world)]
+                for r in range(1, world):          # rank-order f32 sum, one rounding: the same bits on every rank
+                    assert np.array_equal(ranks[0], ranks[r]), (name, mode, r)
+                got = bf16_from_bits(ranks[0])
+                cos = (got * ref).sum(-1) / np.linalg.norm(got, axis=-1) / np.linalg.norm(ref, axis=-1)
+                assert cos.min() > 0.9995 and np.abs(got - ref).max() <= 0.5, (name, mode, cos.min(), np.abs(got - ref).max())
+            a = np.load(os.path.join(d, f"tp_{name}_mode0_rank0.npy"))
+            b = np.load(os.path.join(d, f"tp_{name}_mode1_rank0.npy"))
+            assert np.array_equal(a, b), name      # fused == reference op sequence under TP too

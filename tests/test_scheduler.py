@@ -218,17 +218,18 @@ def test_executor_vtbl_is_size_versioned():
     lib = ffi.host_lib()
     ex = FakeExecutor(8)                       # no max_batch_size attribute -> the short table
     assert not hasattr(ex, "max_batch_size")
-    s = Scheduler.over_callbacks(ex)
+    s = Scheduler.over_callbacks(ex, logprobs=False)     # a caller built before the logprobs block existed either
     vt = s._keep[0]
-    assert vt.struct_size == ExecutorVtbl.max_batch_size.offset < ctypes.sizeof(ExecutorVtbl)
-    # poison the slot behind the declared size on a copy and create a second scheduler from it
+    assert vt.struct_size == ExecutorVtbl.max_batch_size.offset < ExecutorVtbl.logprobs.offset < ctypes.sizeof(ExecutorVtbl)
+    # poison every slot behind the declared size on a copy and create a second scheduler from it
     raw = (ctypes.c_char * ctypes.sizeof(ExecutorVtbl)).from_buffer_copy(vt)
     poisoned = ExecutorVtbl.from_buffer(raw)
-    ctypes.memset(ctypes.addressof(poisoned) + ExecutorVtbl.max_batch_size.offset, 0x41, ctypes.sizeof(ctypes.c_void_p))
+    ctypes.memset(ctypes.addressof(poisoned) + ExecutorVtbl.max_batch_size.offset, 0x41,
+                  ctypes.sizeof(ExecutorVtbl) - ExecutorVtbl.max_batch_size.offset)
     h = lib.pegainfer_sched_create(ctypes.addressof(poisoned), 42)
     assert h
     s2 = Scheduler(h, keep=(poisoned, raw, s))
-    rid = s2.submit([1] * 16, 2)
+    rid = s2.submit([1] * 16, 2, logprobs=3, echo=True)   # ... nor the logprobs / echo callbacks (no logprob comes back)
     ev = run_until_idle(s2)                     # admission consults max_batch_size when non-NULL: must not be called
     assert events_of(ev, rid)[-1][1] == FINISHED
     s2.close()
@@ -236,3 +237,95 @@ def test_executor_vtbl_is_size_versioned():
     poisoned.struct_size = ExecutorVtbl.execute.offset
     assert not lib.pegainfer_sched_create(ctypes.addressof(poisoned), 42)
     s.close()
+
+
+# ---------------------------------------------------------------- logprobs / echo (round 4; executor.rs:211-284, 400-434)
+def test_logprobs_from_logits_matches_the_oracle_restatement():
+    """pegainfer_logprobs_from_logits (the C++ of compute_logprobs_from_cpu) == oracle.ops.compute_logprobs on rows with
+    ties, top_k 0 / 1 / 5 / > n: ids identical (the reference's insertion order on ties), logprobs within 2 f32 ulp (expf)."""
+    import ctypes
+    from oracle import ops as O
+    from pegainfer_amd import ffi
+    lib = ffi.host_lib()
+    rng = np.random.default_rng(11)
+    for n, k in ((7, 0), (7, 1), (7, 5), (7, 9), (1024, 5), (151936, 20), (5, 3)):
+        x = rng.standard_normal(n).astype(np.float32) * 3
+        x = np.round(x * 4) / 4 if n <= 1024 else x           # coarse grid: exact ties
+        tok = int(rng.integers(0, n))
+        lp = ctypes.c_float(0)
+        ids, vals = np.zeros(max(k, 1), np.uint32), np.zeros(max(k, 1), np.float32)
+        got_n = lib.pegainfer_logprobs_from_logits(x.ctypes.data, n, tok, k, ctypes.addressof(lp), ids.ctypes.data,
+                                                   vals.ctypes.data)
+        want_lp, want_top = O.compute_logprobs(x, tok, k)
+        assert got_n == len(want_top) == min(k, n)
+        assert [int(i) for i in ids[:got_n]] == [t for t, _ in want_top], (n, k)
+        assert abs(lp.value - want_lp) <= 4e-6 * max(1.0, abs(want_lp))
+        assert np.allclose(vals[:got_n], [v for _, v in want_top], rtol=0, atol=4e-6 * max(1.0, abs(want_lp)))
+    assert lib.pegainfer_logprobs_from_logits(x.ctypes.data, 0, 0, 1, None, None, None) == -1     # None in the reference
+    assert lib.pegainfer_logprobs_from_logits(x.ctypes.data, 5, 5, 1, None, None, None) == -1
+
+
+def _lp_close(a, b):
+    if a is None or b is None:
+        return a is None and b is None
+    return abs(a[0] - b[0]) < 1e-6 and [t for t, _ in a[1]] == [t for t, _ in b[1]] and \
+        all(abs(x - y) < 1e-6 for (_, x), (_, y) in zip(a[1], b[1]))
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_token_logprobs_and_prompt_echo(kind):
+    """One request with logprobs = 2 + echo prefilled alone (PromptTokens with logprobs [None, lp...], then every
+    token with its TokenLogprob), one arriving while it decodes (Unified: echo comes back with None logprobs,
+    executor.rs:352-358), one without logprobs (None everywhere)."""
+    from oracle.scheduler_ref import PROMPT_TOKEN
+    ex = FakeExecutor(20)
+    s = make(kind, ex)
+    a = s.submit([11, 12, 13], 3, logprobs=2, echo=True)
+    assert s.step() == 1
+    ev = s.poll()
+    echo = [e for e in ev if e[1] == PROMPT_TOKEN]
+    assert [(e[2], e[4], e[5]) for e in echo] == [(11, 0, 3), (12, 1, 3), (13, 2, 3)]
+    assert echo[0][7] is None and _lp_close(echo[1][7], (-0.25, [(12, -2.0), (13, -3.0)]))
+    assert _lp_close(echo[2][7], (-0.5, [(13, -2.0), (14, -3.0)]))
+    tok = [e for e in ev if e[1] == TOKEN][0]
+    assert tok[2] == 100 + a and _lp_close(tok[7], ex.logprobs(0, 100 + a, 2))
+    assert ex.echo_calls == [True]
+    b = s.submit([21, 22], 2, logprobs=1, echo=True)      # admitted next to the active request: Unified
+    c = s.submit([31], 2)
+    assert s.step() == 3
+    ev = s.poll()
+    echo_b = [e for e in ev if e[1] == PROMPT_TOKEN and e[0] == b]
+    assert [e[2] for e in echo_b] == [21, 22] and all(e[7] is None for e in echo_b)
+    assert ex.echo_calls == [True, False]
+    order = [(e[0], e[1]) for e in ev]
+    assert order.index((b, PROMPT_TOKEN)) < order.index((a, TOKEN)) < order.index((b, TOKEN))   # echoes first, decode, prefill
+    tb = [e for e in ev if e[0] == b and e[1] == TOKEN][0]
+    assert _lp_close(tb[7], ex.logprobs(0, 100 + b, 1))
+    tc = [e for e in ev if e[0] == c and e[1] == TOKEN][0]
+    assert tc[7] is None
+    ta = [e for e in ev if e[0] == a and e[1] == TOKEN][0]
+    assert _lp_close(ta[7], ex.logprobs(2, 200 + a, 2))   # decode rows follow the two prompts
+    run_until_idle(s)
+
+
+def test_logprobs_trace_cxx_equals_oracle():
+    """Randomized arrivals with random logprobs / echo settings: the C++ scheduler and the oracle emit the same events
+    with the same TokenLogprobs and make the same executor calls (incl. which steps asked for echo logits)."""
+    rng = np.random.default_rng(5)
+    for trial in range(4):
+        pages = int(rng.integers(8, 40))
+        exo, exc = FakeExecutor(pages), FakeExecutor(pages)
+        so, sc = make("oracle", exo, 9), make("cxx", exc, 9)
+        evo, evc = [], []
+        for it in range(80):
+            for _ in range(int(rng.integers(0, 3))):
+                plen, mx = int(rng.integers(1, 60)), int(rng.integers(1, 20))
+                lpk, echo = int(rng.integers(0, 4)), bool(rng.integers(0, 2))
+                assert so.submit([7] * plen, mx, logprobs=lpk, echo=echo) == sc.submit([7] * plen, mx, logprobs=lpk, echo=echo)
+            assert so.step() == sc.step()
+            evo += so.poll()
+            evc += sc.poll()
+        assert [e[:6] for e in evo] == [e[:6] for e in evc] and len(evo) > 50
+        assert all(_lp_close(a[7], b[7]) for a, b in zip(evo, evc))
+        assert any(e[7] is not None for e in evo) and any(e[1] == 5 for e in evo)
+        assert exo.calls == exc.calls and exo.echo_calls == exc.echo_calls
