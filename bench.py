@@ -13,7 +13,9 @@ Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line f
   value = whole-job decode tokens/s over the K timed steps (max over ranks of the wall time).
   N > 1 (torchrun, one rank per GPU): independent requests shard across ranks with no data-path
   collective ("replicas": weak scaling, every rank decodes its own request); see DESIGN.md §multi-GPU.
-Extra objects: roofline (dominant kernel, HBM bound), cpu_baseline (oracle port on host cores).
+Extra objects: roofline (dominant kernel, HBM bound), cpu_baseline (the reference's CPU path - HF Transformers bf16 - on the
+host cores, on the engine's own checkpoint), parity (the benchmarked 36-layer model vs the oracle and vs HF, outside the
+timed region).
 """
 import argparse
 import json
@@ -47,69 +49,202 @@ def algorithmic_bytes_per_token(cfg, ctx, batch=1):
     return weights + batch * (kv_tok * ctx + kv_tok + 2 * H + 2 * V)
 
 
-def cpu_baseline(cfg, steps, threads, ctx=1024):
-    """Oracle ("port") decode on the host cores: the numpy restatement of the same DAG on a synthetic
-    checkpoint of the SAME shape, bounded to `steps` decode steps at the bench's own context length.
-    Reported baseline only."""
+def export_checkpoint(eng, cfg):
+    """The checkpoint the engine computes with (device-generated synthetic, or real weights), as HF name -> bf16 bits on
+    the host: the CPU legs below run on EXACTLY these weights, so their logits can be compared with the engine's."""
+    c = cfg
+    hd = c["head_dim"]
+    qd, kvd, H, I, V = c["num_attention_heads"] * hd, c["num_key_value_heads"] * hd, c["hidden_size"], c["intermediate_size"], c["vocab_size"]
+    shapes = {"model.embed_tokens.weight": (V, H), "model.norm.weight": (H,)}
+    if not c["tie_word_embeddings"]:
+        shapes["lm_head.weight"] = (V, H)
+    for i in range(c["num_hidden_layers"]):
+        p = f"model.layers.{i}."
+        shapes.update({p + "self_attn.q_proj.weight": (qd, H), p + "self_attn.k_proj.weight": (kvd, H),
+                       p + "self_attn.v_proj.weight": (kvd, H), p + "self_attn.o_proj.weight": (H, qd),
+                       p + "self_attn.q_norm.weight": (hd,), p + "self_attn.k_norm.weight": (hd,),
+                       p + "mlp.gate_proj.weight": (I, H), p + "mlp.up_proj.weight": (I, H),
+                       p + "mlp.down_proj.weight": (H, I), p + "input_layernorm.weight": (H,),
+                       p + "post_attention_layernorm.weight": (H,)})
+    bits = {}
+    for name, shp in shapes.items():
+        a = np.empty(shp, dtype=np.uint16)
+        eng._chk(eng.lib.pegainfer_qwen3_export_tensor(eng.h, name.encode(), a.ctypes.data, a.size), "export " + name)
+        bits[name] = a
+    return bits
+
+
+def gpu_parity_run(eng, prompt, steps):
+    """Outside the timed region: the engine's own greedy run on the bench prompt (prefill + `steps` decode steps, the
+    same graph-captured decode path the timed steps used), logits rows kept for the CPU checkers."""
+    rid = eng.new_request()
+    tok, lg = eng.prefill([rid], [prompt], return_logits=True)
+    toks, rows = [int(tok[0])], [lg[0].copy()]
+    for _ in range(steps):
+        tok, lg = eng.decode([rid], [toks[-1]], return_logits=True)
+        toks.append(int(tok[0]))
+        rows.append(lg[0].copy())
+    eng.drop_request(rid)
+    return toks, np.stack(rows)
+
+
+def cpu_legs(cfg, bits, prompt, gpu_tokens, gpu_rows_bits, steps, threads, hf_repeats=3, hf_new_tokens=33):
+    """bench.py's CPU side, on the host cores of the GPU box, on the SAME checkpoint and the SAME prompt as the GPU leg
+    (rank 0, N = 1 only; a bounded sample).  Two engines:
+
+      * the reference's CPU path: HF Transformers bf16 greedy `generate` (scripts/generate_test_data.py --device cpu;
+        oracle/hf_engine.py) - timed: `cpu_baseline` with kind "reference" (the reference's own engine for this path, imported - it is Python) (TTFT, steady decode tok/s as
+        bench_serving.rs:1005-1008 over `hf_new_tokens` - 1 inter-token gaps, median and spread of `hf_repeats`);
+      * the oracle (oracle/qwen3_ref.py, numpy restatement with the reference's rounding points), teacher-forced on the
+        GPU's own greedy tokens: the parity checker (cosine / max |dlogit| / greedy agreement per step) and the "port"
+        timing of the previous rounds.
+
+    Both are checkers / baselines only: nothing here is on the product path."""
+    from concurrent.futures import ThreadPoolExecutor
+
     from oracle import ops as oracle_ops
-    from oracle.bf16 import bf16_round
+    from oracle.bf16 import bf16_from_bits
     from oracle.qwen3_ref import KvState, Qwen3Config, Qwen3Oracle
-    oracle_ops.GEMM_ACCUM = np.float32   # timing leg: fp32 sgemm like a CPU engine would use
     keys = ["hidden_size", "num_hidden_layers", "num_attention_heads", "num_key_value_heads", "head_dim",
             "intermediate_size", "vocab_size", "rms_norm_eps", "rope_theta", "tie_word_embeddings"]
     c = Qwen3Config(**{k: cfg[k] for k in keys})
-    rng = np.random.default_rng(42)
-    t_gen = time.perf_counter()
+    gpu_rows = bf16_from_bits(gpu_rows_bits)
+    V = gpu_rows.shape[-1]
 
-    class Lazy(dict):
-        """weights materialised layer by layer from a small seeded pool (shape-faithful, values irrelevant
-        for timing; avoids 16 GB of RNG work before the timed region)."""
-    pool = bf16_round((rng.standard_normal(1 << 22) * 0.02).astype(np.float32))
+    def cos_rows(a, b):
+        a, b = a.astype(np.float64), b.astype(np.float64)
+        return (a * b).sum(-1) / np.linalg.norm(a, axis=-1) / np.linalg.norm(b, axis=-1)
 
-    def t(*shape, mean=0.0):
-        n = int(np.prod(shape))
-        reps = -(-n // pool.size)
-        a = np.tile(pool, reps)[:n].reshape(shape)
-        return a + np.float32(mean) if mean else a
-    w = {"model.embed_tokens.weight": t(c.vocab_size, c.hidden_size), "model.norm.weight": t(c.hidden_size, mean=1.0)}
-    if not c.tie_word_embeddings:
-        w["lm_head.weight"] = t(c.vocab_size, c.hidden_size)
-    for i in range(c.num_hidden_layers):
-        p = f"model.layers.{i}."
-        w[p + "self_attn.q_proj.weight"] = t(c.q_dim, c.hidden_size)
-        w[p + "self_attn.k_proj.weight"] = t(c.kv_dim, c.hidden_size)
-        w[p + "self_attn.v_proj.weight"] = t(c.kv_dim, c.hidden_size)
-        w[p + "self_attn.o_proj.weight"] = t(c.hidden_size, c.q_dim)
-        w[p + "self_attn.q_norm.weight"] = t(c.head_dim, mean=1.0)
-        w[p + "self_attn.k_norm.weight"] = t(c.head_dim, mean=1.0)
-        w[p + "mlp.gate_proj.weight"] = t(c.intermediate_size, c.hidden_size)
-        w[p + "mlp.up_proj.weight"] = t(c.intermediate_size, c.hidden_size)
-        w[p + "mlp.down_proj.weight"] = t(c.hidden_size, c.intermediate_size)
-        w[p + "input_layernorm.weight"] = t(c.hidden_size, mean=1.0)
-        w[p + "post_attention_layernorm.weight"] = t(c.hidden_size, mean=1.0)
-    # the SAME workload as the timed GPU leg: one request at --ctx cached tokens.  The prompt's KV is not computed
-    # (a 36-layer numpy prefill of 1024 tokens would be minutes of untimed CPU work): the request's pages are
-    # filled with seeded bf16 values directly - decode cost depends on the KV bytes scanned, not on their values
-    npages = -(-(ctx + steps + 1) // 16) + 2
-    m = Qwen3Oracle(c, w, num_pages=npages, rope_positions=ctx + steps + 16)
+    parity = {"checkpoint": "the engine's own weights exported to the host (pegainfer_qwen3_export_tensor)",
+              "prompt_tokens": len(prompt), "steps": len(gpu_tokens), "gpu_tokens": gpu_tokens}
+    baseline = None
+    # ---- the reference's CPU path: HF Transformers on the same weights ----
+    try:
+        from oracle import hf_engine
+        t0 = time.perf_counter()
+        model = hf_engine.build_qwen3(cfg, bits, threads=threads)
+        build_s = time.perf_counter() - t0
+        rates, ttfts, hf_tokens = [], [], None
+        for rep in range(hf_repeats):
+            t0 = time.perf_counter()
+            toks, stamps, lg = hf_engine.generate_greedy(model, prompt, hf_new_tokens, return_logits=(rep == 0))
+            if rep == 0:
+                hf_tokens, hf_logits = toks, lg
+            ttfts.append(stamps[1] - t0)
+            rates.append((len(stamps) - 2) / (stamps[-1] - stamps[1]))
+        del model
+        n = min(len(gpu_tokens), len(hf_tokens))
+        first_diff = next((i for i in range(n) if gpu_tokens[i] != hf_tokens[i]), None)
+        # logits are comparable while both engines are on the same token stream, i.e. up to the first difference
+        m = n if first_diff is None else first_diff + 1
+        cs = cos_rows(gpu_rows[:m], hf_logits[:m])
+        srt = np.sort(hf_logits[:n], axis=-1)
+        parity["hf"] = {"engine": "transformers bf16 generate(do_sample=False), the reference's truth engine",
+                        "tokens": hf_tokens[:n], "tokens_equal_prefix": n if first_diff is None else first_diff,
+                        "first_diff_step": first_diff, "steps_compared": m, "cos_min": round(float(cs.min()), 6),
+                        "max_dlogit": round(float(np.abs(gpu_rows[:m] - hf_logits[:m]).max()), 4),
+                        "hf_top1_margin": [round(float(x), 4) for x in (srt[:, -1] - srt[:, -2])[:m]]}
+        baseline = {"value": round(float(np.median(rates)), 3), "unit": "tokens/s", "cores": int(threads),
+                    "kind": "reference", "engine": "hf-transformers " + __import__("transformers").__version__,
+                    "spread": {"min": round(float(min(rates)), 3), "max": round(float(max(rates)), 3), "repeats": hf_repeats},
+                    "ttft_s": round(float(np.median(ttfts)), 3),
+                    "sample": f"HF Transformers Qwen3ForCausalLM bf16 on the host cores ({threads} torch threads), the "
+                              f"reference's CPU path (scripts/generate_test_data.py --device cpu) on the engine's own "
+                              f"checkpoint: {hf_repeats} x generate({len(prompt)}-token bench prompt -> {hf_new_tokens} tokens, "
+                              f"greedy); value = steady decode tokens/s over the {hf_new_tokens - 1} inter-token gaps "
+                              f"(median of the repeats), model build {build_s:.0f} s untimed"}
+    except Exception as e:  # noqa: BLE001 - transformers absent / out of memory: the port below still reports
+        parity["hf"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    # ---- the oracle on the same weights, teacher-forced on the GPU's tokens ----
+    oracle_ops.GEMM_ACCUM = np.float32   # fp32 sgemm: what a CPU engine (and cuBLAS COMPUTE_32F) accumulates in
+    t_setup = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=max(1, min(32, threads))) as pool:
+        names = list(bits)
+        w = dict(zip(names, pool.map(lambda k: bf16_from_bits(bits[k]), names)))
+    m = Qwen3Oracle(c, w, num_pages=-(-(len(prompt) + steps + 1) // 16) + 2, rope_positions=len(prompt) + steps + 16)
     st = KvState()
-    m._ensure(st, ctx)
-    st.seq_len = ctx
-    kvpool = bf16_round((np.random.default_rng(7).standard_normal(1 << 20) * 0.5).astype(np.float32))
-    m.kv[m.layout.page_stride:] = np.resize(kvpool, m.kv.size - m.layout.page_stride)
-    setup_s = time.perf_counter() - t_gen
+    rows = [m.batch_prefill([prompt], [st])[0]]
+    setup_s = time.perf_counter() - t_setup
     t0 = time.perf_counter()
-    tok = 100
-    for _ in range(steps):
-        tok = int(m.batch_decode([tok], [st])[0].argmax())
+    for tk in gpu_tokens[:-1]:
+        rows.append(m.batch_decode([tk], [st])[0])
     dt = time.perf_counter() - t0
-    return {"value": steps / dt, "unit": "tokens/s", "cores": threads, "kind": "port",
-            "sample": f"{steps} greedy decode steps, bs=1, ctx {ctx}->{ctx + steps} (the GPU leg's workload; KV pages "
-                      f"seeded directly, no CPU prefill), oracle/qwen3_ref.py (numpy fp32 matmul over bf16-valued "
-                      f"weights) on a synthetic checkpoint of the same shape; {dt:.1f} s timed, {setup_s:.0f} s "
-                      f"untimed setup"}
+    R = np.stack(rows)
+    cs = cos_rows(gpu_rows, R)
+    dl = np.abs(gpu_rows - R).max(-1)
+    agree = gpu_rows.argmax(-1) == R.argmax(-1)
+    srt = np.sort(R, axis=-1)
+    margin = srt[:, -1] - srt[:, -2]
+    parity.update({"cos_min": round(float(cs.min()), 6), "max_dlogit": round(float(dl.max()), 4),
+                   "logit_scale": round(float(np.abs(R).max()), 3),
+                   "tokens_equal": int(agree.sum()), "tokens_differing_away_from_a_near_tie": int((~agree & (margin > 2 * dl)).sum()),
+                   "oracle": "oracle/qwen3_ref.py teacher-forced on the GPU's greedy tokens (prefill + every decode step)"})
+    port = {"value": round((len(gpu_tokens) - 1) / dt, 3), "unit": "tokens/s", "cores": int(threads), "kind": "port",
+            "sample": f"{len(gpu_tokens) - 1} decode steps of oracle/qwen3_ref.py (numpy fp32 sgemm) at ctx {len(prompt)}, same "
+                      f"checkpoint; {dt:.1f} s timed, {setup_s:.0f} s untimed (weights to f32 + the {len(prompt)}-token prefill)"}
+    if baseline is None:
+        baseline = port
+    else:
+        baseline["port"] = port
+    return baseline, parity
 
 
+def traffic_probe_main(model, bs):
+    """`bench.py --traffic-probe` (run UNDER rocprofv3 --pmc by measure_traffic): a 2-layer engine of the benchmarked
+    shape launches the dominant kernel - the gate_up GEMV with its add + RMSNorm prologue and SwiGLU epilogue - 40
+    times over cold weights.  No torch, no timing: the counters are the product."""
+    from pegainfer_amd.qwen3 import QWEN3_4B, QWEN3_8B, Qwen3Engine
+    cfg = dict(QWEN3_4B if model == "qwen3-4b" else QWEN3_8B, num_hidden_layers=2)
+    eng = Qwen3Engine(cfg, num_kv_pages=8, max_batch_size=max(bs, 1), decode_mode=1, max_positions=4096)
+    eng.fill_synthetic(seed=42, std=0.02)
+    eng.bench_gemv(5, 40, bs)
+    eng.close()
+    return 0
+
+
+def measure_traffic(model, bs, kernel_prefix="gemv_fused_kernel<1, 1, 1, 1"):
+    """HBM bytes per launch of the dominant kernel from the PMC counters, measured NOW: FETCH_SIZE and WRITE_SIZE in their
+    own rocprofv3 passes (they do not fit one pass: MI355X_MICROARCH.md 'rocprofv3 PMC slots'), --kernel-trace only, KiB
+    per dispatch, FETCH_SIZE x 2 (the guide's gfx950 correction: a wide coalesced stream is reported at half).  Returns
+    (bytes, description) or (None, reason)."""
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not exe:
+        return None, "rocprofv3 not on this box"
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        with tempfile.TemporaryDirectory(dir="/tmp") as d:
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "-d", d, "-o", "run", "--", sys.executable,
+                   os.path.abspath(__file__), "--traffic-probe", "--model", model, "--batch", str(bs)]
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE,
+                                   stderr=subprocess.STDOUT, timeout=180)
+            except subprocess.TimeoutExpired:
+                return None, f"rocprofv3 --pmc {counter} timed out"
+            dbs = [os.path.join(r_, f) for r_, _, fs in os.walk(d) for f in fs if f.endswith(".db")]
+            if r.returncode != 0 or not dbs:
+                return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode})"
+            db = sqlite3.connect(dbs[0])
+            cols = [c[1] for c in db.execute("pragma table_info(counters_collection)")]
+            kname = "kernel_name" if "kernel_name" in cols else [c for c in cols if "name" in c and "kernel" in c][0]
+            cname = "counter_name" if "counter_name" in cols else [c for c in cols if "counter" in c and "name" in c][0]
+            vname = "value" if "value" in cols else [c for c in cols if "value" in c][0]
+            tot, n = 0.0, 0
+            for k, c, v in db.execute(f"select {kname}, {cname}, {vname} from counters_collection"):
+                if c == counter and kernel_prefix in k.replace("void ", "").replace("pk::", ""):
+                    tot += float(v)
+                    n += 1
+            db.close()
+            if n == 0:
+                return None, f"no {kernel_prefix} dispatch in the {counter} pass"
+            vals[counter] = (tot / n, n)
+    traffic = int(2 * vals["FETCH_SIZE"][0] * 1024 + vals["WRITE_SIZE"][0] * 1024)
+    return traffic, ("measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) "
+                     f"over {vals['FETCH_SIZE'][1]} dispatches of the kernel on cold weights; KiB per dispatch, FETCH_SIZE x 2 "
+                     "(gfx950 correction, MI355X_MICROARCH.md)")
 
 
 MFMA_PEAK_TFLOPS = 2500.0  # MI355X dense bf16 (MI355X_MICROARCH.md); never the 2:1-sparsity figure
@@ -304,7 +439,9 @@ def main():
                     help="0 = reference op sequence 1:1, 1 = fused MI355X decode kernels (bit-identical)")
     ap.add_argument("--split-policy", type=int, default=1)
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=12, help="decode steps for the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-steps", type=int, default=8,
+                    help="decode steps of the parity run (GPU vs oracle vs HF on the same checkpoint) and of the oracle's "
+                         "timing; 0 = skip the whole CPU side")
     ap.add_argument("--ttft-iters", type=int, default=20, help="TTFT iterations at --ctx (reference: warmup 5, iters 20)")
     ap.add_argument("--ttft10k-iters", type=int, default=5,
                     help="iterations of the reference's prefill_heavy profile (10 000-token prompt -> 1 token, "
@@ -323,7 +460,10 @@ def main():
                     help="N>1: 'replicas' = one independent request stream per GPU (weak scaling, no data-path "
                          "collective; default); 'tp' = the reference's Qwen3 tensor parallel over RCCL "
                          "(strong scaling, 72 all-reduces per step)")
+    ap.add_argument("--traffic-probe", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.traffic_probe:
+        return traffic_probe_main(args.model, args.batch)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: become the launcher - one process per GPU over RCCL, exactly what the
@@ -541,13 +681,17 @@ def main():
         gate_up_bytes = 2 * I * H * 2 + args.batch * (2 * H * 2 + H * 2 + I * 2) + H * 2
         ms = eng.bench_gemv(5 if fused else 2, 360, args.batch)
         achieved = gate_up_bytes / (ms * 1e-3) / 1e9
-        # HBM bytes per launch from the PMC counters: collected in their own rocprofv3 --pmc passes (tools/
-        # gpu_refresh_profiles.sh) and REPLAYED here from the committed CSVs of the newest round - not measured in this run
-        traffic, traffic_src = None, None
+        # HBM bytes per launch from the PMC counters.  Measured live (two rocprofv3 --pmc passes over a probe process that
+        # launches this kernel, after the timed region) when rocprofv3 is on the box; otherwise REPLAYED from the committed
+        # CSVs of the newest round and labelled so.  PEGAINFER_BENCH_TRAFFIC=0 skips the live passes.
+        traffic, traffic_src, replayed = None, None, False
+        if fused and world == 1 and os.environ.get("PEGAINFER_BENCH_TRAFFIC", "1") != "0":
+            traffic, traffic_src = measure_traffic(args.model, args.batch)
         prof = next((q for q in (os.path.join(ROOT, "profiles", f"r{r}_fused_pmc_FETCH_SIZE.csv") for r in (5, 4, 3, 2, 1))
                      if os.path.exists(q)), None)
-        if prof and fused and args.batch == 1 and args.model == "qwen3-4b":
+        if traffic is None and prof and fused and args.batch == 1 and args.model == "qwen3-4b":
             import csv
+            why = traffic_src
             fetch = {r["kernel"]: float(r["avg_value"]) for r in csv.DictReader(open(prof)) if r["counter"] == "FETCH_SIZE"}
             wprof = prof.replace("FETCH_SIZE", "WRITE_SIZE")
             wr = {r["kernel"]: float(r["avg_value"]) for r in csv.DictReader(open(wprof))} if os.path.exists(wprof) else {}
@@ -555,13 +699,14 @@ def main():
             kname = next((k for k in fetch if k.startswith("gemv_fused_kernel<1, 1, 1, 1")), None)
             if kname:   # KiB per dispatch; gfx950 FETCH_SIZE reports 1/2 of a wide coalesced stream -> x2
                 traffic = int(2 * fetch[kname] * 1024 + wr.get(kname, 0.0) * 1024)
+                replayed = True
                 traffic_src = ("replayed from " + os.path.relpath(prof, ROOT) + " (x2 gfx950 correction) + WRITE_SIZE, separate "
-                               "rocprofv3 --pmc passes; not measured in this run")
+                               "rocprofv3 --pmc passes; not measured in this run" + (f" ({why})" if why else ""))
         out["roofline"] = {"bound": "hbm",
                            "kernel": ("gemv_fused_kernel<NT=1,RPW=1,KSPLIT=1,EPI=silu> (gate_up, M=%d K=%d N=%d)" if fused
                                       else "gemv_fused_kernel<NT,RPW=2,KSPLIT=1,EPI=store> (gate_up, M=%d K=%d N=%d)") % (2 * I, H, args.batch),
                            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_replayed": traffic is not None,
+                           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_replayed": replayed,
                            "traffic_source": traffic_src,
                            "bytes_per_launch": gate_up_bytes, "avg_launch_us": round(ms * 1e3, 2)}
         per_site = {}
@@ -571,18 +716,26 @@ def main():
             t = eng.bench_gemv(which, 72 if which != 4 else 20, args.batch)
             per_site[name] = {"us": round(t * 1e3, 2), "GBps": round(M * K * 2 / (t * 1e-3) / 1e9, 1)}
         out["gemv_sites"] = per_site
+    # ---- CPU side (rank 0, N = 1): parity of the benchmarked model + the reference's CPU path as the baseline ----
+    cpu_inputs = None
+    if rank == 0 and args.cpu_steps > 0 and world == 1 and not mp8_hung:
+        try:
+            gtoks, grows = gpu_parity_run(eng, prompt, args.cpu_steps)
+            cpu_inputs = (export_checkpoint(eng, cfg), gtoks, grows)
+        except Exception as e:  # noqa: BLE001
+            out["parity"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     if not mp8_hung:   # freeing device memory synchronises the device - behind a stuck collective it never returns
         eng.close()
     if rank == 0:
-        if args.cpu_steps > 0 and world == 1:
-            threads = os.cpu_count() or 1
+        out["cpu_baseline"] = None
+        if cpu_inputs is not None:
+            threads = int(os.environ.get("PEGAINFER_CPU_THREADS", "0")) or (os.cpu_count() or 1)
             try:
-                out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_steps, threads, args.ctx)
+                out["cpu_baseline"], out["parity"] = cpu_legs(cfg, cpu_inputs[0], prompt, cpu_inputs[1], cpu_inputs[2],
+                                                              args.cpu_steps, threads)
             except MemoryError:
                 out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": threads, "kind": "port",
                                        "sample": "skipped: host RAM too small for the fp32 oracle weights"}
-        else:
-            out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
     if mp8_hung:
         os._exit(0)   # a stuck collective would also block the teardown; the line is out

@@ -108,3 +108,41 @@ def test_committed_bench_line_carries_the_contract_fields():
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in c, key
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0
+    if "parity" in d:   # since round 4: the benchmarked 36-layer model against the oracle (and HF) on its own checkpoint
+        p = d["parity"]
+        for key in ("steps", "cos_min", "max_dlogit", "tokens_equal"):
+            assert key in p, key
+        assert p["cos_min"] > 0.99 and p["tokens_differing_away_from_a_near_tie"] == 0
+
+
+def test_cpu_legs_run_on_a_tiny_checkpoint():
+    """bench.py's CPU side end to end on a tiny seeded checkpoint (no GPU): the HF reference engine and the oracle run on
+    the same exported-style bits, the parity block compares them with 'GPU' rows (here: the oracle's own, so the oracle
+    distance is exactly zero and HF sits at the oracle-vs-HF distance), and the baseline carries the contract keys."""
+    pytest.importorskip("transformers")
+    import numpy as np
+    from oracle import ops as O
+    from oracle.bf16 import bf16_bits
+    from oracle.qwen3_ref import KvState, Qwen3Config, Qwen3Oracle, synthetic_weights
+    cfgd = dict(hidden_size=256, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2, head_dim=128,
+                intermediate_size=512, vocab_size=1024, rms_norm_eps=1e-6, rope_theta=1e6, tie_word_embeddings=True,
+                max_position_embeddings=4096)
+    cfg = Qwen3Config(**cfgd)
+    w, bits = synthetic_weights(cfg, seed=3, std=0.05, with_bits=True)
+    prompt = [100 + (i % 900) for i in range(40)]
+    old = O.GEMM_ACCUM
+    O.GEMM_ACCUM = np.float32
+    try:
+        m = Qwen3Oracle(cfg, w, num_pages=16)
+        st = KvState()
+        rows = [m.batch_prefill([prompt], [st])[0]]
+        toks = [int(rows[0].argmax())]
+        for _ in range(4):
+            rows.append(m.batch_decode([toks[-1]], [st])[0])
+            toks.append(int(rows[-1].argmax()))
+        base, par = bench.cpu_legs(cfgd, bits, prompt, toks, bf16_bits(np.stack(rows)), 4, 4, hf_repeats=1, hf_new_tokens=6)
+    finally:
+        O.GEMM_ACCUM = old
+    assert base["kind"] == "reference" and base["value"] > 0 and base["port"]["kind"] == "port"
+    assert par["cos_min"] == 1.0 and par["max_dlogit"] == 0.0 and par["tokens_equal"] == 5
+    assert par["hf"]["cos_min"] > 0.999 and par["hf"]["steps_compared"] >= 1
