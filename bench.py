@@ -88,7 +88,7 @@ def gpu_parity_run(eng, prompt, steps):
     return toks, np.stack(rows)
 
 
-def cpu_legs(cfg, bits, prompt, gpu_tokens, gpu_rows_bits, steps, threads, hf_repeats=3, hf_new_tokens=33):
+def cpu_legs(cfg, bits, prompt, gpu_tokens, gpu_rows_bits, steps, threads, hf_repeats=3, hf_new_tokens=33, hf_threads=None):
     """bench.py's CPU side, on the host cores of the GPU box, on the SAME checkpoint and the SAME prompt as the GPU leg
     (rank 0, N = 1 only; a bounded sample).  Two engines:
 
@@ -122,7 +122,8 @@ def cpu_legs(cfg, bits, prompt, gpu_tokens, gpu_rows_bits, steps, threads, hf_re
     try:
         from oracle import hf_engine
         t0 = time.perf_counter()
-        model = hf_engine.build_qwen3(cfg, bits, threads=threads)
+        hf_threads = int(hf_threads or threads)
+        model = hf_engine.build_qwen3(cfg, bits, threads=hf_threads)
         build_s = time.perf_counter() - t0
         rates, ttfts, hf_tokens = [], [], None
         for rep in range(hf_repeats):
@@ -144,11 +145,11 @@ def cpu_legs(cfg, bits, prompt, gpu_tokens, gpu_rows_bits, steps, threads, hf_re
                         "first_diff_step": first_diff, "steps_compared": m, "cos_min": round(float(cs.min()), 6),
                         "max_dlogit": round(float(np.abs(gpu_rows[:m] - hf_logits[:m]).max()), 4),
                         "hf_top1_margin": [round(float(x), 4) for x in (srt[:, -1] - srt[:, -2])[:m]]}
-        baseline = {"value": round(float(np.median(rates)), 3), "unit": "tokens/s", "cores": int(threads),
+        baseline = {"value": round(float(np.median(rates)), 3), "unit": "tokens/s", "cores": int(hf_threads),
                     "kind": "reference", "engine": "hf-transformers " + __import__("transformers").__version__,
                     "spread": {"min": round(float(min(rates)), 3), "max": round(float(max(rates)), 3), "repeats": hf_repeats},
                     "ttft_s": round(float(np.median(ttfts)), 3),
-                    "sample": f"HF Transformers Qwen3ForCausalLM bf16 on the host cores ({threads} torch threads), the "
+                    "sample": f"HF Transformers Qwen3ForCausalLM bf16 on the host cores ({hf_threads} torch threads of {threads} cores), the "
                               f"reference's CPU path (scripts/generate_test_data.py --device cpu) on the engine's own "
                               f"checkpoint: {hf_repeats} x generate({len(prompt)}-token bench prompt -> {hf_new_tokens} tokens, "
                               f"greedy); value = steady decode tokens/s over the {hf_new_tokens - 1} inter-token gaps "
@@ -729,10 +730,14 @@ def main():
     if rank == 0:
         out["cpu_baseline"] = None
         if cpu_inputs is not None:
-            threads = int(os.environ.get("PEGAINFER_CPU_THREADS", "0")) or (os.cpu_count() or 1)
+            threads = os.cpu_count() or 1
+            # torch threads of the HF leg: measured on the pool's 256-core hosts with tools/hf_threads_probe.py (8 layers of
+            # this shape, decode tok/s): 32 threads 15.1, 64 -> 7.4, 128 -> 2.3 (a 2560-wide GEMV per op does not feed 256
+            # threads; their barriers dominate) - so 32 unless PEGAINFER_CPU_THREADS says otherwise
+            hf_threads = int(os.environ.get("PEGAINFER_CPU_THREADS", "0")) or min(32, threads)
             try:
                 out["cpu_baseline"], out["parity"] = cpu_legs(cfg, cpu_inputs[0], prompt, cpu_inputs[1], cpu_inputs[2],
-                                                              args.cpu_steps, threads)
+                                                              args.cpu_steps, threads, hf_threads=hf_threads)
             except MemoryError:
                 out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": threads, "kind": "port",
                                        "sample": "skipped: host RAM too small for the fp32 oracle weights"}

@@ -19,6 +19,12 @@
 // acc_even[i = 2 r] + acc_odd[i = 2 r + 1] - both in the same lane of the D layout, so no cross-lane traffic.
 // Half of the MFMA work is discarded on purpose: the op is priced against the HBM roofline, not the MFMA one.
 //
+// Row blocks are at most 16 rows high, but not necessarily 16 (round 4): a launch whose 16-row blocks would not deal
+// evenly onto the 256 CUs takes the block height that does (2560 rows: 160 blocks of 16 -> 256 blocks of 10; a streaming
+// CU ingests ~24 GB/s, so 160 busy CUs cap the launch at 3.8 TB/s).  Rows past a block's height are clamped duplicates
+// of its last row in the loads (same cache lines, no extra HBM traffic) and never stored; a row's K order does not
+// depend on the block it sits in, so the bits do not change.
+//
 // x sits in LDS ([T][KT] tile, or the whole [T][K] block in the resident variant) with the 16-byte chunk index
 // XOR-swizzled by token so the 16 token rows of a fragment read hit 16 different bank groups.  The 8 waves'
 // partial sums meet in LDS and are added in fixed wave order.
@@ -164,8 +170,10 @@ __global__ __launch_bounds__(kSkinnyThreads) void skinny_mfma_kernel(const GemvF
   float* sm_inv = reinterpret_cast<float*>(smem_raw + (size_t)skinny_xs_bytes(NB, T, KT));  // [64] inverse RMS per token
   const SkinnyLane L;
   const int tid = threadIdx.x;
-  const int rows_total = EPI == kEpiSilu ? a.I : a.M;
-  const int row0 = blockIdx.x * 16 * RB;
+  const int rpb = RB == 1 && a.rpb ? a.rpb : 16;   // rows per row block (launcher: skinny_pick_rpb)
+  const int row0 = blockIdx.x * rpb * RB;
+  const int rows_all = EPI == kEpiSilu ? a.I : a.M;
+  const int rows_total = RB == 1 ? (row0 + rpb < rows_all ? row0 + rpb : rows_all) : rows_all;   // this block's row limit
   const Half* wptr[NW][RB][2];
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb)
@@ -382,7 +390,8 @@ __global__ __launch_bounds__(kSkinnyThreads) void skinny_resident_kernel(const G
   const SkinnyLane L;
   const int tid = threadIdx.x;
   const int rows_total = EPI == kEpiSilu ? a.I : a.M;
-  const int nrb = (rows_total + 15) >> 4;
+  const int rpb = a.rpb ? a.rpb : 16;          // rows per row block (launcher: skinny_pick_rpb)
+  const int nrb = (rows_total + rpb - 1) / rpb;
   const int np = K >> 6;                       // 64-wide K pairs (K % 64 == 0)
   const int my_np = (np + kSkinnyWaves - 1) / kSkinnyWaves;   // items per row block, same for every wave
   const int my_rb = (nrb - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
@@ -394,13 +403,15 @@ __global__ __launch_bounds__(kSkinnyThreads) void skinny_resident_kernel(const G
     for (int c = 0; c < CH; ++c) {
       const int item = item0 + c < total ? item0 + c : total - 1;
       const int rbi = item / my_np, pi = item - rbi * my_np;
-      const int row0 = ((int)blockIdx.x + rbi * (int)gridDim.x) * 16 + L.prow;
+      const int blk0 = ((int)blockIdx.x + rbi * (int)gridDim.x) * rpb;
+      const int lim = blk0 + rpb < rows_total ? blk0 + rpb : rows_total;   // rows of this block: [blk0, lim)
+      const int row0 = blk0 + L.prow;
       int pair = L.wave + kSkinnyWaves * pi;
       pair = pair < np ? pair : np - 1;          // clamped load of a valid address; skipped in the MFMA loop
 #pragma unroll
       for (int rh = 0; rh < 2; ++rh) {
         int row = row0 + rh * 8;
-        row = row < rows_total ? row : rows_total - 1;
+        row = row < lim ? row : lim - 1;
 #pragma unroll
         for (int w = 0; w < NW; ++w)
           av[w][c][rh] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(
@@ -521,7 +532,8 @@ __global__ __launch_bounds__(kSkinnyThreads) void skinny_resident_kernel(const G
       for (int nb = 0; nb < NB; ++nb) red[((L.wave * NW + w) * NB + nb) * 64 + L.lane] = skinny_fold(acc[w][nb]);
     zero();
     __syncthreads();
-    skinny_reduce_store<NB, EPI>(a, red, ((int)blockIdx.x + rbi * (int)gridDim.x) * 16, rows_total, tid);
+    const int blk0 = ((int)blockIdx.x + rbi * (int)gridDim.x) * rpb;
+    skinny_reduce_store<NB, EPI>(a, red, blk0, blk0 + rpb < rows_total ? blk0 + rpb : rows_total, tid);
     __syncthreads();
   };
   auto compute = [&](int item0, const u32x4 (&av)[NW][CH][2]) {
@@ -561,12 +573,30 @@ __global__ __launch_bounds__(kSkinnyThreads) void skinny_resident_kernel(const G
   }
 }
 
+// Row-block height (<= 16) that deals the row blocks evenly onto the CUs: k = the rounds 16-row blocks would need,
+// height = ceil(rows / (k * CUs)).  2560 rows -> 10 (256 blocks), 6144 -> 12 (512), 9728 -> 13 (749 of 768), 4096 -> 16.
+// PEGAINFER_SKINNY_RPB=0 keeps 16-row blocks (A/B); a positive value forces that height.
+inline int skinny_pick_rpb(int rows) {
+  static const int env = [] { const char* e = getenv("PEGAINFER_SKINNY_RPB"); return e && *e ? atoi(e) : -1; }();
+  if (env == 0) return 16;
+  if (env > 0) return env > 16 ? 16 : env;
+  static const int cus = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 0 ? n : 256;
+  }();
+  const int rounds = ceil_div(ceil_div(rows, 16), cus);
+  int h = ceil_div(rows, rounds * cus);
+  return h < 1 ? 1 : (h > 16 ? 16 : h);
+}
+
 template <int NB, int EPI>
 inline void skinny_launch_resident(GemvFusedArgs a, hipStream_t s) {
   constexpr int NW = EPI == kEpiSilu ? 2 : 1;
   a.KT = a.K;
   const int rows = EPI == kEpiSilu ? a.I : a.M;
-  const int nrb = ceil_div(rows, 16);
+  a.rpb = skinny_pick_rpb(rows);
+  const int nrb = ceil_div(rows, a.rpb);
   const int lds = ((a.T * a.K * 2 + 15) & ~15) + 8 * NW * NB * 64 * 16 + 64 * 4;
   auto kern = &skinny_resident_kernel<NB, EPI>;
   static const bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -586,8 +616,9 @@ inline void skinny_launch_resident(GemvFusedArgs a, hipStream_t s) {
 }
 
 template <int NB, int EPI, int RB>
-inline void skinny_launch_rb(const GemvFusedArgs& a, hipStream_t s) {
+inline void skinny_launch_rb(GemvFusedArgs a, hipStream_t s) {
   const int rows = EPI == kEpiSilu ? a.I : a.M;
+  a.rpb = RB == 1 ? skinny_pick_rpb(rows) : 16;
   // the LDS-DMA form of the kernel (plain x, <= 16 columns, 2048-wide tiles) keeps two x tile buffers
   const bool dma_form = NB == 1 && RB == 1 && EPI != kEpiSilu && !a.norm_w && a.KT == 2048 && (a.K & 511) == 0 && a.T <= 16;
   const int lds = skinny_xs_bytes(NB, a.T, a.KT) * (dma_form ? 2 : 1) + (64 + 4) * 4;
@@ -595,7 +626,7 @@ inline void skinny_launch_rb(const GemvFusedArgs& a, hipStream_t s) {
   static const bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
   (void)once;
-  kern<<<ceil_div(rows, 16 * RB), kSkinnyThreads, lds, s>>>(a);
+  kern<<<ceil_div(rows, a.rpb * RB), kSkinnyThreads, lds, s>>>(a);
 }
 template <int NB, int EPI>
 inline void skinny_launch(GemvFusedArgs a, hipStream_t s) {
