@@ -35,7 +35,7 @@ pegainfer_status_t pegainfer_batched_top1(const Half* logits, int32_t vocab_size
  * take (K % 8, misaligned, ...) so the caller can fall back to the unfused sequence. */
 pegainfer_status_t pegainfer_gemv_fused(const Half* W, const Half* X, Half* Y, int32_t M, int32_t T, int32_t K, const Half* residual, const Half* norm_weight, Half* hidden_out, float eps, int32_t silu_intermediate, pegainfer_stream_t stream);
 
-/* pegainfer_gemv_fused with the Qwen3.5 rounding points (T <= 4): flags bit 0 = the norm weight is (1 + w)
+/* pegainfer_gemv_fused with other rounding points (bits 0 and 2: T <= 4; bit 1 alone: T <= 16): flags bit 0 = the norm weight is (1 + w)
  * (rms_norm_batched_offset_cuda), bit 1 = hidden_out = bf16(X + residual) and the norm runs over that ROUNDED sum
  * (add_cuda then rms_norm_batched_offset_cuda, batch_decode.rs:246-262) instead of FlashInfer's fused add+norm,
  * bit 2 = SwiGLU as bf16(bf16(silu(gate)) * up) (silu_mul_triton_aot_cuda, elementwise.cu:28-42).  Bit-identical to
@@ -82,6 +82,11 @@ pegainfer_status_t pegainfer_gemm_add_then_rms_norm(const Half* W, const Half* X
  * of every token go to cache slot page_indices[page_indptr[batch_indices[i]] + positions[i] / page_size] - the same
  * bytes the two calls leave in q, k and the cache. */
 int32_t pegainfer_qk_norm_rope_scatter(Half* q, Half* k, const Half* v, const Half* q_norm_weight, const Half* k_norm_weight, const Half* cos_cache, const Half* sin_cache, const int32_t* positions, const int32_t* batch_indices, Half* kv_data, int64_t k_offset_elems, int64_t v_offset_elems, const int32_t* page_indices, const int32_t* page_indptr, int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim, int32_t page_size, int64_t stride_page, int32_t tokens, float rms_eps, pegainfer_stream_t stream);
+/* the same over the row-stacked output of ONE q|k|v GEMM (qkv [tokens][(Hq + 2 Hkv) * 128], the fused decode path's
+ * layout): normalised + rotated q heads go to the dense q_out [tokens][Hq * 128] the prefill attention reads, k heads
+ * (normalised + rotated) and v heads straight to their cache slots.  Same bytes in q and in the cache as the three-buffer
+ * form; used by the short-prompt prefill path (<= 16 tokens: one stacked GEMV with the norm in its prologue). */
+int32_t pegainfer_qkv_stacked_norm_rope_scatter(const Half* qkv, Half* q_out, const Half* q_norm_weight, const Half* k_norm_weight, const Half* cos_cache, const Half* sin_cache, const int32_t* positions, const int32_t* batch_indices, Half* kv_data, int64_t k_offset_elems, int64_t v_offset_elems, const int32_t* page_indices, const int32_t* page_indptr, int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim, int32_t page_size, int64_t stride_page, int32_t tokens, float rms_eps, pegainfer_stream_t stream);
 
 /* Decode attention with the per-head q/k RMSNorm + RoPE and the KV append folded in (head_dim 128):
  * reads the raw fused-QKV GEMV output qkv[bs, (Hq + 2 Hkv) * 128], writes the new K (normalised, rotated)

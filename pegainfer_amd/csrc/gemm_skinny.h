@@ -133,7 +133,7 @@ __device__ inline void skinny_stage_rows(const GemvFusedArgs& a, u32x4* xs, cons
           if (NORM) {
             if (a.residual) {
               u32x4 nh;
-              v = norm_scale8(h[j], &r[j], gw[j], inv, 0.f, &nh);
+              v = norm_scale8(h[j], &r[j], gw[j], inv, 0.f, &nh, (a.flags & kGemvRoundSum) != 0);
               if (blockIdx.x == 0) *reinterpret_cast<u32x4*>(a.hidden_out + row + c * 8) = nh;
             } else {
               v = norm_scale8(h[j], nullptr, gw[j], inv, 0.f, nullptr);
@@ -198,7 +198,8 @@ __global__ __launch_bounds__(kSkinnyThreads) void skinny_mfma_kernel(const GemvF
   // ---- prologue: per-token inverse RMS, canonical one-wave-per-row order, 8 tokens at a time ----
   if (a.norm_w) {
     for (int t = L.wave; t < T; t += kSkinnyWaves) {
-      const float v = wave_row_inv_rms(a.X + (size_t)t * K, a.residual ? a.residual + (size_t)t * K : nullptr, K, a.eps);
+      const float v = wave_row_inv_rms(a.X + (size_t)t * K, a.residual ? a.residual + (size_t)t * K : nullptr, K, a.eps,
+                                       (a.flags & kGemvRoundSum) != 0);
       if (L.lane == 0) sm_inv[t] = v;
     }
     __syncthreads();
@@ -427,6 +428,9 @@ __global__ __launch_bounds__(kSkinnyThreads) void skinny_resident_kernel(const G
   //        add + RMSNorm (qkv, gate_up; K <= 2560, T <= 16): wave w's token rows w, w + 8 (+ residual, + norm weight)
   //          into registers first, weights behind; the wave holds its rows in the canonical distribution of
   //          norm_core.h (lane l: vectors l, l + 64, ...), so the sum of squares needs no second pass - same bits.
+  // kGemvRoundSum (the only flag these kernels take): "add, then norm" - hidden_out = bf16(X + residual) and the norm
+  // runs over that ROUNDED sum (add_cuda then rms_norm_batched_cuda: the prefill residual chain, prefill.rs:183 + :89)
+  const bool round_sum = (a.flags & kGemvRoundSum) != 0;
   constexpr int XV = 5;   // 16-byte vectors per lane and row of the register-staged form (K <= 2560)
   const int nvec_row = K >> 3;
   const bool early_plain = !a.norm_w && (K & 511) == 0;
@@ -477,7 +481,8 @@ __global__ __launch_bounds__(kSkinnyThreads) void skinny_resident_kernel(const G
 #pragma unroll
       for (int j = 0; j < XV; ++j) {
         if (L.lane + 64 * j < nvec_row) {
-          if (a.residual) add_sq8(hx[u][j], rx[u][j], ss);
+          if (a.residual && round_sum) add_round_sq8(hx[u][j], rx[u][j], ss);
+          else if (a.residual) add_sq8(hx[u][j], rx[u][j], ss);
           else sq8(hx[u][j], ss);
         }
       }
@@ -490,7 +495,7 @@ __global__ __launch_bounds__(kSkinnyThreads) void skinny_resident_kernel(const G
           u32x4 v;
           if (a.residual) {
             u32x4 nh;
-            v = norm_scale8(hx[u][j], &rx[u][j], gx[j], inv, 0.f, &nh);
+            v = norm_scale8(hx[u][j], &rx[u][j], gx[j], inv, 0.f, &nh, round_sum);
             if (blockIdx.x == 0) reinterpret_cast<u32x4*>(a.hidden_out + (size_t)t * K)[c] = nh;
           } else {
             v = norm_scale8(hx[u][j], nullptr, gx[j], inv, 0.f, nullptr);
@@ -505,7 +510,8 @@ __global__ __launch_bounds__(kSkinnyThreads) void skinny_resident_kernel(const G
     if (total > CH) issue(CH, avB);
     if (a.norm_w) {
       for (int t = L.wave; t < T; t += kSkinnyWaves) {
-        const float v = wave_row_inv_rms(a.X + (size_t)t * K, a.residual ? a.residual + (size_t)t * K : nullptr, K, a.eps);
+        const float v = wave_row_inv_rms(a.X + (size_t)t * K, a.residual ? a.residual + (size_t)t * K : nullptr, K, a.eps,
+                                         round_sum);
         if (L.lane == 0) sm_inv[t] = v;
       }
       __syncthreads();

@@ -106,7 +106,14 @@ struct SplitPlan {
 // workgroups towards >= 256 (256 CUs): chunks/request = clamp(ceil(256/(bs*kv_heads)), 1, 64),
 // chunk = max(64, round_up16(ceil(L/chunks))); 64 tokens = one 16-token tile per wave, i.e. a workgroup's
 // whole K/V fetch is a single round trip.
-constexpr int kOprojFusedMaxSeq = 18 * 128;
+constexpr int kOprojFusedMaxSeqDefault = 18 * 128;
+// longest single request whose decode step keeps the fused attention + o_proj launch (18 chunks; PEGAINFER_OPROJ_MAX_SEQ
+// is the A/B knob: beyond 2304 tokens a chunk is more than one tile per wave, so the scan gets longer while the o_proj
+// launch it hides stays 6 us)
+inline int oproj_fused_max_seq() {
+  static const int v = [] { const char* e = getenv("PEGAINFER_OPROJ_MAX_SEQ"); const int x = e && *e ? atoi(e) : kOprojFusedMaxSeqDefault; return x < 128 ? 128 : x; }();
+  return v;
+}
 // chunks a single request of up to kOprojFusedMaxSeq tokens is cut into (PEGAINFER_OPROJ_CHUNKS, A/B knob)
 inline int oproj_fused_max_chunks() {
   static const int c = [] { const char* e = getenv("PEGAINFER_OPROJ_CHUNKS"); const int v = e && *e ? atoi(e) : 18; return v < 2 ? 2 : (v > 30 ? 30 : v); }();
@@ -139,7 +146,7 @@ inline SplitPlan make_split_plan(int policy, const std::vector<int>& seq_lens, i
     // tokens in one tile per wave) - the other slots of the launch grid stay
     // padding, and the fused attention + o_proj launch gives their workgroups the o_proj rows (attn_oproj_kernel)
     const int grid_slots = want;   // the launch grid keeps its one-workgroup-per-CU size
-    if (fused_oproj_usable && pairs <= num_kv_heads && max_seq <= kOprojFusedMaxSeq && target_env <= 0)
+    if (fused_oproj_usable && pairs <= num_kv_heads && max_seq <= oproj_fused_max_seq() && target_env <= 0)
       want = std::min(want, oproj_fused_max_chunks());
     int chunk = (max_seq + want - 1) / want;
     chunk = std::max(64, (chunk + 15) / 16 * 16);

@@ -742,7 +742,7 @@ struct Model {
     }
     const bool oproj_usable = attn_oproj && attn_done && fused_merge && !tp_comm && decode_mode >= 1 && D == 128 && oproj_shape_ok;
     const SplitPlan plan = make_split_plan(split_policy, seq_lens, padded, Hkv, oproj_usable);
-    oproj_plan = oproj_usable && split_policy == 1 && padded == 1 && plan.use_split && seq_lens[0] <= pq::kOprojFusedMaxSeq &&
+    oproj_plan = oproj_usable && split_policy == 1 && padded == 1 && plan.use_split && seq_lens[0] <= pq::oproj_fused_max_seq() &&
                  plan.slots > pq::oproj_fused_max_chunks();
     std::memcpy(mh<int32_t>(ml.split_request_indices), plan.request_indices.data(), plan.slots * 4);
     std::memcpy(mh<int32_t>(ml.split_kv_tile_indices), plan.kv_tile_indices.data(), plan.slots * 4);
@@ -952,7 +952,54 @@ struct Model {
     const char* pf_env = getenv("PEGAINFER_PREFILL_FUSE");   // read per call: tests flip it between two engines
     const bool pf_fuse = !(pf_env && pf_env[0] == '0');
     bool normed_ready = false;   // pf_normed already holds rms_norm(hid, this layer's ln1)
-    for (int li = 0; li < L; ++li) {
+    // ---- short prompts (<= 16 token columns, round 4): the launch-lean layer of the fused decode path around the prefill
+    //      attention - 6 launches per layer instead of 12.  ONE stacked q|k|v GEMV with the layer-input norm in its prologue
+    //      (li > 0: "add, then norm" = prefill.rs:183 + :89, the kGemvRoundSum form), per-head norm + RoPE + KV append +
+    //      q de-interleave in one launch, attention, o_proj, gate_up with the fused add + RMSNorm prologue (prefill.rs:157)
+    //      and the SwiGLU epilogue, down_proj.  Every piece shares its arithmetic core with the reference-named op it
+    //      replaces (row slices of a stacked GEMV == three GEMVs; prologue == stand-alone norm): bit-identical to the 1:1
+    //      sequence (PEGAINFER_PREFILL_FUSE=0 / PEGAINFER_PREFILL_SHORT=0), tested.
+    const char* short_e = getenv("PEGAINFER_PREFILL_SHORT");   // read per call: tests flip it between two engines
+    const bool short_env = !(short_e && short_e[0] == '0');
+    const bool short_path = short_env && pf_fuse && Ti <= 16 && D == 128 && !tp_comm && (H & 63) == 0 && (I & 63) == 0 &&
+                            (q_dim & 63) == 0 && q_dim + 2 * kv_dim <= 2 * I && !out_all_logits_host;
+    if (short_path) {
+      Half* qkv_st = pf_gate_up;          // [Ti, q_dim + 2 kv_dim] stacked rows (the gate|up scratch is unused: SwiGLU is fused)
+      const Half* resid = nullptr;        // pending residual: the previous layer's down_proj output (in pf_o)
+      for (int li = 0; li < L; ++li) {
+        const Layer& ly = layers[li];
+        int rc = pegainfer_gemv_fused_ex(ly.qkv, hid, qkv_st, q_dim + 2 * kv_dim, Ti, H, resid, ly.ln1,
+                                         resid ? hid_out : nullptr, eps, 0, resid ? 2 : 0, S());
+        if (rc) { set_error("short prefill: fused qkv GEMV failed"); return -1; }
+        if (resid) std::swap(hid, hid_out);
+        rc = pegainfer_qkv_stacked_norm_rope_scatter(qkv_st, pf_q, ly.q_norm, ly.k_norm, cos, sin, D32(5), D32(4), kv_buffer,
+                                                     layout.k_offset(li), layout.v_offset(li), D32(1), D32(2), Hq, Hkv, D,
+                                                     layout.page_size, layout.page_stride, Ti, eps, S());
+        if (rc) { set_error("pegainfer_qkv_stacked_norm_rope_scatter failed"); return -1; }
+        rc = batch_prefill_paged_cuda_with_cta_tile_q(
+            pf_q, pf_attn, kv_buffer, layout.k_offset(li), layout.v_offset(li), D32(1), D32(2), D32(3), D32(6), D32(7),
+            D32(8), D32(9), D32(10), reinterpret_cast<uint32_t*>(pf_meta_dev + offs[11]), Hq, Hkv, D, layout.page_size,
+            P, n_pf, num_tiles, layout.page_stride, sm, cta, S());
+        if (rc) { set_error("batch_prefill_paged_cuda failed"); return -1; }
+        if (n_decode_tail > 0) {
+          rc = paged_attention_decode_cuda(pf_q + (size_t)P * q_dim, pf_attn + (size_t)P * q_dim, kv_buffer,
+                                           layout.k_offset(li), layout.v_offset(li), D32(1), D32(2) + n_pf,
+                                           D32(3) + n_pf, D32(12), D32(13), D32(10) + n_pf, Hq, Hkv, D,
+                                           layout.page_size, n_decode_tail, layout.page_stride, sm, S());
+          if (rc) { set_error("paged_attention_decode_cuda (unified) failed"); return -1; }
+        }
+        rc = pegainfer_gemv_fused(ly.o, pf_attn, pf_o, H, Ti, q_dim, nullptr, nullptr, nullptr, 0.f, 0, S());
+        if (!rc) rc = pegainfer_gemv_fused(ly.gate_up, hid, pf_act, 2 * I, Ti, H, pf_o, ly.ln2, hid_out, eps, I, S());
+        if (rc) { set_error("short prefill: o_proj / fused gate_up failed"); return -1; }
+        std::swap(hid, hid_out);
+        rc = pegainfer_gemv_fused(ly.down, pf_act, pf_o, H, Ti, I, nullptr, nullptr, nullptr, 0.f, 0, S());
+        if (rc) { set_error("short prefill: down_proj failed"); return -1; }
+        resid = pf_o;
+      }
+      if (add_cuda(hid, pf_o, hid_out, Ti * H, S())) { set_error("add_cuda failed"); return -1; }   // prefill.rs:183, last layer
+      std::swap(hid, hid_out);
+    }
+    for (int li = short_path ? L : 0; li < L; ++li) {
       const Layer& ly = layers[li];
       if (!normed_ready) rms_norm_batched_cuda(hid, ly.ln1, pf_normed, H, Ti, eps, S());
       normed_ready = false;
@@ -960,7 +1007,10 @@ struct Model {
         if (Ti == 1) gemm_graphsafe_cuda(w, x, y, M, 1, K, S());
         else gemm_cuda(w, x, y, M, Ti, K, S());
       };
-      if (Ti > 64) {  // one launch over the stacked q/k/v rows, three outputs (bit-identical to three calls)
+      // one launch over the stacked q/k/v rows, three outputs (bit-identical to three calls; from 17 tokens on - the
+      // tiled kernels' range - since round 4: at 17..64 tokens the three calls were six launches, split-K GEMM + slice sum each)
+      static const int split3_min = [] { const char* e = getenv("PEGAINFER_PREFILL_SPLIT3_MIN"); return e && *e ? atoi(e) : 17; }();
+      if (Ti >= split3_min) {
         if (pegainfer_gemm_split3(ly.qkv, pf_normed, pf_q, q_dim, pf_k, kv_dim, pf_v, kv_dim, Ti, H, S())) {
           set_error("pegainfer_gemm_split3 failed"); return -1;
         }

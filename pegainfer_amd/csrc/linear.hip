@@ -702,7 +702,10 @@ static bool decode_gemm_dispatch(const GemvFusedArgs& a, hipStream_t s) {
     if (mid_batch_gemm(a.W, a.X, a.Y, a.M, a.T, a.K, SplitOut{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0}, s)) return true;
   }
   static const int skinny_min_t = [] { const char* e = getenv("PEGAINFER_SKINNY_MIN_T"); return e && *e ? atoi(e) : 3; }();
-  if ((a.T >= 5 || (a.T >= skinny_min_t && a.flags == 0) || t1_uses_mfma()) && a.T <= 64 && (a.K & 63) == 0) {
+  // the skinny kernels take one flag, kGemvRoundSum (the prefill residual chain at 5..16 token columns); the other
+  // Qwen3.5 forms exist on the dot2 kernel only (T <= 4, enforced by gemv_fused_impl)
+  if ((a.T >= 5 || (a.T >= skinny_min_t && a.flags == 0) || t1_uses_mfma()) && a.T <= 64 && (a.K & 63) == 0 &&
+      (a.flags & ~kGemvRoundSum) == 0) {
     if (a.T == 1) { skinny_launch<1, EPI>(a, s); return true; }
     return skinny_dispatch<EPI>(a, s);
   }
@@ -797,7 +800,10 @@ static pegainfer_status_t gemv_fused_impl(const Half* W, const Half* X, Half* Y,
     return (pegainfer_status_t)hipErrorInvalidValue;
   if (residual && (!norm_weight || !hidden_out || hidden_out == X)) return (pegainfer_status_t)hipErrorInvalidValue;
   if (silu_intermediate > 0 && M != 2 * silu_intermediate) return (pegainfer_status_t)hipErrorInvalidValue;
-  if (flags != 0 && (T > 4 || t1_uses_mfma())) return (pegainfer_status_t)hipErrorInvalidValue;  // dot2 path only
+  // (1 + w) norm weights and the rounded silu exist on the dot2 kernel only (T <= 4); "add, then norm" (bit 1) also on
+  // the skinny kernels (T <= 16, K % 64 == 0)
+  if ((flags & ~kGemvRoundSum) != 0 && (T > 4 || t1_uses_mfma())) return (pegainfer_status_t)hipErrorInvalidValue;
+  if (flags == kGemvRoundSum && T > 4 && (T > 16 || (K & 63) != 0)) return (pegainfer_status_t)hipErrorInvalidValue;
   GemvFusedArgs a{W, X, Y, M, T, K, residual, norm_weight, hidden_out, eps, silu_intermediate, 0, flags};
   const bool ok = silu_intermediate > 0 ? decode_gemm_dispatch<kEpiSilu>(a, as_stream(stream))
                                         : decode_gemm_dispatch<kEpiStore>(a, as_stream(stream));

@@ -121,6 +121,37 @@ __global__ __launch_bounds__(256) void qk_norm_rope128_scatter_kernel(
   *reinterpret_cast<u32x4*>(kv + dst + sub * 8) = r;
 }
 
+// The same work on the STACKED q|k|v rows of one GEMM (qkv [tokens][(Hq + 2 Hkv) * 128], the layout of the fused decode
+// path): q heads are normalised + rotated into the dense q_out [tokens][Hq * 128] the prefill attention reads, k heads are
+// normalised + rotated straight into their cache slot, v heads are copied into theirs.  The de-interleave costs nothing
+// extra: every byte is read once and written once, as in the three-buffer form.  Same per-head arithmetic (rope_core.h).
+__global__ __launch_bounds__(256) void qkv_stacked_norm_rope128_scatter_kernel(
+    const Half* __restrict__ qkv, Half* __restrict__ q_out, const Half* __restrict__ q_w, const Half* __restrict__ k_w,
+    const Half* __restrict__ cos_cache, const Half* __restrict__ sin_cache, const int* __restrict__ positions,
+    const int* __restrict__ batch_indices, Half* __restrict__ kv, long k_off, long v_off,
+    const int* __restrict__ page_indices, const int* __restrict__ page_indptr, int num_q_heads, int num_kv_heads,
+    int page_size, long stride_page, int tokens, float eps) {
+  const int heads = num_q_heads + 2 * num_kv_heads;
+  const long unit = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+  if (unit >= (long)tokens * heads) return;  // whole 16-lane rows drop out together (DPP stays inside a row)
+  const int token = (int)(unit / heads);
+  const int hg = (int)(unit - (long)token * heads);
+  const int sub = threadIdx.x & 15;
+  const int pos = positions[token];
+  const u32x4 x = *reinterpret_cast<const u32x4*>(qkv + ((size_t)token * heads + hg) * 128 + sub * 8);
+  if (hg < num_q_heads) {
+    *reinterpret_cast<u32x4*>(q_out + ((size_t)token * num_q_heads + hg) * 128 + sub * 8) =
+        head_norm_rope16(x, q_w, cos_cache + (size_t)pos * 128, sin_cache + (size_t)pos * 128, sub, eps);
+    return;
+  }
+  const bool is_v = hg >= num_q_heads + num_kv_heads;
+  const int h = hg - num_q_heads - (is_v ? num_kv_heads : 0);
+  const int page = page_indices[page_indptr[batch_indices[token]] + pos / page_size];
+  const long dst = (long)page * stride_page + (is_v ? v_off : k_off) + ((long)(pos % page_size) * num_kv_heads + h) * 128;
+  const u32x4 r = is_v ? x : head_norm_rope16(x, k_w, cos_cache + (size_t)pos * 128, sin_cache + (size_t)pos * 128, sub, eps);
+  *reinterpret_cast<u32x4*>(kv + dst + sub * 8) = r;
+}
+
 static void launch(Half* q, Half* k, const Half* qw, const Half* kw, const Half* c, const Half* s, int hq,
                    int hkv, int hd, int tokens, int start_pos, const int* positions, float eps,
                    hipStream_t stream) {
@@ -177,6 +208,29 @@ int32_t pegainfer_qk_norm_rope_scatter(Half* q, Half* k, const Half* v, const Ha
   const long units = (long)tokens * (num_q_heads + 2 * num_kv_heads);
   qk_norm_rope128_scatter_kernel<<<ceil_div(units, 16), 256, 0, as_stream(stream)>>>(
       q, k, v, q_norm_weight, k_norm_weight, cos_cache, sin_cache, positions, batch_indices, kv_data, k_offset_elems,
+      v_offset_elems, page_indices, page_indptr, num_q_heads, num_kv_heads, page_size, stride_page, tokens, rms_eps);
+  return static_cast<int32_t>(hipGetLastError());
+}
+
+// pegainfer_qk_norm_rope_scatter over the row-stacked output of ONE q|k|v GEMM (extension; short-prompt prefill): qkv
+// [tokens][(Hq + 2 Hkv) * 128] in, dense q_out [tokens][Hq * 128] + the K / V cache slots out.  The same bytes the
+// three-buffer form leaves in q and in the cache (k is not written back: prefill attention reads it from the cache).
+int32_t pegainfer_qkv_stacked_norm_rope_scatter(const Half* qkv, Half* q_out, const Half* q_norm_weight,
+                                                const Half* k_norm_weight, const Half* cos_cache, const Half* sin_cache,
+                                                const int32_t* positions, const int32_t* batch_indices, Half* kv_data,
+                                                int64_t k_offset_elems, int64_t v_offset_elems, const int32_t* page_indices,
+                                                const int32_t* page_indptr, int32_t num_q_heads, int32_t num_kv_heads,
+                                                int32_t head_dim, int32_t page_size, int64_t stride_page, int32_t tokens,
+                                                float rms_eps, pegainfer_stream_t stream) {
+  using namespace pk;
+  if (tokens <= 0) return 0;
+  if (head_dim != 128 || page_size <= 0 || !host_aligned16(qkv) || !host_aligned16(q_out) || !host_aligned16(kv_data) ||
+      !host_aligned16(q_norm_weight) || !host_aligned16(k_norm_weight) || !host_aligned16(cos_cache) ||
+      !host_aligned16(sin_cache) || (stride_page & 7) || (k_offset_elems & 7) || (v_offset_elems & 7))
+    return static_cast<int32_t>(hipErrorInvalidValue);
+  const long units = (long)tokens * (num_q_heads + 2 * num_kv_heads);
+  qkv_stacked_norm_rope128_scatter_kernel<<<ceil_div(units, 16), 256, 0, as_stream(stream)>>>(
+      qkv, q_out, q_norm_weight, k_norm_weight, cos_cache, sin_cache, positions, batch_indices, kv_data, k_offset_elems,
       v_offset_elems, page_indices, page_indptr, num_q_heads, num_kv_heads, page_size, stride_page, tokens, rms_eps);
   return static_cast<int32_t>(hipGetLastError());
 }

@@ -44,7 +44,7 @@ def generate(sched, tok, prompt, max_tokens):
     out, reason = [], None
     for _ in range(100000):
         sched.step()
-        for (r, kind, token, fin, _pt, _ct) in sched.poll():
+        for (r, kind, token, fin, *_rest) in sched.poll():
             if r != rid:
                 continue
             if kind == S.TOKEN:

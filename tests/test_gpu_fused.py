@@ -333,6 +333,23 @@ def test_model_prefill_fusions_bitwise_equal_reference_sequence(built_libs, monk
         eng.prefill([r], [prompts[2][:20]])
         _, lg2 = eng.prefill([r], [prompts[2][20:]], return_logits=True)
         rows.append(lg2.copy())
+        # short prompts (<= 16 token columns): the 6-launch layer of round 4 (stacked q|k|v GEMV with the norm in its
+        # prologue, kGemvRoundSum between layers, stacked norm + RoPE + scatter) - 1 / 5 / 16 tokens (dot2 and skinny
+        # kernels), a ragged pair, a 9-token continuation of a cached prefix, then decode steps over that KV
+        for group in ([prompts[0][:1]], [prompts[0]], [prompts[1]], [prompts[0], prompts[2][:9]], [prompts[2][:3], prompts[1][:4], prompts[0][:2]]):
+            rs = [eng.new_request() for _ in group]
+            tk, lg3 = eng.prefill(rs, group, return_logits=True)
+            rows.append(lg3.copy())
+            tk, lg3 = eng.decode(rs, tk, return_logits=True)
+            rows.append(lg3.copy())
+        r2 = eng.new_request()
+        eng.prefill([r2], [prompts[2][:20]])
+        tk, lg4 = eng.prefill([r2], [prompts[2][20:29]], return_logits=True)
+        rows.append(lg4.copy())
+        # unified step with few columns: a 6-token prompt arrives while r2 decodes
+        r3 = eng.new_request()
+        (tp, td), (lp, ld) = eng.unified_step([r3], [prompts[1][:6]], [r2], tk, return_logits=True)
+        rows += [lp.copy(), ld.copy()]
         eng.close()
         runs.append(rows)
     for a, b in zip(*runs):

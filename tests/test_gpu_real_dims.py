@@ -328,3 +328,42 @@ def test_real_dims_fused_path_bit_identical_to_reference_sequence(built_libs, re
             eng.close()
             outs.append(bf16_bits(dec))
         assert np.array_equal(outs[0], outs[1]), name
+
+
+def test_real_dims_short_prompt_prefill_path(built_libs, real2, monkeypatch):
+    """Prompts of <= 16 tokens take the 6-launch prefill layer (stacked q|k|v GEMV with the layer-input norm in its
+    prologue, "add, then norm" between layers, fused gate_up) - at the REAL widths: K = 2560 register-staged prologue of
+    the skinny kernel at 5 / 16 columns, the dot2 kernel at 1 / 3 columns, 6144-row stacked output.  Bit-identical to the
+    reference op sequence 1:1 (PEGAINFER_PREFILL_SHORT=0) and inside the oracle bar."""
+    cfg, state, _ = real2
+    rng = np.random.default_rng(99)
+    groups = [[_prompt(rng, n)] for n in (1, 3, 5, 16)] + [[_prompt(rng, 7), _prompt(rng, 2), _prompt(rng, 6)]]
+    old = O.GEMM_ACCUM
+    O.GEMM_ACCUM = np.float32
+    try:
+        want = []
+        for g in groups:
+            orc = Qwen3Oracle(cfg, {k: bf16_from_bits(v) for k, v in state.items()}, num_pages=64, rope_positions=4096)
+            want.append(np.stack(orc.batch_prefill(g, [KvState() for _ in g])))
+    finally:
+        O.GEMM_ACCUM = old
+    runs = []
+    for short in ("0", "1"):
+        monkeypatch.setenv("PEGAINFER_PREFILL_SHORT", short)
+        eng = _engine(state, decode_mode=1, max_batch_size=4)
+        rows = []
+        for g in groups:
+            rids = [eng.new_request() for _ in g]
+            tok, lg = eng.prefill(rids, g, return_logits=True)
+            rows.append(lg.copy())
+            _, lg = eng.decode(rids, tok, return_logits=True)     # the KV the short path appended
+            rows.append(lg.copy())
+            for r in rids:
+                eng.drop_request(r)
+        eng.close()
+        runs.append(rows)
+    for a, b in zip(*runs):
+        assert np.array_equal(a, b)
+    for g, ref, got in zip(groups, want, runs[1][0::2]):
+        c, r = _close(bf16_from_bits(got), ref)
+        assert c > COS_MIN and r <= REL_MAX, ([len(p) for p in g], c, r)
