@@ -106,7 +106,7 @@ struct SplitPlan {
 // workgroups towards >= 256 (256 CUs): chunks/request = clamp(ceil(256/(bs*kv_heads)), 1, 64),
 // chunk = max(64, round_up16(ceil(L/chunks))); 64 tokens = one 16-token tile per wave, i.e. a workgroup's
 // whole K/V fetch is a single round trip.
-constexpr int kOprojFusedMaxSeqDefault = 18 * 128;
+constexpr int kOprojFusedMaxSeqDefault = 12288;   // measured: ctx 4096 2.213 -> 2.166 ms per step, ctx 10 000 2.422 -> 2.409 (profiles/r4_oproj_maxseq_ab.txt)
 // longest single request whose decode step keeps the fused attention + o_proj launch (18 chunks; PEGAINFER_OPROJ_MAX_SEQ
 // is the A/B knob: beyond 2304 tokens a chunk is more than one tile per wave, so the scan gets longer while the o_proj
 // launch it hides stays 6 us)
