@@ -345,12 +345,75 @@ def run_qwen35(args, rank, world, local, dist, torch):
             "bytes_per_launch": int(step_bytes)},
         "cpu_baseline": None,
     }
+    # ---- CPU side (rank 0, N = 1): the reference's CPU path (HF Transformers bf16, the hybrid model with its torch
+    #      fallbacks of the gated delta rule) on the engine's own exported checkpoint: cpu_baseline + a parity block ----
+    cpu_in = None
+    if rank == 0 and world == 1 and args.cpu_steps > 0:
+        try:
+            for r in rids:
+                eng.drop_request(r)
+            r = eng.new_request()
+            tok, lg = eng.prefill(r, prompt, want_logits=True)
+            gtoks, grows = [int(tok)], [lg]
+            for _ in range(args.cpu_steps):
+                t, lg = eng.decode([r], [gtoks[-1]], want_logits=True)
+                gtoks.append(int(t[0]))
+                grows.append(lg[0])
+            cpu_in = (eng.export_state(), gtoks, np.stack(grows))
+        except Exception as e:  # noqa: BLE001
+            out["parity"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    eng.close()
+    if cpu_in is not None:
+        try:
+            out["cpu_baseline"], out["parity"] = cpu_leg_qwen35(cfg, cpu_in[0], prompt, cpu_in[1], cpu_in[2],
+                                                                min(32, os.cpu_count() or 1), os.cpu_count() or 1)
+        except Exception as e:  # noqa: BLE001
+            out["parity"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     if rank == 0:
         print(json.dumps(out))
-    eng.close()
     if world > 1:
         dist.destroy_process_group()
     return 0
+
+
+def cpu_leg_qwen35(cfg, tensors, prompt, gpu_tokens, gpu_rows, hf_threads, cores, hf_repeats=2, hf_new_tokens=17):
+    """configs[3]'s CPU side: HF Transformers Qwen3_5ForCausalLM bf16 greedy generate (the reference's truth engine for this
+    model too, scripts/generate_test_data.py) on the engine's exported weights - timed as the cpu_baseline, and compared
+    with the GPU's greedy tokens / logits up to the first difference.  Checker / baseline only."""
+    from oracle import hf_engine
+    t0 = time.perf_counter()
+    model = hf_engine.build_qwen35(dict(cfg, max_position_embeddings=max(4096, len(prompt) + 64)), tensors, threads=hf_threads)
+    build_s = time.perf_counter() - t0
+    rates, ttfts, hf_tokens, hf_logits = [], [], None, None
+    for rep in range(hf_repeats):
+        t0 = time.perf_counter()
+        toks, stamps, lg = hf_engine.generate_greedy(model, prompt, hf_new_tokens, return_logits=(rep == 0))
+        if rep == 0:
+            hf_tokens, hf_logits = toks, lg
+        ttfts.append(stamps[1] - t0)
+        rates.append((len(stamps) - 2) / (stamps[-1] - stamps[1]))
+    n = min(len(gpu_tokens), len(hf_tokens))
+    first_diff = next((i for i in range(n) if gpu_tokens[i] != hf_tokens[i]), None)
+    m = n if first_diff is None else first_diff + 1
+    a, b = gpu_rows[:m].astype(np.float64), hf_logits[:m].astype(np.float64)
+    cs = (a * b).sum(-1) / np.linalg.norm(a, axis=-1) / np.linalg.norm(b, axis=-1)
+    srt = np.sort(hf_logits[:m], axis=-1)
+    parity = {"checkpoint": "the engine's own weights exported to the host (pegainfer_qwen35_export_tensor)",
+              "prompt_tokens": len(prompt), "steps": n, "gpu_tokens": gpu_tokens[:n],
+              "hf": {"engine": "transformers Qwen3_5ForCausalLM bf16 generate(do_sample=False)", "tokens": hf_tokens[:n],
+                     "tokens_equal_prefix": n if first_diff is None else first_diff, "first_diff_step": first_diff,
+                     "steps_compared": m, "cos_min": round(float(cs.min()), 6),
+                     "max_dlogit": round(float(np.abs(a - b).max()), 4), "logit_scale": round(float(np.abs(b).max()), 3),
+                     "hf_top1_margin": [round(float(x), 4) for x in (srt[:, -1] - srt[:, -2])]}}
+    baseline = {"value": round(float(np.median(rates)), 3), "unit": "tokens/s", "cores": int(hf_threads), "kind": "reference",
+                "engine": "hf-transformers " + __import__("transformers").__version__,
+                "spread": {"min": round(float(min(rates)), 3), "max": round(float(max(rates)), 3), "repeats": hf_repeats},
+                "ttft_s": round(float(np.median(ttfts)), 3),
+                "sample": f"HF Transformers Qwen3_5ForCausalLM bf16 ({hf_threads} torch threads of {cores} cores; torch fallbacks "
+                          f"of the gated delta rule) on the engine's own checkpoint: {hf_repeats} x generate({len(prompt)}-token "
+                          f"bench prompt -> {hf_new_tokens} tokens, greedy); value = steady decode tokens/s over the "
+                          f"{hf_new_tokens - 1} inter-token gaps, model build {build_s:.0f} s untimed"}
+    return baseline, parity
 
 
 

@@ -41,6 +41,8 @@ const char* pegainfer_qwen35_last_error(pegainfer_qwen35_t m);
 /* is_f32 = 1 for ...linear_attn.A_log and ...linear_attn.norm.weight (host float32), else host bf16 bits */
 int32_t pegainfer_qwen35_load_tensor(pegainfer_qwen35_t m, const char* name, const void* host, int64_t numel,
                                      int32_t is_f32);
+/* the stored image of one tensor (bf16 bits, or f32 for A_log / linear_attn.norm.weight) back on the host */
+int32_t pegainfer_qwen35_export_tensor(pegainfer_qwen35_t m, const char* name, void* host, int64_t numel, int32_t is_f32);
 int32_t pegainfer_qwen35_fill_synthetic(pegainfer_qwen35_t m, uint64_t seed, float std);
 int32_t pegainfer_qwen35_finalize(pegainfer_qwen35_t m);
 /* native mmap load of a .safetensors file / HF directory (tensors under model.language_model.); finalises */

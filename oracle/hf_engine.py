@@ -106,3 +106,54 @@ def teacher_forced_logits(model, prompt_tokens, forced_tokens):
             past = out.past_key_values
             rows.append(out.logits[0, -1].float().numpy())
     return np.stack(rows)
+
+
+def build_qwen35(cfg, tensors, threads=None):
+    """Qwen3_5ForCausalLM (the hybrid linear / full attention text model) holding exactly the given tensors: dict of the
+    reference's names (``model.language_model.*``, pegainfer-qwen35-4b/src/weights.rs:118) -> uint16 bf16 bits, or float32
+    for ``A_log`` / ``linear_attn.norm.weight`` (weights.rs:226-241).  Same recipe as tests/golden/
+    make_qwen35_tiny_golden.py (HF runs its torch fallbacks of the gated delta rule on CPU)."""
+    import torch
+    from transformers import Qwen3_5ForCausalLM, Qwen3_5TextConfig
+    if threads:
+        torch.set_num_threads(int(threads))
+    keys = ["hidden_size", "intermediate_size", "num_hidden_layers", "vocab_size", "num_attention_heads",
+            "num_key_value_heads", "head_dim", "linear_num_key_heads", "linear_num_value_heads", "linear_key_head_dim",
+            "linear_value_head_dim", "linear_conv_kernel_dim", "rms_norm_eps", "layer_types"]
+    hf = Qwen3_5TextConfig(**{k: cfg[k] for k in keys if k in cfg}, tie_word_embeddings=True,
+                           max_position_embeddings=int(cfg.get("max_position_embeddings", 4096)), attention_bias=False,
+                           rope_parameters=dict(rope_type="default", rope_theta=float(cfg.get("rope_theta", 1e7)),
+                                                partial_rotary_factor=float(cfg.get("partial_rotary_factor", 0.25)),
+                                                mrope_section=[11, 11, 10]),
+                           attn_implementation="eager")
+    try:
+        try:
+            from transformers.initialization import no_init_weights
+        except ImportError:
+            from transformers.modeling_utils import no_init_weights
+        ctx = no_init_weights()
+    except Exception:  # noqa: BLE001
+        import contextlib
+        ctx = contextlib.nullcontext()
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.bfloat16)
+    try:
+        with ctx:
+            model = Qwen3_5ForCausalLM(hf)
+    finally:
+        torch.set_default_dtype(old)
+    new = {}
+    for name, ref in model.state_dict().items():
+        src = "model.language_model." + (name[len("model."):] if name.startswith("model.") else name)
+        if name == "lm_head.weight":
+            src = "model.language_model.embed_tokens.weight"          # tied
+        if src not in tensors:
+            raise KeyError(f"checkpoint has no tensor for {name} ({src})")
+        a = tensors[src]
+        if a.dtype == np.float32:      # A_log / gated-norm weight: the reference keeps them f32; HF's module dtype is bf16
+            new[name] = torch.from_numpy(np.ascontiguousarray(a)).reshape(tuple(ref.shape)).to(torch.bfloat16)
+        else:
+            new[name] = _bits_to_bf16(a, tuple(ref.shape))
+    model.load_state_dict(new, assign=True)
+    model.tie_weights()
+    return model.eval()

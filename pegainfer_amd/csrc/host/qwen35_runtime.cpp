@@ -274,8 +274,8 @@ struct Model35 {
 
   // shape / ndim given (native loader): a transposed or re-shaped tensor with the right element count is still wrong.
   // The depthwise conv weight is [C, 1, K] in HF checkpoints ([C, K] accepted too).
-  int load_tensor(const char* name_c, const void* host, int64_t numel, int is_f32, const int64_t* shape = nullptr,
-                  int ndim = 0) {
+  // reference tensor name (weights.rs:102-296, prefix model.language_model.) -> device address, logical shape, dtype
+  int resolve_tensor(const char* name_c, void** dst_out, int64_t* rows_out, int64_t* cols_out, bool* f32_out) {
     std::string name(name_c);
     const std::string wp = "model.language_model.";
     if (name.rfind(wp, 0) != 0) { set_error("tensor outside " + wp + ": " + name); return -1; }
@@ -322,6 +322,27 @@ struct Model35 {
       }
     }
     if (!dst) { set_error("unknown tensor name: " + std::string(name_c)); return -1; }
+    *dst_out = dst; *rows_out = rows; *cols_out = cols; *f32_out = f32;
+    return 0;
+  }
+  // a loaded (or synthetic) tensor back on the host, bf16 bits or f32 as it is stored: hands the checkpoint the engine
+  // computes with to a checker (bench.py's Qwen3.5 CPU leg)
+  int export_tensor(const char* name_c, void* host, int64_t numel, int is_f32) {
+    void* src = nullptr;
+    int64_t rows = 0, cols = 0;
+    bool f32 = false;
+    if (resolve_tensor(name_c, &src, &rows, &cols, &f32)) return -1;
+    if (numel != rows * cols || (is_f32 != 0) != f32) { set_error("shape/dtype mismatch for " + std::string(name_c)); return -1; }
+    P35_HIP(hipStreamSynchronize(stream));
+    P35_HIP(hipMemcpy(host, src, (size_t)numel * (f32 ? 4 : 2), hipMemcpyDeviceToHost));
+    return 0;
+  }
+  int load_tensor(const char* name_c, const void* host, int64_t numel, int is_f32, const int64_t* shape = nullptr,
+                  int ndim = 0) {
+    void* dst = nullptr;
+    int64_t rows = 0, cols = 0;
+    bool f32 = false;
+    if (resolve_tensor(name_c, &dst, &rows, &cols, &f32)) return -1;
     if (numel != rows * cols || (is_f32 != 0) != f32) { set_error("shape/dtype mismatch for " + std::string(name_c)); return -1; }
     if (shape) {
       bool ok;
@@ -865,6 +886,9 @@ const char* pegainfer_qwen35_last_error(pegainfer_qwen35_t m) { return M35(m)->e
 int32_t pegainfer_qwen35_load_tensor(pegainfer_qwen35_t m, const char* name, const void* host, int64_t numel,
                                      int32_t is_f32) {
   return M35(m)->load_tensor(name, host, numel, is_f32);
+}
+int32_t pegainfer_qwen35_export_tensor(pegainfer_qwen35_t m, const char* name, void* host, int64_t numel, int32_t is_f32) {
+  return M35(m)->export_tensor(name, host, numel, is_f32);
 }
 int32_t pegainfer_qwen35_fill_synthetic(pegainfer_qwen35_t m, uint64_t seed, float std) { return M35(m)->fill_synthetic(seed, std); }
 int32_t pegainfer_qwen35_finalize(pegainfer_qwen35_t m) { return M35(m)->finalize(); }

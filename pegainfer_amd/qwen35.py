@@ -85,6 +85,40 @@ class Qwen35Engine:
         self._chk(self.lib.pegainfer_qwen35_load_safetensors(self.h, os.fsencode(path)), "load_safetensors")
         return self
 
+    def export_state(self):
+        """{reference tensor name: uint16 bf16 bits | float32 (A_log, linear_attn.norm.weight)} of the checkpoint the
+        engine computes with, copied back from the device (pegainfer_qwen35_export_tensor)."""
+        c = self.cfg
+        H, I, V, D = c["hidden_size"], c["intermediate_size"], c["vocab_size"], c["head_dim"]
+        qd, kvd = c["num_attention_heads"] * D, c["num_key_value_heads"] * D
+        kh, vh, K = c["linear_num_key_heads"], c["linear_num_value_heads"], c.get("linear_conv_kernel_dim", 4)
+        C, Z = 2 * kh * 128 + vh * 128, vh * 128
+        shapes = {"embed_tokens.weight": (V, H), "norm.weight": (H,)}
+        for i, kind in enumerate(c["layer_types"]):
+            p = f"layers.{i}."
+            shapes.update({p + "input_layernorm.weight": (H,), p + "post_attention_layernorm.weight": (H,),
+                           p + "mlp.gate_proj.weight": (I, H), p + "mlp.up_proj.weight": (I, H),
+                           p + "mlp.down_proj.weight": (H, I)})
+            if kind == "full_attention":
+                shapes.update({p + "self_attn.q_proj.weight": (2 * qd, H), p + "self_attn.k_proj.weight": (kvd, H),
+                               p + "self_attn.v_proj.weight": (kvd, H), p + "self_attn.o_proj.weight": (H, qd),
+                               p + "self_attn.q_norm.weight": (D,), p + "self_attn.k_norm.weight": (D,)})
+            else:
+                shapes.update({p + "linear_attn.in_proj_qkv.weight": (C, H), p + "linear_attn.in_proj_z.weight": (Z, H),
+                               p + "linear_attn.in_proj_b.weight": (vh, H), p + "linear_attn.in_proj_a.weight": (vh, H),
+                               p + "linear_attn.conv1d.weight": (C, 1, K), p + "linear_attn.dt_bias": (vh,),
+                               p + "linear_attn.A_log": (vh,), p + "linear_attn.norm.weight": (128,),
+                               p + "linear_attn.out_proj.weight": (H, Z)})
+        out = {}
+        for name, shp in shapes.items():
+            f32 = name.endswith("A_log") or name.endswith("linear_attn.norm.weight")
+            a = np.empty(shp, dtype=np.float32 if f32 else np.uint16)
+            full = "model.language_model." + name
+            self._chk(self.lib.pegainfer_qwen35_export_tensor(self.h, full.encode(), a.ctypes.data, a.size, 1 if f32 else 0),
+                      "export " + name)
+            out[full] = a
+        return out
+
     def fill_synthetic(self, seed=42, std=0.02):
         self._chk(self.lib.pegainfer_qwen35_fill_synthetic(self.h, seed, std), "fill_synthetic")
         self._chk(self.lib.pegainfer_qwen35_finalize(self.h), "finalize")

@@ -146,3 +146,33 @@ def test_cpu_legs_run_on_a_tiny_checkpoint():
     assert base["kind"] == "reference" and base["value"] > 0 and base["port"]["kind"] == "port"
     assert par["cos_min"] == 1.0 and par["max_dlogit"] == 0.0 and par["tokens_equal"] == 5
     assert par["hf"]["cos_min"] > 0.999 and par["hf"]["steps_compared"] >= 1
+
+
+def test_cpu_leg_qwen35_runs_on_the_tiny_golden_checkpoint():
+    """configs[3]'s CPU side end to end (no GPU): HF Qwen3_5ForCausalLM built by oracle/hf_engine.py from the committed tiny
+    hybrid checkpoint reproduces the committed HF golden's tokens on a case without near-ties (the fixture came from another
+    CPU: bf16 GEMMs differ by ~1 % of the logit scale between hosts, so logits are compared by tolerance), and the baseline /
+    parity blocks carry their keys."""
+    pytest.importorskip("transformers")
+    import json
+    import struct
+
+    import numpy as np
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    meta = json.load(open(os.path.join(g, "qwen35_tiny_golden.json")))
+    lgz = np.load(os.path.join(g, "qwen35_tiny_logits.npz"))
+    t = {}
+    with open(os.path.join(g, "qwen35_tiny.safetensors"), "rb") as f:
+        n = struct.unpack("<Q", f.read(8))[0]
+        hdr = json.loads(f.read(n))
+        for name, info in hdr.items():
+            if name == "__metadata__":
+                continue
+            lo, hi = info["data_offsets"]
+            f.seek(8 + n + lo)
+            t[name] = np.frombuffer(f.read(hi - lo), dtype=np.uint16 if info["dtype"] == "BF16" else np.float32).copy()
+    c = meta["cases"][1]
+    base, par = bench.cpu_leg_qwen35(meta["config"], t, c["prompt_tokens"], c["output_tokens"][:9], lgz[c["name"]][:9], 4, 4,
+                                     hf_repeats=1, hf_new_tokens=9)
+    assert base["kind"] == "reference" and base["value"] > 0
+    assert par["hf"]["tokens_equal_prefix"] == 9 and par["hf"]["cos_min"] > 0.9995
