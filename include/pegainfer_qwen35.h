@@ -55,6 +55,7 @@ int32_t pegainfer_qwen35_available_pages(pegainfer_qwen35_t m);
 int32_t pegainfer_qwen35_capacity_pages(pegainfer_qwen35_t m);
 /* the max_batch_size the model was created with (rows of the decode buffers) */
 int32_t pegainfer_qwen35_max_batch_size(pegainfer_qwen35_t m);
+int32_t pegainfer_qwen35_vocab_size(pegainfer_qwen35_t m);
 
 /* prefill_forward (prefill.rs:21-120): appends n_tokens to the request (recurrent + conv state carried over),
  * returns the greedy token of the last position and optionally its logits (bf16 bits [vocab]). */
@@ -63,6 +64,13 @@ int32_t pegainfer_qwen35_prefill(pegainfer_qwen35_t m, int32_t request_id, int32
 /* batch_decode_graph (batch_decode.rs:113-196): one token per request; greedy tokens + optional logits [n, vocab] */
 int32_t pegainfer_qwen35_decode(pegainfer_qwen35_t m, int32_t n_requests, const int32_t* request_ids,
                                 const uint32_t* token_ids, int32_t* out_tokens, void* out_logits_host);
+/* Sample row `column` of the LAST prefill (one row) / decode step's logits with the reference's gpu_sample rule
+ * (ops/sampling.rs:109-170), and its TokenLogprob (compute_logprobs_from_cpu, executor.rs:400-434): as
+ * pegainfer_qwen3_sample / pegainfer_qwen3_logprobs. */
+int32_t pegainfer_qwen35_sample(pegainfer_qwen35_t m, int32_t column, float temperature, int32_t top_k, float top_p,
+                                float random_val, int32_t* out_token);
+int32_t pegainfer_qwen35_logprobs(pegainfer_qwen35_t m, int32_t column, uint32_t token, int32_t top_k, float* out_logprob,
+                                  uint32_t* out_top_ids, float* out_top_logprobs);
 float pegainfer_qwen35_last_step_ms(pegainfer_qwen35_t m);
 int64_t pegainfer_qwen35_weight_bytes(pegainfer_qwen35_t m);
 

@@ -94,7 +94,8 @@ pegainfer_sched_t pegainfer_sched_create(const pegainfer_executor_vtbl* executor
  * `model` is a pegainfer_qwen3_t and must outlive the scheduler. */
 pegainfer_sched_t pegainfer_sched_create_qwen3(void* model, uint64_t seed, const uint32_t* stop_tokens, int32_t n_stop);
 /* scheduler over the Qwen3.5 hybrid runtime (pegainfer_qwen35.h): one prefill call per admitted prompt, one batched
- * decode per iteration; greedy requests only.  `model` is a pegainfer_qwen35_t. */
+ * decode per iteration; sampled requests draw through pegainfer_qwen35_sample, logprobs through pegainfer_qwen35_logprobs
+ * (round 4; echo logits are not computed for this model).  `model` is a pegainfer_qwen35_t. */
 pegainfer_sched_t pegainfer_sched_create_qwen35(void* model, uint64_t seed, const uint32_t* stop_tokens, int32_t n_stop);
 void pegainfer_sched_destroy(pegainfer_sched_t s);
 

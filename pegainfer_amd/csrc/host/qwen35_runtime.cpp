@@ -19,6 +19,7 @@
 #include "safetensors_loader.h"
 #include "pegainfer_kernels.h"
 #include "pegainfer_kernels_ext.h"
+#include "pegainfer_qwen3.h"    // pegainfer_logprobs_from_logits (pure host)
 #include "pegainfer_qwen35.h"
 
 namespace pq35 {
@@ -103,6 +104,15 @@ struct Model35 {
   int32_t* tokens_out_d = nullptr;
   uint8_t* top1_state = nullptr;
   int32_t* tokens_out_host = nullptr;
+  // per-request sampling / logprobs over the LAST step's logits (ops/sampling.rs:109-170, executor.rs:400-434)
+  const Half* last_logits = nullptr;
+  int last_rows = 0;
+  float* probs_scratch = nullptr;
+  Half* top1_value = nullptr;
+  uint8_t *row_states = nullptr, *valid_scratch = nullptr;
+  int32_t* sample_out_d = nullptr;
+  std::vector<uint16_t> lp_bits;
+  std::vector<float> lp_row;
   uint8_t *meta_host = nullptr, *meta_dev = nullptr;
   size_t m_tok, m_pos, m_indptr, m_lpl, m_ri, m_kti, m_kcs, m_sri, m_skt, m_skc, m_soi, m_sva, m_pages, m_total;
   // partition-KV decode for the full-attention layers (MI355X policy of kv_pool.h: fill the 256 CUs)
@@ -195,7 +205,8 @@ struct Model35 {
         dalloc(&a_proj, bs * vh) || dalloc(&gdr_out, bs * Z) || dalloc(&normed_gated, bs * Z) ||
         dalloc(&gate_out, bs * I) || dalloc(&up_out, bs * I) || dalloc(&act_out, bs * I) ||
         dalloc(&mlp_out, bs * H) || dalloc(&logits, bs * (size_t)V) || dalloc(&tokens_out_d, bs) ||
-        dalloc(&top1_state, bs * 16) || dalloc(&start_pos_d, 1) ||
+        dalloc(&top1_state, bs * 16) || dalloc(&start_pos_d, 1) || dalloc(&probs_scratch, (size_t)V) || dalloc(&top1_value, 1) ||
+        dalloc(&row_states, 1024 * 1024) || dalloc(&valid_scratch, 1) || dalloc(&sample_out_d, 1) ||
         dalloc(&wide, (size_t)std::max(C + Z + 2 * vh, 2 * q_dim + 2 * kv_dim)) ||
         dalloc(&split_tmp_v, bs * pq::kSplitMaxChunksPerRequest * q_dim) ||
         dalloc(&split_tmp_s, bs * pq::kSplitMaxChunksPerRequest * Hq) || dalloc(&merge_ctr, bs * (size_t)Hkv * 32) || dalloc(&pf_last, H) ||
@@ -702,7 +713,40 @@ struct Model35 {
     P35_HIP(hipStreamSynchronize(stream));
     P35_HIP(hipEventElapsedTime(&last_step_ms, ev0, ev1));
     if (out_tokens) std::memcpy(out_tokens, tokens_out_host, (size_t)n * 4);
+    last_logits = logits;
+    last_rows = n;
     return 0;
+  }
+  // gpu_sample rule (ops/sampling.rs:109-170) on one row of the last step's logits - the same symbols the Qwen3 runtime calls
+  int sample(int column, float temperature, int top_k, float top_p, float random_val, int32_t* out) {
+    if (!last_logits || column < 0 || column >= last_rows) { set_error("no logits for that column"); return -1; }
+    const Half* lg = last_logits + (size_t)column * V;
+    if ((temperature <= 0.0f || top_k == 1) && top_p >= 1.0f) {
+      flashinfer_top1_cuda(lg, top1_value, row_states, sample_out_d, V, S());
+    } else {
+      uint32_t bits;
+      std::memcpy(&bits, &random_val, 4);
+      gpu_sample_flashinfer_cuda(lg, probs_scratch, valid_scratch, sample_out_d, V, 1.0f / temperature, top_k, top_p,
+                                 (uint64_t)bits, S());
+    }
+    P35_HIP(hipStreamSynchronize(stream));
+    P35_HIP(hipMemcpy(out, sample_out_d, 4, hipMemcpyDeviceToHost));
+    return 0;
+  }
+  // extract_logprobs (executor.rs:807-816 of the qwen3 crate; the qwen35 crate shares the engine types): row -> host f32 ->
+  // compute_logprobs_from_cpu
+  int logprobs(int column, uint32_t token, int top_k, float* out_lp, uint32_t* top_ids, float* top_lps) {
+    if (!last_logits || column < 0 || column >= last_rows) { set_error("no logits for that column"); return -1; }
+    if (token >= (uint32_t)V) { set_error("logprobs: token outside the vocabulary"); return -1; }
+    lp_bits.resize(V);
+    lp_row.resize(V);
+    P35_HIP(hipStreamSynchronize(stream));
+    P35_HIP(hipMemcpy(lp_bits.data(), last_logits + (size_t)column * V, (size_t)V * 2, hipMemcpyDeviceToHost));
+    for (int i = 0; i < V; ++i) {
+      const uint32_t u = (uint32_t)lp_bits[i] << 16;
+      std::memcpy(&lp_row[i], &u, 4);
+    }
+    return pegainfer_logprobs_from_logits(lp_row.data(), V, token, top_k, out_lp, top_ids, top_lps);
   }
 
   // ------------------------------------------------------------------ prefill (prefill.rs:21-449)
@@ -835,6 +879,8 @@ struct Model35 {
     if (out_logits_host) P35_HIP(hipMemcpyAsync(out_logits_host, pf_logits, (size_t)V * 2, hipMemcpyDeviceToHost, stream));
     P35_HIP(hipStreamSynchronize(stream));
     if (out_token) *out_token = tokens_out_host[0];
+    last_logits = pf_logits;
+    last_rows = 1;
     return 0;
   }
 
@@ -886,6 +932,15 @@ const char* pegainfer_qwen35_last_error(pegainfer_qwen35_t m) { return M35(m)->e
 int32_t pegainfer_qwen35_load_tensor(pegainfer_qwen35_t m, const char* name, const void* host, int64_t numel,
                                      int32_t is_f32) {
   return M35(m)->load_tensor(name, host, numel, is_f32);
+}
+int32_t pegainfer_qwen35_vocab_size(pegainfer_qwen35_t m) { return M35(m)->V; }
+int32_t pegainfer_qwen35_sample(pegainfer_qwen35_t m, int32_t column, float temperature, int32_t top_k, float top_p,
+                                float random_val, int32_t* out_token) {
+  return M35(m)->sample(column, temperature, top_k, top_p, random_val, out_token);
+}
+int32_t pegainfer_qwen35_logprobs(pegainfer_qwen35_t m, int32_t column, uint32_t token, int32_t top_k, float* out_logprob,
+                                  uint32_t* out_top_ids, float* out_top_logprobs) {
+  return M35(m)->logprobs(column, token, top_k, out_logprob, out_top_ids, out_top_logprobs);
 }
 int32_t pegainfer_qwen35_export_tensor(pegainfer_qwen35_t m, const char* name, void* host, int64_t numel, int32_t is_f32) {
   return M35(m)->export_tensor(name, host, numel, is_f32);

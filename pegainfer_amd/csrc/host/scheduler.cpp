@@ -183,12 +183,16 @@ struct Qwen3ExecLp {
 // executor bound to the Qwen3.5 hybrid runtime: the reference prefills one request per call (prefill.rs:21) and
 // decodes the active set as one batch (batch_decode.rs:113); a Unified plan is its prefills followed by one batched
 // decode (the recurrent state makes a fused mixed step a different kernel set, unified_forward.rs - not built).
-// Greedy only: the hybrid runtime samples on the device inside the step.
+// Sampled requests draw their token right after their own prefill / the batched decode (gpu_sample over that row);
+// logprobs of prompt rows come from a host copy of the row taken at the same moment (the next prefill reuses the buffer).
 struct Qwen35Exec {
   pegainfer_qwen35_t model;
   std::unordered_set<uint32_t> stop;
   std::unordered_map<uint64_t, int32_t> slot;
   std::string err;
+  int n_pf_last = 0;                              // rows [0, n_pf_last) of the last execute() were prefills
+  std::vector<std::vector<float>> pf_rows;        // their logits rows as f32 (kept only while small: <= 16 prompts)
+  std::vector<uint16_t> row_bits;
   static int32_t page_size(void*) { return 16; }
   static int32_t max_request_pages(void* u) { return pegainfer_qwen35_capacity_pages(((Qwen35Exec*)u)->model) - 1; }
   static int32_t available_pages(void* u) { return pegainfer_qwen35_available_pages(((Qwen35Exec*)u)->model); }
@@ -203,24 +207,32 @@ struct Qwen35Exec {
     return rc;
   }
   static const char* last_error(void* u) { return ((Qwen35Exec*)u)->err.c_str(); }
+  static bool greedy(float t, int32_t k, float p) { return (t <= 0.0f || k == 1) && p >= 1.0f; }   // ops/sampling.rs:122
   static int32_t execute(void* u, int32_t n_pf, int32_t n_dec, const uint64_t* ids, const int32_t* lens,
                          const uint32_t* tokens, const float* temp, const int32_t* top_k, const float* top_p,
-                         const float*, uint32_t* out) {
+                         const float* rv, uint32_t* out) {
     auto* e = (Qwen35Exec*)u;
     auto fail = [&](const char* what) {
       const char* m = pegainfer_qwen35_last_error(e->model);
       e->err = std::string(what) + ": " + (m ? m : "");
       return -1;
     };
-    for (int i = 0; i < n_pf + n_dec; ++i)
-      if (!((temp[i] <= 0.0f || top_k[i] == 1) && top_p[i] >= 1.0f)) { e->err = "Qwen3.5 executor is greedy-only"; return -1; }
+    e->n_pf_last = n_pf;
+    e->pf_rows.assign((size_t)n_pf, {});
+    const int32_t V = pegainfer_qwen35_vocab_size(e->model);
     size_t off = 0;
     for (int i = 0; i < n_pf; ++i) {
       const int32_t r = pegainfer_qwen35_new_request(e->model);
       if (r < 0) return fail("new_request");
       e->slot[ids[i]] = r;
       int32_t tok = 0;
-      if (pegainfer_qwen35_prefill(e->model, r, lens[i], tokens + off, &tok, nullptr)) return fail("prefill");
+      e->row_bits.resize((size_t)V);
+      if (pegainfer_qwen35_prefill(e->model, r, lens[i], tokens + off, &tok, e->row_bits.data())) return fail("prefill");
+      if (!greedy(temp[i], top_k[i], top_p[i]) &&
+          pegainfer_qwen35_sample(e->model, 0, temp[i], top_k[i], top_p[i], rv[i], &tok))
+        return fail("sample");
+      e->pf_rows[i].resize((size_t)V);
+      for (int32_t j = 0; j < V; ++j) { const uint32_t w = (uint32_t)e->row_bits[j] << 16; std::memcpy(&e->pf_rows[i][j], &w, 4); }
       out[i] = (uint32_t)tok;
       off += (size_t)lens[i];
     }
@@ -232,9 +244,25 @@ struct Qwen35Exec {
         mids[j] = it->second;
       }
       if (pegainfer_qwen35_decode(e->model, n_dec, mids.data(), tokens + off, toks.data(), nullptr)) return fail("decode");
-      for (int j = 0; j < n_dec; ++j) out[n_pf + j] = (uint32_t)toks[j];
+      for (int j = 0; j < n_dec; ++j) {
+        const int i = n_pf + j;
+        if (!greedy(temp[i], top_k[i], top_p[i]) &&
+            pegainfer_qwen35_sample(e->model, j, temp[i], top_k[i], top_p[i], rv[i], &toks[j]))
+          return fail("sample");
+        out[i] = (uint32_t)toks[j];
+      }
     }
     return 0;
+  }
+  static int32_t logprobs(void* u, int32_t row, uint32_t token, int32_t top_k, float* lp, uint32_t* ids, float* vals) {
+    auto* e = (Qwen35Exec*)u;
+    if (row < e->n_pf_last) {
+      const std::vector<float>& r = e->pf_rows[(size_t)row];
+      return pegainfer_logprobs_from_logits(r.data(), (int32_t)r.size(), token, top_k, lp, ids, vals);
+    }
+    const int32_t rc = pegainfer_qwen35_logprobs(e->model, row - e->n_pf_last, token, top_k, lp, ids, vals);
+    if (rc < 0) { const char* m = pegainfer_qwen35_last_error(e->model); e->err = m ? m : "logprobs failed"; }
+    return rc;
   }
 };
 
@@ -489,7 +517,7 @@ pegainfer_sched_t pegainfer_sched_create_qwen35(void* model, uint64_t seed, cons
   pegainfer_executor_vtbl v{sizeof(pegainfer_executor_vtbl), e, &psched::Qwen35Exec::page_size, &psched::Qwen35Exec::max_request_pages,
                             &psched::Qwen35Exec::available_pages, &psched::Qwen35Exec::is_stop_token,
                             &psched::Qwen35Exec::drop_request, &psched::Qwen35Exec::execute, &psched::Qwen35Exec::last_error,
-                            &psched::Qwen35Exec::max_batch_size, nullptr, nullptr, nullptr};
+                            &psched::Qwen35Exec::max_batch_size, &psched::Qwen35Exec::logprobs, nullptr, nullptr};
   Scheduler* s = static_cast<Scheduler*>(pegainfer_sched_create(&v, seed));
   s->owned35 = e;
   return s;

@@ -203,6 +203,51 @@ def test_qwen35_scheduler_streams_equal_per_request_generation(built_libs, golde
     eng.close()
 
 
+def test_qwen35_scheduler_sampling_and_logprobs(built_libs, golden35):
+    """Round 4: the Qwen3.5 executor is no longer greedy-only.  A sampled request (T 0.8, top_k 5, top_p 0.9) draws every
+    token from the top-k / top-p support of that step's logits (FlashInfer's Philox stream is parity-unpinned: the support is
+    what can be checked), and a greedy request with logprobs = 3 carries TokenLogprobs equal to compute_logprobs_from_cpu
+    over the logits the engine returns for the same prompt - prompt row and decode rows."""
+    from oracle import ops as O
+    from pegainfer_amd.scheduler import FINISHED, TOKEN, Scheduler
+    meta, _ = golden35
+    prompt = meta["cases"][1]["prompt_tokens"]
+    eng = make_engine(meta, split_policy=0, max_batch_size=4)
+    # expected logprobs from the engine's own logits
+    r = eng.new_request()
+    t, lg = eng.prefill(r, prompt, want_logits=True)
+    want = [O.compute_logprobs(lg, t, 3)]
+    toks = [t]
+    for _ in range(3):
+        o, lgd = eng.decode([r], [toks[-1]], want_logits=True)
+        toks.append(int(o[0]))
+        want.append(O.compute_logprobs(lgd[0], toks[-1], 3))
+    eng.drop_request(r)
+    s = Scheduler.over_engine(eng)
+    a = s.submit(prompt, 4, (0.0, -1, 1.0, True), logprobs=3)
+    b = s.submit(prompt, 4, (0.8, 5, 0.9, True))
+    ev = []
+    while s.step() != 0:
+        ev += s.poll()
+    ev += s.poll()
+    s.close()
+    got = [e for e in ev if e[0] == a and e[1] == TOKEN]
+    assert [e[2] for e in got] == toks
+    for e, w in zip(got, want):
+        assert e[7] is not None and abs(e[7][0] - w[0]) < 2e-5 and [i for i, _ in e[7][1]] == [i for i, _ in w[1]]
+    sampled = [e[2] for e in ev if e[0] == b and e[1] == TOKEN]
+    assert len(sampled) == 4 and all(e[7] is None for e in ev if e[0] == b)
+    # every sampled token lies in the support of the logits the same engine produces on that token stream
+    r = eng.new_request()
+    _, lg = eng.prefill(r, prompt, want_logits=True)
+    for i, tk in enumerate(sampled):
+        keep = O.top_k_top_p_support(O.logits_to_probs(lg if i == 0 else lg[0], 1.0 / 0.8), 5, 0.9)
+        assert keep[tk], (i, tk)
+        _, lg = eng.decode([r], [tk], want_logits=True)
+    eng.drop_request(r)
+    eng.close()
+
+
 def test_qwen35_native_loader_equals_python_loader(built_libs, golden35):
     from pegainfer_amd.qwen35 import Qwen35Engine
     meta, _ = golden35
