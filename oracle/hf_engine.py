@@ -150,8 +150,10 @@ def build_qwen35(cfg, tensors, threads=None):
         if src not in tensors:
             raise KeyError(f"checkpoint has no tensor for {name} ({src})")
         a = tensors[src]
-        if a.dtype == np.float32:      # A_log / gated-norm weight: the reference keeps them f32; HF's module dtype is bf16
-            new[name] = torch.from_numpy(np.ascontiguousarray(a)).reshape(tuple(ref.shape)).to(torch.bfloat16)
+        if a.dtype == np.float32:      # A_log / gated-norm weight: the reference keeps them f32 (weights.rs:226-241) and so
+            # does this model - HF's forward upcasts A_log with .float() anyway; rounding a synthetic A_log to bf16 would
+            # change every decay rate by up to 2^-9 and the recurrent state drifts over a 1024-token prompt
+            new[name] = torch.from_numpy(np.ascontiguousarray(a)).reshape(tuple(ref.shape))
         else:
             new[name] = _bits_to_bf16(a, tuple(ref.shape))
     model.load_state_dict(new, assign=True)
