@@ -167,6 +167,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 }  // namespace pk
 #include "gemm256.h"   // 256 x 256 tiles, 8 waves, 8-phase schedule (long prompts); uses SplitOut / lds_slot
+#include "gemm_stream.h"   // CU-count-sized row tiles for 17..64 token columns (round 4); uses SplitOut / lds_slot / BK
 namespace pk {
 
 // SPLITK: blockIdx.y = K slice z of `ksplit` (each nk_slice K tiles); the workgroup writes its fp32 partial tile to
@@ -681,14 +682,22 @@ constexpr int kMidBatchMinRows = 5120;
 // 17..64 columns, plain (optionally row-segmented) output: 1 = tiled LDS-DMA GEMM, 2 = its split-K form, 0 = not
 // taken (skinny kernel / separate calls).  One decision for gemm_cuda, pegainfer_gemm_split and pegainfer_gemm_silu,
 // so that a stacked launch and the plain launch over the same matrix always run the same kernel.
-static int mid_batch_route(const Half* W, const Half* X, const Half* Y, int M, int T, int K) {
+// 3 = the weight-streaming kernel of gemm_stream.h (round 4): row tiles sized to the CU count, full K per workgroup - taken
+// whenever its plan exists (up to 96 rows per tile, i.e. everything but lm_head), PEGAINFER_STREAM_GEMM=0 switches it off.
+static bool stream_gemm_on() {
+  static const bool v = [] { const char* e = getenv("PEGAINFER_STREAM_GEMM"); return !(e && e[0] == '0'); }();
+  return v;
+}
+static int mid_batch_route(const Half* W, const Half* X, const Half* Y, int M, int T, int K, int silu_I = 0) {
   static const int min_rows = [] { const char* e = getenv("PEGAINFER_MID_MIN_ROWS"); return e && *e ? atoi(e) : kMidBatchMinRows; }();
   if (T <= 16 || T > 64 || !glds_gemm_ok(W, X, Y, M, K)) return 0;
+  if (stream_gemm_on() && stream_plan(M, silu_I).rt > 0) return 3;
   if (splitk_plan(M, T, K).nk_slice > 0) return 2;
   return M >= min_rows ? 1 : 0;
 }
 static bool mid_batch_gemm(const Half* W, const Half* X, Half* Y, int M, int T, int K, const SplitOut& so, hipStream_t s) {
-  const int route = mid_batch_route(W, X, Y, M, T, K);
+  const int route = mid_batch_route(W, X, Y, M, T, K, so.silu_I);
+  if (route == 3) return stream_gemm_launch<64>(W, X, Y, M, T, K, so, s);
   if (route == 2) glds_splitk_launch(W, X, Y, M, T, K, so, splitk_plan(M, T, K), s);
   else if (route == 1) glds_gemm_launch(W, X, Y, M, T, K, so, 23, s);
   return route != 0;
@@ -872,10 +881,12 @@ static pegainfer_status_t gemm_silu_impl(const Half* W, const Half* X, Half* Y, 
   using namespace pk;
   if (I <= 0 || T <= 0 || K <= 0) return (pegainfer_status_t)hipErrorInvalidValue;
   const int M = 2 * I;
+  const int mroute = T <= 64 ? mid_batch_route(W, X, Y, M, T, K, I) : 0;
   if (T > 16 && (I & 3) == 0 && glds_gemm_ok(W, X, Y, M, K) &&
-      (T > 64 ? splitk_plan(M, T, K).nk_slice == 0 : mid_batch_route(W, X, Y, M, T, K) == 1)) {
+      (T > 64 ? splitk_plan(M, T, K).nk_slice == 0 : (mroute == 1 || mroute == 3))) {
     SplitOut so{nullptr, nullptr, nullptr, 0, 0, 0, I, double_round};
-    glds_gemm_launch(W, X, Y, M, T, K, so, T <= 64 ? 23 : 0, as_stream(stream));
+    if (mroute == 3) stream_gemm_launch<64>(W, X, Y, M, T, K, so, as_stream(stream));   // 40 + 40 rows per tile: 244 workgroups
+    else glds_gemm_launch(W, X, Y, M, T, K, so, T <= 64 ? 23 : 0, as_stream(stream));
     return (pegainfer_status_t)hipGetLastError();
   }
   if (!gate_up_scratch) return (pegainfer_status_t)hipErrorInvalidValue;
