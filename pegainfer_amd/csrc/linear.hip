@@ -691,7 +691,8 @@ static bool stream_gemm_on() {
 static int mid_batch_route(const Half* W, const Half* X, const Half* Y, int M, int T, int K, int silu_I = 0) {
   static const int min_rows = [] { const char* e = getenv("PEGAINFER_MID_MIN_ROWS"); return e && *e ? atoi(e) : kMidBatchMinRows; }();
   if (T <= 16 || T > 64 || !glds_gemm_ok(W, X, Y, M, K)) return 0;
-  if (stream_gemm_on() && stream_plan(M, silu_I).rt > 0) return 3;
+  static const int stream_min_rt = [] { const char* e = getenv("PEGAINFER_STREAM_MIN_RT"); return e && *e ? atoi(e) : 1; }();
+  if (stream_gemm_on() && stream_plan(M, silu_I).rt >= stream_min_rt) return 3;
   if (splitk_plan(M, T, K).nk_slice > 0) return 2;
   return M >= min_rows ? 1 : 0;
 }

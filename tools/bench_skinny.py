@@ -22,7 +22,7 @@ SITES = [(0, "qkv", 6144, 2560), (1, "o", 2560, 4096), (2, "gate_up", 19456, 256
 
 def main():
     Ts = [int(x) for x in sys.argv[1:]] or [8, 16]
-    knobs = ("PEGAINFER_SKINNY_", "PEGAINFER_SPLITK", "PEGAINFER_MID_")
+    knobs = ("PEGAINFER_SKINNY_", "PEGAINFER_SPLITK", "PEGAINFER_MID_", "PEGAINFER_STREAM_")
     tag = " ".join(f"{k[10:]}={v}" for k, v in sorted(os.environ.items()) if k.startswith(knobs)) or "default"
     dev = torch.device("cuda:0")
     eng = Qwen3Engine(dict(QWEN3_4B), num_kv_pages=64, max_batch_size=max(Ts), enable_graph=False, device=0)
