@@ -42,7 +42,7 @@ def main():
     g = torch.Generator(device="cpu").manual_seed(11)
     for name, M, K in [("o", 2560, 4096), ("down", 2560, 9728), ("qkv", 6144, 2560), ("ragged", 1000, 2560)]:
         W = (torch.randn(M, K, generator=g) * 0.05).to(torch.bfloat16).to(dev)
-        for T in (5, 16):
+        for T in (5, 16, 32, 64):
             X = torch.randn(T, K, generator=g).to(torch.bfloat16).to(dev)
             Y = torch.empty(T, M, dtype=torch.bfloat16, device=dev)
             ops.gemm_into(W, X, Y)
