@@ -238,11 +238,13 @@ inline StreamPlan stream_plan(int M, int silu_cols /* 0 = plain */) {
   return {r / 16, r, ceil_div(M, r)};
 }
 
-// Ring depths: W so that ~40-48 KB of weights are in flight per workgroup (= per CU: 24 GB/s x ~2 us), X three tiles
-// (six for the 16-row tiles, whose K steps are only ~85 ns of W ingest each).
+// Ring depths = latency x rate of each stream.  W: ~2 us x 24 GB/s per CU = 40-48 KB ahead whatever RT is.  X: the tile
+// rate is the W rate / (RT x 2 KB), and an X tile (L2-resident, but 8 scattered rows per DMA) takes ~1.2 us under load
+// (measured: with 3 X tiles the K loop ran at 0.6 us per step for RT = 5 and 0.24 us for RT = 1 - X-latency-bound), so
+// the X ring must hold 1.2 us of K steps: 4 tiles for 80-row tiles, 8 for 32-row, 12 for 16-row.
 template <int RT> struct StreamDepth {
-  static constexpr int W = RT == 1 ? 24 : RT == 2 ? 12 : RT == 3 ? 8 : RT == 4 ? 6 : 5;
-  static constexpr int X = RT == 1 ? 6 : RT == 2 ? 4 : 3;
+  static constexpr int W = RT == 1 ? 20 : RT == 2 ? 12 : RT == 3 ? 8 : RT == 4 ? 6 : 6;
+  static constexpr int X = RT == 1 ? 13 : RT == 2 ? 9 : RT == 3 ? 7 : RT == 4 ? 6 : 5;
 };
 template <int RT, int TT>
 inline void stream_gemm_launch_rt(const Half* W, const Half* X, Half* Y, int M, int T, int K, const StreamPlan& pl,
