@@ -238,10 +238,10 @@ inline StreamPlan stream_plan(int M, int silu_cols /* 0 = plain */) {
   return {r / 16, r, ceil_div(M, r)};
 }
 
-// Ring depths = latency x rate of each stream.  W: ~2 us x 24 GB/s per CU = 40-48 KB ahead whatever RT is.  X: the tile
-// rate is the W rate / (RT x 2 KB), and an X tile (L2-resident, but 8 scattered rows per DMA) takes ~1.2 us under load
-// (measured: with 3 X tiles the K loop ran at 0.6 us per step for RT = 5 and 0.24 us for RT = 1 - X-latency-bound), so
-// the X ring must hold 1.2 us of K steps: 4 tiles for 80-row tiles, 8 for 32-row, 12 for 16-row.
+// Ring depths.  W: ~2 us x 24 GB/s per CU = 40-48 KB ahead whatever RT is; X: a few tiles.  Measured: going from 3 X tiles
+// to 5-13 changed NOTHING (gate_up 25.2 us, down_proj at RT = 1 38.6 us either way) - the K loop is not latency-bound but
+// bound by the CU's total ingest, W + X bytes alike at ~30-40 GB/s per CU (RT = 5: 18 KB per K step in 0.63 us; RT = 1:
+// 10 KB in 0.25 us).  What lowers the time is fewer bytes per CU: that is K split over workgroups, not this kernel.
 template <int RT> struct StreamDepth {
   static constexpr int W = RT == 1 ? 20 : RT == 2 ? 12 : RT == 3 ? 8 : RT == 4 ? 6 : 6;
   static constexpr int X = RT == 1 ? 13 : RT == 2 ? 9 : RT == 3 ? 7 : RT == 4 ? 6 : 5;

@@ -682,8 +682,12 @@ constexpr int kMidBatchMinRows = 5120;
 // 17..64 columns, plain (optionally row-segmented) output: 1 = tiled LDS-DMA GEMM, 2 = its split-K form, 0 = not
 // taken (skinny kernel / separate calls).  One decision for gemm_cuda, pegainfer_gemm_split and pegainfer_gemm_silu,
 // so that a stacked launch and the plain launch over the same matrix always run the same kernel.
-// 3 = the weight-streaming kernel of gemm_stream.h (round 4): row tiles sized to the CU count, full K per workgroup - taken
-// whenever its plan exists (up to 96 rows per tile, i.e. everything but lm_head), PEGAINFER_STREAM_GEMM=0 switches it off.
+// 3 = the weight-streaming kernel of gemm_stream.h (round 4): row tiles sized to the CU count, full K per workgroup.  Taken
+// for tiles of >= 3 row blocks (gate_up: 27.0 -> 25.3 us at 32 columns, 29.8 -> 25.2 at 64; same bits as the 128-row kernel).
+// Smaller matrices keep the split-K route: measured (profiles/r4_stream_gemm_ab.txt) a CU's memory path delivers ~30-40 GB/s
+// in TOTAL - the L2-resident x tiles cost what HBM weights cost - so with full K per workgroup o_proj / down_proj pull
+// 0.5-1.2 MB of x per CU for 130-310 KB of weights (18 / 39 us against 13 / 19 with K split over workgroups).
+// PEGAINFER_STREAM_GEMM=0 switches it off, PEGAINFER_STREAM_MIN_RT moves the threshold.
 static bool stream_gemm_on() {
   static const bool v = [] { const char* e = getenv("PEGAINFER_STREAM_GEMM"); return !(e && e[0] == '0'); }();
   return v;
@@ -691,7 +695,7 @@ static bool stream_gemm_on() {
 static int mid_batch_route(const Half* W, const Half* X, const Half* Y, int M, int T, int K, int silu_I = 0) {
   static const int min_rows = [] { const char* e = getenv("PEGAINFER_MID_MIN_ROWS"); return e && *e ? atoi(e) : kMidBatchMinRows; }();
   if (T <= 16 || T > 64 || !glds_gemm_ok(W, X, Y, M, K)) return 0;
-  static const int stream_min_rt = [] { const char* e = getenv("PEGAINFER_STREAM_MIN_RT"); return e && *e ? atoi(e) : 1; }();
+  static const int stream_min_rt = [] { const char* e = getenv("PEGAINFER_STREAM_MIN_RT"); return e && *e ? atoi(e) : 3; }();
   if (stream_gemm_on() && stream_plan(M, silu_I).rt >= stream_min_rt) return 3;
   if (splitk_plan(M, T, K).nk_slice > 0) return 2;
   return M >= min_rows ? 1 : 0;
