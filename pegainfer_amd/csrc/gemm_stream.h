@@ -20,13 +20,10 @@
 
 namespace pk {
 
-// SPLITK: blockIdx.y = K slice z (nk_slice K tiles each); the workgroup writes its fp32 partial tile to part[z][T][M] - the
-// layout of mfma_gemm_glds_kernel<.., true> - and the slice sum is one of the splitk_reduce* launches of linear.hip.
-template <int RT, int TT, int STW, int STX, bool SPLITK = false>
+template <int RT, int TT, int STW, int STX>
 __global__ __launch_bounds__(256) void stream_gemm_kernel(const Half* __restrict__ W, const Half* __restrict__ X,
                                                           Half* __restrict__ Y, int M, int T, int K, int m_tiles,
-                                                          int t_tiles, int rows_per_tile, SplitOut so,
-                                                          float* __restrict__ part = nullptr, int nk_slice = 0) {
+                                                          int t_tiles, int rows_per_tile, SplitOut so) {
   constexpr int TJ = TT / 64;                 // 16-token blocks per wave
   constexpr int NWG = RT * 2;                 // 8-row groups of the W tile
   constexpr int DWW = (NWG + 1) / 2;          // W DMAs per W wave per K tile (groups past NWG re-send the last one)
@@ -54,8 +51,6 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const Half* __restrict
   // per CU whatever RT is, X (L2-resident, shared by all workgroups) two or more tiles ahead.
   const bool w_role = wave < 2;
   const int ww = wave & 1;
-  const int kt_begin = SPLITK ? (int)blockIdx.y * nk_slice : 0;
-  const size_t kofs = (size_t)kt_begin * BK;
 
   const Half* src[DWW > DXX ? DWW : DXX];
   if (w_role) {
@@ -77,7 +72,7 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const Half* __restrict
         mr = m0 + r;
         mr = mr < M ? mr : M - 1;
       }
-      src[j] = W + (size_t)mr * K + kofs + ((ls ^ (row & 7)) << 3);
+      src[j] = W + (size_t)mr * K + ((ls ^ (row & 7)) << 3);
     }
   } else {
 #pragma unroll
@@ -85,7 +80,7 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const Half* __restrict
       const int row = (ww + 2 * j) * 8 + lr;
       int tr = t0 + row;
       tr = tr < T ? tr : T - 1;
-      src[j] = X + (size_t)tr * K + kofs + ((ls ^ (row & 7)) << 3);
+      src[j] = X + (size_t)tr * K + ((ls ^ (row & 7)) << 3);
     }
   }
   f32x4 acc[RT][TJ];
@@ -114,8 +109,7 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const Half* __restrict
                    :: "v"(src[j] + (size_t)kt * BK), "s"(dst) : "memory", "m0");
     }
   };
-  const int nk_all = K / BK;
-  const int nk = SPLITK ? (nk_all - kt_begin < nk_slice ? nk_all - kt_begin : nk_slice) : nk_all;
+  const int nk = K / BK;
   if (w_role) {
 #pragma unroll
     for (int p = 0; p < STW - 1; ++p)
@@ -164,21 +158,6 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const Half* __restrict
     nxtx = nxtx + 1 == STX ? 0 : nxtx + 1;
   }
   // C layout (16x16x32): col = lane & 15 -> token, rows (lane >> 4) * 4 + e -> 4 consecutive tile rows
-  if constexpr (SPLITK) {   // fp32 partial tile (M % 4 == 0: a lane's 4 rows are all in or all out); plain form only
-    float* dst = part + (size_t)blockIdx.y * T * M;
-#pragma unroll
-    for (int j = 0; j < TJ; ++j) {
-      const int t = t0 + wt + j * 16 + l15;
-      if (t >= T) continue;
-#pragma unroll
-      for (int i = 0; i < RT; ++i) {
-        const int rl = i * 16 + g * 4;
-        const int m = m0 + rl;
-        if (rl < rows_per_tile && m < M) *reinterpret_cast<f32x4*>(dst + (size_t)t * M + m) = acc[i][j];
-      }
-    }
-    return;
-  }
   if (silu) {
     if constexpr (RT >= 2) {
 #pragma unroll
@@ -284,58 +263,6 @@ inline void stream_gemm_launch_rt(const Half* W, const Half* X, Half* Y, int M, 
   stream_gemm_kernel<RT, TT, STW, STX><<<pl.m_tiles * t_tiles, 256, kLds, s>>>(W, X, Y, M, T, K, pl.m_tiles, t_tiles,
                                                                               pl.rows_per_tile, so);
 }
-// K split over workgroups for the small matrices (17..64 columns).  A CU's memory path delivers ~30-40 GB/s in total, x
-// from L2 included, so the bytes PER CU decide: M K 2 / 256 (W) + T K 2 / s (the K slice of x) + s M T 4 / 256 (the partial)
-// -> s ~ sqrt(85 K / M) slices, row tiles s times taller so the grid stays at ~one workgroup per CU.  Bounded by the reduce
-// kernels (8 slices) and the instantiated tile heights (96 rows): qkv 4 x 96 rows (256 workgroups), o_proj / down_proj
-// 8 x 80 rows (256).  Chosen by (M, K) only.  s < 2 = not taken.
-struct StreamSplitPlan { int s, nk_slice, rt, rows_per_tile, m_tiles; };
-inline StreamSplitPlan stream_splitk_plan(int M, int K) {
-  constexpr int kCus = 256;
-  const int nk_all = K / BK;
-  int want = 1;
-  while (want < 8 && (want + 1) * (want + 1) * (long)M <= 85L * K) ++want;   // floor(sqrt(85 K / M)), at most 8
-  for (int sp = want; sp >= 2; --sp) {
-    const int rows = ceil_div(ceil_div(sp * M, kCus), 16) * 16;
-    if (rows > 96) continue;
-    int nk_slice = ceil_div(nk_all, sp);
-    if (nk_slice < 4) continue;
-    const int ks = ceil_div(nk_all, nk_slice);   // no empty slice
-    if (ks < 2) continue;
-    return {ks, nk_slice, rows / 16, rows, ceil_div(M, rows)};
-  }
-  return {0, 0, 0, 0, 0};
-}
-template <int RT>
-inline void stream_splitk_launch_rt(const Half* W, const Half* X, int M, int T, int K, const StreamSplitPlan& pl, float* part,
-                                    hipStream_t s) {
-  constexpr int TT = 64;
-  constexpr int STW = StreamDepth<RT>::W, STX = StreamDepth<RT>::X;
-  constexpr int kLds = (STW * RT * 16 + STX * TT) * 8 * 16;
-  static const bool once = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stream_gemm_kernel<RT, TT, STW, STX, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
-    return true;
-  }();
-  (void)once;
-  const int t_tiles = ceil_div(T, TT);
-  stream_gemm_kernel<RT, TT, STW, STX, true><<<dim3(pl.m_tiles * t_tiles, pl.s), 256, kLds, s>>>(
-      W, X, nullptr, M, T, K, pl.m_tiles, t_tiles, pl.rows_per_tile, SplitOut{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0}, part,
-      pl.nk_slice);
-}
-inline bool stream_splitk_launch(const Half* W, const Half* X, int M, int T, int K, float* part, hipStream_t s) {
-  const StreamSplitPlan pl = stream_splitk_plan(M, K);
-  switch (pl.s >= 2 ? pl.rt : 0) {
-    case 1: stream_splitk_launch_rt<1>(W, X, M, T, K, pl, part, s); return true;
-    case 2: stream_splitk_launch_rt<2>(W, X, M, T, K, pl, part, s); return true;
-    case 3: stream_splitk_launch_rt<3>(W, X, M, T, K, pl, part, s); return true;
-    case 4: stream_splitk_launch_rt<4>(W, X, M, T, K, pl, part, s); return true;
-    case 5: stream_splitk_launch_rt<5>(W, X, M, T, K, pl, part, s); return true;
-    case 6: stream_splitk_launch_rt<6>(W, X, M, T, K, pl, part, s); return true;
-    default: return false;
-  }
-}
-
 template <int TT>
 inline bool stream_gemm_launch(const Half* W, const Half* X, Half* Y, int M, int T, int K, const SplitOut& so, hipStream_t s) {
   const StreamPlan pl = stream_plan(M, so.silu_I > 0 ? silu_cols_end(so) - so.silu_c0 : 0);

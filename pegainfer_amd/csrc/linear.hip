@@ -490,15 +490,6 @@ static void glds_gemm_launch_t(const Half* W, const Half* X, Half* Y, int M, int
 //    resident.  o_proj / down_proj at 1024 tokens (160 tiles): 3 slices, 45 -> 40 and 100 -> 78 us (2 slices leave a
 //    quarter of the CUs with two workgroups: the makespan does not move); at 128 tokens qkv / o / down have 48 / 20 / 20
 //    tiles of 128x128 and ran at 95-150 TFLOP/s un-split.
-static bool stream_gemm_on() {
-  static const bool v = [] { const char* e = getenv("PEGAINFER_STREAM_GEMM"); return !(e && e[0] == '0'); }();
-  return v;
-}
-// PEGAINFER_STREAM_SPLITK=0: the 17..64-column split-K GEMMs keep the 128-row tiles (A/B)
-static bool stream_splitk_on() {
-  static const bool v = [] { const char* e = getenv("PEGAINFER_STREAM_SPLITK"); return !(e && e[0] == '0'); }();
-  return v && stream_gemm_on();
-}
 static bool gemm128x256_on() {
   static const bool v = [] { const char* e = getenv("PEGAINFER_GEMM128X256"); return !(e && e[0] == '0'); }();
   return v;
@@ -552,12 +543,6 @@ static SplitKPlan splitk_plan(int M, int T, int K, bool assume_ws = false) {
     return {ksplit, nk_slice, tt};
   }
   if (M >= kSplitKMaxRows) return {0, 0, 0};
-  // 17..64 columns (round 4): K slices and tile heights from the bytes a CU has to pull (gemm_stream.h); tt == 65 marks
-  // the plan.  By (M, K) only, like the plan below it replaces.
-  if (stream_splitk_on()) {
-    const StreamSplitPlan sp = stream_splitk_plan(M, K);
-    if (sp.s >= 2 && (size_t)sp.s * T * M * 4 <= kSplitKWorkspaceBytes) return {sp.s, sp.nk_slice, 65};
-  }
   int want = ceil_div(192, m_tiles);
   want = want > 8 ? 8 : want;
   if (want < 2 || nk_all < 8) return {0, 0, 0};
@@ -572,9 +557,7 @@ static SplitKPlan splitk_plan(int M, int T, int K, bool assume_ws = false) {
 static void glds_splitk_launch(const Half* W, const Half* X, Half* Y, int M, int T, int K, SplitOut so, SplitKPlan pl,
                                hipStream_t s, bool reduce = true) {
   const int m_tiles = ceil_div(M, BM);
-  if (pl.tt == 65) {
-    stream_splitk_launch(W, X, M, T, K, g_splitk_ws, s);
-  } else if (pl.tt == 256) {
+  if (pl.tt == 256) {
     gemm256_splitk_launch(W, X, M, T, K, g_splitk_ws, pl.ksplit, pl.nk_slice, s);
   } else if (pl.tt == 129) {
     gemm128x256_launch(W, X, Y, M, T, K, so, g_splitk_ws, pl.ksplit, pl.nk_slice, s);
@@ -705,6 +688,10 @@ constexpr int kMidBatchMinRows = 5120;
 // in TOTAL - the L2-resident x tiles cost what HBM weights cost - so with full K per workgroup o_proj / down_proj pull
 // 0.5-1.2 MB of x per CU for 130-310 KB of weights (18 / 39 us against 13 / 19 with K split over workgroups).
 // PEGAINFER_STREAM_GEMM=0 switches it off, PEGAINFER_STREAM_MIN_RT moves the threshold.
+static bool stream_gemm_on() {
+  static const bool v = [] { const char* e = getenv("PEGAINFER_STREAM_GEMM"); return !(e && e[0] == '0'); }();
+  return v;
+}
 static int mid_batch_route(const Half* W, const Half* X, const Half* Y, int M, int T, int K, int silu_I = 0) {
   static const int min_rows = [] { const char* e = getenv("PEGAINFER_MID_MIN_ROWS"); return e && *e ? atoi(e) : kMidBatchMinRows; }();
   if (T <= 16 || T > 64 || !glds_gemm_ok(W, X, Y, M, K)) return 0;
