@@ -242,14 +242,15 @@ inline StreamPlan stream_plan(int M, int silu_cols /* 0 = plain */) {
 // to 5-13 changed NOTHING (gate_up 25.2 us, down_proj at RT = 1 38.6 us either way) - the K loop is not latency-bound but
 // bound by the CU's total ingest, W + X bytes alike at ~30-40 GB/s per CU (RT = 5: 18 KB per K step in 0.63 us; RT = 1:
 // 10 KB in 0.25 us).  What lowers the time is fewer bytes per CU: that is K split over workgroups, not this kernel.
-template <int RT> struct StreamDepth {
+template <int RT, int TT = 64> struct StreamDepth {
   static constexpr int W = RT == 1 ? 20 : RT == 2 ? 12 : RT == 3 ? 8 : RT == 4 ? 6 : 6;
-  static constexpr int X = RT == 1 ? 13 : RT == 2 ? 9 : RT == 3 ? 7 : RT == 4 ? 6 : 5;
+  static constexpr int X64 = RT == 1 ? 13 : RT == 2 ? 9 : RT == 3 ? 7 : RT == 4 ? 6 : 5;
+  static constexpr int X = TT == 64 ? X64 : (X64 > 5 ? 5 : X64);   // 128-token tiles: 16 KB per X stage, 160 KB of LDS in all
 };
 template <int RT, int TT>
 inline void stream_gemm_launch_rt(const Half* W, const Half* X, Half* Y, int M, int T, int K, const StreamPlan& pl,
                                   const SplitOut& so, hipStream_t s) {
-  constexpr int STW = StreamDepth<RT>::W, STX = StreamDepth<RT>::X;
+  constexpr int STW = StreamDepth<RT, TT>::W, STX = StreamDepth<RT, TT>::X;
   static_assert((STW - 2) * ((RT * 2 + 1) / 2) <= 63 && (STX - 2) * (TT / 16) <= 63, "vmcnt immediate");
   constexpr int kLds = (STW * RT * 16 + STX * TT) * 8 * 16;
   static_assert(kLds <= 160 * 1024, "LDS");
@@ -266,9 +267,11 @@ inline void stream_gemm_launch_rt(const Half* W, const Half* X, Half* Y, int M, 
 template <int TT>
 inline bool stream_gemm_launch(const Half* W, const Half* X, Half* Y, int M, int T, int K, const SplitOut& so, hipStream_t s) {
   const StreamPlan pl = stream_plan(M, so.silu_I > 0 ? silu_cols_end(so) - so.silu_c0 : 0);
-  switch (pl.rt) {
-    case 1: stream_gemm_launch_rt<1, TT>(W, X, Y, M, T, K, pl, so, s); return true;
-    case 2: stream_gemm_launch_rt<2, TT>(W, X, Y, M, T, K, pl, so, s); return true;
+  if constexpr (TT == 64) {
+    if (pl.rt == 1) { stream_gemm_launch_rt<1, TT>(W, X, Y, M, T, K, pl, so, s); return true; }
+    if (pl.rt == 2) { stream_gemm_launch_rt<2, TT>(W, X, Y, M, T, K, pl, so, s); return true; }
+  }
+  switch (pl.rt) {   // 128-token tiles exist for >= 3 row blocks only (the 16 / 32-row tiles are not routed at all)
     case 3: stream_gemm_launch_rt<3, TT>(W, X, Y, M, T, K, pl, so, s); return true;
     case 4: stream_gemm_launch_rt<4, TT>(W, X, Y, M, T, K, pl, so, s); return true;
     case 5: stream_gemm_launch_rt<5, TT>(W, X, Y, M, T, K, pl, so, s); return true;

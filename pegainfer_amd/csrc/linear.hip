@@ -490,6 +490,14 @@ static void glds_gemm_launch_t(const Half* W, const Half* X, Half* Y, int M, int
 //    resident.  o_proj / down_proj at 1024 tokens (160 tiles): 3 slices, 45 -> 40 and 100 -> 78 us (2 slices leave a
 //    quarter of the CUs with two workgroups: the makespan does not move); at 128 tokens qkv / o / down have 48 / 20 / 20
 //    tiles of 128x128 and ran at 95-150 TFLOP/s un-split.
+static bool stream_gemm_on() {
+  static const bool v = [] { const char* e = getenv("PEGAINFER_STREAM_GEMM"); return !(e && e[0] == '0'); }();
+  return v;
+}
+static int stream_min_rt() {
+  static const int v = [] { const char* e = getenv("PEGAINFER_STREAM_MIN_RT"); return e && *e ? atoi(e) : 3; }();
+  return v;
+}
 static bool gemm128x256_on() {
   static const bool v = [] { const char* e = getenv("PEGAINFER_GEMM128X256"); return !(e && e[0] == '0'); }();
   return v;
@@ -617,6 +625,12 @@ static TiledRoute tiled_route(int M, int T, int K, const SplitOut& so) {
       return {256, 0};
     }
   }
+  // 65..128 tokens on a gate_up-sized matrix (round 4): the weight-streaming kernel with 128-token tiles - row tiles sized
+  // to the CU count (244 workgroups instead of 152), same per-element K order as every un-split tiled kernel.  kind 3000 + RT.
+  if (T <= 128 && so.silu_c1 == 0 && stream_gemm_on()) {
+    const StreamPlan sp = stream_plan(M, so.silu_I > 0 ? so.silu_I : 0);
+    if (sp.rt >= stream_min_rt()) return {3000 + sp.rt, 0};
+  }
   // SwiGLU GEMM on short prompts (65..256 tokens: 152 tiles of (64 + 64) x 256 for Qwen3-4B, one round) - the 128 x 128
   // kernel runs these at one 4-wave workgroup per CU.  Same per-element K order: bit-identical to gemm + silu_mul
   // (tested).  TTFT(128) 4.85 -> 4.63 ms, TTFT(256) 5.79 -> 5.27 ms same-box (PEGAINFER_GEMM128X256_SILU=0 for the A/B)
@@ -654,6 +668,7 @@ static void glds_gemm_launch(const Half* W, const Half* X, Half* Y, int M, int T
     }
     if (r.kind == 256) { gemm256_launch(W, X, Y, M, T, K, so, s); return; }
     if (r.kind == 1280 || r.kind == 1281) { gemm128x256_launch(W, X, Y, M, T, K, so, nullptr, 1, 0, s); return; }
+    if (r.kind >= 3000) { stream_gemm_launch<128>(W, X, Y, M, T, K, so, s); return; }
     variant = r.kind;
   }
   switch (variant) {
@@ -688,15 +703,10 @@ constexpr int kMidBatchMinRows = 5120;
 // in TOTAL - the L2-resident x tiles cost what HBM weights cost - so with full K per workgroup o_proj / down_proj pull
 // 0.5-1.2 MB of x per CU for 130-310 KB of weights (18 / 39 us against 13 / 19 with K split over workgroups).
 // PEGAINFER_STREAM_GEMM=0 switches it off, PEGAINFER_STREAM_MIN_RT moves the threshold.
-static bool stream_gemm_on() {
-  static const bool v = [] { const char* e = getenv("PEGAINFER_STREAM_GEMM"); return !(e && e[0] == '0'); }();
-  return v;
-}
 static int mid_batch_route(const Half* W, const Half* X, const Half* Y, int M, int T, int K, int silu_I = 0) {
   static const int min_rows = [] { const char* e = getenv("PEGAINFER_MID_MIN_ROWS"); return e && *e ? atoi(e) : kMidBatchMinRows; }();
   if (T <= 16 || T > 64 || !glds_gemm_ok(W, X, Y, M, K)) return 0;
-  static const int stream_min_rt = [] { const char* e = getenv("PEGAINFER_STREAM_MIN_RT"); return e && *e ? atoi(e) : 3; }();
-  if (stream_gemm_on() && stream_plan(M, silu_I).rt >= stream_min_rt) return 3;
+  if (stream_gemm_on() && stream_plan(M, silu_I).rt >= stream_min_rt()) return 3;
   if (splitk_plan(M, T, K).nk_slice > 0) return 2;
   return M >= min_rows ? 1 : 0;
 }
