@@ -243,11 +243,9 @@ inline StreamPlan stream_plan(int M, int silu_cols /* 0 = plain */) {
 // bound by the CU's total ingest, W + X bytes alike at ~30-40 GB/s per CU (RT = 5: 18 KB per K step in 0.63 us; RT = 1:
 // 10 KB in 0.25 us).  What lowers the time is fewer bytes per CU: that is K split over workgroups, not this kernel.
 template <int RT, int TT = 64> struct StreamDepth {
-  static constexpr int W64 = RT == 1 ? 20 : RT == 2 ? 12 : RT == 3 ? 8 : RT == 4 ? 6 : 6;
+  static constexpr int W = RT == 1 ? 20 : RT == 2 ? 12 : RT == 3 ? 8 : RT == 4 ? 6 : 6;
   static constexpr int X64 = RT == 1 ? 13 : RT == 2 ? 9 : RT == 3 ? 7 : RT == 4 ? 6 : 5;
-  // 128 / 256-token tiles: 16 / 32 KB per X stage and 160 KB of LDS in all -> 5 / 3 X stages, 4 W stages at 256 tokens
-  static constexpr int W = TT == 256 ? (W64 > 4 ? 4 : W64) : W64;
-  static constexpr int X = TT == 64 ? X64 : TT == 128 ? (X64 > 5 ? 5 : X64) : 3;
+  static constexpr int X = TT == 64 ? X64 : (X64 > 5 ? 5 : X64);   // 128-token tiles: 16 KB per X stage, 160 KB of LDS in all
 };
 template <int RT, int TT>
 inline void stream_gemm_launch_rt(const Half* W, const Half* X, Half* Y, int M, int T, int K, const StreamPlan& pl,

@@ -625,10 +625,9 @@ static TiledRoute tiled_route(int M, int T, int K, const SplitOut& so) {
       return {256, 0};
     }
   }
-  // 65..256 tokens on a gate_up-sized matrix (round 4): the weight-streaming kernel with ONE 128- / 256-token tile - row
-  // tiles sized to the CU count (244 workgroups instead of 152), same per-element K order as every un-split tiled kernel:
-  // gate_up 47.5 -> 32.9 us at 128 tokens, sha-identical (profiles/r4_stream128_ab.txt).  kind 3000 + RT.
-  if (T <= 256 && so.silu_c1 == 0 && stream_gemm_on()) {
+  // 65..128 tokens on a gate_up-sized matrix (round 4): the weight-streaming kernel with 128-token tiles - row tiles sized
+  // to the CU count (244 workgroups instead of 152), same per-element K order as every un-split tiled kernel.  kind 3000 + RT.
+  if (T <= 128 && so.silu_c1 == 0 && stream_gemm_on()) {
     const StreamPlan sp = stream_plan(M, so.silu_I > 0 ? so.silu_I : 0);
     if (sp.rt >= stream_min_rt()) return {3000 + sp.rt, 0};
   }
@@ -669,11 +668,7 @@ static void glds_gemm_launch(const Half* W, const Half* X, Half* Y, int M, int T
     }
     if (r.kind == 256) { gemm256_launch(W, X, Y, M, T, K, so, s); return; }
     if (r.kind == 1280 || r.kind == 1281) { gemm128x256_launch(W, X, Y, M, T, K, so, nullptr, 1, 0, s); return; }
-    if (r.kind >= 3000) {
-      if (T <= 128) stream_gemm_launch<128>(W, X, Y, M, T, K, so, s);
-      else stream_gemm_launch<256>(W, X, Y, M, T, K, so, s);
-      return;
-    }
+    if (r.kind >= 3000) { stream_gemm_launch<128>(W, X, Y, M, T, K, so, s); return; }
     variant = r.kind;
   }
   switch (variant) {

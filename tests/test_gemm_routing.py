@@ -29,7 +29,7 @@ def test_decode_family_is_not_routed_here(route):
 @pytest.mark.parametrize("T,qkv,o,down,gate_up", [
     # kind 1000 + tt = K-split plan on tt-token tiles (129: 128 x 256 kernel, 256: 256 x 256 kernel), (slices, K tiles per slice)
     (128, (1064, 5, 8), (1064, 8, 8), (1064, 8, 19), (3006, 1, 0)),     # gate_up: the weight-streaming kernel, 40 + 40-row SwiGLU tiles (3000 + row blocks)
-    (256, (23, 1, 0), (1064, 6, 11), (1064, 6, 26), (3006, 1, 0)),      # gate_up: the weight-streaming kernel, one 256-token tile
+    (256, (23, 1, 0), (1064, 6, 11), (1064, 6, 26), (1281, 1, 0)),      # gate_up: SwiGLU form of the 128 x 256 kernel
     (512, (1129, 2, 20), (1129, 6, 11), (1129, 6, 26), (256, 1, 0)),    # gate_up: 152 tiles of 256 x 256, one round
     (1024, (1280, 1, 0), (1129, 3, 22), (1129, 3, 51), (257, 1, 64)),   # the headline TTFT shape
     (2048, (256, 1, 0), (1256, 3, 22), (1256, 3, 52), (257, 1, 64)),
