@@ -223,7 +223,11 @@ def gemm_check(P, M, T, K, seed=0):
                                    (6, 3, 5), (64, 20, 72),
                                    # 128 x 256-tile kernel (gemm256.h): K-split plans, the un-split round, ragged M / T / K tiles
                                    (2560, 1024, 4096), (6144, 1024, 2560), (1000, 600, 2560), (2500, 515, 4160),
-                                   (5004, 520, 1024), (10000, 530, 1024), (2560, 512, 128)])
+                                   (5004, 520, 1024), (10000, 530, 1024), (2560, 512, 128),
+                                   # weight-streaming kernel (gemm_stream.h): 80 / 64-row tiles at 17..64 columns (64-token
+                                   # tile) and 65..128 (128-token tile), last row tile ragged / almost empty
+                                   (19456, 17, 2560), (19460, 40, 2560), (19460, 100, 2560), (20000, 128, 2560),
+                                   (12292, 64, 1024), (16388, 96, 512)])
 def test_gemm_shapes(P, M, T, K):
     gemm_check(P, M, T, K)
 
@@ -261,7 +265,10 @@ def test_gemm_split3_equals_three_gemms(P, T, K, ms):
 
 
 @pytest.mark.parametrize("T,I,K", [(1024, 9728, 2560), (130, 512, 256), (40, 9728, 2560), (40, 512, 256), (100, 1000, 128),
-                                   (7, 9728, 2560), (256, 9728, 2560), (200, 9730 - 2, 2560), (100, 8200, 1024)])
+                                   (7, 9728, 2560), (256, 9728, 2560), (200, 9730 - 2, 2560), (100, 8200, 1024),
+                                   # weight-streaming kernel, SwiGLU form (40 + 40 rows as 3 + 3 blocks): ragged last tile,
+                                   # both tile widths, the Qwen3-8B (48 + 48 rows) and Qwen3.5 (36 + 36) column counts
+                                   (64, 9732, 2560), (128, 9728, 2560), (17, 12288, 1024), (90, 9216, 512)])
 def test_gemm_silu_epilogue_equals_gemm_then_silu_mul_fused(P, T, I, K):
     """SwiGLU in the tiled GEMM's epilogue (64 gate rows + their 64 up rows per workgroup) == gemm_cuda +
     silu_mul_fused_cuda, bit for bit, incl. partial row tiles, the mid-batch (17..64) family and the small-shape
