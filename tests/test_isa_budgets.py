@@ -78,6 +78,9 @@ def test_decode_gemv_and_gemm_kernels_keep_their_occupancy():
     check(md, r"mfma_gemm128x256_kernel<(true|false)>", 256, at_least=2)
     check(md, r"mfma_gemm_glds_kernel<\d+, \d, (true|false)>", 256, at_least=6)
     check(md, r"splitk_reduce\w*kernel", 256, at_least=3)
+    # round 4: the weight-streaming GEMM (one 4-wave workgroup per CU; 64- and 128-token tiles): lean and spill-free
+    check(md, r"stream_gemm_kernel<[1-6], 64, \d+, \d+>", 128, at_least=6)
+    check(md, r"stream_gemm_kernel<[3-6], 128, \d+, \d+>", 168, at_least=4)
 
 
 def test_attention_kernels_keep_their_occupancy():
