@@ -104,8 +104,12 @@ __global__ __launch_bounds__(512) void mfma_gemm256_kernel(const Half* __restric
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const uint32_t dst = __builtin_amdgcn_readfirstlane(slot + (uint32_t)(j * 8 + wave) * 1024u);
-      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
-                   :: "v"(src[which][j] + (size_t)ktc * G256_BK), "s"(dst) : "memory", "m0");
+      if ((which == kHalfAlo || which == kHalfAhi) && so.w_nt)   // a single token tile: W bytes have one reader (SplitOut::w_nt)
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt"
+                     :: "v"(src[which][j] + (size_t)ktc * G256_BK), "s"(dst) : "memory", "m0");
+      else
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                     :: "v"(src[which][j] + (size_t)ktc * G256_BK), "s"(dst) : "memory", "m0");
     }
   };
   auto half_ptr = [&](int par, int which) { return g256_smem + (size_t)(par * 4 + which) * (kG256HalfBytes / 16); };
@@ -274,6 +278,7 @@ inline bool gemm256_ok(int M, int T, int K) { return (K % 128) == 0 && K >= 256 
 inline void gemm256_launch(const Half* W, const Half* X, Half* Y, int M, int T, int K, SplitOut so, hipStream_t s) {
   const bool silu = so.silu_I > 0;
   const int m_tiles = silu ? ceil_div(silu_cols_end(so) - so.silu_c0, 128) : ceil_div(M, G256_BM), t_tiles = ceil_div(T, G256_BT);
+  so.w_nt = t_tiles == 1 && weights_nt_on();
   if (silu) {
     static const bool once = [] {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_gemm256_kernel<true>),
@@ -304,7 +309,8 @@ inline void gemm256_splitk_launch(const Half* W, const Half* X, int M, int T, in
   }();
   (void)once;
   mfma_gemm256_kernel<false><<<dim3(m_tiles * t_tiles, ksplit), 512, kG256LdsBytes, s>>>(
-      W, X, nullptr, M, T, K, m_tiles, t_tiles, SplitOut{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0}, part, nk_slice);
+      W, X, nullptr, M, T, K, m_tiles, t_tiles,
+      SplitOut{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0, t_tiles == 1 && weights_nt_on()}, part, nk_slice);
 }
 
 // ---- 128 x 256 tiles: the same machinery for matrices with too few 256-row tiles to fill the chip (qkv / o_proj /
@@ -382,8 +388,12 @@ __global__ __launch_bounds__(512) void mfma_gemm128x256_kernel(const Half* __res
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const uint32_t dst = __builtin_amdgcn_readfirstlane(slot + (uint32_t)(j * 8 + wave) * 1024u);
-      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
-                   :: "v"(src[which][j] + (size_t)ktc * G256_BK), "s"(dst) : "memory", "m0");
+      if (which == kG128A && so.w_nt)   // a single token tile: W bytes have one reader (SplitOut::w_nt)
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt"
+                     :: "v"(src[which][j] + (size_t)ktc * G256_BK), "s"(dst) : "memory", "m0");
+      else
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                     :: "v"(src[which][j] + (size_t)ktc * G256_BK), "s"(dst) : "memory", "m0");
     }
   };
   auto half_ptr = [&](int ring, int which) { return g256_smem + (size_t)(ring * 3 + which) * (kG256HalfBytes / 16); };
@@ -540,6 +550,7 @@ inline bool gemm128x256_ok(int M, int T, int K) { return (K % G256_BK) == 0 && K
 inline void gemm128x256_launch(const Half* W, const Half* X, Half* Y, int M, int T, int K, SplitOut so, float* part,
                                int ksplit, int nk_slice, hipStream_t s) {
   const int t_tiles = ceil_div(T, G256_BT);
+  so.w_nt = t_tiles == 1 && weights_nt_on();
   if (so.silu_I > 0) {   // SwiGLU form (un-split only): a tile = 64 gate rows + their 64 up rows
     static const bool once = [] {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_gemm128x256_kernel<true>),

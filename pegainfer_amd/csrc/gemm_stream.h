@@ -97,8 +97,12 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const Half* __restrict
       int rg = ww + 2 * j;
       rg = rg < NWG ? rg : NWG - 1;
       const uint32_t dst = __builtin_amdgcn_readfirstlane(ws_lds + (uint32_t)(buf * RT * 16 * 8 + rg * 64) * 16u);
-      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
-                   :: "v"(src[j] + (size_t)kt * BK), "s"(dst) : "memory", "m0");
+      if (so.w_nt)   // one token tile: this workgroup is the only reader of these W bytes (SplitOut::w_nt)
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt"
+                     :: "v"(src[j] + (size_t)kt * BK), "s"(dst) : "memory", "m0");
+      else
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                     :: "v"(src[j] + (size_t)kt * BK), "s"(dst) : "memory", "m0");
     }
   };
   auto stage_x = [&](int buf, int kt) {
@@ -261,8 +265,10 @@ inline void stream_gemm_launch_rt(const Half* W, const Half* X, Half* Y, int M, 
   }();
   (void)once;
   const int t_tiles = ceil_div(T, TT);
+  SplitOut sk = so;
+  sk.w_nt = t_tiles == 1 && weights_nt_on();
   stream_gemm_kernel<RT, TT, STW, STX><<<pl.m_tiles * t_tiles, 256, kLds, s>>>(W, X, Y, M, T, K, pl.m_tiles, t_tiles,
-                                                                              pl.rows_per_tile, so);
+                                                                              pl.rows_per_tile, sk);
 }
 template <int TT>
 inline bool stream_gemm_launch(const Half* W, const Half* X, Half* Y, int M, int T, int K, const SplitOut& so, hipStream_t s) {

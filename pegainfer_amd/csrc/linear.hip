@@ -159,11 +159,19 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(const Half* __restrict__
 // silu_round: the Qwen3.5 activation bf16(bf16(silu(g)) * u) (elementwise.cu:28-42) instead of one rounding.
 // silu_c0 / silu_c1: the activation columns [c0, c1) this launch computes (0, 0 = all of [0, silu_I)): lets two launches
 // with different tile shapes share one SwiGLU GEMM (the thin last round of the 256 x 256 tiling, glds_gemm_launch)
-struct SplitOut { Half* Y1; Half* Y2; Half* Y3; int M0; int M1; int M2; int silu_I; int silu_round; int silu_c0; int silu_c1; };
+// w_nt (set by the launchers, never by callers): the W tiles are requested with the non-temporal policy - each W byte is
+// read by ONE workgroup once (a single token tile), so it should not displace the x rows every workgroup re-reads from L2.
+struct SplitOut { Half* Y1; Half* Y2; Half* Y3; int M0; int M1; int M2; int silu_I; int silu_round; int silu_c0; int silu_c1; int w_nt; };
 __host__ __device__ inline int silu_cols_end(const SplitOut& so) { return so.silu_c1 > 0 ? so.silu_c1 : so.silu_I; }
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
+
+// PEGAINFER_WEIGHTS_NT=0: A/B switch for SplitOut::w_nt (tools/bench_prefill_gemm.py, tools/batch_sweep.py)
+inline bool weights_nt_on() {
+  static const bool v = [] { const char* e = getenv("PEGAINFER_WEIGHTS_NT"); return !(e && e[0] == '0'); }();
+  return v;
+}
 
 }  // namespace pk
 #include "gemm256.h"   // 256 x 256 tiles, 8 waves, 8-phase schedule (long prompts); uses SplitOut / lds_slot
@@ -236,8 +244,12 @@ __global__ __launch_bounds__(256) void mfma_gemm_glds_kernel(const Half* __restr
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const uint32_t dst = __builtin_amdgcn_readfirstlane(ws_lds + (uint32_t)(buf * BM * 8 + (wave + 4 * j) * 64) * 16u);
-      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
-                   :: "v"(wsrc[j] + (size_t)kt * BK), "s"(dst) : "memory", "m0");
+      if (so.w_nt)
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt"
+                     :: "v"(wsrc[j] + (size_t)kt * BK), "s"(dst) : "memory", "m0");
+      else
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                     :: "v"(wsrc[j] + (size_t)kt * BK), "s"(dst) : "memory", "m0");
     }
 #pragma unroll
     for (int j = 0; j < XG; ++j) {
@@ -480,6 +492,7 @@ static void glds_gemm_launch_t(const Half* W, const Half* X, Half* Y, int M, int
   }();
   (void)once;
   const int m_tiles = so.silu_I > 0 ? ceil_div(silu_cols_end(so) - so.silu_c0, 64) : ceil_div(M, BM), t_tiles = ceil_div(T, TT);
+  so.w_nt = t_tiles == 1 && weights_nt_on();
   mfma_gemm_glds_kernel<TT, ST><<<m_tiles * t_tiles, 256, kLds, s>>>(W, X, Y, M, T, K, m_tiles, t_tiles, so);
 }
 // Split-K plans (nk_slice == 0: not applicable), both chosen by shape only:
@@ -578,6 +591,7 @@ static void glds_splitk_launch(const Half* W, const Half* X, Half* Y, int M, int
     }();
     (void)once;
     const int t_tiles = ceil_div(T, 64);
+    so.w_nt = t_tiles == 1 && weights_nt_on();
     mfma_gemm_glds_kernel<64, 3, true><<<dim3(m_tiles * t_tiles, pl.ksplit), 256, kLds, s>>>(
         W, X, Y, M, T, K, m_tiles, t_tiles, so, g_splitk_ws, pl.nk_slice);
   } else {
@@ -589,6 +603,7 @@ static void glds_splitk_launch(const Half* W, const Half* X, Half* Y, int M, int
     }();
     (void)once;
     const int t_tiles = ceil_div(T, 128);
+    so.w_nt = t_tiles == 1 && weights_nt_on();
     mfma_gemm_glds_kernel<128, 2, true><<<dim3(m_tiles * t_tiles, pl.ksplit), 256, kLds, s>>>(
         W, X, Y, M, T, K, m_tiles, t_tiles, so, g_splitk_ws, pl.nk_slice);
   }
