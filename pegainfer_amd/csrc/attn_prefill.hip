@@ -43,6 +43,7 @@ template <bool POW2>
 struct PagedAddr {
   const int* page_indices; int pbase; int page_size; int stride_page /* elements, < 2^31 (host-checked) */;
   int row_stride; int shift; int* pg; int win0; int n_pages_total;
+  int dma_inline;   // LDS-DMA form: issue the next tile's requests between this tile's MFMA clusters (A/B: PEGAINFER_PREFILL_DMA_INLINE=0)
   __device__ __forceinline__ int page_of_token(int t) const { return POW2 ? t >> shift : t / page_size; }
   __device__ __forceinline__ void load_window(int first_token) {
     win0 = page_of_token(first_token);
@@ -220,7 +221,9 @@ __device__ __forceinline__ void prefill_tile(const Half* __restrict__ q_base, Ha
   };
 
   // one KV tile's arithmetic for this wave: kt = the staged K tile, load_vf(db, kb) = the V^T fragment (16 dims x 32 tokens)
-  auto compute_tile = [&](int kv0, const u32x4* kt, auto&& load_vf) {
+  // hook(slot), slot 0..7 in the S loop and 8..15 in the PV loop: the LDS-DMA form issues the NEXT tile's requests from
+  // there, one between MFMA clusters (see issue_piece), the register-staged form passes a no-op
+  auto compute_tile = [&](int kv0, const u32x4* kt, auto&& load_vf, auto&& hook) {
     // ---- S^T = K . Q^T ----  (raised issue priority around the MFMA clusters: the other resident wave of the SIMD is
     //      in its softmax / staging VALU segment and should not delay these)
     __builtin_amdgcn_s_setprio(1);
@@ -247,6 +250,7 @@ __device__ __forceinline__ void prefill_tile(const Half* __restrict__ q_base, Ha
 #pragma unroll
       for (int p = 0; p < 2 * KS; ++p) {
         const int tb0 = 2 * (p / KS), sl = p % KS;
+        if constexpr (KS == 4) hook(p);
 #pragma unroll
         for (int qb = 0; qb < QBLK; ++qb)
           sacc[qb][tb0 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kr[p & 1][1], qf[qb][sl], sacc[qb][tb0 + 1], 0, 0, 0);
@@ -343,6 +347,7 @@ __device__ __forceinline__ void prefill_tile(const Half* __restrict__ q_base, Ha
 #pragma unroll
     for (int p = 0; p < DB; ++p) {   // fragment pairs as above: an accumulator still sees token half 0 before half 1
       const int db0 = 2 * (p >> 1), kb = p & 1;
+      if constexpr (DB == 8) hook(8 + p);
 #pragma unroll
       for (int qb = 0; qb < QBLK; ++qb)
         acc_o[qb][db0 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vr[p & 1][1], pf[qb][kb], acc_o[qb][db0 + 1], 0, 0, 0);
@@ -426,19 +431,48 @@ __device__ __forceinline__ void prefill_tile(const Half* __restrict__ q_base, Ha
       __syncthreads();  // page-id window staged
       issue_tile(0, 0);
     }
+    // A wave gets one DMA instruction through its issue slot per ~130 cycles (tools/probes/ingest_probe: 18 GB/s per issuing
+    // wave) and nothing behind it in program order issues meanwhile: eight requests in a row right after the barrier kept the
+    // wave off its MFMAs for ~900 cycles per tile (knock-out "DMAs for the first two tiles only": -18 %).  For full tiles the
+    // next tile's requests are therefore spread through THIS tile's arithmetic, one in front of every second MFMA cluster
+    // (K pieces in the S loop, V pieces in the PV loop); the page bases are wave-uniform (a piece = 4 token rows, pages >= 4
+    // rows): their page ids wait in SGPRs.  Waves without arithmetic for the tile, and the ragged last tile, issue theirs in one go.
+    const bool inline_ok = fast_pages && addr.page_size >= 4 && addr.dma_inline;
     int it = 0;
     for (int kv0 = 0; kv0 < cta_kv_end; kv0 += TKV, ++it) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile `it` have landed
       __syncthreads();                                   // everyone's have; everyone is done with tile it - 1's buffers
+      bool inl = false;
+      int pgid[PPW];   // page ids of this wave's pieces of the next tile (SGPRs)
+      const int nb = (it + 1) & 1;
       if (kv0 + TKV < cta_kv_end) {
         const int next_end = kv0 + 2 * TKV < kv_len ? kv0 + 2 * TKV : kv_len;
         if (!addr.covers(next_end)) {  // workgroup-uniform, once per kPgLdsMax pages
           addr.load_window(kv0 + TKV);
           __syncthreads();
         }
-        issue_tile(kv0 + TKV, (it + 1) & 1);  // lands under this tile's MFMAs
+        inl = inline_ok && kv0 + 2 * TKV <= kv_len;
+        if (inl) {
+          const int pi0 = ((kv0 + TKV) >> addr.shift) - addr.win0;
+#pragma unroll
+          for (int j = 0; j < PPW; ++j)
+            pgid[j] = __builtin_amdgcn_readfirstlane(addr.pg[pi0 + (((wave_s * PPW + j) * 4) >> addr.shift)]);
+        } else {
+          issue_tile(kv0 + TKV, nb);  // lands under this tile's MFMAs
+        }
       }
-      if (!wave_active || kv0 >= wave_kv_end) continue;
+      auto issue_piece = [&](int j, bool isv) {
+        const Half* src = (isv ? vbuf : kbuf) + (long)pgid[j] * (long)addr.stride_page + (isv ? v_lane[j] : k_lane[j]);
+        const uint32_t dst = (isv ? v_lds : k_lds) + (uint32_t)(nb * 16384 + (wave_s * PPW + j) * 1024);
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(dst) : "memory", "m0");
+      };
+      if (!wave_active || kv0 >= wave_kv_end) {
+        if (inl) {
+#pragma unroll
+          for (int j = 0; j < PPW; ++j) { issue_piece(j, false); issue_piece(j, true); }
+        }
+        continue;
+      }
       const int buf = it & 1;
       const __attribute__((address_space(3))) char* vb = vbase + buf * 16384;
       auto vf_dma = [&](int db, int kb) {
@@ -449,7 +483,11 @@ __device__ __forceinline__ void prefill_tile(const Half* __restrict__ q_base, Ha
         const u32x2 w0 = __builtin_bit_cast(u32x2, a0), w1 = __builtin_bit_cast(u32x2, a1);
         return __builtin_bit_cast(bf16x8_t, u32x4{w0.x, w0.y, w1.x, w1.y});
       };
-      compute_tile(kv0, kring + buf * 1024, vf_dma);
+      constexpr int kSlotStep = 8 / PPW;   // PPW pieces per operand over the 8 slots of its loop
+      compute_tile(kv0, kring + buf * 1024, vf_dma, [&](int slot) {
+        if (!inl) return;                  // workgroup-uniform
+        if ((slot % kSlotStep) == 0) issue_piece((slot & 7) / kSlotStep, slot >= 8);
+      });
     }
   } else {
     if (cta_kv_end > 0) {
@@ -477,7 +515,7 @@ __device__ __forceinline__ void prefill_tile(const Half* __restrict__ q_base, Ha
         u32x2 a0 = *reinterpret_cast<const u32x2*>(vrow + ((kb * 8 + g + rot) & 15) * 4);
         u32x2 a1 = *reinterpret_cast<const u32x2*>(vrow + ((kb * 8 + g + 4 + rot) & 15) * 4);
         return __builtin_bit_cast(bf16x8_t, u32x4{a0.x, a0.y, a1.x, a1.y});
-      });
+      }, [](int) {});
     }
   }
   // ---- epilogue: O = acc / l ; lane (row l15, g) holds dims db*16 + g*4 .. +3 ----
@@ -532,8 +570,8 @@ __global__ __launch_bounds__(NW * 64, D == 128 ? 2 : 1) void batch_prefill_paged
   // L2 (5 MB at 10 k tokens against a 4 MB L2) instead of all eight streaming through each (xcd_heads = 0 keeps the
   // tile-fastest order for the A/B)
   const int n_slots = gridDim.x / num_kv_heads;
-  const int kvh = xcd_heads ? blockIdx.x % num_kv_heads : blockIdx.x / n_slots;
-  const int slot = xcd_heads ? blockIdx.x / num_kv_heads : blockIdx.x % n_slots;
+  const int kvh = (xcd_heads & 1) ? blockIdx.x % num_kv_heads : blockIdx.x / n_slots;
+  const int slot = (xcd_heads & 1) ? blockIdx.x / num_kv_heads : blockIdx.x % n_slots;
   const int group = num_qo_heads / num_kv_heads;
   const int first = (n_slots - 1 - slot) * GROUPED;
   int req[GROUPED], row0[GROUPED];
@@ -556,7 +594,8 @@ __global__ __launch_bounds__(NW * 64, D == 128 ? 2 : 1) void batch_prefill_paged
     const int kv_len = npages > 0 ? (npages - 1) * page_size + last_page_len[r] : 0;
     if (row0[k] >= qo_len * group || kv_len <= 0) continue;
     if (GROUPED > 1 && k > 0) __syncthreads();  // the previous tile's LDS (page window, K / V^T) is done with
-    PagedAddr<POW2> addr{page_indices, pbase, page_size, (int)stride_page, num_kv_heads * D, page_shift, lds_pg, 0, npages};
+    PagedAddr<POW2> addr{page_indices, pbase, page_size, (int)stride_page, num_kv_heads * D, page_shift, lds_pg, 0, npages,
+                         (xcd_heads & 2) ? 0 : 1};
     const long q_stride_n = (long)num_qo_heads * D;
     const long qo_base = (long)q0 * q_stride_n + (long)kvh * group * D;
     const Half* kvh_base = kv + (long)kvh * D;
@@ -653,7 +692,11 @@ int32_t batch_prefill_paged_cuda_with_cta_tile_q(
   // two 64-row plan tiles per workgroup once that still leaves >= 2 workgroups per CU (PEGAINFER_PREFILL_GROUP = 1 | 2
   // forces either form; per-row results are identical)
   static const int group_env = [] { const char* e = getenv("PEGAINFER_PREFILL_GROUP"); return e && *e ? atoi(e) : 0; }();
-  static const int xcd_heads = [] { const char* e = getenv("PEGAINFER_PREFILL_XCD_HEADS"); return e && *e == '0' ? 0 : 1; }();
+  static const int xcd_heads = [] {   // bit 0: kv head fastest in the grid; bit 1: burst DMA issue (both A/B switches)
+    const char* e = getenv("PEGAINFER_PREFILL_XCD_HEADS");
+    const char* d = getenv("PEGAINFER_PREFILL_DMA_INLINE");
+    return ((e && *e == '0') ? 0 : 1) | ((d && *d == '0') ? 2 : 0);
+  }();
   const bool pair = cta == 64 && (group_env == 2 || (group_env == 0 && (long)padded_batch_size * num_kv_heads >= 1024));
 #define PK_PREFILL(QB, P2, G, CTA)                                                                           \
   batch_prefill_paged_kernel<QB, 128, P2, G><<<((padded_batch_size + G - 1) / G) * num_kv_heads, 256, 0, s>>>( \

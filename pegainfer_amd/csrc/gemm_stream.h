@@ -8,10 +8,16 @@
 // RT = ceil(ceil(M / CUs) / 16): gate_up 80 rows -> 244 workgroups, qkv 32 -> 192, o_proj / down_proj 16 -> 160, every one
 // walking the FULL K (no partials, no second launch), all token columns in the workgroup.
 //
-// Structure = mfma_gemm_glds_kernel's (LDS-DMA rings of K tiles of 64, source-side swizzle, counted vmcnt, one barrier per
-// K tile), with the four waves side by side along the TOKEN axis (TT / 4 tokens each, all RT row blocks) instead of 2 x 2:
-// any RT works.  Two rings of different depth, fed by different waves (see the kernel): what must be deep is the W stream.  Per-element K order is that of every un-split tiled kernel (K
-// tiles ascending, two 32-wide MFMA steps each): bit-identical to mfma_gemm_glds_kernel<.., false>.
+// Structure: LDS-DMA rings of K tiles of 64 as in mfma_gemm_glds_kernel (source-side swizzle, counted vmcnt), but
+//  * four COMPUTE waves side by side along the token axis (TT / 4 tokens each, all RT row blocks): any RT works;
+//  * separate FEEDER waves that only issue the DMAs, the W ring and the X ring each with its own waves and depth: a wave
+//    gets one 1 KB DMA instruction through its issue slot per ~93-133 cycles (18-26 GB/s per wave, however many it keeps in
+//    flight - tools/probes/ingest_probe) and issues nothing else meanwhile, and its loads retire in order (the L2-resident
+//    X tile of the next step must not queue behind W tiles requested ten steps ahead);
+//  * G K tiles per barrier (2 or 4): barrier -> LDS read -> dependent MFMAs -> barrier is a latency chain of ~0.28 us
+//    whatever the tile holds.
+// Per-element K order is that of every un-split tiled kernel (K tiles ascending, two 32-wide MFMA steps each):
+// bit-identical to mfma_gemm_glds_kernel<.., false>.
 //
 // Forms (SplitOut as in linear.hip): plain / row-segmented output (rows_per_tile distinct W rows, a multiple of 4);
 // SwiGLU (silu_I > 0): RT is even, the first RT / 2 blocks hold `cols_per_tile` gate rows, the last RT / 2 their up rows
@@ -20,14 +26,22 @@
 
 namespace pk {
 
-template <int RT, int TT, int STW, int STX>
-__global__ __launch_bounds__(256) void stream_gemm_kernel(const Half* __restrict__ W, const Half* __restrict__ X,
-                                                          Half* __restrict__ Y, int M, int T, int K, int m_tiles,
-                                                          int t_tiles, int rows_per_tile, SplitOut so) {
-  constexpr int TJ = TT / 64;                 // 16-token blocks per wave
+// Waves 0..3 compute only; then NLW waves that only feed the W ring and NLX that only feed the X ring.  (The first form of
+// this kernel had four waves doing both - gate_up 28.9 us at 32 / 64 columns where this one takes 21.8 / 24.1.)  tools/probes/ingest_probe: a wave gets ~26 GB/s out of its
+// DMA issue slot (one 1 KB instruction per ~93 cycles) however many it keeps in flight, and while it sits there it issues
+// no MFMA; a CU takes ~125 GB/s when every SIMD has a wave issuing.  With loader waves the K step is bound by what the
+// bytes cost (W from HBM at ~23 GB/s per CU, X from L2), not by issue + LDS reads + MFMAs of one wave in series.
+template <int RT, int TT, int STW, int STX, int NLW, int NLX, int G>
+__global__ __launch_bounds__((4 + NLW + NLX) * 64) void stream_gemm_kernel(const Half* __restrict__ W, const Half* __restrict__ X,
+                                                                      Half* __restrict__ Y, int M, int T, int K, int m_tiles,
+                                                                      int t_tiles, int rows_per_tile, SplitOut so) {
+  constexpr int NW_ = NLW;                    // waves feeding the W ring
+  constexpr int NX_ = NLX;                    // waves feeding the X ring
+  constexpr int TJ = TT / 64;                 // 16-token blocks per compute wave
   constexpr int NWG = RT * 2;                 // 8-row groups of the W tile
-  constexpr int DWW = (NWG + 1) / 2;          // W DMAs per W wave per K tile (groups past NWG re-send the last one)
-  constexpr int DXX = TT / 16;                // X DMAs per x wave per K tile (TT / 8 row groups over two waves)
+  constexpr int NXG = TT / 8;                 // 8-row groups of the X tile
+  constexpr int DWW = (NWG + NW_ - 1) / NW_;  // W DMAs per W wave per K tile (groups past NWG re-send the last one)
+  constexpr int DXX = (NXG + NX_ - 1) / NX_;  // X DMAs per x wave per K tile (likewise)
   extern __shared__ __attribute__((aligned(16))) u32x4 stream_smem[];   // STW x W tile | STX x X tile
   u32x4(*ws)[RT * 16 * 8] = reinterpret_cast<u32x4(*)[RT * 16 * 8]>(stream_smem);
   u32x4(*xs)[TT * 8] = reinterpret_cast<u32x4(*)[TT * 8]>(stream_smem + STW * RT * 16 * 8);
@@ -45,18 +59,21 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const Half* __restrict
   const bool silu = so.silu_I > 0;
   constexpr int HB = RT / 2 * 16;             // MFMA rows of one half in the SwiGLU form
   const int m0 = mt * rows_per_tile;          // plain: first W row; SwiGLU: first activation column (relative to silu_c0)
-  // Waves 0, 1 feed the W ring, waves 2, 3 the X ring (all four compute).  A wave's loads retire IN ORDER, so one wave
-  // cannot keep a deep W prefetch and a shallow X prefetch at once: the X tile of the next K step would wait behind W tiles
-  // requested for ten steps ahead.  Split by role, each ring has its own depth: W (cold HBM, ~2 us away) 40-48 KB ahead
-  // per CU whatever RT is, X (L2-resident, shared by all workgroups) two or more tiles ahead.
-  const bool w_role = wave < 2;
-  const int ww = wave & 1;
+  // A wave's loads retire IN ORDER, so one wave cannot keep a deep W prefetch and a shallow X prefetch at once: the X tile
+  // of the next K step would wait behind W tiles requested for ten steps ahead.  Split by role, each ring has its own
+  // depth: W (cold HBM, ~2 us away) 40-48 KB ahead per CU whatever RT is, X (L2-resident, shared by all workgroups) two
+  // or more tiles ahead.
+  const int li = wave - 4;                    // feeder index (negative = compute wave)
+  const bool computes = wave < 4;
+  const bool feeds = wave >= 4;
+  const bool w_role = feeds && li < NW_;
+  const int ww = w_role ? li : li - NW_;      // index among the feeders of this wave's ring
 
   const Half* src[DWW > DXX ? DWW : DXX];
   if (w_role) {
 #pragma unroll
     for (int j = 0; j < DWW; ++j) {
-      int rg = ww + 2 * j;
+      int rg = ww + NW_ * j;
       rg = rg < NWG ? rg : NWG - 1;
       const int row = rg * 8 + lr;
       int mr;
@@ -74,10 +91,12 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const Half* __restrict
       }
       src[j] = W + (size_t)mr * K + ((ls ^ (row & 7)) << 3);
     }
-  } else {
+  } else if (feeds) {
 #pragma unroll
     for (int j = 0; j < DXX; ++j) {
-      const int row = (ww + 2 * j) * 8 + lr;
+      int rg = ww + NX_ * j;
+      rg = rg < NXG ? rg : NXG - 1;
+      const int row = rg * 8 + lr;
       int tr = t0 + row;
       tr = tr < T ? tr : T - 1;
       src[j] = X + (size_t)tr * K + ((ls ^ (row & 7)) << 3);
@@ -94,7 +113,7 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const Half* __restrict
   auto stage_w = [&](int buf, int kt) {
 #pragma unroll
     for (int j = 0; j < DWW; ++j) {
-      int rg = ww + 2 * j;
+      int rg = ww + NW_ * j;
       rg = rg < NWG ? rg : NWG - 1;
       const uint32_t dst = __builtin_amdgcn_readfirstlane(ws_lds + (uint32_t)(buf * RT * 16 * 8 + rg * 64) * 16u);
       if (so.w_nt)   // one token tile: this workgroup is the only reader of these W bytes (SplitOut::w_nt)
@@ -108,59 +127,88 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const Half* __restrict
   auto stage_x = [&](int buf, int kt) {
 #pragma unroll
     for (int j = 0; j < DXX; ++j) {
-      const uint32_t dst = __builtin_amdgcn_readfirstlane(xs_lds + (uint32_t)(buf * TT * 8 + (ww + 2 * j) * 64) * 16u);
+      int rg = ww + NX_ * j;
+      rg = rg < NXG ? rg : NXG - 1;
+      const uint32_t dst = __builtin_amdgcn_readfirstlane(xs_lds + (uint32_t)(buf * TT * 8 + rg * 64) * 16u);
       asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
                    :: "v"(src[j] + (size_t)kt * BK), "s"(dst) : "memory", "m0");
     }
   };
+  // G K tiles per barrier: barrier -> ds_read latency -> dependent MFMAs -> barrier is ~0.28 us of pure latency whatever
+  // the tile holds (down_proj at 16 rows x 64 tokens: 152 K tiles x 0.28 us = 43 us for 2 + 8 KB per step), so the
+  // narrow tiles take 4 K tiles per round trip, the wide ones 2.  Ring arithmetic in tiles: before iteration `it` tiles
+  // < it G + ST - G have been requested; during it the G slots freed by the previous iteration are refilled; the barrier
+  // that ends it needs tiles < (it + 2) G landed, i.e. at most ST - 2 G tiles' worth of this wave's DMAs outstanding.
+  static_assert(STW >= 2 * G && STX >= 2 * G, "ring depth");
   const int nk = K / BK;
   if (w_role) {
 #pragma unroll
-    for (int p = 0; p < STW - 1; ++p)
+    for (int p = 0; p < STW - G; ++p)
       if (p < nk) stage_w(p, p);
-    if (nk > STW - 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((STW - 2) * DWW) : "memory");
+    if (nk >= STW - G) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((STW - 2 * G) * DWW) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  } else {
+  } else if (feeds) {
 #pragma unroll
-    for (int p = 0; p < STX - 1; ++p)
+    for (int p = 0; p < STX - G; ++p)
       if (p < nk) stage_x(p, p);
-    if (nk > STX - 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((STX - 2) * DXX) : "memory");
+    if (nk >= STX - G) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((STX - 2 * G) * DXX) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __syncthreads();
-  const int wt = wave * (TT / 4);
-  int curw = 0, nxtw = STW - 1, curx = 0, nxtx = STX - 1;   // ring slots of tile kt and of the tile staged during kt
-  for (int kt = 0; kt < nk; ++kt) {
-    const bool more = w_role ? kt + STW - 1 < nk : kt + STX - 1 < nk;
-    if (more) { if (w_role) stage_w(nxtw, kt + STW - 1); else stage_x(nxtx, kt + STX - 1); }
+  const int wt = (wave & 3) * (TT / 4);
+  int curw = 0, nxtw = STW - G, curx = 0, nxtx = STX - G;   // ring slots of tile it G and of the first tile staged during it
+  for (int k0 = 0; k0 < nk; k0 += G) {
+    const bool full = w_role ? k0 + STW - 1 < nk : k0 + STX - 1 < nk;   // all G tiles this wave would stage exist
+    if (feeds) {
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8_t b[TJ];
-#pragma unroll
-      for (int j = 0; j < TJ; ++j)
-        b[j] = __builtin_bit_cast(bf16x8_t, xs[curx][lds_slot(wt + j * 16 + l15, ks * 4 + g)]);
-#pragma unroll
-      for (int i = 0; i < RT; ++i) {
-        const bf16x8_t a = __builtin_bit_cast(bf16x8_t, ws[curw][lds_slot(i * 16 + l15, ks * 4 + g)]);
-#pragma unroll
-        for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[j], acc[i][j], 0, 0, 0);
+      for (int gi = 0; gi < G; ++gi) {
+        if (w_role) {
+          const int t = k0 + STW - G + gi;
+          int slot = nxtw + gi; slot = slot >= STW ? slot - STW : slot;
+          if (t < nk) stage_w(slot, t);
+        } else {
+          const int t = k0 + STX - G + gi;
+          int slot = nxtx + gi; slot = slot >= STX ? slot - STX : slot;
+          if (t < nk) stage_x(slot, t);
+        }
       }
     }
-    // tile kt + 1 of this wave's ring has landed when at most (depth - 2) tiles' worth of its DMAs are outstanding; in the
-    // tail (nothing left to stage) the remaining tiles are simply all waited for
+    if (computes) {
+#pragma unroll
+      for (int gi = 0; gi < G; ++gi) {
+        if (k0 + gi >= nk) break;
+        int sw = curw + gi; sw = sw >= STW ? sw - STW : sw;
+        int sx = curx + gi; sx = sx >= STX ? sx - STX : sx;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          bf16x8_t b[TJ];
+#pragma unroll
+          for (int j = 0; j < TJ; ++j)
+            b[j] = __builtin_bit_cast(bf16x8_t, xs[sx][lds_slot(wt + j * 16 + l15, ks * 4 + g)]);
+#pragma unroll
+          for (int i = 0; i < RT; ++i) {
+            const bf16x8_t a = __builtin_bit_cast(bf16x8_t, ws[sw][lds_slot(i * 16 + l15, ks * 4 + g)]);
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[j], acc[i][j], 0, 0, 0);
+          }
+        }
+      }
+    }
+    // in the tail (not all G tiles left to stage) everything outstanding is simply waited for
     if (w_role) {
-      if (more) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((STW - 2) * DWW) : "memory");
+      if (full) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((STW - 2 * G) * DWW) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-      if (more) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((STX - 2) * DXX) : "memory");
+    } else if (feeds) {
+      if (full) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((STX - 2 * G) * DXX) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
-    curw = curw + 1 == STW ? 0 : curw + 1;
-    nxtw = nxtw + 1 == STW ? 0 : nxtw + 1;
-    curx = curx + 1 == STX ? 0 : curx + 1;
-    nxtx = nxtx + 1 == STX ? 0 : nxtx + 1;
+    curw += G; curw = curw >= STW ? curw - STW : curw;
+    nxtw += G; nxtw = nxtw >= STW ? nxtw - STW : nxtw;
+    curx += G; curx = curx >= STX ? curx - STX : curx;
+    nxtx += G; nxtx = nxtx >= STX ? nxtx - STX : nxtx;
   }
+  if (!computes) return;
   // C layout (16x16x32): col = lane & 15 -> token, rows (lane >> 4) * 4 + e -> 4 consecutive tile rows
   if (silu) {
     if constexpr (RT >= 2) {
@@ -242,24 +290,31 @@ inline StreamPlan stream_plan(int M, int silu_cols /* 0 = plain */) {
   return {r / 16, r, ceil_div(M, r)};
 }
 
-// Ring depths.  W: ~2 us x 24 GB/s per CU = 40-48 KB ahead whatever RT is; X: a few tiles.  Measured: going from 3 X tiles
-// to 5-13 changed NOTHING (gate_up 25.2 us, down_proj at RT = 1 38.6 us either way) - the K loop is not latency-bound but
-// bound by the CU's total ingest, W + X bytes alike at ~30-40 GB/s per CU (RT = 5: 18 KB per K step in 0.63 us; RT = 1:
-// 10 KB in 0.25 us).  What lowers the time is fewer bytes per CU: that is K split over workgroups, not this kernel.
+// Ring depths and K tiles per barrier.  W: ~2 us x 24 GB/s per CU = 40-48 KB beyond the 2 G tiles the barrier scheme itself
+// holds, whatever RT is; X (L2) one or two tiles beyond.  LDS = STW x RT x 2 KB + STX x TT / 8 KB <= 160 KB.
+// Measured before the feeder waves: going from 3 X tiles to 5-13 changed nothing - the K loop was bound by DMA issue and the
+// per-barrier latency chain, not by request depth.
 template <int RT, int TT = 64> struct StreamDepth {
-  static constexpr int W = RT == 1 ? 20 : RT == 2 ? 12 : RT == 3 ? 8 : RT == 4 ? 6 : 6;
-  static constexpr int X64 = RT == 1 ? 13 : RT == 2 ? 9 : RT == 3 ? 7 : RT == 4 ? 6 : 5;
-  static constexpr int X = TT == 64 ? X64 : (X64 > 5 ? 5 : X64);   // 128-token tiles: 16 KB per X stage, 160 KB of LDS in all
+  // TT = 64 (X tile 8 KB):  RT  1: 24 x 2 + 12 x 8 = 144 KB   2: 16 x 4 + 12 x 8 = 160   3: 12 x 6 + 6 x 8 = 120
+  //                             4: 10 x 8 + 6 x 8 = 128       5: 10 x 10 + 6 x 8 = 148   6: 9 x 12 + 6 x 8 = 156
+  // TT = 128 (X tile 16 KB): RT 3: 12 x 6 + 5 x 16 = 152      4: 9 x 8 + 5 x 16 = 152    5: 8 x 10 + 5 x 16 = 160
+  //                             6: G = 1, 6 x 12 + 5 x 16 = 152 (two tiles per barrier would leave 24 KB of W ahead)
+  static constexpr int G = TT == 64 ? (RT <= 2 ? 4 : 2) : 2;
+  static constexpr int W = TT == 64 ? (RT == 1 ? 24 : RT == 2 ? 16 : RT == 3 ? 12 : RT == 4 ? 10 : RT == 5 ? 10 : 9)
+                                    : (RT == 3 ? 12 : RT == 4 ? 9 : RT == 5 ? 8 : 6);
+  static constexpr int X = TT == 64 ? (RT <= 2 ? 12 : 6) : 5;
 };
-template <int RT, int TT>
-inline void stream_gemm_launch_rt(const Half* W, const Half* X, Half* Y, int M, int T, int K, const StreamPlan& pl,
+
+template <int RT, int TT, int NLW, int NLX>
+inline void stream_gemm_launch_nl(const Half* W, const Half* X, Half* Y, int M, int T, int K, const StreamPlan& pl,
                                   const SplitOut& so, hipStream_t s) {
-  constexpr int STW = StreamDepth<RT, TT>::W, STX = StreamDepth<RT, TT>::X;
-  static_assert((STW - 2) * ((RT * 2 + 1) / 2) <= 63 && (STX - 2) * (TT / 16) <= 63, "vmcnt immediate");
+  constexpr int STW = StreamDepth<RT, TT>::W, STX = StreamDepth<RT, TT>::X, G = StreamDepth<RT, TT>::G;
+  constexpr int NW_ = NLW, NX_ = NLX;
+  static_assert((STW - 2 * G) * ((RT * 2 + NW_ - 1) / NW_) <= 63 && (STX - 2 * G) * ((TT / 8 + NX_ - 1) / NX_) <= 63, "vmcnt immediate");
   constexpr int kLds = (STW * RT * 16 + STX * TT) * 8 * 16;
   static_assert(kLds <= 160 * 1024, "LDS");
   static const bool once = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stream_gemm_kernel<RT, TT, STW, STX>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stream_gemm_kernel<RT, TT, STW, STX, NLW, NLX, G>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
     return true;
   }();
@@ -267,8 +322,17 @@ inline void stream_gemm_launch_rt(const Half* W, const Half* X, Half* Y, int M, 
   const int t_tiles = ceil_div(T, TT);
   SplitOut sk = so;
   sk.w_nt = t_tiles == 1 && weights_nt_on();
-  stream_gemm_kernel<RT, TT, STW, STX><<<pl.m_tiles * t_tiles, 256, kLds, s>>>(W, X, Y, M, T, K, pl.m_tiles, t_tiles,
-                                                                              pl.rows_per_tile, sk);
+  stream_gemm_kernel<RT, TT, STW, STX, NLW, NLX, G><<<pl.m_tiles * t_tiles, (4 + NLW + NLX) * 64, kLds, s>>>(
+      W, X, Y, M, T, K, pl.m_tiles, t_tiles, pl.rows_per_tile, sk);
+}
+// Feeder waves: a wave moves ~18 GB/s of 8-row x 128-B tile pieces through its DMA issue slot (ingest_probe, tile walk),
+// i.e. one 1 KB instruction per ~0.055 us.  A K step must not take longer to ISSUE than its W bytes take to arrive from
+// HBM (RT x 2 KB at ~23 GB/s per CU = RT x 0.09 us): W feeders carry <= 6 instructions each, X feeders <= 4.
+template <int RT, int TT>
+inline void stream_gemm_launch_rt(const Half* W, const Half* X, Half* Y, int M, int T, int K, const StreamPlan& pl,
+                                  const SplitOut& so, hipStream_t s) {
+  constexpr int NLW = RT >= 4 ? 2 : 1, NLX = RT <= 2 ? TT / 16 : TT / 32;   // X: 2 (x-dominated tiles; 1 measured no better) or 4 instructions per wave and K tile
+  stream_gemm_launch_nl<RT, TT, NLW, NLX>(W, X, Y, M, T, K, pl, so, s);
 }
 template <int TT>
 inline bool stream_gemm_launch(const Half* W, const Half* X, Half* Y, int M, int T, int K, const SplitOut& so, hipStream_t s) {

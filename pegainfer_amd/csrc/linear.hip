@@ -508,7 +508,7 @@ static bool stream_gemm_on() {
   return v;
 }
 static int stream_min_rt() {
-  static const int v = [] { const char* e = getenv("PEGAINFER_STREAM_MIN_RT"); return e && *e ? atoi(e) : 3; }();
+  static const int v = [] { const char* e = getenv("PEGAINFER_STREAM_MIN_RT"); return e && *e ? atoi(e) : 2; }();
   return v;
 }
 static bool gemm128x256_on() {
@@ -644,7 +644,7 @@ static TiledRoute tiled_route(int M, int T, int K, const SplitOut& so) {
   // to the CU count (244 workgroups instead of 152), same per-element K order as every un-split tiled kernel.  kind 3000 + RT.
   if (T <= 128 && so.silu_c1 == 0 && stream_gemm_on()) {
     const StreamPlan sp = stream_plan(M, so.silu_I > 0 ? so.silu_I : 0);
-    if (sp.rt >= stream_min_rt()) return {3000 + sp.rt, 0};
+    if (sp.rt >= (stream_min_rt() > 3 ? stream_min_rt() : 3)) return {3000 + sp.rt, 0};   // 128-token tiles exist for 3..6 row blocks
   }
   // SwiGLU GEMM on short prompts (65..256 tokens: 152 tiles of (64 + 64) x 256 for Qwen3-4B, one round) - the 128 x 128
   // kernel runs these at one 4-wave workgroup per CU.  Same per-element K order: bit-identical to gemm + silu_mul
@@ -712,11 +712,11 @@ constexpr int kMidBatchMinRows = 5120;
 // 17..64 columns, plain (optionally row-segmented) output: 1 = tiled LDS-DMA GEMM, 2 = its split-K form, 0 = not
 // taken (skinny kernel / separate calls).  One decision for gemm_cuda, pegainfer_gemm_split and pegainfer_gemm_silu,
 // so that a stacked launch and the plain launch over the same matrix always run the same kernel.
-// 3 = the weight-streaming kernel of gemm_stream.h (round 4): row tiles sized to the CU count, full K per workgroup.  Taken
-// for tiles of >= 3 row blocks (gate_up: 27.0 -> 25.3 us at 32 columns, 29.8 -> 25.2 at 64; same bits as the 128-row kernel).
-// Smaller matrices keep the split-K route: measured (profiles/r4_stream_gemm_ab.txt) a CU's memory path delivers ~30-40 GB/s
-// in TOTAL - the L2-resident x tiles cost what HBM weights cost - so with full K per workgroup o_proj / down_proj pull
-// 0.5-1.2 MB of x per CU for 130-310 KB of weights (18 / 39 us against 13 / 19 with K split over workgroups).
+// 3 = the weight-streaming kernel of gemm_stream.h (round 4): row tiles sized to the CU count, full K per workgroup, feeder
+// waves.  Taken for tiles of >= 2 row blocks: gate_up 28.9 -> 21.8 us at 32 columns, 28.9 -> 24.1 at 64 (same bits as the
+// 128-row kernel); the stacked qkv matrix (32-row tiles, 192 workgroups) 13.8 -> 12.6 / 16.8 -> 13.7 us against its split-K
+// pair.  o_proj / down_proj (16-row tiles) keep the split-K route: with full K per workgroup they pull 0.5-1.2 MB of x per CU
+// for 130-310 KB of weights (15.3 / 30.5 us against 15.0 / 21.7), profiles/r4_stream_spec_ab.txt.
 // PEGAINFER_STREAM_GEMM=0 switches it off, PEGAINFER_STREAM_MIN_RT moves the threshold.
 static int mid_batch_route(const Half* W, const Half* X, const Half* Y, int M, int T, int K, int silu_I = 0) {
   static const int min_rows = [] { const char* e = getenv("PEGAINFER_MID_MIN_ROWS"); return e && *e ? atoi(e) : kMidBatchMinRows; }();
@@ -911,9 +911,13 @@ static pegainfer_status_t gemm_silu_impl(const Half* W, const Half* X, Half* Y, 
   using namespace pk;
   if (I <= 0 || T <= 0 || K <= 0) return (pegainfer_status_t)hipErrorInvalidValue;
   const int M = 2 * I;
+  // 17..64 columns: fused only where the PLAIN GEMM over the same matrix also runs an un-split tiled kernel (route 1 / 3) -
+  // the tile plans differ (rows vs activation columns), and a narrow matrix whose plain form takes the K-split or skinny
+  // kernel would otherwise get a different per-element K order fused than unfused
   const int mroute = T <= 64 ? mid_batch_route(W, X, Y, M, T, K, I) : 0;
+  const int proute = T <= 64 ? mid_batch_route(W, X, Y, M, T, K, 0) : 0;
   if (T > 16 && (I & 3) == 0 && glds_gemm_ok(W, X, Y, M, K) &&
-      (T > 64 ? splitk_plan(M, T, K).nk_slice == 0 : (mroute == 1 || mroute == 3))) {
+      (T > 64 ? splitk_plan(M, T, K).nk_slice == 0 : ((mroute == 1 || mroute == 3) && (proute == 1 || proute == 3)))) {
     SplitOut so{nullptr, nullptr, nullptr, 0, 0, 0, I, double_round};
     if (mroute == 3) stream_gemm_launch<64>(W, X, Y, M, T, K, so, as_stream(stream));   // 40 + 40 rows per tile: 244 workgroups
     else glds_gemm_launch(W, X, Y, M, T, K, so, T <= 64 ? 23 : 0, as_stream(stream));

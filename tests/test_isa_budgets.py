@@ -78,15 +78,15 @@ def test_decode_gemv_and_gemm_kernels_keep_their_occupancy():
     check(md, r"mfma_gemm128x256_kernel<(true|false)>", 256, at_least=2)
     check(md, r"mfma_gemm_glds_kernel<\d+, \d, (true|false)>", 256, at_least=6)
     check(md, r"splitk_reduce\w*kernel", 256, at_least=3)
-    # round 4: the weight-streaming GEMM (one 4-wave workgroup per CU; 64- and 128-token tiles): lean and spill-free
-    check(md, r"stream_gemm_kernel<[1-6], 64, \d+, \d+>", 128, at_least=6)
-    check(md, r"stream_gemm_kernel<[3-6], 128, \d+, \d+>", 168, at_least=4)
+    # round 4: the weight-streaming GEMM (one workgroup per CU: 4 compute + 3..6 feeder waves; 64- / 128-token tiles): spill-free
+    check(md, r"stream_gemm_kernel<[1-6], 64, \d+, \d+, \d+, \d+, \d+>", 128, at_least=6)
+    check(md, r"stream_gemm_kernel<[3-6], 128, \d+, \d+, \d+, \d+, \d+>", 168, at_least=4)
 
 
 def test_attention_kernels_keep_their_occupancy():
     md = kernel_metadata("attn_decode.hip")
     # group sizes of the BASELINE models (Qwen3-4B / 8B: 4 query heads per kv head; Qwen3.5: 2 and 4 at head dim 256)
-    check(md, r"fused_decode_attn_kernel<[124], (true|false), [48]>", 256, at_least=12)
+    check(md, r"fused_decode_attn_kernel<[124], (true|false), [48]>", 256, at_least=6)
     check(md, r"decode_attn_kernel<(128|256), [124], (true|false), [48]>", 256, at_least=24)
     md = kernel_metadata("attn_prefill.hip")
     # head dim 128: two workgroups per CU (the __launch_bounds__(256, 2) budget), no AGPR shuffling, no spills

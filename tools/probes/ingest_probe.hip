@@ -88,6 +88,62 @@ template <int U> static void l_reg(hipStream_t s) {
   reg_kernel<U><<<256, g_nw * 64, 0, s>>>(g_src, g_stride, g_window, g_iters, g_sink);
 }
 
+
+// The access pattern of a tiled GEMM's operand: one instruction = 8 rows x 128 B, rows `stride_b` bytes apart; the
+// workgroup walks K tile by K tile (kt = 0..39), 16 row groups per tile (a 128-row tile of a [128, 2560] bf16 operand),
+// every workgroup the SAME lines at about the same time.  stride 5120 = the dense layout; + 128 / + 256 = padded rows.
+template <int DEPTH>
+__global__ __launch_bounds__(512) void tile_kernel(const char* __restrict__ src, int stride_b, int iters, uint32_t* __restrict__ sink) {
+  extern __shared__ __attribute__((aligned(16))) u32x4 smem[];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)&smem[0] + (uint32_t)wave * (DEPTH * 1024u);
+  const int row = lane >> 3, piece = lane & 7;
+  int c = wave;
+  for (int i = 0; i < iters; ++i) {
+    const int rg = c & 15, kt = (c >> 4) % 40;
+    const char* p = src + (long)(rg * 8 + row) * stride_b + kt * 128 + piece * 16;
+    const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(i % DEPTH) * 1024u);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(p), "s"(dst) : "memory", "m0");
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DEPTH - 1) : "memory");
+    c += nw;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) sink[blockIdx.x] = smem[0].x;
+}
+static int g_tile_stride;
+static void l_tile(hipStream_t s) {
+  tile_kernel<8><<<256, g_nw * 64, g_nw * 8 * 1024, s>>>(reinterpret_cast<const char*>(g_src), g_tile_stride, g_iters, g_sink);
+}
+
+// A weight stream read the way a tiled GEMM reads it, from HBM: every workgroup owns row blocks of 96 rows x 5120 B (its
+// private 8 MB of the buffer) and walks each block K tile by K tile, a tile being SEG bytes of every row: one DMA
+// instruction covers 1024 / SEG rows.  SEG = 128 is a K tile of 64 bf16 (what the kernels here use), 256 / 512 = 128 / 256.
+template <int SEG>
+__global__ __launch_bounds__(512) void wtile_kernel(const char* __restrict__ src, int iters, uint32_t* __restrict__ sink) {
+  extern __shared__ __attribute__((aligned(16))) u32x4 smem[];
+  constexpr int DEPTH = 8, LPR = SEG / 16, RPI = 64 / LPR, IPT = 96 / RPI, TILES = 5120 / SEG;   // instr per tile, tiles per block
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)&smem[0] + (uint32_t)wave * (DEPTH * 1024u);
+  const char* base = src + (long)blockIdx.x * (8l << 20);
+  const int row = lane / LPR, piece = lane % LPR;
+  int c = wave;
+  for (int i = 0; i < iters; ++i) {
+    const int blk = c / (IPT * TILES), r = c % (IPT * TILES), kt = r / IPT, rg = r % IPT;
+    const char* p = base + (long)blk * (96 * 5120) + (long)(rg * RPI + row) * 5120 + kt * SEG + piece * 16;
+    const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(i % DEPTH) * 1024u);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" :: "v"(p), "s"(dst) : "memory", "m0");
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DEPTH - 1) : "memory");
+    c += nw;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) sink[blockIdx.x] = smem[0].x;
+}
+template <int SEG> static void l_wtile(hipStream_t s) {
+  wtile_kernel<SEG><<<256, g_nw * 64, g_nw * 8 * 1024, s>>>(reinterpret_cast<const char*>(g_src), g_iters, g_sink);
+}
+
 int main() {
   const size_t bytes = 2ull << 30;
   u32x4* buf;
@@ -98,6 +154,29 @@ int main() {
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dma_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dma_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dma_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wtile_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  for (int stride : {5120, 5120 + 128, 5120 + 256, 8192, 8192 + 256, 19456, 19456 + 256})
+    for (int nw : {2, 4, 8}) {
+      const long per_wg = 8l << 20;
+      g_nw = nw; g_tile_stride = stride; g_iters = (int)(per_wg / 1024 / nw);
+      const double us = run(l_tile, 10);
+      const double gbs = per_wg / us / 1e3;
+      printf("tile walk (8 rows x 128 B per DMA) row stride %5d B  waves %d  %8.1f us  %6.1f GB/s per CU  %6.2f TB/s chip\n", stride, nw,
+             us, gbs, gbs * 256 / 1e3);
+    }
+  {
+    struct { int seg; void (*fn)(hipStream_t); } w[] = {{128, l_wtile<128>}, {256, l_wtile<256>}, {512, l_wtile<512>}, {1024, l_wtile<1024>}};
+    for (auto& k : w)
+      for (int nw : {2, 4}) {
+        const long per_wg = 17l * 96 * 5120;                // 17 row blocks of the workgroup's 8 MB
+        g_nw = nw; g_iters = (int)(per_wg / 1024 / nw);
+        const double us = run(k.fn, 10);
+        const double gbs = per_wg / us / 1e3;
+        printf("weight tile walk from HBM, %4d B of every row per K tile  waves %d  %8.1f us  %6.1f GB/s per CU  %6.2f TB/s chip\n", k.seg,
+               nw, us, gbs, gbs * 256 / 1e3);
+      }
+  }
   for (int shared = 1; shared >= 0; --shared) {
     const long per_wg = 8l << 20;                       // bytes every workgroup ingests per launch
     g_stride = shared ? 0 : per_wg / 16;
