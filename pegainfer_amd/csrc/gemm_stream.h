@@ -31,10 +31,13 @@ namespace pk {
 // DMA issue slot (one 1 KB instruction per ~93 cycles) however many it keeps in flight, and while it sits there it issues
 // no MFMA; a CU takes ~125 GB/s when every SIMD has a wave issuing.  With loader waves the K step is bound by what the
 // bytes cost (W from HBM at ~23 GB/s per CU, X from L2), not by issue + LDS reads + MFMAs of one wave in series.
+// part != nullptr: the K-split form - blockIdx.y = K slice z of nk_slice K tiles (the last one shorter), the workgroup's
+// fp32 tile goes to part[z][T][M] and a slice-sum launch adds the slices in z order (linear.hip, splitk_reduce kernels).
 template <int RT, int TT, int STW, int STX, int NLW, int NLX, int G>
 __global__ __launch_bounds__((4 + NLW + NLX) * 64) void stream_gemm_kernel(const Half* __restrict__ W, const Half* __restrict__ X,
                                                                       Half* __restrict__ Y, int M, int T, int K, int m_tiles,
-                                                                      int t_tiles, int rows_per_tile, SplitOut so) {
+                                                                      int t_tiles, int rows_per_tile, SplitOut so,
+                                                                      float* __restrict__ part, int nk_slice) {
   constexpr int NW_ = NLW;                    // waves feeding the W ring
   constexpr int NX_ = NLX;                    // waves feeding the X ring
   constexpr int TJ = TT / 64;                 // 16-token blocks per compute wave
@@ -69,6 +72,8 @@ __global__ __launch_bounds__((4 + NLW + NLX) * 64) void stream_gemm_kernel(const
   const bool w_role = feeds && li < NW_;
   const int ww = w_role ? li : li - NW_;      // index among the feeders of this wave's ring
 
+  const int kt_begin = part ? (int)blockIdx.y * nk_slice : 0;
+  const size_t kofs = (size_t)kt_begin * BK;
   const Half* src[DWW > DXX ? DWW : DXX];
   if (w_role) {
 #pragma unroll
@@ -89,7 +94,7 @@ __global__ __launch_bounds__((4 + NLW + NLX) * 64) void stream_gemm_kernel(const
         mr = m0 + r;
         mr = mr < M ? mr : M - 1;
       }
-      src[j] = W + (size_t)mr * K + ((ls ^ (row & 7)) << 3);
+      src[j] = W + (size_t)mr * K + kofs + ((ls ^ (row & 7)) << 3);
     }
   } else if (feeds) {
 #pragma unroll
@@ -99,7 +104,7 @@ __global__ __launch_bounds__((4 + NLW + NLX) * 64) void stream_gemm_kernel(const
       const int row = rg * 8 + lr;
       int tr = t0 + row;
       tr = tr < T ? tr : T - 1;
-      src[j] = X + (size_t)tr * K + ((ls ^ (row & 7)) << 3);
+      src[j] = X + (size_t)tr * K + kofs + ((ls ^ (row & 7)) << 3);
     }
   }
   f32x4 acc[RT][TJ];
@@ -140,7 +145,8 @@ __global__ __launch_bounds__((4 + NLW + NLX) * 64) void stream_gemm_kernel(const
   // < it G + ST - G have been requested; during it the G slots freed by the previous iteration are refilled; the barrier
   // that ends it needs tiles < (it + 2) G landed, i.e. at most ST - 2 G tiles' worth of this wave's DMAs outstanding.
   static_assert(STW >= 2 * G && STX >= 2 * G, "ring depth");
-  const int nk = K / BK;
+  const int nk_all = K / BK;
+  const int nk = part ? (nk_all - kt_begin < nk_slice ? nk_all - kt_begin : nk_slice) : nk_all;
   if (w_role) {
 #pragma unroll
     for (int p = 0; p < STW - G; ++p)
@@ -209,6 +215,20 @@ __global__ __launch_bounds__((4 + NLW + NLX) * 64) void stream_gemm_kernel(const
     nxtx += G; nxtx = nxtx >= STX ? nxtx - STX : nxtx;
   }
   if (!computes) return;
+  if (part) {   // fp32 partial tile (M % 4 == 0: a lane's 4 rows are all in or all out)
+    float* dst = part + (size_t)blockIdx.y * T * M;
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+      const int t = t0 + wt + j * 16 + l15;
+      if (t >= T) continue;
+#pragma unroll
+      for (int i = 0; i < RT; ++i) {
+        const int rl = i * 16 + g * 4, m = m0 + rl;
+        if (rl < rows_per_tile && m < M) *reinterpret_cast<f32x4*>(dst + (size_t)t * M + m) = acc[i][j];
+      }
+    }
+    return;
+  }
   // C layout (16x16x32): col = lane & 15 -> token, rows (lane >> 4) * 4 + e -> 4 consecutive tile rows
   if (silu) {
     if constexpr (RT >= 2) {
@@ -323,7 +343,46 @@ inline void stream_gemm_launch_nl(const Half* W, const Half* X, Half* Y, int M, 
   SplitOut sk = so;
   sk.w_nt = t_tiles == 1 && weights_nt_on();
   stream_gemm_kernel<RT, TT, STW, STX, NLW, NLX, G><<<pl.m_tiles * t_tiles, (4 + NLW + NLX) * 64, kLds, s>>>(
-      W, X, Y, M, T, K, pl.m_tiles, t_tiles, pl.rows_per_tile, sk);
+      W, X, Y, M, T, K, pl.m_tiles, t_tiles, pl.rows_per_tile, sk, nullptr, 0);
+}
+// K-split launch (T <= TT): grid (row tiles, K slices), fp32 partials into part[ksplit][T][M]
+template <int RT, int TT>
+inline void stream_splitk_launch_rt(const Half* W, const Half* X, int M, int T, int K, const StreamPlan& pl, float* part,
+                                    int ksplit, int nk_slice, hipStream_t s) {
+  constexpr int NLW = RT >= 4 ? 2 : 1, NLX = RT <= 2 ? TT / 16 : TT / 32;
+  constexpr int STW = StreamDepth<RT, TT>::W, STX = StreamDepth<RT, TT>::X, G = StreamDepth<RT, TT>::G;
+  constexpr int kLds = (STW * RT * 16 + STX * TT) * 8 * 16;
+  static const bool once = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stream_gemm_kernel<RT, TT, STW, STX, NLW, NLX, G>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+    return true;
+  }();
+  (void)once;
+  SplitOut sk{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0, weights_nt_on()};
+  stream_gemm_kernel<RT, TT, STW, STX, NLW, NLX, G><<<dim3(pl.m_tiles, ksplit), (4 + NLW + NLX) * 64, kLds, s>>>(
+      W, X, nullptr, M, T, K, pl.m_tiles, 1, pl.rows_per_tile, sk, part, nk_slice);
+}
+// Row tiles of the K-split form: as many as fill the chip together with the K slices (256 / ksplit row tiles; o_proj /
+// down_proj with 8 slices: 32 tiles of 80 rows = 256 workgroups where the 128-row tiles made 160).  rt == 0: not taken.
+inline StreamPlan stream_splitk_plan(int M, int ksplit) {
+  const int want = 256 / ksplit;
+  if (want < 1) return {0, 0, 0};
+  const int r = ceil_div(ceil_div(M, want), 16) * 16;
+  if (r > 96 || (M & 3)) return {0, 0, 0};
+  return {r / 16, r, ceil_div(M, r)};
+}
+inline bool stream_splitk_launch(const Half* W, const Half* X, int M, int T, int K, float* part, int ksplit, int nk_slice,
+                                 hipStream_t s) {
+  const StreamPlan pl = stream_splitk_plan(M, ksplit);
+  switch (pl.rt) {
+    case 1: stream_splitk_launch_rt<1, 64>(W, X, M, T, K, pl, part, ksplit, nk_slice, s); return true;
+    case 2: stream_splitk_launch_rt<2, 64>(W, X, M, T, K, pl, part, ksplit, nk_slice, s); return true;
+    case 3: stream_splitk_launch_rt<3, 64>(W, X, M, T, K, pl, part, ksplit, nk_slice, s); return true;
+    case 4: stream_splitk_launch_rt<4, 64>(W, X, M, T, K, pl, part, ksplit, nk_slice, s); return true;
+    case 5: stream_splitk_launch_rt<5, 64>(W, X, M, T, K, pl, part, ksplit, nk_slice, s); return true;
+    case 6: stream_splitk_launch_rt<6, 64>(W, X, M, T, K, pl, part, ksplit, nk_slice, s); return true;
+    default: return false;
+  }
 }
 // Feeder waves: a wave moves ~18 GB/s of 8-row x 128-B tile pieces through its DMA issue slot (ingest_probe, tile walk),
 // i.e. one 1 KB instruction per ~0.055 us.  A K step must not take longer to ISSUE than its W bytes take to arrive from

@@ -507,6 +507,10 @@ static bool stream_gemm_on() {
   static const bool v = [] { const char* e = getenv("PEGAINFER_STREAM_GEMM"); return !(e && e[0] == '0'); }();
   return v;
 }
+static bool stream_splitk_on() {   // PEGAINFER_STREAM_SPLITK=0: the 128-row split-K kernel at 17..64 columns (A/B)
+  static const bool v = [] { const char* e = getenv("PEGAINFER_STREAM_SPLITK"); return !(e && e[0] == '0'); }();
+  return v;
+}
 static int stream_min_rt() {
   static const int v = [] { const char* e = getenv("PEGAINFER_STREAM_MIN_RT"); return e && *e ? atoi(e) : 2; }();
   return v;
@@ -582,6 +586,10 @@ static void glds_splitk_launch(const Half* W, const Half* X, Half* Y, int M, int
     gemm256_splitk_launch(W, X, M, T, K, g_splitk_ws, pl.ksplit, pl.nk_slice, s);
   } else if (pl.tt == 129) {
     gemm128x256_launch(W, X, Y, M, T, K, so, g_splitk_ws, pl.ksplit, pl.nk_slice, s);
+  } else if (pl.tt == 64 && T <= 64 && stream_gemm_on() && stream_splitk_on() &&
+             stream_splitk_launch(W, X, M, T, K, g_splitk_ws, pl.ksplit, pl.nk_slice, s)) {
+    // same K slices, same partial layout, same slice sum: bit-identical to the 128-row kernel below, with row tiles
+    // sized so that tiles x slices fill the chip, and feeder waves (gemm_stream.h)
   } else if (pl.tt == 64) {
     constexpr int kLds = 3 * (BM + 64) * 8 * 16;
     static const bool once = [] {

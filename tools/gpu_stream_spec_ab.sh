@@ -1,13 +1,16 @@
-# Run on the GPU box (via gpurun): stream GEMM with / without feeder waves (PEGAINFER_STREAM_SPEC) and with the qkv-sized
-# matrices routed to it (PEGAINFER_STREAM_MIN_RT), in the pipeline: TTFT at short prompts and batched decode
+# Run on the GPU box (via gpurun): A/B of one stream-GEMM switch (default PEGAINFER_STREAM_SPLITK), stand-alone layer GEMMs and
+# in the pipeline (TTFT at short prompts, batched decode).  usage: bash tools/gpu_stream_spec_ab.sh [ENV_NAME]
+var=${1:-PEGAINFER_STREAM_SPLITK}
 mkdir -p gpurun_out
-out=gpurun_out/r4_stream_spec_pipeline.txt; : > $out
-for cfg in "0 3" "1 3" "1 2"; do
-  set -- $cfg
-  export PEGAINFER_STREAM_SPEC=$1 PEGAINFER_STREAM_MIN_RT=$2
-  python tools/ttft_probe.py 17 32 64 128 2>&1 | grep TTFT | sed "s/^/[SPEC=$1 MIN_RT=$2] /" >> $out
+out=gpurun_out/r4_stream_ab_$var.txt; : > $out
+for v in 0 1 0 1; do
+  export $var=$v
+  for T in 32 64; do
+    python tools/bench_prefill_gemm.py $T 12 2>&1 | grep -v "amdgpu\|ragged" | sed "s/^/[$var=$v] /" >> $out
+  done
+  python tools/ttft_probe.py 17 32 64 2>&1 | grep TTFT | sed "s/^/[$var=$v] /" >> $out
   for b in 32 64; do
-    timeout 200 python bench.py --batch $b --steps 48 --cpu-steps 0 --ttft-iters 1 --profile-iters 0 --ttft10k-iters 0 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('[SPEC=$1 MIN_RT=$2] bs', d['config']['batch_per_gpu'], 'tok/s', d['value'], 'device_ms', d['tpot_ms']['device_p50'])" >> $out
+    timeout 200 python bench.py --batch $b --steps 48 --cpu-steps 0 --ttft-iters 1 --profile-iters 0 --ttft10k-iters 0 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('[$var=$v] bs', d['config']['batch_per_gpu'], 'tok/s', d['value'], 'device_ms', d['tpot_ms']['device_p50'])" >> $out
   done
 done
 cat $out
