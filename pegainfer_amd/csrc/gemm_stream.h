@@ -368,12 +368,21 @@ inline StreamPlan stream_splitk_plan(int M, int ksplit) {
   const int want = 256 / ksplit;
   if (want < 1) return {0, 0, 0};
   const int r = ceil_div(ceil_div(M, want), 16) * 16;
-  if (r > 96 || (M & 3)) return {0, 0, 0};
+  if (r > 96 || (M & 3)) return {0, 0, 0};   // taller (stacked qkv at 65..128 tokens, 5 slices): two rounds of 64-row tiles measured 28 us against 24
   return {r / 16, r, ceil_div(M, r)};
 }
 inline bool stream_splitk_launch(const Half* W, const Half* X, int M, int T, int K, float* part, int ksplit, int nk_slice,
                                  hipStream_t s) {
   const StreamPlan pl = stream_splitk_plan(M, ksplit);
+  if (T > 64) {   // one 128-token tile (W read once where the 64-token tiles of the 128-row kernel read it twice)
+    switch (T <= 128 ? pl.rt : 0) {
+      case 3: stream_splitk_launch_rt<3, 128>(W, X, M, T, K, pl, part, ksplit, nk_slice, s); return true;
+      case 4: stream_splitk_launch_rt<4, 128>(W, X, M, T, K, pl, part, ksplit, nk_slice, s); return true;
+      case 5: stream_splitk_launch_rt<5, 128>(W, X, M, T, K, pl, part, ksplit, nk_slice, s); return true;
+      case 6: stream_splitk_launch_rt<6, 128>(W, X, M, T, K, pl, part, ksplit, nk_slice, s); return true;
+      default: return false;
+    }
+  }
   switch (pl.rt) {
     case 1: stream_splitk_launch_rt<1, 64>(W, X, M, T, K, pl, part, ksplit, nk_slice, s); return true;
     case 2: stream_splitk_launch_rt<2, 64>(W, X, M, T, K, pl, part, ksplit, nk_slice, s); return true;
@@ -384,6 +393,7 @@ inline bool stream_splitk_launch(const Half* W, const Half* X, int M, int T, int
     default: return false;
   }
 }
+
 // Feeder waves: a wave moves ~18 GB/s of 8-row x 128-B tile pieces through its DMA issue slot (ingest_probe, tile walk),
 // i.e. one 1 KB instruction per ~0.055 us.  A K step must not take longer to ISSUE than its W bytes take to arrive from
 // HBM (RT x 2 KB at ~23 GB/s per CU = RT x 0.09 us): W feeders carry <= 6 instructions each, X feeders <= 4.

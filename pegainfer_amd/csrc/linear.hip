@@ -586,7 +586,7 @@ static void glds_splitk_launch(const Half* W, const Half* X, Half* Y, int M, int
     gemm256_splitk_launch(W, X, M, T, K, g_splitk_ws, pl.ksplit, pl.nk_slice, s);
   } else if (pl.tt == 129) {
     gemm128x256_launch(W, X, Y, M, T, K, so, g_splitk_ws, pl.ksplit, pl.nk_slice, s);
-  } else if (pl.tt == 64 && T <= 64 && stream_gemm_on() && stream_splitk_on() &&
+  } else if (pl.tt == 64 && T <= 128 && stream_gemm_on() && stream_splitk_on() &&
              stream_splitk_launch(W, X, M, T, K, g_splitk_ws, pl.ksplit, pl.nk_slice, s)) {
     // same K slices, same partial layout, same slice sum: bit-identical to the 128-row kernel below, with row tiles
     // sized so that tiles x slices fill the chip, and feeder waves (gemm_stream.h)
