@@ -331,8 +331,12 @@ constexpr int G128_BM = 128;
 constexpr int kG128LdsBytes = 9 * kG256HalfBytes;
 enum { kG128A = 0, kG128Blo = 1, kG128Bhi = 2 };
 
-template <bool SILU>
-__global__ __launch_bounds__(512) void mfma_gemm128x256_kernel(const Half* __restrict__ W, const Half* __restrict__ X,
+// NF = 4 (round 4): four more waves that do nothing but issue the DMAs (12 per K tile each), in the barrier rhythm of a
+// wave-row-0 wave; the eight compute waves issue none.  A DMA instruction costs its wave ~133 cycles of issue slot
+// (tools/probes/ingest_probe) - six per wave and K tile were 800 cycles next to 32 MFMAs = 512.  159 VGPRs: three waves
+// per SIMD fit.  NF = 0: the round-3 form (every wave stages its share), kept for the A/B (PEGAINFER_GEMM128X256_FEED=0).
+template <bool SILU, int NF>
+__global__ __launch_bounds__(512 + NF * 64) void mfma_gemm128x256_kernel(const Half* __restrict__ W, const Half* __restrict__ X,
                                                                Half* __restrict__ Y, int M, int T, int K, int m_tiles,
                                                                int t_tiles, SplitOut so, float* __restrict__ part,
                                                                int nk_slice) {
@@ -349,10 +353,14 @@ __global__ __launch_bounds__(512) void mfma_gemm128x256_kernel(const Half* __res
   const int wr = wave >> 2, wc = wave & 3;
   const int l15 = lane & 15, g = lane >> 4;
 
-  const Half* src[3][2];
+  constexpr int NI = NF ? NF : 8;           // waves that issue DMAs
+  constexpr int PPW = 16 / NI;              // 1 KiB pieces per issuing wave and half-tile
+  const bool feeder = NF && wave >= 8;
+  const int wi = NF ? wave - 8 : wave;      // index among the issuing waves (compute waves of the NF form: negative, unused)
+  const Half* src[3][PPW];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int p = (j * 8 + wave) * 64 + lane, hrow = p >> 3, cs = (p & 7) ^ (hrow & 7);
+  for (int j = 0; j < PPW; ++j) {
+    const int p = (j * NI + (wi < 0 ? 0 : wi)) * 64 + lane, hrow = p >> 3, cs = (p & 7) ^ (hrow & 7);
     int row;
     if (SILU) {   // a wave row's m-tiles 0, 1 are 32 gate rows, 2, 3 their 32 up rows: gate and up of an element meet in one lane
       int gr = so.silu_c0 + mt * 64 + (hrow >> 6) * 32 + ((hrow >> 4) & 1) * 16 + (hrow & 15);
@@ -379,15 +387,15 @@ __global__ __launch_bounds__(512) void mfma_gemm128x256_kernel(const Half* __res
 #pragma unroll
   for (int w = 0; w < 3; ++w)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) src[w][j] += (size_t)kt_begin * G256_BK;
+    for (int j = 0; j < PPW; ++j) src[w][j] += (size_t)kt_begin * G256_BK;
   // stage half-tile `which` of K tile kt into ring slot `ring` (clamped past the end: a dead slot, the load only keeps
   // vmcnt uniform)
   auto stage = [&](int which, int kt, int ring) {
     const int ktc = kt < nk ? kt : nk - 1;
     const uint32_t slot = lds0 + (uint32_t)((ring * 3 + which) * kG256HalfBytes);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const uint32_t dst = __builtin_amdgcn_readfirstlane(slot + (uint32_t)(j * 8 + wave) * 1024u);
+    for (int j = 0; j < PPW; ++j) {
+      const uint32_t dst = __builtin_amdgcn_readfirstlane(slot + (uint32_t)(j * NI + wi) * 1024u);
       if (which == kG128A && so.w_nt)   // a single token tile: W bytes have one reader (SplitOut::w_nt)
         asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt"
                      :: "v"(src[which][j] + (size_t)ktc * G256_BK), "s"(dst) : "memory", "m0");
@@ -432,10 +440,37 @@ __global__ __launch_bounds__(512) void mfma_gemm128x256_kernel(const Half* __res
     __builtin_amdgcn_s_setprio(0);
   };
 
+  constexpr int kTileDmas = 3 * PPW;        // DMAs per issuing wave and K tile: the counted wait leaves one tile in flight
+  if (feeder) {
+    // the whole staging side, in the barrier rhythm of a wave-row-0 wave (the EARLIEST any wave of the round-3 form touched
+    // a ring slot, so the hazards are the ones argued above): A + B_lo of tile kt + 2 in phase 1, B_hi in phase 2
+    stage(kG128A, 0, 0); stage(kG128Blo, 0, 0); stage(kG128Bhi, 0, 0);
+    stage(kG128A, 1, 1); stage(kG128Blo, 1, 1); stage(kG128Bhi, 1, 1);
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kTileDmas) : "memory");
+    __builtin_amdgcn_s_barrier();
+    int ring = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      const int ring2 = ring + 2 >= 3 ? ring - 1 : ring + 2;
+      stage(kG128A, kt + 2, ring2);
+      stage(kG128Blo, kt + 2, ring2);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_barrier();
+      stage(kG128Bhi, kt + 2, ring2);
+      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kTileDmas) : "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_barrier();
+      ring = ring + 1 == 3 ? 0 : ring + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail loads must not outlive the workgroup's LDS
+    __builtin_amdgcn_s_barrier();
+    return;
+  }
   // ---- prologue: K tiles 0 and 1 requested, tile 0 landed ----
-  stage(kG128A, 0, 0); stage(kG128Blo, 0, 0); stage(kG128Bhi, 0, 0);
-  stage(kG128A, 1, 1); stage(kG128Blo, 1, 1); stage(kG128Bhi, 1, 1);
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  if constexpr (NF == 0) {
+    stage(kG128A, 0, 0); stage(kG128Blo, 0, 0); stage(kG128Bhi, 0, 0);
+    stage(kG128A, 1, 1); stage(kG128Blo, 1, 1); stage(kG128Bhi, 1, 1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  }
   __builtin_amdgcn_s_barrier();
   if (wr == 1) __builtin_amdgcn_s_barrier();   // the second wave row runs one barrier behind the first
 
@@ -446,14 +481,18 @@ __global__ __launch_bounds__(512) void mfma_gemm128x256_kernel(const Half* __res
     read_b(ring, kG128Blo);
     __builtin_amdgcn_sched_barrier(0);
     read_a(ring);
-    stage(kG128A, kt + 2, ring2);
-    stage(kG128Blo, kt + 2, ring2);
+    if constexpr (NF == 0) {
+      stage(kG128A, kt + 2, ring2);
+      stage(kG128Blo, kt + 2, ring2);
+    }
     __builtin_amdgcn_s_barrier();
     quad(0);
     __builtin_amdgcn_s_barrier();
     read_b(ring, kG128Bhi);
-    stage(kG128Bhi, kt + 2, ring2);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    if constexpr (NF == 0) {
+      stage(kG128Bhi, kt + 2, ring2);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
     quad(1);
     __builtin_amdgcn_s_barrier();
@@ -463,7 +502,7 @@ __global__ __launch_bounds__(512) void mfma_gemm128x256_kernel(const Half* __res
     if (kt + 1 < nk) ktile(kt + 1, 1);
     if (kt + 2 < nk) ktile(kt + 2, 2);
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail loads must not outlive the workgroup's LDS
+  if constexpr (NF == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail loads must not outlive the workgroup's LDS
   if (wr == 0) __builtin_amdgcn_s_barrier();
 
   if (SILU) {
@@ -547,31 +586,36 @@ __global__ __launch_bounds__(512) void mfma_gemm128x256_kernel(const Half* __res
 inline bool gemm128x256_ok(int M, int T, int K) { return (K % G256_BK) == 0 && K >= 128 && M >= 128 && T > 64; }
 
 // plain (part == nullptr, ksplit == 1) or split-K (fp32 partials into part[ksplit][T][M]; the caller sums the slices)
-inline void gemm128x256_launch(const Half* W, const Half* X, Half* Y, int M, int T, int K, SplitOut so, float* part,
-                               int ksplit, int nk_slice, hipStream_t s) {
-  const int t_tiles = ceil_div(T, G256_BT);
-  so.w_nt = t_tiles == 1 && weights_nt_on();
-  if (so.silu_I > 0) {   // SwiGLU form (un-split only): a tile = 64 gate rows + their 64 up rows
-    static const bool once = [] {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_gemm128x256_kernel<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, kG128LdsBytes);
-      return true;
-    }();
-    (void)once;
-    const int m_tiles = ceil_div(silu_cols_end(so) - so.silu_c0, 64);
-    mfma_gemm128x256_kernel<true><<<m_tiles * t_tiles, 512, kG128LdsBytes, s>>>(W, X, Y, M, T, K, m_tiles, t_tiles, so,
-                                                                                nullptr, 0);
-    return;
-  }
+inline bool gemm128x256_feed_on() {
+  static const bool v = [] { const char* e = getenv("PEGAINFER_GEMM128X256_FEED"); return !(e && e[0] == '0'); }();
+  return v;
+}
+template <bool SILU, int NF>
+inline void gemm128x256_launch_nf(const Half* W, const Half* X, Half* Y, int M, int T, int K, const SplitOut& so, float* part,
+                                  int ksplit, int nk_slice, int m_tiles, int t_tiles, hipStream_t s) {
   static const bool once = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_gemm128x256_kernel<false>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_gemm128x256_kernel<SILU, NF>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, kG128LdsBytes);
     return true;
   }();
   (void)once;
-  const int m_tiles = ceil_div(M, G128_BM);
-  mfma_gemm128x256_kernel<false><<<dim3(m_tiles * t_tiles, part ? ksplit : 1), 512, kG128LdsBytes, s>>>(
+  mfma_gemm128x256_kernel<SILU, NF><<<dim3(m_tiles * t_tiles, part ? ksplit : 1), 512 + NF * 64, kG128LdsBytes, s>>>(
       W, X, Y, M, T, K, m_tiles, t_tiles, so, part, nk_slice);
+}
+inline void gemm128x256_launch(const Half* W, const Half* X, Half* Y, int M, int T, int K, SplitOut so, float* part,
+                               int ksplit, int nk_slice, hipStream_t s) {
+  const int t_tiles = ceil_div(T, G256_BT);
+  so.w_nt = t_tiles == 1 && weights_nt_on();
+  const bool feed = gemm128x256_feed_on();
+  if (so.silu_I > 0) {   // SwiGLU form (un-split only): a tile = 64 gate rows + their 64 up rows
+    const int m_tiles = ceil_div(silu_cols_end(so) - so.silu_c0, 64);
+    if (feed) gemm128x256_launch_nf<true, 4>(W, X, Y, M, T, K, so, nullptr, 1, 0, m_tiles, t_tiles, s);
+    else gemm128x256_launch_nf<true, 0>(W, X, Y, M, T, K, so, nullptr, 1, 0, m_tiles, t_tiles, s);
+    return;
+  }
+  const int m_tiles = ceil_div(M, G128_BM);
+  if (feed) gemm128x256_launch_nf<false, 4>(W, X, Y, M, T, K, so, part, ksplit, nk_slice, m_tiles, t_tiles, s);
+  else gemm128x256_launch_nf<false, 0>(W, X, Y, M, T, K, so, part, ksplit, nk_slice, m_tiles, t_tiles, s);
 }
 
 }  // namespace pk
