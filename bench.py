@@ -681,6 +681,21 @@ def main():
         ttft10k = {"prompt_tokens": 10000, "p50": round(float(np.median(t10)), 3), "min": round(min(t10), 3),
                    "iters": len(t10),
                    "prefill_roofline": prefill_roofline(full_cfg, 10000, float(np.median(t10)), world if tp else 1)}
+    # short prompts (the reference's golden prompts and README TTFT are this short, README.md:28-34): TTFT at 32 and 128
+    # tokens, same protocol as ttft_ms (one warm-up, then --ttft-iters timed submissions), outside `value`
+    ttft_short = None
+    if args.ttft_iters > 1 and args.batch == 1:
+        ttft_short = {}
+        for n in (32, 128):
+            sp, ts = synthetic_prompt(n), []
+            for it in range(args.ttft_iters + 1):
+                r = eng.new_request()
+                t0 = time.perf_counter()
+                eng.prefill([r], [sp])
+                ts.append((time.perf_counter() - t0) * 1e3)
+                eng.drop_request(r)
+            ts = ts[1:]
+            ttft_short[str(n)] = {"p50": round(float(np.median(ts)), 3), "min": round(min(ts), 3), "iters": len(ts)}
     # configs[4] side measurement (not part of `value`): the DeepSeek-V4 MP8 collective verbs over the N ranks
     mp8, mp8_hung = None, False
     if world > 1:
@@ -729,6 +744,7 @@ def main():
                     "mean_over_p50": round(mean_ms / p50_ms, 4)},
         "decode_heavy": heavy,
         "ttft_ms_10000": ttft10k,
+        "ttft_ms_short": ttft_short,
         "mp8_collectives_us": mp8,
         "prefill_roofline": prefill_roofline(full_cfg, args.ctx, float(np.median(ttfts)), world if tp else 1),
         "step_roofline": {"algorithmic_bytes_per_step": int(step_bytes),
