@@ -227,7 +227,10 @@ def gemm_check(P, M, T, K, seed=0):
                                    # weight-streaming kernel (gemm_stream.h): 80 / 64-row tiles at 17..64 columns (64-token
                                    # tile) and 65..128 (128-token tile), last row tile ragged / almost empty
                                    (19456, 17, 2560), (19460, 40, 2560), (19460, 100, 2560), (20000, 128, 2560),
-                                   (12292, 64, 1024), (16388, 96, 512)])
+                                   (12292, 64, 1024), (16388, 96, 512),
+                                   # its K-split form (o_proj / down_proj: 8 slices x 32 row tiles of 80), 64- and 128-token tile,
+                                   # ragged last row tile, a short last slice
+                                   (2560, 100, 9728), (2560, 128, 4096), (2564, 70, 9728), (2568, 40, 4160)])
 def test_gemm_shapes(P, M, T, K):
     gemm_check(P, M, T, K)
 
