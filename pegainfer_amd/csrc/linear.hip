@@ -726,11 +726,12 @@ constexpr int kMidBatchMinRows = 5120;
 // pair.  o_proj / down_proj (16-row tiles) keep the split-K route: with full K per workgroup they pull 0.5-1.2 MB of x per CU
 // for 130-310 KB of weights (15.3 / 30.5 us against 15.0 / 21.7), profiles/r4_stream_spec_ab.txt.
 // PEGAINFER_STREAM_GEMM=0 switches it off, PEGAINFER_STREAM_MIN_RT moves the threshold.
-static int mid_batch_route(const Half* W, const Half* X, const Half* Y, int M, int T, int K, int silu_I = 0) {
+static int mid_batch_route(const Half* W, const Half* X, const Half* Y, int M, int T, int K, int silu_I = 0,
+                           bool assume_ws = false) {
   static const int min_rows = [] { const char* e = getenv("PEGAINFER_MID_MIN_ROWS"); return e && *e ? atoi(e) : kMidBatchMinRows; }();
   if (T <= 16 || T > 64 || !glds_gemm_ok(W, X, Y, M, K)) return 0;
   if (stream_gemm_on() && stream_plan(M, silu_I).rt >= stream_min_rt()) return 3;
-  if (splitk_plan(M, T, K).nk_slice > 0) return 2;
+  if (splitk_plan(M, T, K, assume_ws).nk_slice > 0) return 2;
   return M >= min_rows ? 1 : 0;
 }
 static bool mid_batch_gemm(const Half* W, const Half* X, Half* Y, int M, int T, int K, const SplitOut& so, hipStream_t s) {
@@ -957,17 +958,34 @@ pegainfer_status_t pegainfer_gemm_silu_rounded(const Half* W, const Half* X, Hal
 // Debug / test hook (no device work, callable without a GPU): which kernel a prefill-shaped GEMM of this shape takes.
 // silu_I > 0 asks for the SwiGLU form (M is then ignored, the matrix has 2 * silu_I rows).  out[0] = kind, out[1] = K
 // slices (1 = un-split), out[2] = K tiles per slice or, for kind 257, the activation-column tiles of the 256 x 256 head.
-// kind: 0 = decode family (T <= 64: GEMV / skinny / mid-batch routing, not detailed here); the TiledRoute kinds (12, 13,
-// 22, 23, 256, 257, 1280, 1281); 1000 + tt for the K-split plans (tt = 64 / 128: 128-row kernel, 129: 128 x 256 kernel,
-// 256: 256 x 256 kernel).  Assumes the split-K workspace of cublas_init() exists.
+// kind: 0 = GEMV / skinny family (T <= 16, or a 17..64-column shape the tiled kernels do not take); the TiledRoute kinds (12,
+// 13, 22, 23, 256, 257, 1280, 1281, 3000 + row blocks of the stream kernel); 1000 + tt for the K-split plans (tt = 64 / 128:
+// 128-row kernel, 129: 128 x 256 kernel, 256: 256 x 256 kernel), 2000 + row blocks where the GEMM half of a tt = 64 plan
+// runs on the stream kernel (<= 128 tokens).  Assumes the split-K workspace of cublas_init() exists.
 pegainfer_status_t pegainfer_debug_gemm_route(int32_t M, int32_t T, int32_t K, int32_t silu_I, int32_t* out) {
   using namespace pk;
   if (!out || T <= 0 || K <= 0 || (silu_I <= 0 && M <= 0)) return (pegainfer_status_t)hipErrorInvalidValue;
   out[0] = 0; out[1] = 1; out[2] = 0;
-  if (T <= 64) return 0;
+  if (T <= 16) return 0;
+  // the K-split pairs whose GEMM half runs on the stream kernel (glds_splitk_launch): same slices, row tiles of rt blocks
+  auto split_kind = [&](const SplitKPlan& pl) {
+    const StreamPlan sp = stream_splitk_plan(M, pl.ksplit);
+    const bool stream = pl.tt == 64 && T <= 128 && stream_gemm_on() && stream_splitk_on() && sp.rt >= (T > 64 ? 3 : 1);
+    return stream ? 2000 + sp.rt : 1000 + pl.tt;
+  };
+  if (T <= 64) {   // the mid-batch family: 3000 + rt stream kernel, 2000 + rt / 1064 K-split pair, 23 the 128-row kernel, 0 skinny
+    const int rows = silu_I > 0 ? 2 * silu_I : M;
+    const int r = mid_batch_route(nullptr, nullptr, nullptr, rows, T, K, silu_I > 0 ? silu_I : 0, true);
+    if (r == 3) out[0] = 3000 + stream_plan(rows, silu_I > 0 ? silu_I : 0).rt;
+    else if (r == 2) {
+      const SplitKPlan pl = splitk_plan(rows, T, K, true);
+      out[0] = split_kind(pl); out[1] = pl.ksplit; out[2] = pl.nk_slice;
+    } else if (r == 1) out[0] = 23;
+    return 0;
+  }
   if (silu_I <= 0) {
     const SplitKPlan pl = splitk_plan(M, T, K, true);
-    if (pl.nk_slice > 0) { out[0] = 1000 + pl.tt; out[1] = pl.ksplit; out[2] = pl.nk_slice; return 0; }
+    if (pl.nk_slice > 0) { out[0] = split_kind(pl); out[1] = pl.ksplit; out[2] = pl.nk_slice; return 0; }
   }
   SplitOut so{nullptr, nullptr, nullptr, 0, 0, 0, silu_I > 0 ? silu_I : 0, 0, 0, 0};
   const TiledRoute r = tiled_route(silu_I > 0 ? 2 * silu_I : M, T, K, so);

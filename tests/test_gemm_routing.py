@@ -23,12 +23,17 @@ def route():
 
 
 def test_decode_family_is_not_routed_here(route):
-    assert route(2560, 64, 4096)[0] == 0 and route(2560, 1, 4096)[0] == 0
+    assert route(2560, 16, 4096)[0] == 0 and route(2560, 1, 4096)[0] == 0
+    assert route(512, 40, 256)[0] == 0         # a small, short-K matrix at 17..64 columns stays on the skinny kernel
 
 
 @pytest.mark.parametrize("T,qkv,o,down,gate_up", [
-    # kind 1000 + tt = K-split plan on tt-token tiles (129: 128 x 256 kernel, 256: 256 x 256 kernel), (slices, K tiles per slice)
-    (128, (1064, 5, 8), (1064, 8, 8), (1064, 8, 19), (3006, 1, 0)),     # gate_up: the weight-streaming kernel, 40 + 40-row SwiGLU tiles (3000 + row blocks)
+    # kind 1000 + tt = K-split plan on tt-token tiles (129: 128 x 256 kernel, 256: 256 x 256 kernel), (slices, K tiles per slice);
+    # 2000 + row blocks = the same plan with its GEMM half on the stream kernel; 3000 + row blocks = the stream kernel un-split
+    (17, (3002, 1, 0), (2005, 8, 8), (2005, 8, 19), (3006, 1, 0)),      # round 4: the whole 17..64-column layer on gemm_stream.h
+    (64, (3002, 1, 0), (2005, 8, 8), (2005, 8, 19), (3006, 1, 0)),
+    (65, (1064, 5, 8), (2005, 8, 8), (2005, 8, 19), (3006, 1, 0)),      # qkv (5 slices) would need 121-row tiles: the 128-row kernel
+    (128, (1064, 5, 8), (2005, 8, 8), (2005, 8, 19), (3006, 1, 0)),     # gate_up: 40 + 40-row SwiGLU tiles
     (256, (23, 1, 0), (1064, 6, 11), (1064, 6, 26), (1281, 1, 0)),      # gate_up: SwiGLU form of the 128 x 256 kernel
     (512, (1129, 2, 20), (1129, 6, 11), (1129, 6, 26), (256, 1, 0)),    # gate_up: 152 tiles of 256 x 256, one round
     (1024, (1280, 1, 0), (1129, 3, 22), (1129, 3, 51), (257, 1, 64)),   # the headline TTFT shape
@@ -48,9 +53,18 @@ def test_split_plans_cover_k_exactly(route):
     for (M, K) in (QKV, O, DOWN, (4096, 4096), (4096, 12288), (1024, 2560)):
         for T in (65, 128, 200, 256, 512, 777, 1024, 1536, 2048, 3000):
             kind, ks, per = route(M, T, K)
-            if kind in (1064, 1128, 1129, 1256):   # the K-split plans
+            if kind in (1064, 1128, 1129, 1256) or 2000 < kind < 3000:   # the K-split plans
                 nk = K // 64
                 assert ks >= 2 and (ks - 1) * per < nk <= ks * per, (M, K, T, kind, ks, per)
+
+
+def test_plain_gate_up_and_swiglu_gate_up_are_both_unsplit_stream_shapes(route):
+    """gemm_silu fuses at 17..64 columns only where the plain GEMM over the same matrix is un-split too (same K order):
+    the model shapes are; a narrow matrix whose plain form is K-split is not (linear.hip gemm_silu_impl)"""
+    for I in (9728, 12288, 9216):
+        for T in (17, 40, 64):
+            assert route(0, T, 2560, I)[0] // 1000 == 3 and route(2 * I, T, 2560)[0] // 1000 == 3, (I, T)
+    assert route(0, 40, 256, 512)[0] // 1000 == 3 and route(1024, 40, 256)[0] // 1000 != 3   # the case that needs the guard
 
 
 def test_invalid_arguments(route):
