@@ -5,8 +5,10 @@
 // 128-row tiles of mfma_gemm_glds_kernel give gate_up (19 456 rows) 152 workgroups - 152 of 256 CUs carry 655 KB each while
 // 104 idle (28 us at 32 columns for 99.6 MB = 3.6 TB/s) - and the small matrices (qkv 48 tiles, o_proj / down_proj 20) had
 // to split K over workgroups and pay fp32 partials + a slice-sum launch.  Here a tile is RT x 16 rows with
-// RT = ceil(ceil(M / CUs) / 16): gate_up 80 rows -> 244 workgroups, qkv 32 -> 192, o_proj / down_proj 16 -> 160, every one
-// walking the FULL K (no partials, no second launch), all token columns in the workgroup.
+// RT = ceil(ceil(M / CUs) / 16): gate_up 80 rows -> 244 workgroups, qkv 32 -> 192, every one walking the FULL K (no
+// partials, no second launch), all token columns in the workgroup.  o_proj / down_proj (16-row tiles would re-read all of x
+// per 16 rows of W) keep their K slices and slice-sum launch, but the GEMM half is this kernel too (part != nullptr):
+// 256 / slices row tiles, so tiles x slices fill the chip.
 //
 // Structure: LDS-DMA rings of K tiles of 64 as in mfma_gemm_glds_kernel (source-side swizzle, counted vmcnt), but
 //  * four COMPUTE waves side by side along the token axis (TT / 4 tokens each, all RT row blocks): any RT works;
@@ -318,7 +320,7 @@ template <int RT, int TT = 64> struct StreamDepth {
   // TT = 64 (X tile 8 KB):  RT  1: 24 x 2 + 12 x 8 = 144 KB   2: 16 x 4 + 12 x 8 = 160   3: 12 x 6 + 6 x 8 = 120
   //                             4: 10 x 8 + 6 x 8 = 128       5: 10 x 10 + 6 x 8 = 148   6: 9 x 12 + 6 x 8 = 156
   // TT = 128 (X tile 16 KB): RT 3: 12 x 6 + 5 x 16 = 152      4: 9 x 8 + 5 x 16 = 152    5: 8 x 10 + 5 x 16 = 160
-  //                             6: G = 1, 6 x 12 + 5 x 16 = 152 (two tiles per barrier would leave 24 KB of W ahead)
+  //                             6: 6 x 12 + 5 x 16 = 152 (24-48 KB of W ahead; one tile per barrier with 48-60 KB ahead measured the same)
   static constexpr int G = TT == 64 ? (RT <= 2 ? 4 : 2) : 2;
   static constexpr int W = TT == 64 ? (RT == 1 ? 24 : RT == 2 ? 16 : RT == 3 ? 12 : RT == 4 ? 10 : RT == 5 ? 10 : 9)
                                     : (RT == 3 ? 12 : RT == 4 ? 9 : RT == 5 ? 8 : 6);
