@@ -51,7 +51,7 @@ def test_qwen3_4b_projection_routes(route, T, qkv, o, down, gate_up):
 def test_split_plans_cover_k_exactly(route):
     """every K-split plan walks all K tiles: (slices - 1) * per_slice < K / 64 <= slices * per_slice"""
     for (M, K) in (QKV, O, DOWN, (4096, 4096), (4096, 12288), (1024, 2560)):
-        for T in (65, 128, 200, 256, 512, 777, 1024, 1536, 2048, 3000):
+        for T in (17, 40, 64, 65, 128, 200, 256, 512, 777, 1024, 1536, 2048, 3000):
             kind, ks, per = route(M, T, K)
             if kind in (1064, 1128, 1129, 1256) or 2000 < kind < 3000:   # the K-split plans
                 nk = K // 64
