@@ -323,7 +323,7 @@ template <int RT, int TT = 64> struct StreamDepth {
   //                             6: 6 x 12 + 5 x 16 = 152 (24-48 KB of W ahead; one tile per barrier with 48-60 KB ahead measured the same)
   static constexpr int G = TT == 64 ? (RT <= 2 ? 4 : 2) : 2;
   static constexpr int W = TT == 64 ? (RT == 1 ? 24 : RT == 2 ? 16 : RT == 3 ? 12 : RT == 4 ? 10 : RT == 5 ? 10 : 9)
-                                    : (RT == 3 ? 12 : RT == 4 ? 9 : RT == 5 ? 8 : 6);
+                                    : (RT <= 2 ? 16 : RT == 3 ? 12 : RT == 4 ? 9 : RT == 5 ? 8 : 6);   // RT 2: 16 x 4 + 5 x 16 = 144 KB
   static constexpr int X = TT == 64 ? (RT <= 2 ? 12 : 6) : 5;
 };
 
@@ -412,7 +412,8 @@ inline bool stream_gemm_launch(const Half* W, const Half* X, Half* Y, int M, int
     if (pl.rt == 1) { stream_gemm_launch_rt<1, TT>(W, X, Y, M, T, K, pl, so, s); return true; }
     if (pl.rt == 2) { stream_gemm_launch_rt<2, TT>(W, X, Y, M, T, K, pl, so, s); return true; }
   }
-  switch (pl.rt) {   // 128-token tiles exist for >= 3 row blocks only (the 16 / 32-row tiles are not routed at all)
+  switch (pl.rt) {   // 128-token tiles exist for >= 2 row blocks (16-row tiles are not routed un-split at all)
+    case 2: if constexpr (TT == 128) { stream_gemm_launch_rt<2, TT>(W, X, Y, M, T, K, pl, so, s); return true; } return false;
     case 3: stream_gemm_launch_rt<3, TT>(W, X, Y, M, T, K, pl, so, s); return true;
     case 4: stream_gemm_launch_rt<4, TT>(W, X, Y, M, T, K, pl, so, s); return true;
     case 5: stream_gemm_launch_rt<5, TT>(W, X, Y, M, T, K, pl, so, s); return true;

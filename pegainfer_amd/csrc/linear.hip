@@ -556,6 +556,9 @@ static SplitKPlan splitk_plan(int M, int T, int K, bool assume_ws = false) {
         if (ksplit >= 2 && (size_t)ksplit * T * M * 4 <= kSplitKWorkspaceBytes) return {ksplit, nk_slice, 129};
       }
     }
+    // 65..128 tokens on a matrix the stream kernel takes un-split on 32-row tiles (the stacked qkv: 192 workgroups, one
+    // 128-token tile, W read once): no K-split pair (24 us for 5 slices on 128-row tiles + the slice sum)
+    if (T <= 128 && stream_gemm_on() && stream_min_rt() <= 2 && stream_plan(M, 0).rt == 2) return {0, 0, 0};
     const int tt = T <= 256 ? 64 : 128;
     const long tiles = (long)m_tiles * ceil_div(T, tt);
     if (tiles > 170) return {0, 0, 0};
@@ -652,7 +655,7 @@ static TiledRoute tiled_route(int M, int T, int K, const SplitOut& so) {
   // to the CU count (244 workgroups instead of 152), same per-element K order as every un-split tiled kernel.  kind 3000 + RT.
   if (T <= 128 && so.silu_c1 == 0 && stream_gemm_on()) {
     const StreamPlan sp = stream_plan(M, so.silu_I > 0 ? so.silu_I : 0);
-    if (sp.rt >= (stream_min_rt() > 3 ? stream_min_rt() : 3)) return {3000 + sp.rt, 0};   // 128-token tiles exist for 3..6 row blocks
+    if (sp.rt >= (stream_min_rt() > 2 ? stream_min_rt() : 2)) return {3000 + sp.rt, 0};   // 128-token tiles exist for 2..6 row blocks
   }
   // SwiGLU GEMM on short prompts (65..256 tokens: 152 tiles of (64 + 64) x 256 for Qwen3-4B, one round) - the 128 x 128
   // kernel runs these at one 4-wave workgroup per CU.  Same per-element K order: bit-identical to gemm + silu_mul

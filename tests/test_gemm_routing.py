@@ -32,8 +32,9 @@ def test_decode_family_is_not_routed_here(route):
     # 2000 + row blocks = the same plan with its GEMM half on the stream kernel; 3000 + row blocks = the stream kernel un-split
     (17, (3002, 1, 0), (2005, 8, 8), (2005, 8, 19), (3006, 1, 0)),      # round 4: the whole 17..64-column layer on gemm_stream.h
     (64, (3002, 1, 0), (2005, 8, 8), (2005, 8, 19), (3006, 1, 0)),
-    (65, (1064, 5, 8), (2005, 8, 8), (2005, 8, 19), (3006, 1, 0)),      # qkv (5 slices) would need 121-row tiles: the 128-row kernel
-    (128, (1064, 5, 8), (2005, 8, 8), (2005, 8, 19), (3006, 1, 0)),     # gate_up: 40 + 40-row SwiGLU tiles
+    (65, (3002, 1, 0), (2005, 8, 8), (2005, 8, 19), (3006, 1, 0)),      # qkv un-split on 32-row tiles x ONE 128-token tile
+    (128, (3002, 1, 0), (2005, 8, 8), (2005, 8, 19), (3006, 1, 0)),     # gate_up: 40 + 40-row SwiGLU tiles
+    (129, (1064, 3, 14), (1064, 8, 8), (1064, 8, 19), (1281, 1, 0)),    # from 129 tokens on: the round-3 kernels
     (256, (23, 1, 0), (1064, 6, 11), (1064, 6, 26), (1281, 1, 0)),      # gate_up: SwiGLU form of the 128 x 256 kernel
     (512, (1129, 2, 20), (1129, 6, 11), (1129, 6, 26), (256, 1, 0)),    # gate_up: 152 tiles of 256 x 256, one round
     (1024, (1280, 1, 0), (1129, 3, 22), (1129, 3, 51), (257, 1, 64)),   # the headline TTFT shape

@@ -230,7 +230,9 @@ def gemm_check(P, M, T, K, seed=0):
                                    (12292, 64, 1024), (16388, 96, 512),
                                    # its K-split form (o_proj / down_proj: 8 slices x 32 row tiles of 80), 64- and 128-token tile,
                                    # ragged last row tile, a short last slice
-                                   (2560, 100, 9728), (2560, 128, 4096), (2564, 70, 9728), (2568, 40, 4160)])
+                                   (2560, 100, 9728), (2560, 128, 4096), (2564, 70, 9728), (2568, 40, 4160),
+                                   # 32-row tiles x one 128-token tile (the stacked qkv at 65..128 tokens), Qwen3-8B's K, ragged M
+                                   (6144, 100, 2560), (6144, 128, 4096), (6148, 65, 2560)])
 def test_gemm_shapes(P, M, T, K):
     gemm_check(P, M, T, K)
 
