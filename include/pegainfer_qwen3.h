@@ -125,6 +125,15 @@ int32_t pegainfer_qwen3_logprobs(pegainfer_qwen3_t m, int32_t column, uint32_t t
 int32_t pegainfer_logprobs_from_logits(const float* logits_f32, int32_t n, uint32_t token, int32_t top_k,
                                        float* out_logprob, uint32_t* out_top_ids, float* out_top_logprobs);
 
+/* Per-layer hidden-state tap - the reference's own debugging method (docs/playbooks/accuracy-parity-playbook.md:15-24:
+ * find the first-diff token, then compare LAYERS).  While enabled, prefill / decode steps run eagerly (same kernels,
+ * same bits as the graph replay) and the residual stream leaving every layer - one row per request: all columns of a
+ * decode step, each request's LAST prompt position of a prefill - is kept on the device.
+ * pegainfer_qwen3_debug_hidden copies layer `layer`'s rows of the last step, bf16 bits [rows, hidden], to the host and
+ * returns the row count (<= max_rows), or < 0.  Test / diagnosis only; costs one D2D copy per layer while on. */
+int32_t pegainfer_qwen3_debug_hidden_enable(pegainfer_qwen3_t m, int32_t enable);
+int32_t pegainfer_qwen3_debug_hidden(pegainfer_qwen3_t m, int32_t layer, void* out_host_bf16, int32_t max_rows);
+
 /* device-side timing of the last decode step's graph (hipEvent pair on the model stream), ms */
 float pegainfer_qwen3_last_step_ms(pegainfer_qwen3_t m);
 int32_t pegainfer_qwen3_last_attention_path(pegainfer_qwen3_t m);

@@ -72,6 +72,11 @@ int32_t pegainfer_qwen35_sample(pegainfer_qwen35_t m, int32_t column, float temp
 int32_t pegainfer_qwen35_logprobs(pegainfer_qwen35_t m, int32_t column, uint32_t token, int32_t top_k, float* out_logprob,
                                   uint32_t* out_top_ids, float* out_top_logprobs);
 float pegainfer_qwen35_last_step_ms(pegainfer_qwen35_t m);
+/* Per-layer hidden-state tap, the twin of pegainfer_qwen3_debug_hidden (accuracy-parity-playbook.md:15-24): while
+ * enabled steps run eagerly and the residual stream leaving every layer (decode: all columns; prefill: the last prompt
+ * position) stays on the device; debug_hidden copies one layer's rows, bf16 bits [rows, hidden], returns the row count */
+int32_t pegainfer_qwen35_debug_hidden_enable(pegainfer_qwen35_t m, int32_t enable);
+int32_t pegainfer_qwen35_debug_hidden(pegainfer_qwen35_t m, int32_t layer, void* out_host_bf16, int32_t max_rows);
 int64_t pegainfer_qwen35_weight_bytes(pegainfer_qwen35_t m);
 
 #ifdef __cplusplus

@@ -87,6 +87,7 @@ class Qwen35Oracle:
 
     def __init__(self, cfg, weights, num_pages=64, rope_positions=4096):
         self.cfg = c = cfg
+        self.taps = None   # a list: every layer appends its output rows (prefill: the last row; decode: all rows)
         self.w = weights
         g = lambda name: weights[f"{WP}.{name}"]
         self.embed = g("embed_tokens.weight")
@@ -192,6 +193,8 @@ class Qwen35Oracle:
             mid = ops.add(hidden, attn)
             normed = ops.rms_norm(mid, L["ln2"], c.rms_norm_eps, offset=True)
             hidden = ops.add(mid, self._mlp(L, normed))
+            if self.taps is not None:
+                self.taps.append(hidden[T - 1:T].copy())
         last = ops.rms_norm(hidden[T - 1][None, :], self.norm, c.rms_norm_eps, offset=True)
         return ops.gemm(self.embed, last)[0]
 
@@ -231,6 +234,8 @@ class Qwen35Oracle:
             mid = ops.add(hidden, attn)
             normed = ops.rms_norm(mid, L["ln2"], c.rms_norm_eps, offset=True)
             hidden = ops.add(mid, self._mlp(L, normed))
+            if self.taps is not None:
+                self.taps.append(hidden.copy())
         normed = ops.rms_norm(hidden, self.norm, c.rms_norm_eps, offset=True)
         return ops.gemm(self.embed, normed)
 

@@ -69,6 +69,8 @@ class Qwen3Oracle:
         """all_reduce: optional callable(float32 array) -> summed array; applied to the bf16 O-proj and
         down-proj outputs exactly where the reference's TP all-reduces (weights.rs:396-405)."""
         self.all_reduce = all_reduce
+        self.taps = None   # a list: every layer appends its output rows (prefill: each request's last row; decode: all rows) -
+        #                    the per-layer comparison of docs/playbooks/accuracy-parity-playbook.md:15-24
         self.cfg = cfg
         self.w = weights
         c = cfg
@@ -159,6 +161,8 @@ class Qwen3Oracle:
             hidden, normed = ops.fused_add_rms_norm(hidden, o, L["ln2"], c.rms_norm_eps)
             mlp = self._mlp(L, normed)
             hidden = ops.add(hidden, mlp)                        # prefill.rs:183 plain add
+            if self.taps is not None:
+                self.taps.append(hidden[q_indptr[1:] - 1].copy())
         logits = []
         for b in range(len(prompts)):
             last = hidden[int(q_indptr[b + 1]) - 1][None, :]
@@ -188,6 +192,8 @@ class Qwen3Oracle:
             mlp = self._mlp(L, normed)
             nxt = self.layers[li + 1]["ln1"] if li + 1 < len(self.layers) else self.norm
             hidden, normed = ops.fused_add_rms_norm(hidden, mlp, nxt, c.rms_norm_eps)
+            if self.taps is not None:
+                self.taps.append(hidden.copy())
         return ops.gemm(self.lm_head, normed)                   # [bs, vocab]
 
     # -- greedy generate: the reference's e2e loop (tests/e2e.rs:108-221) ----

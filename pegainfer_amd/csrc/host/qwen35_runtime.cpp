@@ -121,6 +121,10 @@ struct Model35 {
   int32_t* merge_ctr = nullptr;  // in-launch split-KV merge tickets, zeroed at the head of every step
   hipGraphExec_t graph = nullptr;
   std::vector<int> graph_ids;   // request ids of the captured step, then the attention path
+  // debug tap (include/pegainfer_qwen35.h, accuracy-parity-playbook.md:15-24): the residual stream leaving every layer
+  Half* tap = nullptr;
+  bool tap_on = false;
+  int tap_rows = 0;
   // prefill workspace (grow-only)
   size_t pf_cap = 0;
   std::vector<void*> pf_owned;
@@ -161,6 +165,27 @@ struct Model35 {
     (owner ? owner : &owned)->push_back(raw);
     *p = static_cast<T*>(raw);
     return 0;
+  }
+
+  int tap_layer(int layer, const Half* src, int rows) {
+    if (!tap_on) return 0;
+    rows = std::min(rows, max_bs);
+    P35_HIP(hipMemcpyAsync(tap + (size_t)layer * max_bs * H, src, (size_t)rows * H * 2, hipMemcpyDeviceToDevice, stream));
+    tap_rows = rows;
+    return 0;
+  }
+  int debug_hidden_enable(int on) {
+    if (on && !tap && dalloc(&tap, (size_t)L * max_bs * H)) return -1;
+    tap_on = on != 0;
+    tap_rows = 0;
+    return 0;
+  }
+  int debug_hidden(int layer, void* host, int max_rows) {
+    if (!tap || layer < 0 || layer >= L) { set_error("debug_hidden: tap not enabled or bad layer"); return -1; }
+    const int rows = std::min(tap_rows, max_rows);
+    P35_HIP(hipStreamSynchronize(stream));
+    if (rows > 0) P35_HIP(hipMemcpy(host, tap + (size_t)layer * max_bs * H, (size_t)rows * H * 2, hipMemcpyDeviceToHost));
+    return rows;
   }
 
   int init() {
@@ -559,6 +584,7 @@ struct Model35 {
       rms_norm_batched_offset_cuda(hidden_mid, ly.ln2, normed, H, bs, eps, S());
       if (mlp(ly, normed, gate_out, up_out, act_out, mlp_out, bs)) return -1;
       if (add_cuda(hidden_mid, mlp_out, hidden, bs * H, S())) { set_error("add failed"); return -1; }
+      if (tap_layer(lin + full - 1, hidden, bs)) return -1;
     }
     rms_norm_batched_offset_cuda(hidden, final_norm, normed, H, bs, eps, S());
     G(embed, normed, logits, V, bs, H);
@@ -587,6 +613,7 @@ struct Model35 {
         rc = pegainfer_gemv_fused_ex(ly.q_proj, cur, wide, 2 * q_dim + 2 * kv_dim, 1, H, resid, ly.ln1,
                                      resid ? nxt : nullptr, eps, 0, OFF | (resid ? RSUM : 0), S());
         if (resid) std::swap(cur, nxt);
+        if (resid && tap_layer(lin + full - 1, cur, 1)) return -1;   // cur = the previous layer's output
         Half *qf = wide, *kk = wide + 2 * q_dim, *vv = kk + kv_dim;   // [q|gate per head | k | v] of this token
         if (!rc) {
           qk_norm_partial_rope_batched_decode_hd256_cuda(qf, kk, ly.q_norm, ly.k_norm, cos, sin, md(m_pos), q_attn, Hq,
@@ -613,6 +640,7 @@ struct Model35 {
                                      eps, 0, OFF | (resid ? RSUM : 0), S());
         if (rc) { set_error("fused linear-attention projection failed"); return -1; }
         if (resid) std::swap(cur, nxt);
+        if (resid && tap_layer(lin + full - 1, cur, 1)) return -1;
         conv1d_prefill_cuda(wide, ly.conv_w, r->conv[lin], qkv_conv, C, 1, convK, S());
         gated_delta_rule_decode_cuda(qkv_conv, wide + C + Z, wide + C + Z + vh, ly.dt_bias, ly.a_log, r->state[lin],
                                      gdr_out, kh, vh, LK, LK, S());
@@ -628,6 +656,7 @@ struct Model35 {
       resid = mlp_out;
     }
     rc = pegainfer_gemv_fused_ex(embed, cur, logits, V, 1, H, resid, final_norm, nxt, eps, 0, OFF | RSUM, S());
+    if (!rc) rc = tap_layer(L - 1, nxt, 1);
     if (rc || pegainfer_batched_top1(logits, V, 1, V, top1_state, tokens_out_d, S())) { set_error("fused lm_head failed"); return -1; }
     return 0;
   }
@@ -690,7 +719,7 @@ struct Model35 {
     key.push_back(decode_mode);
     P35_HIP(hipMemcpyAsync(meta_dev, meta_host, m_total, hipMemcpyHostToDevice, stream));
     P35_HIP(hipEventRecord(ev0, stream));
-    if (enable_graph) {
+    if (enable_graph && !tap_on) {
       if (!graph || graph_ids != key) {
         if (graph) { P35_HIP(hipGraphExecDestroy(graph)); graph = nullptr; }
         hipGraph_t g = nullptr;
@@ -870,6 +899,7 @@ struct Model35 {
       rms_norm_batched_offset_cuda(alt, ly.ln2, pf_normed, H, T, eps, S());
       if (mlp(ly, pf_normed, pf_big0, pf_big1, pf_big2, pf_attn_res, T)) return -1;
       if (add_cuda(alt, pf_attn_res, hid, T * H, S())) { set_error("add failed"); return -1; }
+      if (tap_layer(lin + full - 1, hid + (size_t)(T - 1) * H, 1)) return -1;
     }
     P35_HIP(hipMemcpyAsync(pf_last, hid + (size_t)(T - 1) * H, (size_t)H * 2, hipMemcpyDeviceToDevice, stream));
     rms_norm_offset_cuda(pf_last, final_norm, pf_last_normed, H, eps, S());
@@ -966,6 +996,10 @@ int32_t pegainfer_qwen35_available_pages(pegainfer_qwen35_t m) { return M35(m)->
 int32_t pegainfer_qwen35_capacity_pages(pegainfer_qwen35_t m) { return M35(m)->pool.capacity(); }
 int32_t pegainfer_qwen35_max_batch_size(pegainfer_qwen35_t m) { return M35(m)->max_bs; }
 float pegainfer_qwen35_last_step_ms(pegainfer_qwen35_t m) { return M35(m)->last_step_ms; }
+int32_t pegainfer_qwen35_debug_hidden_enable(pegainfer_qwen35_t m, int32_t enable) { return M35(m)->debug_hidden_enable(enable); }
+int32_t pegainfer_qwen35_debug_hidden(pegainfer_qwen35_t m, int32_t layer, void* out_host_bf16, int32_t max_rows) {
+  return M35(m)->debug_hidden(layer, out_host_bf16, max_rows);
+}
 int64_t pegainfer_qwen35_weight_bytes(pegainfer_qwen35_t m) { return M35(m)->weight_bytes; }
 
 }  // extern "C"

@@ -144,6 +144,12 @@ struct Model {
   int tp_rank = 0, tp_world = 1;
   bool tp_comm_owned = false;
   uint32_t* tp_status_host = nullptr;   // pinned: the one-shot status block of the step, copied back with the tokens
+  // debug tap (accuracy-parity-playbook.md:15-24: "find the first-diff token, then compare LAYERS"): while enabled every
+  // step runs eagerly and the residual stream that leaves layer l - one row per request (prefill: the last prompt
+  // position) - is copied to tap[l][row]; pegainfer_qwen3_debug_hidden hands a layer's rows to the host
+  Half* tap = nullptr;
+  bool tap_on = false;
+  int tap_rows = 0;
   // last step
   const Half* last_logits = nullptr;
   int last_rows = 0;
@@ -253,6 +259,33 @@ struct Model {
       return -1;
     }
     return 0;
+  }
+  // rows of `src` ([rows, H], row r at src + row_index[r] * H, or r * H when row_index is null) -> tap[layer]
+  int tap_layer(int layer, const Half* src, int rows, const int32_t* row_index = nullptr) {
+    if (!tap_on) return 0;
+    rows = std::min(rows, max_bs);
+    if (!row_index) {
+      PQ_HIP(hipMemcpyAsync(tap + (size_t)layer * max_bs * H, src, (size_t)rows * H * 2, hipMemcpyDeviceToDevice, stream));
+    } else {
+      for (int r = 0; r < rows; ++r)
+        PQ_HIP(hipMemcpyAsync(tap + ((size_t)layer * max_bs + r) * H, src + (size_t)row_index[r] * H, (size_t)H * 2,
+                              hipMemcpyDeviceToDevice, stream));
+    }
+    tap_rows = rows;
+    return 0;
+  }
+  int debug_hidden_enable(int on) {
+    if (on && !tap && dalloc(&tap, (size_t)L * max_bs * H)) return -1;
+    tap_on = on != 0;
+    tap_rows = 0;
+    return 0;
+  }
+  int debug_hidden(int layer, void* host, int max_rows) {
+    if (!tap || layer < 0 || layer >= L) { set_error("debug_hidden: tap not enabled or bad layer"); return -1; }
+    const int rows = std::min(tap_rows, max_rows);
+    PQ_HIP(hipStreamSynchronize(stream));
+    if (rows > 0) PQ_HIP(hipMemcpy(host, tap + (size_t)layer * max_bs * H, (size_t)rows * H * 2, hipMemcpyDeviceToHost));
+    return rows;
   }
   int attach_tp(int rank, int world, const void* unique_id) {
     if (world < 1 || rank < 0 || rank >= world) { set_error("bad TP rank/world"); return -1; }
@@ -535,7 +568,7 @@ struct Model {
     } else if (pegainfer_gemm_add_rms_norm(ly.down, mlp_act, mlp_out, hidden, next_w, normed, H, bs, I, eps, S())) {
       set_error("pegainfer_gemm_add_rms_norm (down_proj) failed"); return -1;
     }
-    return 0;
+    return tap_layer(li, hidden, bs);
   }
 
   int decode_layer_reference(int li, int bs, bool split, int split_slots) {
@@ -608,6 +641,7 @@ struct Model {
       int rc = pegainfer_gemv_fused(ly.qkv, cur, qkv_out, q_dim + 2 * kv_dim, bs, H, resid, ly.ln1,
                                     resid ? nxt : nullptr, eps, 0, S());
       if (resid) std::swap(cur, nxt);
+      if (resid && tap_layer(li - 1, cur, bs)) return -1;   // cur = hidden + the previous layer's down_proj = its output
       bool fused_o = false;
       if (!rc && oproj_step) {
         const int r2 = pegainfer_fused_decode_attention_oproj(
@@ -646,6 +680,7 @@ struct Model {
       set_error("fused lm_head failed");
       return -1;
     }
+    if (tap_layer(L - 1, nxt, bs)) return -1;   // the lm_head prologue wrote the last layer's residual sum to nxt
     if (pegainfer_batched_top1(logits, V, bs, V, top1_state, tokens_out_d, S())) {
       set_error("pegainfer_batched_top1 failed");
       return -1;
@@ -673,6 +708,7 @@ struct Model {
       }
       if (decode_layer_reference(li, bs, split, split_slots)) return -1;
       fused_add_rms_norm_batched_cuda(hidden, mlp_out, next_w, normed, H, bs, eps, S());
+      if (tap_layer(li, hidden, bs)) return -1;
     }
     gemm_graphsafe_cuda(lm_head, normed, logits, V, bs, H, S());
     // greedy token for every column inside the captured step
@@ -782,7 +818,7 @@ struct Model {
     // back.  The loop runs until an attempt took no fallback (every fallback disables its cause for good), capped at 3.
     for (int attempt = 0;; ++attempt) {
       PQ_HIP(hipEventRecord(ev0, stream));
-      if (enable_graph) {
+      if (enable_graph && !tap_on) {
         const int bi = bucket_index(padded);
         const int gv = !split ? 0 : (oproj_plan && attn_oproj && padded == 1 && !tp_comm && decode_mode >= 1 ? 2 : 1);
         hipGraphExec_t& exec = graphs[bi][gv];
@@ -943,6 +979,8 @@ struct Model {
     const uint32_t* tok_d = reinterpret_cast<uint32_t*>(pf_meta_dev + offs[0]);
 
     const int Ti = (int)T;
+    std::vector<int32_t> tap_last(n);   // debug tap: each request's last token column
+    for (int i = 0; i < n; ++i) tap_last[i] = qind[i + 1] - 1;
     if (embedding_batched_cuda(embed, tok_d, pf_hidden, H, Ti, S())) { set_error("embedding failed"); return -1; }
     Half *hid = pf_hidden, *hid_out = pf_hidden_out;
     const float sm = 1.0f / std::sqrt((float)D);
@@ -972,6 +1010,7 @@ struct Model {
                                          resid ? hid_out : nullptr, eps, 0, resid ? 2 : 0, S());
         if (rc) { set_error("short prefill: fused qkv GEMV failed"); return -1; }
         if (resid) std::swap(hid, hid_out);
+        if (resid && tap_layer(li - 1, hid, n, tap_last.data())) return -1;
         rc = pegainfer_qkv_stacked_norm_rope_scatter(qkv_st, pf_q, ly.q_norm, ly.k_norm, cos, sin, D32(5), D32(4), kv_buffer,
                                                      layout.k_offset(li), layout.v_offset(li), D32(1), D32(2), Hq, Hkv, D,
                                                      layout.page_size, layout.page_stride, Ti, eps, S());
@@ -998,6 +1037,7 @@ struct Model {
       }
       if (add_cuda(hid, pf_o, hid_out, Ti * H, S())) { set_error("add_cuda failed"); return -1; }   // prefill.rs:183, last layer
       std::swap(hid, hid_out);
+      if (tap_layer(L - 1, hid, n, tap_last.data())) return -1;
     }
     for (int li = short_path ? L : 0; li < L; ++li) {
       const Layer& ly = layers[li];
@@ -1073,6 +1113,7 @@ struct Model {
         set_error("pegainfer_gemm_add (prefill down_proj) failed"); return -1;
       }
       std::swap(hid, hid_out);  // prefill.rs:183-185
+      if (tap_layer(li, hid, n, tap_last.data())) return -1;
     }
     // echo = true (compute_all_position_logits, prefill.rs:196-212): final RMSNorm + lm_head over EVERY position,
     // [total_tokens, vocab] bf16 to the host.  The GEMM output is staged through the gate|up scratch (pf_cap_tokens x
@@ -1389,6 +1430,10 @@ int32_t pegainfer_qwen3_attach_tp(pegainfer_qwen3_t m, int32_t rank, int32_t wor
 int32_t pegainfer_qwen3_attach_comm(pegainfer_qwen3_t m, void* comm) { return M(m)->attach_comm(comm); }
 int32_t pegainfer_qwen3_tp_oneshot_active(pegainfer_qwen3_t m) {
   return M(m)->tp_comm ? pegainfer_comm_oneshot_active(M(m)->tp_comm) : 0;
+}
+int32_t pegainfer_qwen3_debug_hidden_enable(pegainfer_qwen3_t m, int32_t enable) { return M(m)->debug_hidden_enable(enable); }
+int32_t pegainfer_qwen3_debug_hidden(pegainfer_qwen3_t m, int32_t layer, void* out_host_bf16, int32_t max_rows) {
+  return M(m)->debug_hidden(layer, out_host_bf16, max_rows);
 }
 float pegainfer_qwen3_last_step_ms(pegainfer_qwen3_t m) { return M(m)->last_step_ms; }
 float pegainfer_qwen3_bench_gemv(pegainfer_qwen3_t m, int32_t which, int32_t iters, int32_t bs) {

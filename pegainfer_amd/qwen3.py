@@ -156,6 +156,23 @@ class Qwen3Engine:
     def last_step_ms(self):
         return self.lib.pegainfer_qwen3_last_step_ms(self.h)
 
+    # ---- per-layer hidden tap (accuracy-parity-playbook.md:15-24) ----
+    def debug_hidden_enable(self, on=True):
+        self._chk(self.lib.pegainfer_qwen3_debug_hidden_enable(self.h, int(bool(on))), "debug_hidden_enable")
+
+    def debug_hidden(self, max_rows=64):
+        """bf16 bits [layers, rows, hidden] of the last step: the residual stream leaving every layer (decode: every
+        column; prefill: each request's last prompt position)."""
+        H, L = self.cfg["hidden_size"], self.cfg["num_hidden_layers"]
+        out = []
+        for li in range(L):
+            buf = np.zeros((max_rows, H), dtype=np.uint16)
+            n = self.lib.pegainfer_qwen3_debug_hidden(self.h, li, buf.ctypes.data, max_rows)
+            if n < 0:
+                self._chk(n, "debug_hidden")
+            out.append(buf[:n])
+        return np.stack(out)
+
     def bench_gemv(self, which, iters=200, bs=1):
         return self.lib.pegainfer_qwen3_bench_gemv(self.h, which, iters, bs)
 

@@ -39,6 +39,22 @@ class Qwen35Engine:
             raise RuntimeError("pegainfer_qwen35_create failed")
         self.vocab = c["vocab_size"]
 
+    # ---- per-layer hidden tap (accuracy-parity-playbook.md:15-24) ----
+    def debug_hidden_enable(self, on=True):
+        self._chk(self.lib.pegainfer_qwen35_debug_hidden_enable(self.h, int(bool(on))), "debug_hidden_enable")
+
+    def debug_hidden(self, max_rows=8):
+        """bf16 bits [layers, rows, hidden] of the last step (decode: every column; prefill: the last prompt position)"""
+        H, L = self.cfg["hidden_size"], self.cfg["num_hidden_layers"]
+        out = []
+        for li in range(L):
+            buf = np.zeros((max_rows, H), dtype=np.uint16)
+            n = self.lib.pegainfer_qwen35_debug_hidden(self.h, li, buf.ctypes.data, max_rows)
+            if n < 0:
+                self._chk(n, "debug_hidden")
+            out.append(buf[:n])
+        return np.stack(out)
+
     def _chk(self, rc, what):
         if rc != 0:
             msg = self.lib.pegainfer_qwen35_last_error(self.h)
