@@ -52,26 +52,7 @@ def algorithmic_bytes_per_token(cfg, ctx, batch=1):
 def export_checkpoint(eng, cfg):
     """The checkpoint the engine computes with (device-generated synthetic, or real weights), as HF name -> bf16 bits on
     the host: the CPU legs below run on EXACTLY these weights, so their logits can be compared with the engine's."""
-    c = cfg
-    hd = c["head_dim"]
-    qd, kvd, H, I, V = c["num_attention_heads"] * hd, c["num_key_value_heads"] * hd, c["hidden_size"], c["intermediate_size"], c["vocab_size"]
-    shapes = {"model.embed_tokens.weight": (V, H), "model.norm.weight": (H,)}
-    if not c["tie_word_embeddings"]:
-        shapes["lm_head.weight"] = (V, H)
-    for i in range(c["num_hidden_layers"]):
-        p = f"model.layers.{i}."
-        shapes.update({p + "self_attn.q_proj.weight": (qd, H), p + "self_attn.k_proj.weight": (kvd, H),
-                       p + "self_attn.v_proj.weight": (kvd, H), p + "self_attn.o_proj.weight": (H, qd),
-                       p + "self_attn.q_norm.weight": (hd,), p + "self_attn.k_norm.weight": (hd,),
-                       p + "mlp.gate_proj.weight": (I, H), p + "mlp.up_proj.weight": (I, H),
-                       p + "mlp.down_proj.weight": (H, I), p + "input_layernorm.weight": (H,),
-                       p + "post_attention_layernorm.weight": (H,)})
-    bits = {}
-    for name, shp in shapes.items():
-        a = np.empty(shp, dtype=np.uint16)
-        eng._chk(eng.lib.pegainfer_qwen3_export_tensor(eng.h, name.encode(), a.ctypes.data, a.size), "export " + name)
-        bits[name] = a
-    return bits
+    return eng.export_state()
 
 
 def gpu_parity_run(eng, prompt, steps):
@@ -176,6 +157,28 @@ def cpu_legs(cfg, bits, prompt, gpu_tokens, gpu_rows_bits, steps, threads, hf_re
     agree = gpu_rows.argmax(-1) == R.argmax(-1)
     srt = np.sort(R, axis=-1)
     margin = srt[:, -1] - srt[:, -2]
+    # the fp32 truth pass of the same oracle (no activation rounding) and the DERIVED bar of oracle/parity.py:
+    # err(engine vs truth) / err(oracle vs truth), ~1.0 when the engine differs from the reference by summation order only
+    try:
+        from oracle import parity as par
+        from oracle.bf16 import exact_activations
+        with exact_activations():
+            mt = Qwen3Oracle(c, w, num_pages=-(-(len(prompt) + steps + 1) // 16) + 2, rope_positions=len(prompt) + steps + 16)
+            stt = KvState()
+            trows = [mt.batch_prefill([prompt], [stt])[0]]
+            for tk in gpu_tokens[:-1]:
+                trows.append(mt.batch_decode([tk], [stt])[0])
+        dv = par.derived(gpu_rows, R, np.stack(trows))
+        parity["derived"] = {"ratio_pooled": round(dv["ratio_pooled"], 4), "ratio_max": round(dv["ratio_max"], 4),
+                             "bar": {"pooled": par.AGG_MAX, "single_step": par.STEP_MAX},
+                             "within_bar": bool(dv["ratio_pooled"] <= par.AGG_MAX and dv["ratio_max"] <= par.STEP_MAX),
+                             "cos_engine_vs_truth_min": round(dv["cos_engine_vs_truth_min"], 6),
+                             "cos_oracle_vs_truth_min": round(dv["cos_oracle_vs_truth_min"], 6),
+                             "what": "RMS logit error of the engine against the fp32-activation pass of the oracle, over that of "
+                                     "the bf16 oracle against the same pass, per step and pooled (oracle/parity.py)"}
+        del mt
+    except Exception as e:  # noqa: BLE001
+        parity["derived"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     parity.update({"cos_min": round(float(cs.min()), 6), "max_dlogit": round(float(dl.max()), 4),
                    "logit_scale": round(float(np.abs(R).max()), 3),
                    "tokens_equal": int(agree.sum()), "tokens_differing_away_from_a_near_tie": int((~agree & (margin > 2 * dl)).sum()),
@@ -339,12 +342,30 @@ def run_qwen35(args, rank, world, local, dist, torch):
                     "min": round(float(min(ttfts)), 3), "iters": len(ttfts)},
         "tpot_ms": {"p50": round(float(np.median(step_ms)), 4), "p95": round(float(np.percentile(step_ms, 95)), 4),
                     "device_p50": round(float(np.median(dev_ms)), 4)},
-        "roofline": {"bound": "hbm", "kernel": "whole decode step (graph)", "achieved": round(
-            step_bytes / (np.median(dev_ms) * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(step_bytes / (np.median(dev_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
-            "bytes_per_launch": int(step_bytes)},
+        "roofline": None,
+        "step_roofline": {"algorithmic_bytes_per_step": int(step_bytes),
+                          "achieved_GBps": round(step_bytes / (elapsed / args.steps) / 1e9, 1),
+                          "frac_of_8TBps": round(step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+                          "timed_by": "ms_per_step (wall, the contract's timed region)",
+                          "device_frac_of_8TBps": round(step_bytes / (np.median(dev_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
         "cpu_baseline": None,
     }
+    if rank == 0:
+        # the dominant kernel of the step: the gate|up GEMV (residual add + (1 + w) RMSNorm prologue, SwiGLU epilogue), 32
+        # launches per step, 2 * I * H bf16 weights each = 42 % of the step's bytes; timed live over the layers' weights
+        H, I = cfg["hidden_size"], cfg["intermediate_size"]
+        kbytes = 2 * I * H * 2 + (2 * H * 2 + H * 2 + I * 2) + H * 2
+        ms = eng.bench_gemv(0, 320) if (q35_mode == 1 and args.batch == 1) else -1.0
+        if ms > 0:
+            out["roofline"] = {"bound": "hbm", "kernel": "gemv_fused_kernel (gate|up, M=%d K=%d N=1, add + (1+w) RMSNorm prologue, SwiGLU epilogue)" % (2 * I, H),
+                               "achieved": round(kbytes / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(kbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                               "step_frac": out["step_roofline"]["frac_of_8TBps"], "traffic": None,
+                               "bytes_per_launch": kbytes, "avg_launch_us": round(ms * 1e3, 2)}
+        else:
+            out["roofline"] = {"bound": "hbm", "kernel": "whole decode step (graph)", "achieved": out["step_roofline"]["achieved_GBps"],
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": out["step_roofline"]["frac_of_8TBps"],
+                               "traffic": None, "bytes_per_launch": int(step_bytes)}
     # ---- CPU side (rank 0, N = 1): the reference's CPU path (HF Transformers bf16, the hybrid model with its torch
     #      fallbacks of the gated delta rule) on the engine's own exported checkpoint: cpu_baseline + a parity block ----
     cpu_in = None
@@ -405,6 +426,34 @@ def cpu_leg_qwen35(cfg, tensors, prompt, gpu_tokens, gpu_rows, hf_threads, cores
                      "steps_compared": m, "cos_min": round(float(cs.min()), 6),
                      "max_dlogit": round(float(np.abs(a - b).max()), 4), "logit_scale": round(float(np.abs(b).max()), 3),
                      "hf_top1_margin": [round(float(x), 4) for x in (srt[:, -1] - srt[:, -2])]}}
+    del model
+    # ---- the oracle (oracle/qwen35_ref.py) and its fp32 truth pass, teacher-forced on the GPU's own greedy tokens: where
+    #      the engine stands between them (derived bar, oracle/parity.py).  At 32 layers HF, the oracle and the truth pass are
+    #      mutually ~0.993 apart on N(0, 0.02) weights (tests/golden/qwen35_4b_depth32_hf.json): the cosine against HF above is
+    #      this model's bf16 noise floor, the ratio below says whether the engine adds to it ----
+    try:
+        from oracle import parity as par
+        from oracle.bf16 import bf16_from_bits
+        from oracle.qwen35_ref import Qwen35Config
+        oc = Qwen35Config(**{k: v for k, v in cfg.items() if k != "max_position_embeddings"})
+        w = {k: (v if v.dtype == np.float32 else bf16_from_bits(v)) for k, v in tensors.items()}
+        feed = gpu_tokens[:-1]
+        t0 = time.perf_counter()
+        R = par.qwen35_pass(oc, w, prompt, feed, exact=False, max_pos=len(prompt) + len(feed) + 16)
+        T_ = par.qwen35_pass(oc, w, prompt, feed, exact=True, max_pos=len(prompt) + len(feed) + 16)
+        dv = par.derived(gpu_rows[:len(R)], R, T_)
+        ok, agree, margin, dmax = par.near_tie_ok(gpu_rows[:len(R)], R, R)
+        parity["oracle"] = {"engine": "oracle/qwen35_ref.py teacher-forced on the GPU's greedy tokens (prefill + every decode step)",
+                            "cos_min": round(dv["cos_engine_vs_oracle_min"], 6), "max_dlogit": round(float(dmax.max()), 4),
+                            "tokens_equal": int(agree.sum()), "tokens_differing_away_from_a_near_tie": int((~ok).sum()),
+                            "seconds": round(time.perf_counter() - t0, 1)}
+        parity["derived"] = {"ratio_pooled": round(dv["ratio_pooled"], 4), "ratio_max": round(dv["ratio_max"], 4),
+                             "bar": {"pooled": par.AGG_MAX, "single_step": par.STEP_MAX},
+                             "within_bar": bool(dv["ratio_pooled"] <= par.AGG_MAX and dv["ratio_max"] <= par.STEP_MAX),
+                             "cos_engine_vs_truth_min": round(dv["cos_engine_vs_truth_min"], 6),
+                             "cos_oracle_vs_truth_min": round(dv["cos_oracle_vs_truth_min"], 6)}
+    except Exception as e:  # noqa: BLE001
+        parity["oracle"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     baseline = {"value": round(float(np.median(rates)), 3), "unit": "tokens/s", "cores": int(hf_threads), "kind": "reference",
                 "engine": "hf-transformers " + __import__("transformers").__version__,
                 "spread": {"min": round(float(min(rates)), 3), "max": round(float(max(rates)), 3), "repeats": hf_repeats},
@@ -499,7 +548,7 @@ def main():
     ap.add_argument("--ctx", type=int, default=1024, help="prompt length before the timed decode steps")
     ap.add_argument("--batch", type=int, default=1, help="requests decoded together per rank")
     ap.add_argument("--model", default="qwen3-4b", choices=["qwen3-4b", "qwen3-8b", "qwen3.5-4b"])
-    ap.add_argument("--decode-mode", type=int, default=int(os.environ.get("PEGAINFER_DECODE_MODE", "1")),
+    ap.add_argument("--decode-mode", type=int, choices=[0, 1], default=int(os.environ.get("PEGAINFER_DECODE_MODE", "1")),
                     help="0 = reference op sequence 1:1, 1 = fused MI355X decode kernels (bit-identical)")
     ap.add_argument("--split-policy", type=int, default=1)
     ap.add_argument("--no-graph", action="store_true")
@@ -524,6 +573,9 @@ def main():
                     help="N>1: 'replicas' = one independent request stream per GPU (weak scaling, no data-path "
                          "collective; default); 'tp' = the reference's Qwen3 tensor parallel over RCCL "
                          "(strong scaling, 72 all-reduces per step)")
+    ap.add_argument("--sweep-steps", type=int, default=20,
+                    help="decode steps per point of the side batch sweep (bs 2 / 4 / 8 / 16 at --ctx) and of the drop-in-ABI "
+                         "(decode_mode 0) side number; 0 = skip both")
     ap.add_argument("--traffic-probe", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.traffic_probe:
@@ -747,9 +799,19 @@ def main():
         "ttft_ms_short": ttft_short,
         "mp8_collectives_us": mp8,
         "prefill_roofline": prefill_roofline(full_cfg, args.ctx, float(np.median(ttfts)), world if tp else 1),
+        # the whole step against the HBM roofline, from the DRIVER-TIMED ms_per_step (wall clock of the contract's timed
+        # region: metadata upload, graph replay, token D2H, host loop - what `value` is made of); the graph's own device time
+        # (hipEvent pair, device_p50) is the side figure
         "step_roofline": {"algorithmic_bytes_per_step": int(step_bytes),
-                          "achieved_GBps": round(step_bytes / (np.median(dev_ms) * 1e-3) / 1e9, 1),
-                          "frac_of_8TBps": round(step_bytes / (np.median(dev_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                          "achieved_GBps": round(step_bytes / (mean_ms * 1e-3) / 1e9, 1),
+                          "frac_of_8TBps": round(step_bytes / (mean_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                          "timed_by": "ms_per_step (wall, the contract's timed region)",
+                          "device_frac_of_8TBps": round(step_bytes / (np.median(dev_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+        # which ABI the timed steps ran on: "ext" = the host DAG calls the fused entry points of
+        # include/pegainfer_kernels_ext.h (4-5 launches per layer); "reference" = only the symbols of
+        # pegainfer-kernels/src/ffi.rs (14 launches per layer) - what an UNMODIFIED Rust host gets;
+        # `drop_in_abi` below carries that second number whenever the headline is the first
+        "abi_path": "ext" if args.decode_mode >= 1 else "reference",
     }
     if rank == 0:
         # ---- roofline of the dominant kernel: the gate_up weight-streaming GEMV (45 % of the step's bytes).
@@ -786,7 +848,11 @@ def main():
                            "kernel": ("gemv_fused_kernel<NT=1,RPW=1,KSPLIT=1,EPI=silu> (gate_up, M=%d K=%d N=%d)" if fused
                                       else "gemv_fused_kernel<NT,RPW=2,KSPLIT=1,EPI=store> (gate_up, M=%d K=%d N=%d)") % (2 * I, H, args.batch),
                            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_replayed": replayed,
+                           "frac": round(achieved / HBM_PEAK_GBS, 4),
+                           # the dominant kernel is the best-behaved 45 % of the step; the time-weighted figure is the whole
+                           # step's (every launch, every boundary, the host loop), from ms_per_step
+                           "step_frac": out["step_roofline"]["frac_of_8TBps"],
+                           "traffic": traffic, "traffic_replayed": replayed,
                            "traffic_source": traffic_src,
                            "bytes_per_launch": gate_up_bytes, "avg_launch_us": round(ms * 1e3, 2)}
         per_site = {}
@@ -806,6 +872,41 @@ def main():
             out["parity"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     if not mp8_hung:   # freeing device memory synchronises the device - behind a stuck collective it never returns
         eng.close()
+    # ---- side numbers on fresh engines (rank 0, N = 1, outside `value`): the reference's batch sweep at --ctx
+    #      (bench_serving.rs batch matrix; model-crate.md:151) and the step rate on the STRICT drop-in ABI ----
+    if rank == 0 and world == 1 and args.batch == 1 and args.sweep_steps > 0 and not path:
+        def side_engine(mode, max_bs):
+            e = Qwen3Engine(cfg, num_kv_pages=max_bs * (-(-(args.ctx + args.sweep_steps + 16) // 16) + 1) + 8, max_batch_size=max_bs,
+                            enable_graph=not args.no_graph, decode_mode=mode, split_policy=args.split_policy, device=local,
+                            max_positions=max(4096, args.ctx + args.sweep_steps + 32))
+            return e.fill_synthetic(seed=42 + rank, std=0.02)
+
+        def rate(e, bs):
+            ids = [e.new_request() for _ in range(bs)]
+            tk = e.prefill(ids, [prompt] * bs)
+            for _ in range(5):
+                tk = e.decode(ids, tk)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.sweep_steps):
+                tk = e.decode(ids, tk)
+            dt = (time.perf_counter() - t0) / args.sweep_steps
+            for i in ids:
+                e.drop_request(i)
+            b = algorithmic_bytes_per_token(full_cfg, args.ctx + 5 + args.sweep_steps / 2, bs)
+            return {"ms_per_step": round(dt * 1e3, 4), "tok_s": round(bs / dt, 1), "frac_of_8TBps": round(b / dt / 1e9 / HBM_PEAK_GBS, 4)}
+        try:
+            e2 = side_engine(args.decode_mode, 16)
+            out["batch_sweep"] = {"ctx": args.ctx, "steps": args.sweep_steps, **{str(bs): rate(e2, bs) for bs in (2, 4, 8, 16)}}
+            e2.close()
+            if args.decode_mode >= 1:
+                e3 = side_engine(0, 1)
+                out["drop_in_abi"] = dict(rate(e3, 1), decode_mode=0, note="only the symbols of pegainfer-kernels/src/ffi.rs, 14 launches per "
+                                          "layer, hipGraph on: what an unmodified Rust host gets; the headline needs the host DAG to call "
+                                          "the five fused entry points of include/pegainfer_kernels_ext.h (INTEGRATION.md section 4)")
+                e3.close()
+        except Exception as e:  # noqa: BLE001 - side numbers never take the line down
+            out["batch_sweep"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     if rank == 0:
         out["cpu_baseline"] = None
         if cpu_inputs is not None:

@@ -72,7 +72,10 @@ int32_t pegainfer_qwen3_attach_tp(pegainfer_qwen3_t m, int32_t rank, int32_t wor
  * (pegainfer_comm_create_peer_only: no RCCL, slabs mapped over hipIpc) carries every all-reduce on the one-shot
  * peer-access kernel - prefill-sized payloads in 64 KB pieces - so the sharded runtime also runs with several ranks on
  * ONE device, which is how a single-GPU box executes the TP data path (tests/test_gpu_tp_one_gpu.py).
- * A step whose one-shot all-reduce hit its bounded wait (a peer late or gone) fails with -5; nothing is returned. */
+ * A step whose one-shot all-reduce hit its bounded wait (a peer late or gone) fails with -5; nothing is returned, and the
+ * failure is PERMANENT for this model: the status block is sticky, the ranks' epochs may have diverged and the failing
+ * step had already advanced seq_len / appended KV of its requests.  Every later prefill / decode returns -5 at once; the
+ * host drops the touched requests and rebuilds model + communicator (what a dead NCCL rank costs the reference too). */
 int32_t pegainfer_qwen3_attach_comm(pegainfer_qwen3_t m, void* comm);
 /* 1 when the attached communicator's <= 64 KB all-reduces take the one-shot peer-access kernel */
 int32_t pegainfer_qwen3_tp_oneshot_active(pegainfer_qwen3_t m);

@@ -72,6 +72,10 @@ int32_t pegainfer_qwen35_sample(pegainfer_qwen35_t m, int32_t column, float temp
 int32_t pegainfer_qwen35_logprobs(pegainfer_qwen35_t m, int32_t column, uint32_t token, int32_t top_k, float* out_logprob,
                                   uint32_t* out_top_ids, float* out_top_logprobs);
 float pegainfer_qwen35_last_step_ms(pegainfer_qwen35_t m);
+/* average ms per launch of one GEMV call site over the layers' real weights, hipEvents on the model stream (bench.py
+ * roofline): which 0 = gate|up with the residual add + (1 + w) RMSNorm prologue and SwiGLU epilogue (the dominant kernel of
+ * the fused bs = 1 step), 1 = down_proj */
+float pegainfer_qwen35_bench_gemv(pegainfer_qwen35_t m, int32_t which, int32_t iters);
 /* Per-layer hidden-state tap, the twin of pegainfer_qwen3_debug_hidden (accuracy-parity-playbook.md:15-24): while
  * enabled steps run eagerly and the residual stream leaving every layer (decode: all columns; prefill: the last prompt
  * position) stays on the device; debug_hidden copies one layer's rows, bf16 bits [rows, hidden], returns the row count */

@@ -1,9 +1,8 @@
-// Shared arithmetic core of the paged GQA decode attention (attn_decode.hip kernels and the persistent decode engine,
-// decode_engine.hip).  Everything that determines a result bit lives here exactly once: the per-wave KV scan with its
-// per-lane-row online-softmax states (AttnScan), the in-workgroup merge of those states + the partial / output store
-// (attn_finish_part) and the partition-KV merge (merge_one).  A caller supplies the waves: a real 4- or 8-wave
-// workgroup (attn_decode.hip) or three consumer waves emulating the 8 "virtual" waves of the same plan (the engine),
-// so both produce the same bits for the same (request, KV chunk, kv head).
+// Shared arithmetic core of the paged GQA decode attention kernels of attn_decode.hip (stand-alone, fused with qk-norm +
+// RoPE + KV append, fused with the o_proj).  Everything that determines a result bit lives here exactly once: the per-wave
+// KV scan with its per-lane-row online-softmax states (AttnScan), the in-workgroup merge of those states + the partial /
+// output store (attn_finish_part) and the partition-KV merge (merge_one).  A caller supplies the waves (4- or 8-wave
+// workgroups), so every form produces the same bits for the same (request, KV chunk, kv head).
 #pragma once
 
 #include <type_traits>

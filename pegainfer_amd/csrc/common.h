@@ -112,4 +112,15 @@ inline bool host_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(
 inline hipStream_t as_stream(pegainfer_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 inline int ceil_div(long a, long b) { return static_cast<int>((a + b - 1) / b); }
 
+// CU count of the current device, cached (256 on an MI355X in SPX mode; a CPX partition has 32).  Every "deal the tiles
+// evenly onto the CUs" plan reads it here; without a device (CPU-side routing tests) it is the MI355X figure.
+inline int device_cus() {
+  static const int cus = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 0 ? n : 256;
+  }();
+  return cus;
+}
+
 }  // namespace pk

@@ -586,11 +586,7 @@ inline int skinny_pick_rpb(int rows) {
   static const int env = [] { const char* e = getenv("PEGAINFER_SKINNY_RPB"); return e && *e ? atoi(e) : -1; }();
   if (env == 0) return 16;
   if (env > 0) return env > 16 ? 16 : env;
-  static const int cus = [] {
-    int dev = 0, n = 256;
-    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-    return n > 0 ? n : 256;
-  }();
+  const int cus = device_cus();
   const int rounds = ceil_div(ceil_div(rows, 16), cus);
   int h = ceil_div(rows, rounds * cus);
   return h < 1 ? 1 : (h > 16 ? 16 : h);

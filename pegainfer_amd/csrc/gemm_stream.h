@@ -300,7 +300,7 @@ __global__ __launch_bounds__((4 + NLW + NLX) * 64) void stream_gemm_kernel(const
 // rt == 0: not taken (more than 6 blocks per tile: the 128-row kernel's territory, e.g. lm_head).
 struct StreamPlan { int rt, rows_per_tile, m_tiles; };
 inline StreamPlan stream_plan(int M, int silu_cols /* 0 = plain */) {
-  constexpr int kCus = 256;
+  const int kCus = device_cus();
   if (silu_cols > 0) {
     int c = ceil_div(ceil_div(silu_cols, kCus), 4) * 4;          // activation columns per tile, a multiple of 4
     const int half_blocks = ceil_div(c, 16);
@@ -367,7 +367,7 @@ inline void stream_splitk_launch_rt(const Half* W, const Half* X, int M, int T, 
 // Row tiles of the K-split form: as many as fill the chip together with the K slices (256 / ksplit row tiles; o_proj /
 // down_proj with 8 slices: 32 tiles of 80 rows = 256 workgroups where the 128-row tiles made 160).  rt == 0: not taken.
 inline StreamPlan stream_splitk_plan(int M, int ksplit) {
-  const int want = 256 / ksplit;
+  const int want = device_cus() / ksplit;
   if (want < 1) return {0, 0, 0};
   const int r = ceil_div(ceil_div(M, want), 16) * 16;
   if (r > 96 || (M & 3)) return {0, 0, 0};   // taller (stacked qkv at 65..128 tokens, 5 slices): two rounds of 64-row tiles measured 28 us against 24

@@ -52,6 +52,10 @@ struct Comm {
   bool os_opened[kOsMaxWorld] = {};
   uint32_t *os_epoch = nullptr, *os_status = nullptr;
   unsigned char* os_stage = nullptr;   // 64 KB: unaligned / ragged payloads are staged through it
+  unsigned char* os_xchg = nullptr;    // RCCL communicators: the handle / flag exchange buffer of oneshot_enable, allocated
+                                       // at creation so that enable itself cannot fail before its collectives
+  hipStream_t os_stage_stream = nullptr;   // the stream of the last STAGED one-shot call (single-stream contract, enforced)
+  bool os_stage_used = false;
   bool os_active = false;
   unsigned long long os_timeout_ticks = 0;
   std::string err;
@@ -236,6 +240,19 @@ static int oneshot_all_reduce(Comm* c, void* data, int64_t n, int elem, hipStrea
     const int padded = (piece + 15) & ~15;
     if (padded != piece || (reinterpret_cast<uintptr_t>(p + off) & 15)) {
       if (!c->os_stage) { c->err = "one-shot all-reduce: no staging buffer"; return -1; }
+      // ONE staging buffer per communicator: two staged all-reduces on different, un-joined streams would race on it.
+      // A stream change is only accepted while nothing is being captured and after the previous stream drained.
+      if (c->os_stage_used && c->os_stage_stream != s) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(s, &cs);
+        if (cs != hipStreamCaptureStatusNone || hipStreamQuery(c->os_stage_stream) != hipSuccess) {
+          c->err = "one-shot all-reduce: staged payloads of one communicator must stay on one stream (or the previous "
+                   "stream must have drained): single-stream contract";
+          return -1;
+        }
+      }
+      c->os_stage_stream = s;
+      c->os_stage_used = true;
       if (padded != piece && hipMemsetAsync(c->os_stage + piece, 0, (size_t)(padded - piece), s) != hipSuccess) return -1;
       if (hipMemcpyAsync(c->os_stage, p + off, (size_t)piece, hipMemcpyDeviceToDevice, s) != hipSuccess) return -1;
       if (oneshot_launch(c, c->os_stage, padded, elem, s)) return -1;
@@ -545,6 +562,8 @@ static pegainfer_comm_t comm_create(int32_t device_ordinal, int32_t rank, int32_
   bool ok = hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming) == hipSuccess;
+  // before the (collective) RCCL init: a rank that cannot allocate 1 KB fails here, like any rank that dies before init
+  if (ok && rccl && world > 1) ok = hipMalloc(reinterpret_cast<void**>(&c->os_xchg), (size_t)(kOsMaxWorld + 1) * 64 + 64) == hipSuccess;
   if (ok && rccl && world > 1) {
     ncclUniqueId id;
     std::memcpy(&id, unique_id_128, 128);
@@ -625,13 +644,12 @@ int32_t pegainfer_comm_oneshot_enable(pegainfer_comm_t h) {
   int32_t ok = pegainfer_comm_oneshot_handle(h, mine) == 0 ? 1 : 0;
   std::string local_err = ok ? std::string() : c->err;
   if (!ok) std::memset(mine, 0, sizeof(mine));
-  unsigned char* d = nullptr;
   std::vector<unsigned char> all((size_t)c->world * 64);
-  // exchange 1: the handles (a rank that cannot even allocate the exchange buffer cannot take part in RCCL at all)
-  if (hipMalloc(reinterpret_cast<void**>(&d), (size_t)(c->world + 1) * 64 + 64) != hipSuccess) {
-    c->err = "oneshot_enable: hipMalloc of the exchange buffer failed";
-    return -1;
-  }
+  // exchange 1: the handles, through the buffer allocated with the communicator - from here on every rank enters BOTH
+  // collectives whatever happens locally
+  unsigned char* d = c->os_xchg;
+  if (!d || c->world > kOsMaxWorld) { c->err = "oneshot_enable: communicator has no exchange buffer (world too large?)"; ok = 0; }
+  if (!d) return -1;   // cannot happen for a communicator built by pegainfer_comm_create with world > 1
   bool xfer = hipMemcpy(d, mine, 64, hipMemcpyHostToDevice) == hipSuccess;
   xfer = (ncclAllGather(d, d + 64, 64, ncclInt8, c->nccl, c->comm_stream) == ncclSuccess) && xfer;
   xfer = (hipStreamSynchronize(c->comm_stream) == hipSuccess) && xfer;
@@ -652,7 +670,6 @@ int32_t pegainfer_comm_oneshot_enable(pegainfer_comm_t h) {
   red = (hipStreamSynchronize(c->comm_stream) == hipSuccess) && red;
   int32_t all_ok = 0;
   red = red && hipMemcpy(&all_ok, flag, 4, hipMemcpyDeviceToHost) == hipSuccess;
-  (void)hipFree(d);
   if (!red) { c->err = "oneshot_enable: closing all-reduce failed"; return -1; }
   if (all_ok != 1) {
     c->err = local_err.empty() ? "oneshot_enable: a peer could not export or map the slabs; all ranks stay on RCCL" : local_err;
@@ -686,6 +703,7 @@ void pegainfer_comm_destroy(pegainfer_comm_t h) {
   if (c->os_slab) (void)hipFree(c->os_slab);
   if (c->os_epoch) (void)hipFree(c->os_epoch);
   if (c->os_stage) (void)hipFree(c->os_stage);
+  if (c->os_xchg) (void)hipFree(c->os_xchg);
   if (c->nccl) ncclCommDestroy(c->nccl);
   if (c->scratch) (void)hipFree(c->scratch);
   if (c->ev_in) (void)hipEventDestroy(c->ev_in);

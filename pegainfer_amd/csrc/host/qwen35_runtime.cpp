@@ -660,6 +660,26 @@ struct Model35 {
     if (rc || pegainfer_batched_top1(logits, V, 1, V, top1_state, tokens_out_d, S())) { set_error("fused lm_head failed"); return -1; }
     return 0;
   }
+  // bench.py roofline: the dominant kernel of the fused bs = 1 step - the gate|up GEMV with the residual add + (1 + w)
+  // RMSNorm prologue and the SwiGLU epilogue - launched `iters` times over the layers' real weights (each launch streams a
+  // different 94 MB matrix, as in a decode step), hipEvents on the model stream.  which 0 = that kernel, 1 = the plain
+  // down_proj GEMV.  Returns ms per launch (< 0 on error).
+  float bench_gemv(int which, int iters) {
+    if (iters <= 0 || (H & 7)) return -1.f;
+    const int OFF = 1, RSUM = 2, SILU2 = 4;
+    auto launch = [&](int it) {
+      const Layer35& ly = layers[(size_t)it % layers.size()];
+      if (which == 0) (void)pegainfer_gemv_fused_ex(ly.gate, hidden, act_out, 2 * I, 1, H, attn_res, ly.ln2, hidden_mid, eps, I, OFF | RSUM | SILU2, S());
+      else gemm_graphsafe_cuda(ly.down, act_out, mlp_out, H, 1, I, S());
+    };
+    for (int i = 0; i < 3; ++i) launch(i);
+    if (hipEventRecord(ev0, stream) != hipSuccess) return -1.f;
+    for (int i = 0; i < iters; ++i) launch(i + 3);
+    if (hipEventRecord(ev1, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) return -1.f;
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, ev0, ev1);
+    return ms / iters;
+  }
   int run_decode_kernels(int n, const std::vector<Request35*>& rs, bool split) {
     if (decode_mode == 1 && n == 1 && (H & 7) == 0) return decode_kernels_fused1(rs[0], split);
     return decode_kernels(n, rs, split);
@@ -996,6 +1016,7 @@ int32_t pegainfer_qwen35_available_pages(pegainfer_qwen35_t m) { return M35(m)->
 int32_t pegainfer_qwen35_capacity_pages(pegainfer_qwen35_t m) { return M35(m)->pool.capacity(); }
 int32_t pegainfer_qwen35_max_batch_size(pegainfer_qwen35_t m) { return M35(m)->max_bs; }
 float pegainfer_qwen35_last_step_ms(pegainfer_qwen35_t m) { return M35(m)->last_step_ms; }
+float pegainfer_qwen35_bench_gemv(pegainfer_qwen35_t m, int32_t which, int32_t iters) { return M35(m)->bench_gemv(which, iters); }
 int32_t pegainfer_qwen35_debug_hidden_enable(pegainfer_qwen35_t m, int32_t enable) { return M35(m)->debug_hidden_enable(enable); }
 int32_t pegainfer_qwen35_debug_hidden(pegainfer_qwen35_t m, int32_t layer, void* out_host_bf16, int32_t max_rows) {
   return M35(m)->debug_hidden(layer, out_host_bf16, max_rows);

@@ -144,6 +144,12 @@ struct Model {
   int tp_rank = 0, tp_world = 1;
   bool tp_comm_owned = false;
   uint32_t* tp_status_host = nullptr;   // pinned: the one-shot status block of the step, copied back with the tokens
+  // A bounded wait of the one-shot all-reduce expired once: the status block is sticky by design (comm.cpp never clears
+  // it), the epochs of the ranks may have diverged and the failing step had already advanced seq_len / appended KV.
+  // Nothing here tries to resynchronise a world with a late or dead peer: the model is FAILED for good - every later
+  // prefill / decode returns -5 at once, the caller drops the touched requests and rebuilds model + communicator
+  // (include/pegainfer_qwen3.h).
+  bool tp_failed = false;
   // debug tap (accuracy-parity-playbook.md:15-24: "find the first-diff token, then compare LAYERS"): while enabled every
   // step runs eagerly and the residual stream that leaves layer l - one row per request (prefill: the last prompt
   // position) - is copied to tap[l][row]; pegainfer_qwen3_debug_hidden hands a layer's rows to the host
@@ -721,6 +727,7 @@ struct Model {
 
   int decode(int n, const int32_t* ids, const uint32_t* token_ids, int32_t* out_tokens, void* out_logits_host) {
     if (!finalized) { set_error("model not finalized"); return -1; }
+    if (tp_failed) { set_error("tensor-parallel group failed in an earlier step (bounded wait expired): rebuild the model and its communicator"); return -5; }
     if (n <= 0 || n > max_bs) { set_error("bad batch size"); return -1; }
     std::vector<KvState*> st(n);
     std::vector<int> positions(n), seq_lens(n);
@@ -850,7 +857,8 @@ struct Model {
         // late or gone - RCCL would block on it too.  Fail the step loudly; the caller drops the request(s).
         set_error("tensor-parallel one-shot all-reduce: bounded wait expired (missing-rank mask " +
                   std::to_string(tp_status_host[0] & 0xff) + ", epoch " + std::to_string(tp_status_host[1]) +
-                  ", segment " + std::to_string(tp_status_host[2]) + "); step failed");
+                  ", segment " + std::to_string(tp_status_host[2]) + "); step failed, model marked failed");
+        tp_failed = true;
         return -5;
       }
       if (!(oproj_check && attn_status_host[0] != 0)) break;
@@ -907,6 +915,7 @@ struct Model {
   int prefill(int n, const int32_t* ids, const int32_t* lens, const uint32_t* tokens, int32_t* out_tokens,
               void* out_logits_host, int n_decode_tail = 0, void* out_all_logits_host = nullptr) {
     if (!finalized) { set_error("model not finalized"); return -1; }
+    if (tp_failed) { set_error("tensor-parallel group failed in an earlier step (bounded wait expired): rebuild the model and its communicator"); return -5; }
     if (n <= 0) { set_error("empty prefill"); return -1; }
     if (n > max_bs) { set_error("prefill batch larger than max_batch_size"); return -1; }
     const int n_pf = n - n_decode_tail;
@@ -1148,7 +1157,8 @@ struct Model {
     PQ_HIP(hipStreamSynchronize(stream));
     if (os_status_d && tp_status_host[0] != 0) {
       set_error("tensor-parallel one-shot all-reduce: bounded wait expired during prefill (missing-rank mask " +
-                std::to_string(tp_status_host[0] & 0xff) + "); step failed");
+                std::to_string(tp_status_host[0] & 0xff) + "); step failed, model marked failed");
+      tp_failed = true;
       return -5;
     }
     for (int i = 0; i < n; ++i) out_tokens[i] = tokens_out_host[i];
@@ -1268,6 +1278,10 @@ pegainfer_qwen3_t pegainfer_qwen3_create(int32_t device_ordinal, int32_t hidden_
   if (head_dim != 128 || num_kv_heads <= 0 || num_attention_heads % num_kv_heads != 0 || num_kv_pages < 2 ||
       max_batch_size < 1 || max_batch_size > 64) {
     g_create_error = "unsupported configuration";
+    return nullptr;
+  }
+  if (decode_mode != 0 && decode_mode != 1) {   // 2 was the persistent engine, deleted in round 4: do not run something else silently
+    g_create_error = "decode_mode must be 0 (reference op sequence) or 1 (fused decode kernels)";
     return nullptr;
   }
   auto* m = new Model(device_ordinal, hidden_size, num_layers, num_attention_heads, num_kv_heads, head_dim,

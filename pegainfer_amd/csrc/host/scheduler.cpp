@@ -191,7 +191,9 @@ struct Qwen35Exec {
   std::unordered_map<uint64_t, int32_t> slot;
   std::string err;
   int n_pf_last = 0;                              // rows [0, n_pf_last) of the last execute() were prefills
-  std::vector<std::vector<float>> pf_rows;        // their logits rows as f32 (kept only while small: <= 16 prompts)
+  std::vector<std::vector<float>> pf_rows;        // f32 logits rows of the prompts that asked for logprobs (empty otherwise)
+  std::vector<uint8_t> want_lp;                   // per prompt row of the NEXT execute(): the request carries logprobs > 0
+                                                  // (set by the owning scheduler; empty = nobody asked)
   std::vector<uint16_t> row_bits;
   static int32_t page_size(void*) { return 16; }
   static int32_t max_request_pages(void* u) { return pegainfer_qwen35_capacity_pages(((Qwen35Exec*)u)->model) - 1; }
@@ -226,13 +228,18 @@ struct Qwen35Exec {
       if (r < 0) return fail("new_request");
       e->slot[ids[i]] = r;
       int32_t tok = 0;
-      e->row_bits.resize((size_t)V);
-      if (pegainfer_qwen35_prefill(e->model, r, lens[i], tokens + off, &tok, e->row_bits.data())) return fail("prefill");
+      // the 300-500 KB logits row comes back (and is widened to f32) only for a prompt whose request asked for
+      // logprobs: the next prefill reuses the device buffer, so the copy has to be taken now or never
+      const bool keep_row = (size_t)i < e->want_lp.size() && e->want_lp[(size_t)i];
+      if (keep_row) e->row_bits.resize((size_t)V);
+      if (pegainfer_qwen35_prefill(e->model, r, lens[i], tokens + off, &tok, keep_row ? e->row_bits.data() : nullptr)) return fail("prefill");
       if (!greedy(temp[i], top_k[i], top_p[i]) &&
           pegainfer_qwen35_sample(e->model, 0, temp[i], top_k[i], top_p[i], rv[i], &tok))
         return fail("sample");
-      e->pf_rows[i].resize((size_t)V);
-      for (int32_t j = 0; j < V; ++j) { const uint32_t w = (uint32_t)e->row_bits[j] << 16; std::memcpy(&e->pf_rows[i][j], &w, 4); }
+      if (keep_row) {
+        e->pf_rows[i].resize((size_t)V);
+        for (int32_t j = 0; j < V; ++j) { const uint32_t w = (uint32_t)e->row_bits[j] << 16; std::memcpy(&e->pf_rows[i][j], &w, 4); }
+      }
       out[i] = (uint32_t)tok;
       off += (size_t)lens[i];
     }
@@ -258,6 +265,7 @@ struct Qwen35Exec {
     auto* e = (Qwen35Exec*)u;
     if (row < e->n_pf_last) {
       const std::vector<float>& r = e->pf_rows[(size_t)row];
+      if (r.empty()) { e->err = "logprobs of a prompt row that was not flagged in want_lp"; return -1; }
       return pegainfer_logprobs_from_logits(r.data(), (int32_t)r.size(), token, top_k, lp, ids, vals);
     }
     const int32_t rc = pegainfer_qwen35_logprobs(e->model, row - e->n_pf_last, token, top_k, lp, ids, vals);
@@ -365,6 +373,10 @@ struct Scheduler {
     if (plan == PEGAINFER_PLAN_PREFILL)
       for (const Pending& r : pending) any_echo = any_echo || r.echo;
     const bool echo_step = any_echo && ex.execute_echo && ex.prompt_logprobs;
+    if (owned35) {   // its prefill keeps a host copy of a prompt's logits row only when that request wants logprobs
+      owned35->want_lp.assign((size_t)n_pf, 0);
+      for (int i = 0; i < n_pf; ++i) owned35->want_lp[(size_t)i] = pending[i].logprobs > 0;
+    }
     int rc = echo_step ? ex.execute_echo(ex.user, n_pf, ids.data(), lens.data(), tokens.data(), temp.data(), top_k.data(),
                                          top_p.data(), rv.data(), out.data())
                        : ex.execute(ex.user, n_pf, n_dec, ids.data(), lens.data(), tokens.data(), temp.data(), top_k.data(),

@@ -643,7 +643,7 @@ static TiledRoute tiled_route(int M, int T, int K, const SplitOut& so) {
       // that remainder to the 128-row kernel (192 quarter-size tiles: one short round) - both kernels keep the same
       // per-element K order, so the result does not depend on the cut.  PEGAINFER_GEMM256_TAIL=0 switches it off.
       static const bool tail_on = [] { const char* e = getenv("PEGAINFER_GEMM256_TAIL"); return !(e && *e == '0'); }();
-      constexpr int kCus = 256;
+      const int kCus = device_cus();
       const int rem = (int)(tiles256 % kCus);
       const int m_head = (int)((tiles256 / kCus) * kCus / tt256);   // whole activation-column tiles in full rounds
       if (tail_on && so.silu_I > 0 && so.silu_c1 == 0 && rem > 0 && rem * 2 <= kCus && m_head > 0 && m_head < mt256)
@@ -694,8 +694,10 @@ static void glds_gemm_launch(const Half* W, const Half* X, Half* Y, int M, int T
     }
     if (r.kind == 256) { gemm256_launch(W, X, Y, M, T, K, so, s); return; }
     if (r.kind == 1280 || r.kind == 1281) { gemm128x256_launch(W, X, Y, M, T, K, so, nullptr, 1, 0, s); return; }
-    if (r.kind >= 3000) { stream_gemm_launch<128>(W, X, Y, M, T, K, so, s); return; }
-    variant = r.kind;
+    // the plan said a 128-token stream tile exists; should a future plan / route change make the launcher refuse, fall
+    // through to the 128-row kernel (same per-element K order) instead of leaving Y unwritten
+    if (r.kind >= 3000 && stream_gemm_launch<128>(W, X, Y, M, T, K, so, s)) return;
+    variant = r.kind >= 3000 ? 23 : r.kind;
   }
   switch (variant) {
     case 12: glds_gemm_launch_t<128, 2>(W, X, Y, M, T, K, so, s); break;
@@ -931,8 +933,9 @@ static pegainfer_status_t gemm_silu_impl(const Half* W, const Half* X, Half* Y, 
   if (T > 16 && (I & 3) == 0 && glds_gemm_ok(W, X, Y, M, K) &&
       (T > 64 ? splitk_plan(M, T, K).nk_slice == 0 : ((mroute == 1 || mroute == 3) && (proute == 1 || proute == 3)))) {
     SplitOut so{nullptr, nullptr, nullptr, 0, 0, 0, I, double_round};
-    if (mroute == 3) stream_gemm_launch<64>(W, X, Y, M, T, K, so, as_stream(stream));   // 40 + 40 rows per tile: 244 workgroups
-    else glds_gemm_launch(W, X, Y, M, T, K, so, T <= 64 ? 23 : 0, as_stream(stream));
+    // 40 + 40 rows per tile: 244 workgroups; a refused launch (cannot happen under today's plans) takes the 128-row kernel
+    if (!(mroute == 3 && stream_gemm_launch<64>(W, X, Y, M, T, K, so, as_stream(stream))))
+      glds_gemm_launch(W, X, Y, M, T, K, so, T <= 64 ? 23 : 0, as_stream(stream));
     return (pegainfer_status_t)hipGetLastError();
   }
   if (!gate_up_scratch) return (pegainfer_status_t)hipErrorInvalidValue;

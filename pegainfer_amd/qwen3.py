@@ -89,6 +89,32 @@ class Qwen3Engine:
         self._chk(self.lib.pegainfer_qwen3_finalize(self.h), "finalize")
         return self
 
+    def export_state(self):
+        """{HF tensor name: uint16 bf16 bits} of the checkpoint the engine computes with (device-generated synthetic, or
+        loaded weights), copied back from the device (pegainfer_qwen3_export_tensor): a checker can run on EXACTLY these
+        weights."""
+        c = self.cfg
+        hd = c["head_dim"]
+        qd, kvd, H, I, V = (c["num_attention_heads"] * hd, c["num_key_value_heads"] * hd, c["hidden_size"],
+                            c["intermediate_size"], c["vocab_size"])
+        shapes = {"model.embed_tokens.weight": (V, H), "model.norm.weight": (H,)}
+        if not c.get("tie_word_embeddings", True):
+            shapes["lm_head.weight"] = (V, H)
+        for i in range(c["num_hidden_layers"]):
+            p = f"model.layers.{i}."
+            shapes.update({p + "self_attn.q_proj.weight": (qd, H), p + "self_attn.k_proj.weight": (kvd, H),
+                           p + "self_attn.v_proj.weight": (kvd, H), p + "self_attn.o_proj.weight": (H, qd),
+                           p + "self_attn.q_norm.weight": (hd,), p + "self_attn.k_norm.weight": (hd,),
+                           p + "mlp.gate_proj.weight": (I, H), p + "mlp.up_proj.weight": (I, H),
+                           p + "mlp.down_proj.weight": (H, I), p + "input_layernorm.weight": (H,),
+                           p + "post_attention_layernorm.weight": (H,)})
+        bits = {}
+        for name, shp in shapes.items():
+            a = np.empty(shp, dtype=np.uint16)
+            self._chk(self.lib.pegainfer_qwen3_export_tensor(self.h, name.encode(), a.ctypes.data, a.size), "export " + name)
+            bits[name] = a
+        return bits
+
     # ---- requests ----
     def new_request(self):
         r = self.lib.pegainfer_qwen3_new_request(self.h)

@@ -172,6 +172,9 @@ class Qwen35Engine:
     def last_step_ms(self):
         return float(self.lib.pegainfer_qwen35_last_step_ms(self.h))
 
+    def bench_gemv(self, which=0, iters=320):
+        return float(self.lib.pegainfer_qwen35_bench_gemv(self.h, which, iters))
+
     def weight_bytes(self):
         return int(self.lib.pegainfer_qwen35_weight_bytes(self.h))
 

@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--layers", type=int, default=32)
     ap.add_argument("--prompt", type=int, default=1024)
     ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--out", default=HERE, help="output directory (dry runs of the tests write reduced-depth fixtures elsewhere)")
     args = ap.parse_args()
     import torch
     import transformers
@@ -130,10 +131,10 @@ def main():
         print("%-16s cos_min %.6f  max|dlogit| %.4f  rms %.4f (scale %.2f)" % (
             k, meta[k]["cos_min"], max(meta[k]["max_dlogit"]), max(meta[k]["rms_dlogit"]), meta["logit_absmax"]), flush=True)
     tag = "qwen35_4b_depth%d_hf" % args.layers
-    with open(os.path.join(HERE, tag + ".json"), "w") as f:
+    with open(os.path.join(args.out, tag + ".json"), "w") as f:
         json.dump(meta, f, indent=1)
     t_top = np.argsort(-Tr, axis=-1, kind="stable")[:, :N_TOP].astype(np.int32)
-    np.savez_compressed(os.path.join(HERE, tag + ".npz"), top_ids=top_ids, top_vals=top_vals, idx=idx,
+    np.savez_compressed(os.path.join(args.out, tag + ".npz"), top_ids=top_ids, top_vals=top_vals, idx=idx,
                         idx_vals=lg[:, idx].astype(np.float32), truth_idx_vals=Tr[:, idx].astype(np.float32),
                         truth_top_ids=t_top, truth_top_vals=np.take_along_axis(Tr, t_top, axis=-1).astype(np.float32),
                         truth_at_hf_top=np.take_along_axis(Tr, top_ids, axis=-1).astype(np.float32))

@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--layers", type=int, default=36)
     ap.add_argument("--prompt", type=int, default=1024)
     ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--out", default=HERE, help="output directory (dry runs of the tests write reduced-depth fixtures elsewhere)")
     ap.add_argument("--no-oracle", action="store_true")
     args = ap.parse_args()
     import torch
@@ -86,9 +87,9 @@ def main():
         print("oracle vs HF: cos_min %.6f  max|dlogit| %.4f (scale %.2f)  argmax equal %d / %d" % (
             cos.min(), np.abs(R - lg).max(), np.abs(lg).max(), int((R.argmax(-1) == lg.argmax(-1)).sum()), len(cos)))
     tag = "qwen3_4b_depth%d_hf" % args.layers
-    with open(os.path.join(HERE, tag + ".json"), "w") as f:
+    with open(os.path.join(args.out, tag + ".json"), "w") as f:
         json.dump(meta, f, indent=1)
-    np.savez_compressed(os.path.join(HERE, tag + ".npz"), top_ids=top_ids, top_vals=top_vals, idx=idx,
+    np.savez_compressed(os.path.join(args.out, tag + ".npz"), top_ids=top_ids, top_vals=top_vals, idx=idx,
                         idx_vals=lg[:, idx].astype(np.float32))
     print("wrote", tag)
 

@@ -27,12 +27,17 @@ N_NEW, N_TOP, N_IDX = 30, 64, 4096
 
 
 def main():
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dir", default=HERE, help="directory of the base fixture and of the output (dry runs use a scratch one)")
+    ap.add_argument("--base", default="qwen3_4b_depth36_hf.json")
+    args = ap.parse_args()
     import torch
     import transformers
     import depth_common as dc
     from oracle import hf_engine
     from oracle.qwen3_ref import Qwen3Config, synthetic_weights
-    base = json.load(open(os.path.join(HERE, "qwen3_4b_depth36_hf.json")))
+    base = json.load(open(os.path.join(args.dir, args.base)))
     cfgd, seed, std = base["config"], base["seed"], base["std"]
     t0 = time.time()
     _, bits = synthetic_weights(Qwen3Config(**cfgd), seed=seed, std=std, with_bits=True)
@@ -55,9 +60,9 @@ def main():
         arrays["top_vals_%d" % n] = np.take_along_axis(lg, top_ids, axis=-1).astype(np.float32)
         arrays["idx_vals_%d" % n] = lg[:, idx].astype(np.float32)
         print("prompt %d: %.1f s, tokens %s" % (n, time.time() - t0, toks), flush=True)
-    with open(os.path.join(HERE, "qwen3_4b_depth36_short_hf.json"), "w") as f:
+    with open(os.path.join(args.dir, "qwen3_4b_depth36_short_hf.json"), "w") as f:
         json.dump(meta, f, indent=1)
-    np.savez_compressed(os.path.join(HERE, "qwen3_4b_depth36_short_hf.npz"), **arrays)
+    np.savez_compressed(os.path.join(args.dir, "qwen3_4b_depth36_short_hf.npz"), **arrays)
     print("wrote qwen3_4b_depth36_short_hf")
 
 

@@ -1,0 +1,169 @@
+"""GPU parity at FULL DEPTH, BASELINE.json configs[3]: Qwen3.5-4B shape, all 32 layers (24 linear-attention + 8
+full-attention, V = 248 320) - the model ``bench.py --model qwen3.5-4b`` times.  Round 4 stopped at 3 layers
+(tests/test_gpu_real_dims_cfg34.py); the only 32-layer comparison was bench.py's unasserted HF leg (cosine 0.9938, 11 % of
+the logit scale, first token difference at step 2), and nobody knew whether that was HF's fallback kernels or the engine.
+
+Same construction as tests/test_gpu_full_depth.py: oracle (oracle/qwen35_ref.py), fp32 truth pass + derived bar
+(tests/depth_common.py), the committed HF ``Qwen3_5ForCausalLM`` fixture (tests/golden/make_qwen35_4b_depth_golden.py),
+fused == reference-order decode bit for bit (pegainfer-qwen35-4b/src/batch_decode.rs:505-606), per-layer taps
+(pegainfer_qwen35_debug_hidden; docs/playbooks/accuracy-parity-playbook.md:15-24).  Reference gate this stands in for:
+pegainfer-qwen35-4b/tests/e2e.rs (greedy text vs test_data/Qwen3.5-4B.json, needs the real checkpoint).
+"""
+import json
+import os
+import time
+
+import numpy as np
+import pytest
+
+import depth_common as dc
+from oracle.bf16 import bf16_from_bits
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD_DIR = os.environ.get("PEGAINFER_DEPTH_GOLD_DIR") or os.path.join(HERE, "golden")   # tools/dry_run_full_depth.py points it at reduced-depth fixtures
+SANITY_COS = 0.98                # a gross-failure fence only; the tolerance is the derived bar (tests/depth_common.py)
+
+
+def _timed(label, t0):
+    dc.report_kv("durations", label, round(time.time() - t0, 1))
+
+
+GOLD35 = os.path.join(GOLD_DIR, "qwen35_4b_depth32_hf")
+
+
+@pytest.fixture(scope="module")
+def depth35(built_libs):
+    """Seeded 32-layer Qwen3.5-4B-shaped checkpoint, the HF fixture, the engine's runs (fused bs = 1 decode and the
+    reference-order sequence, teacher-forced on HF's tokens; free-running greedy; taps), then the oracle and truth passes."""
+    import importlib.util
+    from oracle.qwen35_ref import Qwen35Config
+    from oracle.qwen35_ref import synthetic_weights as qwen35_weights
+    from pegainfer_amd.qwen35 import Qwen35Engine
+    spec = importlib.util.spec_from_file_location("mk35", os.path.join(HERE, "golden", "make_qwen35_4b_depth_golden.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    t0 = time.time()
+    meta = json.load(open(GOLD35 + ".json"))
+    cfgd = dict(meta["config"])
+    cfg = Qwen35Config(**cfgd)
+    w = qwen35_weights(cfg, seed=meta["seed"], std=meta["std"])
+    state = mk.state_for_engines(w)
+    _timed("ckpt35", t0)
+    t0 = time.time()
+    prompt = [100 + (i % 1000) for i in range(meta["prompt_tokens"])]
+    feed = meta["hf_tokens"][:-1]
+    out = dict(meta=meta, npz=np.load(GOLD35 + ".npz"), feed=feed)
+    for q35_mode in (1, 0):
+        os.environ["PEGAINFER_Q35_DECODE_MODE"] = str(q35_mode)
+        try:
+            eng = Qwen35Engine(cfgd, num_kv_pages=96, max_batch_size=2, max_positions=2048, split_policy=1,
+                               enable_graph=True).load_state(state)
+        finally:
+            del os.environ["PEGAINFER_Q35_DECODE_MODE"]
+        rid = eng.new_request()
+        rows = [eng.prefill(rid, prompt, want_logits=True)[1]]
+        for tk in feed:
+            rows.append(eng.decode([rid], [tk], want_logits=True)[1][0])
+        out[q35_mode] = np.stack(rows)
+        eng.drop_request(rid)
+        if q35_mode == 1:
+            rid = eng.new_request()
+            toks = [eng.prefill(rid, prompt)]
+            for _ in range(len(meta["hf_tokens"]) - 1):
+                toks.append(int(eng.decode([rid], [toks[-1]])[0]))
+            out["greedy"] = toks
+            eng.drop_request(rid)
+            eng.debug_hidden_enable(True)
+            rid = eng.new_request()
+            eng.prefill(rid, prompt)
+            out["taps_prefill"] = bf16_from_bits(eng.debug_hidden(1))
+            eng.decode([rid], [feed[0]])
+            out["taps_decode"] = bf16_from_bits(eng.debug_hidden(1))
+            eng.drop_request(rid)
+            eng.debug_hidden_enable(False)
+        eng.close()
+    _timed("engine35", t0)
+    t0 = time.time()
+    out["oracle"], out["otaps"] = dc.qwen35_pass(cfg, w, prompt, feed, exact=False, taps=True)
+    _timed("oracle35_bf16", t0)
+    t0 = time.time()
+    out["truth"], out["ttaps"] = dc.qwen35_pass(cfg, w, prompt, feed, exact=True, taps=True)
+    _timed("oracle35_truth", t0)
+    return out
+
+
+def test_qwen35_full_depth_logits_match_the_oracle(depth35):
+    """32 layers (24 chunk-wise / recurrent delta-rule layers + 8 HD256 attention layers), V = 248 320, the bench prompt +
+    8 decode steps.  bench.py's HF leg read cosine 0.9938 / 11 % here and could not say whose error it was: the fixture
+    shows HF, the oracle and the truth pass are MUTUALLY ~0.993 apart on this checkpoint (hf_vs_truth / oracle_vs_truth /
+    oracle_vs_hf in tests/golden/qwen35_4b_depth32_hf.json) - it is the bf16 noise floor of this model at this depth - and
+    the derived bar places the engine on the same axis."""
+    d = depth35
+    got, ref, tru = d[1], d["oracle"], d["truth"]
+    dv = dc.derived(got, ref, tru)
+    ok, agree, margin, dmax = dc.near_tie_ok(got, ref, ref)
+    fx = d["meta"]
+    dc.report("qwen35_oracle", dict(dv, tokens_equal=[int(agree.sum()), int(len(agree))], max_dlogit=float(dmax.max()),
+                                    cos=[float(x) for x in dc.cos_rows(got, ref)],
+                                    fixture=dict(hf_vs_truth_cos_min=fx["hf_vs_truth"]["cos_min"],
+                                                 oracle_vs_truth_cos_min=fx["oracle_vs_truth"]["cos_min"],
+                                                 oracle_vs_hf_cos_min=fx["oracle_vs_hf"]["cos_min"],
+                                                 hf_vs_truth_rms=fx["hf_vs_truth"]["rms_dlogit"])))
+    assert dv["cos_engine_vs_oracle_min"] > SANITY_COS
+    dc.assert_derived(dv, "Qwen3.5-4B x 32")
+    assert ok.all(), ("greedy token differs away from a near-tie", agree, margin, dmax)
+    # the live truth pass reproduces the fixture's (same seed, same DAG): the committed HF distances are about THIS model
+    idx = d["npz"]["idx"]
+    assert np.allclose(tru[:, idx], d["npz"]["truth_idx_vals"], atol=2e-3), float(np.abs(tru[:, idx] - d["npz"]["truth_idx_vals"]).max())
+
+
+def test_qwen35_full_depth_fused_equals_reference_sequence_bitwise(depth35):
+    """the bs = 1 fused decode step (8-10 launches per layer) == the reference-order op sequence (16-17) in every logit bit
+    of every step at 32 layers (batch_decode.rs:505-606's idea)"""
+    a, b = depth35[0].view(np.uint32), depth35[1].view(np.uint32)
+    assert np.array_equal(a, b), int((a != b).sum())
+
+
+def test_qwen35_full_depth_against_hf_transformers_fixture(depth35):
+    """HF Qwen3_5ForCausalLM bf16 (the reference's truth engine for this model too) on the same seeded checkpoint: the
+    engine is as close to HF as the ORACLE is (x 1.25 on the RMS over the fixture's 4096-index subset, per step) and - the
+    finding - as close to the TRUTH as HF is; free-running greedy tokens identical to HF's up to a near-tie."""
+    d = depth35
+    meta, npz = d["meta"], d["npz"]
+    got = d[1]
+    idx, sub, tsub = npz["idx"], npz["idx_vals"], npz["truth_idx_vals"]
+    e_hf = dc.rms_rows(got[:, idx], sub)
+    o_hf = dc.rms_rows(d["oracle"][:, idx], sub)
+    e_tr, h_tr = dc.rms_rows(got[:, idx], tsub), dc.rms_rows(sub, tsub)
+    mine, hf_tokens = d["greedy"], meta["hf_tokens"]
+    first_diff = next((i for i, (a, b) in enumerate(zip(mine, hf_tokens)) if a != b), None)
+    top_ids, top_vals = npz["top_ids"], npz["top_vals"]
+    dtop = np.abs(np.take_along_axis(got, top_ids, axis=-1) - top_vals).max(-1)
+    forced_agree = got.argmax(-1) == top_ids[:, 0]
+    margins = np.asarray(meta["top1_margin"])
+    dc.report("qwen35_hf", dict(rms_engine_vs_hf=[float(x) for x in e_hf], rms_oracle_vs_hf=[float(x) for x in o_hf],
+                                rms_engine_vs_truth=[float(x) for x in e_tr], rms_hf_vs_truth=[float(x) for x in h_tr],
+                                cos_engine_vs_hf_min=float(dc.cos_rows(got[:, idx], sub).min()),
+                                hf_tokens=hf_tokens, engine_tokens=mine, first_diff_step=first_diff,
+                                hf_margin=[float(x) for x in margins],
+                                teacher_forced_argmax_equal=[int(forced_agree.sum()), int(len(forced_agree))]))
+    pooled = float(np.sqrt((e_hf ** 2).sum() / (o_hf ** 2).sum()))
+    assert pooled <= dc.AGG_MAX and (e_hf / o_hf).max() <= dc.STEP_MAX, (pooled, e_hf / o_hf)
+    pooled_t = float(np.sqrt((e_tr ** 2).sum() / (h_tr ** 2).sum()))
+    assert pooled_t <= dc.AGG_MAX, ("engine vs truth against HF vs truth", pooled_t)
+    assert (forced_agree | (margins <= 2 * dtop)).all(), (forced_agree, margins, dtop)
+    if first_diff is not None:
+        assert margins[first_diff] <= 2 * dtop.max(), (first_diff, margins[first_diff], mine, hf_tokens)
+
+
+def test_qwen35_per_layer_hidden_states_against_the_oracle(depth35):
+    d, rep = depth35, {}
+    for name, e, step in (("prefill_1024", d["taps_prefill"], 0), ("decode", d["taps_decode"], 1)):
+        cur = dc.layer_curve(e[:, :1], d["otaps"][step][:, :1], d["ttaps"][step][:, :1])
+        pooled = float(np.sqrt(np.mean(np.square(cur["rel_err_engine"])) / np.mean(np.square(cur["rel_err_oracle"]))))
+        rep[name] = dict(cur, ratio_pooled=pooled, layer_types=d["meta"]["config"]["layer_types"])
+        dc.report("qwen35_layers", rep)
+        assert min(cur["cos_engine_vs_oracle"]) > 0.99, (name, cur["cos_engine_vs_oracle"])
+        assert max(cur["ratio"][2:]) <= dc.STEP_MAX and pooled <= dc.AGG_MAX, (name, pooled, cur["ratio"])

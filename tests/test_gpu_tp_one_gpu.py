@@ -117,6 +117,10 @@ def _tp_worker(rank, world, port, out_dir):
                     if rank != world - 1:
                         with pytest.raises(RuntimeError, match="bounded wait expired"):
                             eng.decode([rid], tok)
+                        # the failure is permanent for this model (sticky status, diverged epochs, a half-advanced
+                        # request): every later step fails at once instead of spinning on the dead world again
+                        with pytest.raises(RuntimeError, match="earlier step"):
+                            eng.decode([rid], tok)
                     dist.barrier()
                 eng.close()
             comm.close()
