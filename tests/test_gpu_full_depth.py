@@ -292,7 +292,7 @@ def test_per_layer_hidden_states_against_the_oracle(engine36, oracle36):
         dc.report("layers", rep)
         assert min(cur["cos_engine_vs_oracle"]) > 0.995, (name, cur["cos_engine_vs_oracle"])
         # one row of 2560 elements per layer: the single-row allowance (STEP_MAX); pooled over the depth: the band
-        assert max(cur["ratio"][2:]) <= dc.STEP_MAX, (name, cur["ratio"])
+        assert max(cur["ratio"][min(2, len(cur["ratio"]) - 1):]) <= dc.STEP_MAX, (name, cur["ratio"])
         pooled = float(np.sqrt(np.mean(np.square(cur["rel_err_engine"])) / np.mean(np.square(cur["rel_err_oracle"]))))
         rep[name]["ratio_pooled"] = pooled
         assert pooled <= dc.AGG_MAX, (name, pooled)

@@ -166,4 +166,4 @@ def test_qwen35_per_layer_hidden_states_against_the_oracle(depth35):
         rep[name] = dict(cur, ratio_pooled=pooled, layer_types=d["meta"]["config"]["layer_types"])
         dc.report("qwen35_layers", rep)
         assert min(cur["cos_engine_vs_oracle"]) > 0.99, (name, cur["cos_engine_vs_oracle"])
-        assert max(cur["ratio"][2:]) <= dc.STEP_MAX and pooled <= dc.AGG_MAX, (name, pooled, cur["ratio"])
+        assert max(cur["ratio"][min(2, len(cur["ratio"]) - 1):]) <= dc.STEP_MAX and pooled <= dc.AGG_MAX, (name, pooled, cur["ratio"])

@@ -3,7 +3,7 @@
 
 A GPU minute is the scarce resource of this project (one pool box per call, a fixed budget per round): a shape slip or an
 indexing bug in 500 lines of test harness must not cost one.  This script runs the very same test modules here, where there
-is no GPU, against engines made of the ORACLE with fp64 GEMM accumulation (the reference's rounding points, another
+is no GPU, against engines made of the ORACLE with every GEMM summed in two K halves (the reference's rounding points, another
 summation order - "an honest engine"), on reduced-depth fixtures generated into a scratch directory:
 
     python tools/dry_run_full_depth.py [--layers 2] [--layers35 4] [--keep DIR]
@@ -40,18 +40,23 @@ def make_fixtures(out, layers, layers35):
 
 def install_stand_ins():
     from oracle import ops as O
-    from oracle.bf16 import bf16_bits, bf16_from_bits
+    from oracle.bf16 import bf16_bits, bf16_from_bits, bf16_round
     from oracle.qwen3_ref import KvState, Qwen3Config, Qwen3Oracle
     from oracle.qwen3_ref import synthetic_weights as w3
     from oracle.qwen35_ref import Qwen35Config, Qwen35Oracle
 
-    class fp64:
+    def gemm_two_halves(W, X):
+        """another summation order at sgemm cost: the two K halves summed separately, then added in fp32"""
+        h = W.shape[1] // 2
+        return bf16_round(X[:, :h] @ W[:, :h].T + X[:, h:] @ W[:, h:].T)
+
+    class fp64:   # (historical name) the stand-in's arithmetic: the reference's rounding points, a different summation order
         def __enter__(self):
-            self.old = O.GEMM_ACCUM
-            O.GEMM_ACCUM = np.float64
+            self.old, self.old_acc = O.gemm, O.GEMM_ACCUM
+            O.gemm, O.GEMM_ACCUM = gemm_two_halves, np.float32
 
         def __exit__(self, *a):
-            O.GEMM_ACCUM = self.old
+            O.gemm, O.GEMM_ACCUM = self.old, self.old_acc
 
     class _Lib:
         def __init__(self, eng):
