@@ -107,7 +107,8 @@ int32_t pegainfer_fused_decode_attention(const Half* qkv, Half* output, const Ha
  * the workgroups of the request's KV chunks (slot_desc words 6 / 7 of slot 0, read on the device: a captured launch is
  * replayed while the request grows) run the attention, the workgroups of the padding slots - at least min_padding_slots
  * of them by the caller's plan - request the o_proj rows into registers meanwhile, the merging workgroups publish the attention row
- * write-through and arrive on done_counter (one device int, zero before the launch), then the o_proj workgroups finish
+ * write-through and arrive on done_counter (num_kv_heads device ints, 32 ints = one cache line apart, all zero before the
+ * launch: head group g arrives on int 32 * g when a K block of the o_proj deal is one head group, else all on int 0), then the o_proj workgroups finish
  * their dot products from registers - the bits of the two stand-alone launches.  o_proj [hidden, num_qo_heads * head_dim] row-major,
  * attn_proj_out [hidden], status (optional) receives 0x300 when the bounded wait for the attention rows expired.
  * Returns hipErrorInvalidValue (1) when the shape does not fit; the caller then issues the two launches. */

@@ -95,7 +95,8 @@ __device__ __forceinline__ void decode_attn_body(const DecodeAttnArgs& a, const 
       if (a.done_ctr) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();   // workgroup-uniform branch (sm_last): every merging wave's rows are acknowledged
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(a.done_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0)
+          __hip_atomic_fetch_add(a.done_ctr + (size_t)kvh * a.done_stride, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       PK_ATTN_STAMP(a, slot, kvh, 6);
       if (a.trace && threadIdx.x == 0) a.trace[((size_t)slot * a.num_kv_heads + kvh) * 8 + 7] = 1ull;
@@ -249,29 +250,62 @@ __global__ __launch_bounds__(512) void attn_oproj_kernel(const DecodeAttnArgs a,
   constexpr int kRedStride = 68;
   __shared__ __attribute__((aligned(16))) float red[2 * kOprojMaxRows * 4][kRedStride];
   __shared__ int ok_flag;
-  if (threadIdx.x == 0) {
-    const unsigned long long t0 = wall_clock64();
-    int ok = 1;
-    while (__hip_atomic_load(a.done_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < g.done_target) {
-      if (wall_clock64() - t0 > 3000000ull) { ok = 0; break; }   // 30 ms
-      __builtin_amdgcn_s_sleep(1);
+  // Per-head-group hand-off (round 5): with GROUP x 128 = 512 a K block of the KSPLIT-4 deal IS one kv head group, so wave
+  // w4 needs exactly the attention rows of groups w4 and w4 + 4.  Every wave waits for ITS groups' arrival counters only
+  // and takes its own 16 bytes of each straight from global memory (agent-scope loads; the LDS copy of the whole row, its
+  // barrier and the wait for the slowest merger before anything starts are gone).  Same arithmetic, same bits.
+  const bool group_wait = GROUP == 4 && a.done_stride != 0;
+  u32x4 xg[2] = {u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};
+  if (group_wait) {
+    if (threadIdx.x == 0) ok_flag = 1;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int kb = w4 + u * 4;                       // K block = kv head group
+      const int kk = kb * 512 + lane * 8;
+      if (kk >= g.K) continue;                         // wave-uniform
+      int ok = 1;
+      if (lane == 0) {
+        const unsigned long long t0 = wall_clock64();
+        while (__hip_atomic_load(a.done_ctr + (size_t)kb * a.done_stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 1) {
+          if (wall_clock64() - t0 > 3000000ull) { ok = 0; break; }   // 30 ms
+          __builtin_amdgcn_s_sleep(1);
+        }
+        if (!ok && g.status) g.status[0] = 0x300u;     // the host re-runs the step on two launches; this launch's row is void
+      }
+      ok = __builtin_amdgcn_readfirstlane(ok);
+      if (ot && threadIdx.x == 0 && u == 0) ot[2] = wall_clock64();
+      const unsigned long long* src = reinterpret_cast<const unsigned long long*>(a.o_out + kk);
+      const unsigned long long lo = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long hi = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      xg[u] = u32x4{(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
+      if (!ok) xg[u] = u32x4{0u, 0u, 0u, 0u};
     }
-    ok_flag = ok;
-    if (!ok && g.status) g.status[0] = 0x300u;
+    if (ot && threadIdx.x == 0) ot[3] = wall_clock64();
+  } else {
+    if (threadIdx.x == 0) {
+      const unsigned long long t0 = wall_clock64();
+      int ok = 1;
+      while (__hip_atomic_load(a.done_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < g.done_target) {
+        if (wall_clock64() - t0 > 3000000ull) { ok = 0; break; }   // 30 ms
+        __builtin_amdgcn_s_sleep(1);
+      }
+      ok_flag = ok;
+      if (!ok && g.status) g.status[0] = 0x300u;
+    }
+    __syncthreads();
+    if (!ok_flag) return;
+    if (ot && threadIdx.x == 0) ot[2] = wall_clock64();
+    // x = the merged attention row of request 0, written through by the merging workgroups on other CUs / XCDs
+    const int nvec = g.K >> 3;
+    for (int c = threadIdx.x; c < nvec; c += 512) {
+      const unsigned long long* src = reinterpret_cast<const unsigned long long*>(a.o_out) + (size_t)c * 2;
+      const unsigned long long lo = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long hi = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      xs[c] = u32x4{(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
+    }
+    __syncthreads();
+    if (ot && threadIdx.x == 0) ot[3] = wall_clock64();
   }
-  __syncthreads();
-  if (!ok_flag) return;
-  if (ot && threadIdx.x == 0) ot[2] = wall_clock64();
-  // x = the merged attention row of request 0, written through by the merging workgroups on other CUs / XCDs
-  const int nvec = g.K >> 3;
-  for (int c = threadIdx.x; c < nvec; c += 512) {
-    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(a.o_out) + (size_t)c * 2;
-    const unsigned long long lo = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long hi = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    xs[c] = u32x4{(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
-  }
-  __syncthreads();
-  if (ot && threadIdx.x == 0) ot[3] = wall_clock64();
   for (int base = 0; base < rows_half; base += kOprojMaxRows) {
     if (base > 0) { __syncthreads(); request_rows(base); }   // `red` is reused; only the first pass was prefetched
     // all kOprojMaxRows rows are computed, branch-free (rows past rows_half hold zeros / a previous pass: masked below)
@@ -282,7 +316,7 @@ __global__ __launch_bounds__(512) void attn_oproj_kernel(const DecodeAttnArgs a,
     for (int u = 0; u < 2; ++u) {
       const int kk = (w4 + u * 4) * 512 + lane * 8;
       const bool live = kk < g.K;
-      u32x4 xv = xs[live ? (kk >> 3) : 0];
+      u32x4 xv = group_wait ? xg[u] : xs[live ? (kk >> 3) : 0];
       if (!live) xv = u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
       for (int r = 0; r < kOprojMaxRows; ++r) acc[r] = dot8(wv[r][u], xv, acc[r]);
@@ -534,6 +568,10 @@ int32_t pegainfer_fused_decode_attention_oproj(
   a.qkv = qkv; a.q_norm_w = q_norm_weight; a.k_norm_w = k_norm_weight; a.cos_cache = cos_cache;
   a.sin_cache = sin_cache; a.positions = positions; a.eps = rms_eps; a.slot_desc = slot_desc;
   a.merge_counters = merge_counters; a.o_indptr = split_o_indptr; a.done_ctr = done_counter;
+  // per-head-group arrival counters (done_counter = num_kv_heads ints, kMergeCtrStride apart) when a K block of the
+  // o_proj deal is one kv head group; PEGAINFER_OPROJ_GROUPWAIT=0 keeps the single counter + whole-row wait (A/B, same bits)
+  static const bool gw = [] { const char* e = getenv("PEGAINFER_OPROJ_GROUPWAIT"); return !(e && e[0] == '0'); }();
+  a.done_stride = gw && group == 4 && q_dim / 512 == num_kv_heads ? kMergeCtrStride : 0;
   static const int hold = [] { const char* e = getenv("PEGAINFER_ATTN_OPROJ_HOLD"); return e && *e ? atoi(e) : 0; }();
   OprojArgs g{o_proj, attn_proj_out, hidden, q_dim, split_slots, num_kv_heads, status, hold};
   hipStream_t s = as_stream(stream);

@@ -40,6 +40,10 @@ struct DecodeAttnArgs {
   // fused attention + o_proj launch only (attn_oproj_kernel): the merging workgroup writes its head group's rows
   // write-through and then adds 1 here - the o_proj phase of every workgroup waits for num_kv_heads arrivals per request
   int* done_ctr;
+  // 0: every merging workgroup arrives on done_ctr[0] (the o_proj phase waits for num_kv_heads arrivals);
+  // kMergeCtrStride: head group kvh arrives on done_ctr[kvh * kMergeCtrStride] - a cache line per group - and every o_proj
+  // WAVE waits only for the groups whose K blocks it holds (round 5)
+  int done_stride;
   // debug: 8 wall-clock stamps (100 MHz) per (slot, kv head) written by thread 0 (pegainfer_debug_attn_trace)
   unsigned long long* trace;
 };

@@ -110,7 +110,8 @@ struct Model {
   // requested into registers while the attention's chain of round trips runs.  One arrival counter per layer (a cache
   // line each), cleared once per step; PEGAINFER_ATTN_OPROJ=0 keeps the two launches (A/B, bit-identical).
   bool attn_oproj = [] { const char* e = getenv("PEGAINFER_ATTN_OPROJ"); return !(e && e[0] == '0'); }();
-  int32_t* attn_done = nullptr;
+  int32_t* attn_done = nullptr;   // per layer: one arrival counter per kv head group, a cache line each (kDoneInts ints)
+  size_t kDoneInts = 0;                       // Hkv x 32 ints per layer (set in init)
   uint32_t *attn_status = nullptr, *attn_status_host = nullptr;
   bool oproj_step = false;   // the step being recorded / run uses the fused launch
   bool oproj_shape_ok = true;   // cleared the first time the fused launcher refuses the model's shape (e.g. hidden 4096)
@@ -244,8 +245,9 @@ struct Model {
     if (dalloc(&meta_dev, ml.total)) return -1;
     PQ_HIP(hipHostMalloc(reinterpret_cast<void**>(&tokens_out_host), bs * 4, hipHostMallocDefault));
     if (attn_oproj) {
-      if (dalloc(&attn_done, (size_t)L * 32) || dalloc(&attn_status, 4)) return -1;
-      PQ_HIP(hipMemsetAsync(attn_done, 0, (size_t)L * 32 * sizeof(int32_t), stream));
+      kDoneInts = (size_t)Hkv * 32;
+      if (dalloc(&attn_done, (size_t)L * kDoneInts) || dalloc(&attn_status, 4)) return -1;
+      PQ_HIP(hipMemsetAsync(attn_done, 0, (size_t)L * kDoneInts * sizeof(int32_t), stream));
       PQ_HIP(hipMemsetAsync(attn_status, 0, 16, stream));
       PQ_HIP(hipHostMalloc(reinterpret_cast<void**>(&attn_status_host), 16, hipHostMallocDefault));
       attn_status_host[0] = 0;
@@ -634,7 +636,7 @@ struct Model {
   int decode_kernels_fused(int bs, bool split, int split_slots) {
     if (fused_merge && split) PQ_HIP(hipMemsetAsync(merge_ctr, 0, (size_t)max_bs * Hkv * 32 * sizeof(int32_t), stream));
     oproj_step = attn_oproj && attn_done && fused_merge && split && bs == 1 && !tp_comm && D == 128 && oproj_plan;
-    if (oproj_step) PQ_HIP(hipMemsetAsync(attn_done, 0, (size_t)L * 32 * sizeof(int32_t), stream));
+    if (oproj_step) PQ_HIP(hipMemsetAsync(attn_done, 0, (size_t)L * kDoneInts * sizeof(int32_t), stream));
     if (embedding_batched_cuda(embed, md<uint32_t>(ml.token_ids), hidden, H, bs, S())) {
       set_error("embedding_batched_cuda failed");
       return -1;
@@ -657,7 +659,7 @@ struct Model {
             md<int32_t>(ml.split_kv_chunk_size), md<int32_t>(ml.split_o_indptr), md<uint8_t>(ml.split_valid),
             split_tmp_v, split_tmp_s, Hq, Hkv, D, layout.page_size, bs, split_slots,
             split_slots - pq::oproj_fused_max_chunks(), layout.page_stride, sm, md<int32_t>(ml.slot_desc), merge_ctr, ly.o,
-            attn_proj, H, attn_done + (size_t)li * 32, attn_status, S());
+            attn_proj, H, attn_done + (size_t)li * kDoneInts, attn_status, S());
         if (r2 == 0) fused_o = true;
         else if (r2 != (int)hipErrorInvalidValue) rc = r2;
         else { oproj_step = false; oproj_shape_ok = false; }   // the shape does not fit the form: two launches from here on, and no chunk cap in later plans

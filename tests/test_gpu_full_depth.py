@@ -41,7 +41,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 GOLD_DIR = os.environ.get("PEGAINFER_DEPTH_GOLD_DIR") or os.path.join(HERE, "golden")   # tools/dry_run_full_depth.py points it at reduced-depth fixtures
 GOLD = os.path.join(GOLD_DIR, "qwen3_4b_depth36_hf")
 GOLD_SHORT = os.path.join(GOLD_DIR, "qwen3_4b_depth36_short_hf")
-N_STEPS = 12                     # decode steps checked on every stream (the 1024-token fixture holds 16, the short ones 29)
+N_STEPS = 10                     # decode steps checked on every stream (the 1024-token fixture holds 16, the short ones 29)
 SANITY_COS = 0.98                # a gross-failure fence only; the tolerance is the derived bar
 
 
