@@ -88,6 +88,15 @@ def test_qwen3_8b_full_depth_greedy_and_topk_topp_sampling(built_libs):
     rows_d = lg[0].copy()
     bits = eng.export_state()
     eng.close()
+    # a second engine that never tries the fused attention + o_proj launch (its launcher refuses hidden 4096 inside the
+    # first graph capture of the engine above): same seed, same stream
+    os.environ["PEGAINFER_ATTN_OPROJ"] = "0"
+    try:
+        eng2 = Qwen3Engine(CFG8, num_kv_pages=96, max_batch_size=2, decode_mode=1, max_positions=4096).fill_synthetic(seed=808, std=0.02)
+    finally:
+        del os.environ["PEGAINFER_ATTN_OPROJ"]
+    rows_e = _forced(eng2, prompt, toks[:N_STEPS8])
+    eng2.close()
     _timed("engine8b", t0)
     t0 = time.time()
     names = list(bits)
@@ -100,7 +109,7 @@ def test_qwen3_8b_full_depth_greedy_and_topk_topp_sampling(built_libs):
     t0 = time.time()
     tru = dc.qwen3_pass(cfg, w, [prompt], [toks[:N_STEPS8]], exact=True)[0]
     _timed("oracle8b_truth", t0)
-    runs = {"A": rows_a, "B": rows_b, "C": rows_c}
+    runs = {"A": rows_a, "B": rows_b, "C": rows_c, "E_no_oproj_attempt": rows_e}
     got = bf16_from_bits(rows_b)
     dv = dc.derived(got, ref, tru)
     ok, agree, margin, dmax = dc.near_tie_ok(got, ref, ref)
@@ -111,6 +120,7 @@ def test_qwen3_8b_full_depth_greedy_and_topk_topp_sampling(built_libs):
         cos_vs_oracle={k: [float(x) for x in dc.cos_rows(bf16_from_bits(v), ref)] for k, v in runs.items()},
         rows_differing={"A_vs_B": [int((rows_a[i] != rows_b[i]).sum()) for i in range(len(rows_a))],
                         "B_vs_C": [int((rows_b[i] != rows_c[i]).sum()) for i in range(len(rows_b))],
+                        "B_vs_E": [int((rows_b[i] != rows_e[i]).sum()) for i in range(len(rows_b))],
                         "last_row_D_vs_B": int((rows_d != rows_b[-1]).sum())}))
     assert dv["cos_engine_vs_oracle_min"] > SANITY_COS
     dc.assert_derived(dv, "Qwen3-8B x 36")
