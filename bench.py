@@ -573,6 +573,9 @@ def main():
                     help="N>1: 'replicas' = one independent request stream per GPU (weak scaling, no data-path "
                          "collective; default); 'tp' = the reference's Qwen3 tensor parallel over RCCL "
                          "(strong scaling, 72 all-reduces per step)")
+    ap.add_argument("--chain", type=int, default=32,
+                    help="greedy decode steps enqueued per host synchronisation (pegainfer_qwen3_decode_greedy_chain); 0 = the "
+                         "reference's loop shape, one synchronisation per step")
     ap.add_argument("--sweep-steps", type=int, default=20,
                     help="decode steps per point of the side batch sweep (bs 2 / 4 / 8 / 16 at --ctx) and of the drop-in-ABI "
                          "(decode_mode 0) side number; 0 = skip both")
@@ -622,7 +625,7 @@ def main():
     tp = args.parallelism == "tp" and world > 1
     if tp:
         cfg = parallel.tp_local_config(cfg, world)
-    total_ctx = args.ctx + args.warmup + args.steps + 8
+    total_ctx = args.ctx + args.warmup + args.steps + 8 + 64   # + the sync-per-step side loop behind a chained run
     heavy_out = 256                                   # decode_heavy output length (bench_serving.rs:37-43)
     single_ctx = max(total_ctx, args.ctx + heavy_out + 8 if args.profile_iters > 0 else 0,
                      10000 + 16 if args.ttft10k_iters > 0 else 0)
@@ -654,8 +657,15 @@ def main():
 
     rids = [eng.new_request() for _ in range(args.batch)]
     toks = eng.prefill(rids, [prompt] * args.batch)
-    for _ in range(args.warmup):
+    # greedy steps are enqueued in chains (pegainfer_qwen3_decode_greedy_chain: the token of step s reaches step s + 1 on
+    # the device, every step's tokens still travel to the host asynchronously, ONE host synchronisation per chain) unless
+    # --chain 0; sampling with temperature needs the host between steps, tensor parallel checks its status block per step
+    chain = args.chain if (args.sampling == "greedy" and not tp) else 0
+    n_warm_chain = min(2, args.warmup) if chain else 0      # the pinned metadata ring is allocated by the first chain
+    for _ in range(args.warmup - n_warm_chain):
         toks = eng.decode(rids, toks)
+    if n_warm_chain:
+        toks = eng.decode_greedy_chain(rids, toks, n_warm_chain)[-1]
 
     def barrier():
         if world > 1:
@@ -670,17 +680,33 @@ def main():
     eng.last_step_ms()
     barrier()
     t_start = time.perf_counter()
-    for _ in range(args.steps):
+    done = 0
+    while done < args.steps:
         t0 = time.perf_counter()
-        toks = eng.decode(rids, toks)
-        if samp:   # the reference samples request by request after the step (executor.rs:324-328)
-            toks = np.array([eng.sample(i, samp[0], samp[1], samp[2], float(srng.random())) for i in range(len(rids))],
-                            dtype=np.int32)
-        step_ms.append((time.perf_counter() - t0) * 1e3)
-        dev_ms.append(eng.last_step_ms())
+        if chain:
+            m = min(chain, args.steps - done)
+            toks = eng.decode_greedy_chain(rids, toks, m)[-1]
+        else:
+            m = 1
+            toks = eng.decode(rids, toks)
+            if samp:   # the reference samples request by request after the step (executor.rs:324-328)
+                toks = np.array([eng.sample(i, samp[0], samp[1], samp[2], float(srng.random())) for i in range(len(rids))],
+                                dtype=np.int32)
+        dt = (time.perf_counter() - t0) * 1e3 / m
+        step_ms.extend([dt] * m)
+        dev_ms.extend([eng.last_step_ms()] * m)
+        done += m
     barrier()
     elapsed = time.perf_counter() - t_start
     elapsed = parallel.max_over_ranks(elapsed, device="cuda")
+    # the reference's own loop shape - one host synchronisation per step (executor.rs:541-640) - on the same requests, after
+    # the contract's timed region: the per-step TPOT percentiles, and what the chain is worth
+    sync_ms = []
+    if chain:
+        for _ in range(min(args.steps, 64)):
+            t0 = time.perf_counter()
+            toks = eng.decode(rids, toks)
+            sync_ms.append((time.perf_counter() - t0) * 1e3)
 
     tokens = args.steps * args.batch * (1 if tp else world)
     value = tokens / elapsed
@@ -794,6 +820,14 @@ def main():
         "tpot_ms": {"p50": round(p50_ms, 4), "p95": round(float(np.percentile(step_ms, 95)), 4),
                     "device_p50": round(float(np.median(dev_ms)), 4), "mean": round(mean_ms, 4),
                     "mean_over_p50": round(mean_ms / p50_ms, 4)},
+        # how the timed steps were driven: chains of `chain_steps` greedy steps with the token handed over on the device and
+        # one host synchronisation per chain (every step's tokens are still copied to the host, asynchronously), or the
+        # reference's loop shape - a host synchronisation per step; `sync_per_step` is the second form measured right after
+        "host_loop": ({"form": "chained", "chain_steps": chain,
+                       "sync_per_step": {"tpot_ms_p50": round(float(np.median(sync_ms)), 4),
+                                         "tpot_ms_p95": round(float(np.percentile(sync_ms, 95)), 4),
+                                         "tok_s": round(args.batch * (1 if tp else world) * 1e3 / float(np.mean(sync_ms)), 2),
+                                         "steps": len(sync_ms)}} if chain and sync_ms else {"form": "sync_per_step"}),
         "decode_heavy": heavy,
         "ttft_ms_10000": ttft10k,
         "ttft_ms_short": ttft_short,

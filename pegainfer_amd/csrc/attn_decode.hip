@@ -258,28 +258,36 @@ __global__ __launch_bounds__(512) void attn_oproj_kernel(const DecodeAttnArgs a,
   u32x4 xg[2] = {u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};
   if (group_wait) {
     if (threadIdx.x == 0) ok_flag = 1;
+    // both arrivals first (lane 0 polls, bounded), then the wave's four 8-byte loads in one round trip
+    int ok = 1;
+    if (lane == 0) {
+      const unsigned long long t0 = wall_clock64();
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int kb = w4 + u * 4;                       // K block = kv head group
-      const int kk = kb * 512 + lane * 8;
-      if (kk >= g.K) continue;                         // wave-uniform
-      int ok = 1;
-      if (lane == 0) {
-        const unsigned long long t0 = wall_clock64();
+      for (int u = 0; u < 2; ++u) {
+        const int kb = w4 + u * 4;                       // K block = kv head group
+        if (kb * 512 >= g.K) continue;
         while (__hip_atomic_load(a.done_ctr + (size_t)kb * a.done_stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 1) {
           if (wall_clock64() - t0 > 3000000ull) { ok = 0; break; }   // 30 ms
           __builtin_amdgcn_s_sleep(1);
         }
-        if (!ok && g.status) g.status[0] = 0x300u;     // the host re-runs the step on two launches; this launch's row is void
       }
-      ok = __builtin_amdgcn_readfirstlane(ok);
-      if (ot && threadIdx.x == 0 && u == 0) ot[2] = wall_clock64();
-      const unsigned long long* src = reinterpret_cast<const unsigned long long*>(a.o_out + kk);
-      const unsigned long long lo = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned long long hi = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      xg[u] = u32x4{(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
-      if (!ok) xg[u] = u32x4{0u, 0u, 0u, 0u};
+      if (!ok && g.status) g.status[0] = 0x300u;       // the host re-runs the step on two launches; this launch's row is void
     }
+    ok = __builtin_amdgcn_readfirstlane(ok);
+    if (ot && threadIdx.x == 0) ot[2] = wall_clock64();
+    unsigned long long xl[2][2] = {{0ull, 0ull}, {0ull, 0ull}};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int kk = (w4 + u * 4) * 512 + lane * 8;
+      if (kk >= g.K) continue;
+      const unsigned long long* src = reinterpret_cast<const unsigned long long*>(a.o_out + kk);
+      xl[u][0] = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      xl[u][1] = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      xg[u] = ok ? u32x4{(uint32_t)xl[u][0], (uint32_t)(xl[u][0] >> 32), (uint32_t)xl[u][1], (uint32_t)(xl[u][1] >> 32)}
+                 : u32x4{0u, 0u, 0u, 0u};
     if (ot && threadIdx.x == 0) ot[3] = wall_clock64();
   } else {
     if (threadIdx.x == 0) {

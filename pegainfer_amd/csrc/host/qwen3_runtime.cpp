@@ -727,11 +727,16 @@ struct Model {
     return 0;
   }
 
-  int decode(int n, const int32_t* ids, const uint32_t* token_ids, int32_t* out_tokens, void* out_logits_host) {
+  // One decode step = step_prepare (validate the batch, advance the KvStates, pack + upload the metadata block) +
+  // step_launch (replay - or capture - the (bucket, path) graph).  decode() runs ONE step and synchronises;
+  // decode_greedy_chain() enqueues n steps back to back (below).
+  struct StepCtx { int n = 0, padded = 0, plan_slots = 0; bool split = false; std::vector<KvState*> st; };
+  int step_prepare(int n, const int32_t* ids, const uint32_t* token_ids, StepCtx* c, uint8_t* host_block) {
     if (!finalized) { set_error("model not finalized"); return -1; }
     if (tp_failed) { set_error("tensor-parallel group failed in an earlier step (bounded wait expired): rebuild the model and its communicator"); return -5; }
     if (n <= 0 || n > max_bs) { set_error("bad batch size"); return -1; }
-    std::vector<KvState*> st(n);
+    std::vector<KvState*>& st = c->st;
+    st.assign(n, nullptr);
     std::vector<int> positions(n), seq_lens(n);
     // validate the whole batch first (ids, RoPE range, bucket, total pages): a failed call must leave every
     // request exactly as it was - no seq_len advanced, no page acquired
@@ -756,20 +761,21 @@ struct Model {
       st[i]->seq_len += 1;
       seq_lens[i] = st[i]->seq_len;
     }
-    // ---- pack metadata (batch_decode.rs:45-59, batch_decode_buffers.rs:178-279) ----
-    auto* tok = mh<uint32_t>(ml.token_ids);
-    auto* pos = mh<int32_t>(ml.positions);
-    auto* indptr = mh<int32_t>(ml.page_indptr);
-    auto* lpl = mh<int32_t>(ml.last_page_len);
-    auto* ri = mh<int32_t>(ml.request_indices);
-    auto* kti = mh<int32_t>(ml.kv_tile_indices);
-    auto* kcs = mh<int32_t>(ml.kv_chunk_size);
-    auto* pgs = mh<int32_t>(ml.page_indices);
+    // ---- pack metadata (batch_decode.rs:45-59, batch_decode_buffers.rs:178-279) into `host_block` (pinned) ----
+    auto hb = [&](size_t off) { return host_block + off; };
+    auto* tok = reinterpret_cast<uint32_t*>(hb(ml.token_ids));
+    auto* pos = reinterpret_cast<int32_t*>(hb(ml.positions));
+    auto* indptr = reinterpret_cast<int32_t*>(hb(ml.page_indptr));
+    auto* lpl = reinterpret_cast<int32_t*>(hb(ml.last_page_len));
+    auto* ri = reinterpret_cast<int32_t*>(hb(ml.request_indices));
+    auto* kti = reinterpret_cast<int32_t*>(hb(ml.kv_tile_indices));
+    auto* kcs = reinterpret_cast<int32_t*>(hb(ml.kv_chunk_size));
+    auto* pgs = reinterpret_cast<int32_t*>(hb(ml.page_indices));
     int np = 0;
     indptr[0] = 0;
     for (int i = 0; i < padded; ++i) {
       if (i < n) {
-        tok[i] = token_ids[i];
+        tok[i] = token_ids ? token_ids[i] : 0;   // chained steps: the device copies the previous step's tokens in
         pos[i] = positions[i];
         for (int32_t p : st[i]->pages) pgs[np++] = p;
         lpl[i] = st[i]->last_page_len(layout.page_size);
@@ -789,14 +795,14 @@ struct Model {
     const SplitPlan plan = make_split_plan(split_policy, seq_lens, padded, Hkv, oproj_usable);
     oproj_plan = oproj_usable && split_policy == 1 && padded == 1 && plan.use_split && seq_lens[0] <= pq::oproj_fused_max_seq() &&
                  plan.slots > pq::oproj_fused_max_chunks();
-    std::memcpy(mh<int32_t>(ml.split_request_indices), plan.request_indices.data(), plan.slots * 4);
-    std::memcpy(mh<int32_t>(ml.split_kv_tile_indices), plan.kv_tile_indices.data(), plan.slots * 4);
-    mh<int32_t>(ml.split_kv_chunk_size)[0] = plan.chunk;
-    std::memcpy(mh<int32_t>(ml.split_o_indptr), plan.o_indptr.data(), (padded + 1) * 4);
-    std::memcpy(mh<uint8_t>(ml.split_valid), plan.valid.data(), plan.slots);
+    std::memcpy(hb(ml.split_request_indices), plan.request_indices.data(), plan.slots * 4);
+    std::memcpy(hb(ml.split_kv_tile_indices), plan.kv_tile_indices.data(), plan.slots * 4);
+    reinterpret_cast<int32_t*>(hb(ml.split_kv_chunk_size))[0] = plan.chunk;
+    std::memcpy(hb(ml.split_o_indptr), plan.o_indptr.data(), (padded + 1) * 4);
+    std::memcpy(hb(ml.split_valid), plan.valid.data(), plan.slots);
     // host-resolved slot records for the fused attention kernel (one load instead of four dependent ones)
     {
-      auto* sd = mh<int32_t>(ml.slot_desc);
+      auto* sd = reinterpret_cast<int32_t*>(hb(ml.slot_desc));
       const int nslots = plan.use_split ? plan.slots : padded;
       for (int sl = 0; sl < nslots; ++sl) {
         int32_t* r = sd + 8 * sl;
@@ -816,10 +822,51 @@ struct Model {
       }
     }
     const size_t upload = ml.page_indices + (size_t)np * 4;
-    PQ_HIP(hipMemcpyAsync(meta_dev, meta_host, upload, hipMemcpyHostToDevice, stream));
-    const bool split = plan.use_split;
-    last_path = split ? 1 : 0;
+    PQ_HIP(hipMemcpyAsync(meta_dev, host_block, upload, hipMemcpyHostToDevice, stream));
+    c->n = n; c->padded = padded; c->split = plan.use_split; c->plan_slots = plan.slots;
+    last_path = c->split ? 1 : 0;
+    return 0;
+  }
+  bool step_uses_oproj_form(const StepCtx& c) const {
+    return attn_status && attn_oproj && oproj_plan && c.padded == 1 && c.split && decode_mode >= 1 && !tp_comm;
+  }
+  int step_launch(const StepCtx& c) {
+    if (enable_graph && !tap_on) {
+      const int bi = bucket_index(c.padded);
+      const int gv = !c.split ? 0 : (oproj_plan && attn_oproj && c.padded == 1 && !tp_comm && decode_mode >= 1 ? 2 : 1);
+      hipGraphExec_t& exec = graphs[bi][gv];
+      if (!exec) {  // capture once (cuda_graph.rs:36-55), thread-local mode
+        hipGraph_t graph = nullptr;
+        PQ_HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+        const int rc = decode_kernels(c.padded, c.split, c.plan_slots);
+        hipError_t e = hipStreamEndCapture(stream, &graph);
+        if (rc || e != hipSuccess) { set_error("graph capture failed: " + err); return -1; }
+        PQ_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        PQ_HIP(hipGraphDestroy(graph));
+      }
+      PQ_HIP(hipGraphLaunch(exec, stream));
+      return 0;
+    }
+    return decode_kernels(c.padded, c.split, c.plan_slots) ? -1 : 0;
+  }
+  // the fused attention + o_proj launch reported an expired bounded wait: disable the form for good and drop the graphs
+  // that captured it (the caller re-runs what it enqueued on the two stand-alone launches)
+  int oproj_fall_back() {
+    attn_oproj = false;
+    oproj_fallbacks += 1;
+    PQ_HIP(hipMemsetAsync(attn_status, 0, 4, stream));
+    for (int b = 0; b < kNumBuckets; ++b)
+      for (int q = 0; q < 3; ++q)
+        if (graphs[b][q]) { hipGraphExecDestroy(graphs[b][q]); graphs[b][q] = nullptr; }
+    err = "fused attention + o_proj launch: the bounded wait for the attention rows expired (code " +
+          std::to_string(attn_status_host[0]) + "); step re-run on two launches, form disabled";
+    attn_status_host[0] = 0;
+    return 0;
+  }
 
+  int decode(int n, const int32_t* ids, const uint32_t* token_ids, int32_t* out_tokens, void* out_logits_host) {
+    StepCtx c;
+    if (const int rc = step_prepare(n, ids, token_ids, &c, meta_host)) return rc;
     // one attempt = graph replay (or eager launches) + token D2H + sync.  A step whose fused attention + o_proj launch
     // reported an expired bounded wait is re-run in the SAME call on the two stand-alone launches: the metadata block is
     // already on the device, the step recomputes everything from the embedding and the KV append rewrites the same slots
@@ -827,26 +874,10 @@ struct Model {
     // back.  The loop runs until an attempt took no fallback (every fallback disables its cause for good), capped at 3.
     for (int attempt = 0;; ++attempt) {
       PQ_HIP(hipEventRecord(ev0, stream));
-      if (enable_graph && !tap_on) {
-        const int bi = bucket_index(padded);
-        const int gv = !split ? 0 : (oproj_plan && attn_oproj && padded == 1 && !tp_comm && decode_mode >= 1 ? 2 : 1);
-        hipGraphExec_t& exec = graphs[bi][gv];
-        if (!exec) {  // capture once (cuda_graph.rs:36-55), thread-local mode
-          hipGraph_t graph = nullptr;
-          PQ_HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-          const int rc = decode_kernels(padded, split, plan.slots);
-          hipError_t e = hipStreamEndCapture(stream, &graph);
-          if (rc || e != hipSuccess) { set_error("graph capture failed: " + err); return -1; }
-          PQ_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-          PQ_HIP(hipGraphDestroy(graph));
-        }
-        PQ_HIP(hipGraphLaunch(exec, stream));
-      } else {
-        if (decode_kernels(padded, split, plan.slots)) return -1;
-      }
+      const bool oproj_check = step_uses_oproj_form(c);
+      if (step_launch(c)) return -1;
       PQ_HIP(hipEventRecord(ev1, stream));
       PQ_HIP(hipMemcpyAsync(tokens_out_host, tokens_out_d, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
-      const bool oproj_check = attn_status && attn_oproj && oproj_plan && padded == 1 && split && decode_mode >= 1;
       if (oproj_check) PQ_HIP(hipMemcpyAsync(attn_status_host, attn_status, 4, hipMemcpyDeviceToHost, stream));
       // tensor parallel: the 72 one-shot all-reduces of the step share one status block; it travels back with the tokens
       const uint32_t* os_status_d = tp_comm && tp_status_host && pegainfer_comm_oneshot_active(tp_comm)
@@ -867,21 +898,94 @@ struct Model {
       // the o_proj phase of the fused launch never saw the attention rows (workgroups not co-resident): this attempt's
       // outputs are invalid.  Disable the form, drop the graphs that captured it and take another attempt on the two
       // stand-alone launches (same metadata, same KV slots: the request state stays consistent).
-      attn_oproj = false;
-      oproj_fallbacks += 1;
-      PQ_HIP(hipMemsetAsync(attn_status, 0, 4, stream));
-      for (int b = 0; b < kNumBuckets; ++b)
-        for (int q = 0; q < 3; ++q)
-          if (graphs[b][q]) { hipGraphExecDestroy(graphs[b][q]); graphs[b][q] = nullptr; }
-      err = "fused attention + o_proj launch: the bounded wait for the attention rows expired (code " +
-            std::to_string(attn_status_host[0]) + "); step re-run on two launches, form disabled";
-      attn_status_host[0] = 0;
+      if (oproj_fall_back()) return -1;
       if (attempt >= 2) { set_error("decode step still reported a fallback after every fused form was disabled"); return -4; }
     }
     for (int i = 0; i < n; ++i) out_tokens[i] = tokens_out_host[i];
     last_logits = logits;
     last_rows = n;
     if (out_logits_host) PQ_HIP(hipMemcpy(out_logits_host, logits, (size_t)n * V * 2, hipMemcpyDeviceToHost));
+    return 0;
+  }
+
+  // n_steps GREEDY decode steps of the same batch enqueued back to back, ONE host synchronisation at the end (round 5).
+  // A synchronous step leaves the GPU idle from "tokens on the host" to "next graph launched" (metadata packing, two
+  // runtime calls, the caller's own loop: 30-65 us of a 2 ms step).  Greedy needs no host in between: the token of step s
+  // is already on the device (batched top-1 inside the graph), so step s + 1's metadata block is uploaded and a 4 * n-byte
+  // device-to-device copy drops those tokens into its token_ids slot before the graph replays.  Metadata blocks travel
+  // through a ring of pinned buffers (the upload of step s must have executed before its buffer is repacked: one event per
+  // ring slot).  Same graphs, same kernels, same bits as n_steps calls of decode() (tested); sampling with temperature,
+  // stop tokens and logprobs need the host between steps and keep using decode().
+  // out_tokens: [n_steps][n].  An expired bounded wait of the fused attention + o_proj form re-runs the whole chain on two
+  // launches (the KV appends rewrite the same slots); tensor parallel takes the step-by-step path.
+  static constexpr int kChainRing = 8;
+  uint8_t* chain_ring[kChainRing] = {};
+  hipEvent_t chain_ev[kChainRing] = {};
+  int32_t* chain_tokens_host = nullptr;   // pinned, grow-only
+  size_t chain_tokens_cap = 0;
+  int decode_greedy_chain(int n, const int32_t* ids, const uint32_t* first_tokens, int n_steps, int32_t* out_tokens) {
+    if (n_steps <= 0) { set_error("decode_greedy_chain: n_steps must be positive"); return -1; }
+    if (tp_comm || tap_on) {   // step by step: the one-shot status / the taps are per step
+      std::vector<uint32_t> tk(first_tokens, first_tokens + n);
+      for (int s = 0; s < n_steps; ++s) {
+        if (const int rc = decode(n, ids, tk.data(), out_tokens + (size_t)s * n, nullptr)) return rc;
+        for (int i = 0; i < n; ++i) tk[i] = (uint32_t)out_tokens[(size_t)s * n + i];
+      }
+      return 0;
+    }
+    if (!chain_ring[0]) {
+      for (int r = 0; r < kChainRing; ++r) {
+        PQ_HIP(hipHostMalloc(reinterpret_cast<void**>(&chain_ring[r]), ml.total, hipHostMallocDefault));
+        std::memset(chain_ring[r], 0, ml.total);
+        PQ_HIP(hipEventCreateWithFlags(&chain_ev[r], hipEventDisableTiming));
+      }
+    }
+    if ((size_t)n_steps * n > chain_tokens_cap) {
+      if (chain_tokens_host) PQ_HIP(hipHostFree(chain_tokens_host));
+      chain_tokens_cap = (size_t)n_steps * n;
+      PQ_HIP(hipHostMalloc(reinterpret_cast<void**>(&chain_tokens_host), chain_tokens_cap * 4, hipHostMallocDefault));
+    }
+    // a chain must be admissible as a whole before any request is advanced: positions and pages of ALL its steps
+    {
+      int pages_short = 0;
+      for (int i = 0; i < n; ++i) {
+        KvState* r = req(ids[i]);
+        if (!r) return -1;
+        if (r->seq_len + n_steps > max_pos) { set_error("position exceeds RoPE table"); return -1; }
+        pages_short += r->pages_short(r->seq_len + n_steps, layout.page_size);
+      }
+      if (pages_short > pool.available()) { set_error("KvState: out of pages"); return -2; }
+    }
+    std::vector<int> start_len(n);
+    for (int i = 0; i < n; ++i) start_len[i] = req(ids[i])->seq_len;
+    for (int attempt = 0;; ++attempt) {
+      bool any_oproj = false;
+      PQ_HIP(hipEventRecord(ev0, stream));
+      for (int s = 0; s < n_steps; ++s) {
+        const int slot = s % kChainRing;
+        if (s >= kChainRing) PQ_HIP(hipEventSynchronize(chain_ev[slot]));   // its upload has executed: safe to repack
+        StepCtx c;
+        if (const int rc = step_prepare(n, ids, s == 0 ? first_tokens : nullptr, &c, chain_ring[slot])) return rc;
+        PQ_HIP(hipEventRecord(chain_ev[slot], stream));
+        if (s > 0)   // the previous step's greedy tokens, device to device, into this step's token_ids slot
+          PQ_HIP(hipMemcpyAsync(meta_dev + ml.token_ids, tokens_out_d, (size_t)n * 4, hipMemcpyDeviceToDevice, stream));
+        any_oproj = any_oproj || step_uses_oproj_form(c);
+        if (step_launch(c)) return -1;
+        PQ_HIP(hipMemcpyAsync(chain_tokens_host + (size_t)s * n, tokens_out_d, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
+      }
+      PQ_HIP(hipEventRecord(ev1, stream));
+      if (any_oproj) PQ_HIP(hipMemcpyAsync(attn_status_host, attn_status, 4, hipMemcpyDeviceToHost, stream));
+      PQ_HIP(hipStreamSynchronize(stream));
+      hipEventElapsedTime(&last_step_ms, ev0, ev1);
+      last_step_ms /= (float)n_steps;
+      if (!(any_oproj && attn_status_host[0] != 0)) break;
+      if (oproj_fall_back()) return -1;
+      if (attempt >= 2) { set_error("decode chain still reported a fallback after every fused form was disabled"); return -4; }
+      for (int i = 0; i < n; ++i) req(ids[i])->seq_len = start_len[i];   // pages stay; every step recomputes from the embedding
+    }
+    std::memcpy(out_tokens, chain_tokens_host, (size_t)n_steps * n * 4);
+    last_logits = logits;
+    last_rows = n;
     return 0;
   }
 
@@ -1255,6 +1359,11 @@ struct Model {
     if (meta_host) hipHostFree(meta_host);
     if (tokens_out_host) hipHostFree(tokens_out_host);
     if (attn_status_host) hipHostFree(attn_status_host);
+    for (int r = 0; r < kChainRing; ++r) {
+      if (chain_ring[r]) hipHostFree(chain_ring[r]);
+      if (chain_ev[r]) hipEventDestroy(chain_ev[r]);
+    }
+    if (chain_tokens_host) hipHostFree(chain_tokens_host);
     if (ev0) hipEventDestroy(ev0);
     if (ev1) hipEventDestroy(ev1);
     if (stream) hipStreamDestroy(stream);
@@ -1387,6 +1496,10 @@ int32_t pegainfer_qwen3_unified_step(pegainfer_qwen3_t m, int32_t n_prefill, int
 int32_t pegainfer_qwen3_decode(pegainfer_qwen3_t m, int32_t n, const int32_t* ids, const uint32_t* token_ids,
                                int32_t* out_tokens, void* out_logits_host) {
   return M(m)->decode(n, ids, token_ids, out_tokens, out_logits_host);
+}
+int32_t pegainfer_qwen3_decode_greedy_chain(pegainfer_qwen3_t m, int32_t n_requests, const int32_t* request_ids,
+                                            const uint32_t* first_token_ids, int32_t n_steps, int32_t* out_tokens) {
+  return M(m)->decode_greedy_chain(n_requests, request_ids, first_token_ids, n_steps, out_tokens);
 }
 int32_t pegainfer_qwen3_sample(pegainfer_qwen3_t m, int32_t column, float temperature, int32_t top_k, float top_p,
                                float random_val, int32_t* out_token) {

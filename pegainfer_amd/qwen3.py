@@ -173,6 +173,16 @@ class Qwen3Engine:
                                                   lg.ctypes.data if return_logits else None), "decode")
         return (out, lg) if return_logits else out
 
+    def decode_greedy_chain(self, request_ids, first_tokens, n_steps):
+        """n_steps greedy decode steps enqueued back to back, one host synchronisation (pegainfer_qwen3_decode_greedy_chain).
+        -> int32 [n_steps, n_requests]"""
+        ids = _i32(request_ids)
+        toks = np.ascontiguousarray(first_tokens, dtype=np.uint32)
+        out = np.zeros((int(n_steps), len(ids)), dtype=np.int32)
+        self._chk(self.lib.pegainfer_qwen3_decode_greedy_chain(self.h, len(ids), ids.ctypes.data, toks.ctypes.data,
+                                                               int(n_steps), out.ctypes.data), "decode_greedy_chain")
+        return out
+
     def sample(self, column, temperature, top_k, top_p, random_val):
         out = ctypes.c_int32(0)
         self._chk(self.lib.pegainfer_qwen3_sample(self.h, column, temperature, top_k, top_p, random_val,
