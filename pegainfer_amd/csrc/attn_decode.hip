@@ -96,7 +96,8 @@ __device__ __forceinline__ void decode_attn_body(const DecodeAttnArgs& a, const 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();   // workgroup-uniform branch (sm_last): every merging wave's rows are acknowledged
         if (threadIdx.x == 0)
-          __hip_atomic_fetch_add(a.done_ctr + (size_t)kvh * a.done_stride, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_fetch_add(a.done_ctr + (size_t)(b * num_kv_heads + kvh) * a.done_stride, 1, __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
       }
       PK_ATTN_STAMP(a, slot, kvh, 6);
       if (a.trace && threadIdx.x == 0) a.trace[((size_t)slot * a.num_kv_heads + kvh) * 8 + 7] = 1ull;
@@ -200,7 +201,7 @@ struct OprojArgs {
 };
 constexpr int kOprojMaxRows = 12;  // rows per wave quad
 
-template <int GROUP>
+template <int GROUP, int NB>   // NB = requests of the step (1, or 2 since round 5: VERDICT r4 item 4a)
 __global__ __launch_bounds__(512) void attn_oproj_kernel(const DecodeAttnArgs a, const OprojArgs g) {
   constexpr int NW = 8;
   const int slot = (int)blockIdx.x % g.slots, kvh = (int)blockIdx.x / g.slots;   // the dim3(slots, kv_heads) order
@@ -209,7 +210,9 @@ __global__ __launch_bounds__(512) void attn_oproj_kernel(const DecodeAttnArgs a,
   unsigned long long* ot = a.trace ? a.trace + ((size_t)64 * a.num_kv_heads + blockIdx.x) * 8 : nullptr;
   // valid slots of request 0 = its partial count o_indptr[1] - o_indptr[0], words 6 / 7 of slot 0's record (a captured
   // graph replays this launch while the request grows: the split between the two roles is decided on the device)
-  const int valid_slots = a.slot_desc[7] - a.slot_desc[6];
+  // (NB == 2: the second request's chunks follow the first's, so the count is o_indptr[2] = word 7 of the record of the
+  // second request's first slot, which is slot o_indptr[1] = word 7 of slot 0's record)
+  const int valid_slots = NB == 1 ? a.slot_desc[7] - a.slot_desc[6] : a.slot_desc[8 * a.slot_desc[7] + 7];
   if (slot < valid_slots) {
     fused_decode_attn_workgroup<GROUP, true, NW>(a, slot, kvh);
     return;
@@ -254,8 +257,10 @@ __global__ __launch_bounds__(512) void attn_oproj_kernel(const DecodeAttnArgs a,
   // w4 needs exactly the attention rows of groups w4 and w4 + 4.  Every wave waits for ITS groups' arrival counters only
   // and takes its own 16 bytes of each straight from global memory (agent-scope loads; the LDS copy of the whole row, its
   // barrier and the wait for the slowest merger before anything starts are gone).  Same arithmetic, same bits.
-  const bool group_wait = GROUP == 4 && a.done_stride != 0;
-  u32x4 xg[2] = {u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};
+  const bool group_wait = GROUP == 4 && a.done_stride != 0;   // NB == 2 exists in this form only (launcher)
+  u32x4 xg[NB][2];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) xg[b][0] = xg[b][1] = u32x4{0u, 0u, 0u, 0u};
   if (group_wait) {
     if (threadIdx.x == 0) ok_flag = 1;
     // both arrivals first (lane 0 polls, bounded), then the wave's four 8-byte loads in one round trip
@@ -266,28 +271,36 @@ __global__ __launch_bounds__(512) void attn_oproj_kernel(const DecodeAttnArgs a,
       for (int u = 0; u < 2; ++u) {
         const int kb = w4 + u * 4;                       // K block = kv head group
         if (kb * 512 >= g.K) continue;
-        while (__hip_atomic_load(a.done_ctr + (size_t)kb * a.done_stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 1) {
-          if (wall_clock64() - t0 > 3000000ull) { ok = 0; break; }   // 30 ms
-          __builtin_amdgcn_s_sleep(1);
-        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+          while (__hip_atomic_load(a.done_ctr + (size_t)(b * a.num_kv_heads + kb) * a.done_stride, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT) < 1) {
+            if (wall_clock64() - t0 > 3000000ull) { ok = 0; break; }   // 30 ms
+            __builtin_amdgcn_s_sleep(1);
+          }
       }
       if (!ok && g.status) g.status[0] = 0x300u;       // the host re-runs the step on two launches; this launch's row is void
     }
     ok = __builtin_amdgcn_readfirstlane(ok);
     if (ot && threadIdx.x == 0) ot[2] = wall_clock64();
-    unsigned long long xl[2][2] = {{0ull, 0ull}, {0ull, 0ull}};
+    unsigned long long xl[NB][2][2];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int kk = (w4 + u * 4) * 512 + lane * 8;
-      if (kk >= g.K) continue;
-      const unsigned long long* src = reinterpret_cast<const unsigned long long*>(a.o_out + kk);
-      xl[u][0] = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      xl[u][1] = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    for (int b = 0; b < NB; ++b)
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
-      xg[u] = ok ? u32x4{(uint32_t)xl[u][0], (uint32_t)(xl[u][0] >> 32), (uint32_t)xl[u][1], (uint32_t)(xl[u][1] >> 32)}
-                 : u32x4{0u, 0u, 0u, 0u};
+      for (int u = 0; u < 2; ++u) {
+        xl[b][u][0] = xl[b][u][1] = 0ull;
+        const int kk = (w4 + u * 4) * 512 + lane * 8;
+        if (kk >= g.K) continue;
+        const unsigned long long* src = reinterpret_cast<const unsigned long long*>(a.o_out + (size_t)b * g.K + kk);
+        xl[b][u][0] = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        xl[b][u][1] = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        xg[b][u] = ok ? u32x4{(uint32_t)xl[b][u][0], (uint32_t)(xl[b][u][0] >> 32), (uint32_t)xl[b][u][1], (uint32_t)(xl[b][u][1] >> 32)}
+                      : u32x4{0u, 0u, 0u, 0u};
     if (ot && threadIdx.x == 0) ot[3] = wall_clock64();
   } else {
     if (threadIdx.x == 0) {
@@ -316,50 +329,54 @@ __global__ __launch_bounds__(512) void attn_oproj_kernel(const DecodeAttnArgs a,
   }
   for (int base = 0; base < rows_half; base += kOprojMaxRows) {
     if (base > 0) { __syncthreads(); request_rows(base); }   // `red` is reused; only the first pass was prefetched
-    // all kOprojMaxRows rows are computed, branch-free (rows past rows_half hold zeros / a previous pass: masked below)
-    float acc[kOprojMaxRows];
 #pragma unroll
-    for (int r = 0; r < kOprojMaxRows; ++r) acc[r] = 0.f;
+    for (int b = 0; b < NB; ++b) {
+      if (b > 0) __syncthreads();                            // `red` is reused by the next request's row
+      // all kOprojMaxRows rows are computed, branch-free (rows past rows_half hold zeros / a previous pass: masked below)
+      float acc[kOprojMaxRows];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int kk = (w4 + u * 4) * 512 + lane * 8;
-      const bool live = kk < g.K;
-      u32x4 xv = group_wait ? xg[u] : xs[live ? (kk >> 3) : 0];
-      if (!live) xv = u32x4{0u, 0u, 0u, 0u};
+      for (int r = 0; r < kOprojMaxRows; ++r) acc[r] = 0.f;
 #pragma unroll
-      for (int r = 0; r < kOprojMaxRows; ++r) acc[r] = dot8(wv[r][u], xv, acc[r]);
-    }
-    if (ot && threadIdx.x == 0 && base == 0) ot[5] = wall_clock64();
-    // The 64-lane sums through LDS instead of kOprojMaxRows dependent wave butterflies (1.0 us of the 2.2 us this phase
-    // took): every lane parks its partials, then 4 threads per (quad, row, K-split wave) line rebuild wave_sum's own
-    // addition tree - lane pairs, quads, 8, 16 inside a thread, the 16-lane rows across the 4 threads - and the four
-    // K-split waves are added in order: the bits of gemv_fused_kernel<.., KSPLIT = 4>.
+      for (int u = 0; u < 2; ++u) {
+        const int kk = (w4 + u * 4) * 512 + lane * 8;
+        const bool live = kk < g.K;
+        u32x4 xv = group_wait ? xg[b][u] : xs[live ? (kk >> 3) : 0];
+        if (!live) xv = u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int r = 0; r < kOprojMaxRows; ++r) red[(quad * kOprojMaxRows + r) * 4 + w4][lane] = acc[r];
-    __syncthreads();
-    if (threadIdx.x < 2 * kOprojMaxRows * 16) {
-      const int line = threadIdx.x >> 2, t = threadIdx.x & 3;
-      const float4* p = reinterpret_cast<const float4*>(&red[line][t * 16]);
-      const float4 c0 = p[0], c1 = p[1], c2 = p[2], c3 = p[3];
-      const float s0 = (c0.x + c0.y) + (c0.z + c0.w), s1 = (c1.x + c1.y) + (c1.z + c1.w);
-      const float s2 = (c2.x + c2.y) + (c2.z + c2.w), s3 = (c3.x + c3.y) + (c3.z + c3.w);
-      float v = (s0 + s1) + (s2 + s3);          // one 16-lane row of the wave
-      v += dpp_mov<kDppQuadXor1>(v);            // rows 16 apart
-      v += dpp_mov<kDppQuadXor2>(v);            // rows 32 apart: the wave's sum, in all 4 threads of the line
-      const int rowbase = lane & ~15;           // 16 threads = the 4 K-split lines of one (quad, row)
-      const float p0 = __shfl(v, rowbase, kWave), p1 = __shfl(v, rowbase + 4, kWave);
-      const float p2 = __shfl(v, rowbase + 8, kWave), p3 = __shfl(v, rowbase + 12, kWave);
-      const int qr = threadIdx.x >> 4, q = qr / kOprojMaxRows, r = qr % kOprojMaxRows;
-      const int row = (gi * 2 + q) * rows_half + base + r;
-      if ((threadIdx.x & 15) == 0 && base + r < rows_half && row < g.M) {
-        float y = p0;
-        y += p1;
-        y += p2;
-        y += p3;
-        g.Y[row] = f2bf(y);
+        for (int r = 0; r < kOprojMaxRows; ++r) acc[r] = dot8(wv[r][u], xv, acc[r]);
       }
+      if (ot && threadIdx.x == 0 && base == 0 && b == 0) ot[5] = wall_clock64();
+      // The 64-lane sums through LDS instead of kOprojMaxRows dependent wave butterflies (1.0 us of the 2.2 us this phase
+      // took): every lane parks its partials, then 4 threads per (quad, row, K-split wave) line rebuild wave_sum's own
+      // addition tree - lane pairs, quads, 8, 16 inside a thread, the 16-lane rows across the 4 threads - and the four
+      // K-split waves are added in order: the bits of gemv_fused_kernel<.., KSPLIT = 4>.
+#pragma unroll
+      for (int r = 0; r < kOprojMaxRows; ++r) red[(quad * kOprojMaxRows + r) * 4 + w4][lane] = acc[r];
+      __syncthreads();
+      if (threadIdx.x < 2 * kOprojMaxRows * 16) {
+        const int line = threadIdx.x >> 2, t = threadIdx.x & 3;
+        const float4* p = reinterpret_cast<const float4*>(&red[line][t * 16]);
+        const float4 c0 = p[0], c1 = p[1], c2 = p[2], c3 = p[3];
+        const float s0 = (c0.x + c0.y) + (c0.z + c0.w), s1 = (c1.x + c1.y) + (c1.z + c1.w);
+        const float s2 = (c2.x + c2.y) + (c2.z + c2.w), s3 = (c3.x + c3.y) + (c3.z + c3.w);
+        float v = (s0 + s1) + (s2 + s3);          // one 16-lane row of the wave
+        v += dpp_mov<kDppQuadXor1>(v);            // rows 16 apart
+        v += dpp_mov<kDppQuadXor2>(v);            // rows 32 apart: the wave's sum, in all 4 threads of the line
+        const int rowbase = lane & ~15;           // 16 threads = the 4 K-split lines of one (quad, row)
+        const float p0 = __shfl(v, rowbase, kWave), p1 = __shfl(v, rowbase + 4, kWave);
+        const float p2 = __shfl(v, rowbase + 8, kWave), p3 = __shfl(v, rowbase + 12, kWave);
+        const int qr = threadIdx.x >> 4, q = qr / kOprojMaxRows, r = qr % kOprojMaxRows;
+        const int row = (gi * 2 + q) * rows_half + base + r;
+        if ((threadIdx.x & 15) == 0 && base + r < rows_half && row < g.M) {
+          float y = p0;
+          y += p1;
+          y += p2;
+          y += p3;
+          g.Y[(size_t)b * g.M + row] = f2bf(y);
+        }
+      }
+      if (ot && threadIdx.x == 0 && base == 0 && b == 0) ot[6] = wall_clock64();
     }
-    if (ot && threadIdx.x == 0 && base == 0) ot[6] = wall_clock64();
   }
   if (ot && threadIdx.x == 0) ot[4] = wall_clock64();
 }
@@ -562,7 +579,7 @@ int32_t pegainfer_fused_decode_attention_oproj(
   const int grid = split_slots * num_kv_heads;
   const int n_gemv = min_padding_slots * num_kv_heads;   // the caller's plan never leaves fewer padding slots than this
   const int group = num_kv_heads > 0 ? num_qo_heads / num_kv_heads : 0;
-  if (head_dim != 128 || batch_size != 1 || !merge_counters || !done_counter || !o_proj || !attn_proj_out || !slot_desc ||
+  if (head_dim != 128 || batch_size < 1 || batch_size > 2 || !merge_counters || !done_counter || !o_proj || !attn_proj_out || !slot_desc ||
       split_slots < 1 || min_padding_slots < 1 || min_padding_slots >= split_slots || grid > cus || (q_dim % 2048) != 0 ||
       q_dim / 2048 > 2 /* 2 K blocks per wave */ || hidden < 1 || (group != 1 && group != 2 && group != 4) ||
       !host_aligned16(qkv) || !host_aligned16(kv_data) || !host_aligned16(slot_desc) || !host_aligned16(o_proj) ||
@@ -580,13 +597,18 @@ int32_t pegainfer_fused_decode_attention_oproj(
   // o_proj deal is one kv head group; PEGAINFER_OPROJ_GROUPWAIT=0 keeps the single counter + whole-row wait (A/B, same bits)
   static const bool gw = [] { const char* e = getenv("PEGAINFER_OPROJ_GROUPWAIT"); return !(e && e[0] == '0'); }();
   a.done_stride = gw && group == 4 && q_dim / 512 == num_kv_heads ? kMergeCtrStride : 0;
+  if (batch_size == 2 && a.done_stride == 0) return static_cast<int32_t>(hipErrorInvalidValue);   // two requests: per-group form only
   static const int hold = [] { const char* e = getenv("PEGAINFER_ATTN_OPROJ_HOLD"); return e && *e ? atoi(e) : 0; }();
-  OprojArgs g{o_proj, attn_proj_out, hidden, q_dim, split_slots, num_kv_heads, status, hold};
+  OprojArgs g{o_proj, attn_proj_out, hidden, q_dim, split_slots, num_kv_heads * batch_size, status, hold};
   hipStream_t s = as_stream(stream);
-  switch (group) {
-    case 1: attn_oproj_kernel<1><<<grid, 512, 0, s>>>(a, g); break;
-    case 2: attn_oproj_kernel<2><<<grid, 512, 0, s>>>(a, g); break;
-    default: attn_oproj_kernel<4><<<grid, 512, 0, s>>>(a, g); break;
+  if (batch_size == 2) {
+    attn_oproj_kernel<4, 2><<<grid, 512, 0, s>>>(a, g);
+  } else {
+    switch (group) {
+      case 1: attn_oproj_kernel<1, 1><<<grid, 512, 0, s>>>(a, g); break;
+      case 2: attn_oproj_kernel<2, 1><<<grid, 512, 0, s>>>(a, g); break;
+      default: attn_oproj_kernel<4, 1><<<grid, 512, 0, s>>>(a, g); break;
+    }
   }
   return static_cast<int32_t>(hipGetLastError());
 }

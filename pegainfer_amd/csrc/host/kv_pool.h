@@ -114,7 +114,13 @@ inline int oproj_fused_max_seq() {
   static const int v = [] { const char* e = getenv("PEGAINFER_OPROJ_MAX_SEQ"); const int x = e && *e ? atoi(e) : kOprojFusedMaxSeqDefault; return x < 128 ? 128 : x; }();
   return v;
 }
-// chunks a single request of up to kOprojFusedMaxSeq tokens is cut into (PEGAINFER_OPROJ_CHUNKS, A/B knob)
+// requests per step the fused attention + o_proj launch serves (PEGAINFER_OPROJ_MAX_BATCH=1 restores the round-4 form)
+constexpr int kOprojFusedMaxBatchDefault = 2;
+inline int oproj_fused_max_batch() {
+  static const int v = [] { const char* e = getenv("PEGAINFER_OPROJ_MAX_BATCH"); const int x = e && *e ? atoi(e) : kOprojFusedMaxBatchDefault; return x < 1 ? 1 : (x > 2 ? 2 : x); }();
+  return v;
+}
+// chunks the requests of such a step are cut into, all together (PEGAINFER_OPROJ_CHUNKS, A/B knob)
 inline int oproj_fused_max_chunks() {
   static const int c = [] { const char* e = getenv("PEGAINFER_OPROJ_CHUNKS"); const int v = e && *e ? atoi(e) : 18; return v < 2 ? 2 : (v > 30 ? 30 : v); }();
   return c;
@@ -146,8 +152,9 @@ inline SplitPlan make_split_plan(int policy, const std::vector<int>& seq_lens, i
     // tokens in one tile per wave) - the other slots of the launch grid stay
     // padding, and the fused attention + o_proj launch gives their workgroups the o_proj rows (attn_oproj_kernel)
     const int grid_slots = want;   // the launch grid keeps its one-workgroup-per-CU size
-    if (fused_oproj_usable && pairs <= num_kv_heads && max_seq <= oproj_fused_max_seq() && target_env <= 0)
-      want = std::min(want, oproj_fused_max_chunks());
+    // (round 5) two requests share the same budget: 18 / 2 = 9 chunks each, the launch grid stays 2 x 16 slots x kv heads
+    if (fused_oproj_usable && pairs <= oproj_fused_max_batch() * num_kv_heads && max_seq <= oproj_fused_max_seq() && target_env <= 0)
+      want = std::min(want, std::max(1, oproj_fused_max_chunks() / std::max(1, padded_bs)));
     int chunk = (max_seq + want - 1) / want;
     chunk = std::max(64, (chunk + 15) / 16 * 16);
     p.chunk = chunk;

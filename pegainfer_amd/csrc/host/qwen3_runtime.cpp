@@ -245,7 +245,7 @@ struct Model {
     if (dalloc(&meta_dev, ml.total)) return -1;
     PQ_HIP(hipHostMalloc(reinterpret_cast<void**>(&tokens_out_host), bs * 4, hipHostMallocDefault));
     if (attn_oproj) {
-      kDoneInts = (size_t)Hkv * 32;
+      kDoneInts = (size_t)2 * Hkv * 32;   // one arrival counter per (request <= 2, kv head group), a cache line each
       if (dalloc(&attn_done, (size_t)L * kDoneInts) || dalloc(&attn_status, 4)) return -1;
       PQ_HIP(hipMemsetAsync(attn_done, 0, (size_t)L * kDoneInts * sizeof(int32_t), stream));
       PQ_HIP(hipMemsetAsync(attn_status, 0, 16, stream));
@@ -635,7 +635,7 @@ struct Model {
   // logits are bit-identical to decode_mode 0 (tests/test_gpu_fused.py).
   int decode_kernels_fused(int bs, bool split, int split_slots) {
     if (fused_merge && split) PQ_HIP(hipMemsetAsync(merge_ctr, 0, (size_t)max_bs * Hkv * 32 * sizeof(int32_t), stream));
-    oproj_step = attn_oproj && attn_done && fused_merge && split && bs == 1 && !tp_comm && D == 128 && oproj_plan;
+    oproj_step = attn_oproj && attn_done && fused_merge && split && bs <= pq::oproj_fused_max_batch() && !tp_comm && D == 128 && oproj_plan;
     if (oproj_step) PQ_HIP(hipMemsetAsync(attn_done, 0, (size_t)L * kDoneInts * sizeof(int32_t), stream));
     if (embedding_batched_cuda(embed, md<uint32_t>(ml.token_ids), hidden, H, bs, S())) {
       set_error("embedding_batched_cuda failed");
@@ -793,8 +793,13 @@ struct Model {
     }
     const bool oproj_usable = attn_oproj && attn_done && fused_merge && !tp_comm && decode_mode >= 1 && D == 128 && oproj_shape_ok;
     const SplitPlan plan = make_split_plan(split_policy, seq_lens, padded, Hkv, oproj_usable);
-    oproj_plan = oproj_usable && split_policy == 1 && padded == 1 && plan.use_split && seq_lens[0] <= pq::oproj_fused_max_seq() &&
-                 plan.slots > pq::oproj_fused_max_chunks();
+    int max_seq = 0;
+    for (int v : seq_lens) max_seq = std::max(max_seq, v);
+    // every column of the bucket must be a real request: a padding column's merge would never arrive on its counters
+    oproj_plan = oproj_usable && split_policy == 1 && padded <= pq::oproj_fused_max_batch() && n == padded && plan.use_split &&
+                 max_seq <= pq::oproj_fused_max_seq() && plan.slots > pq::oproj_fused_max_chunks();
+    for (int i = 0; i < n && oproj_plan; ++i)   // ... and must own at least one chunk
+      if (plan.o_indptr[i + 1] <= plan.o_indptr[i]) oproj_plan = false;
     std::memcpy(hb(ml.split_request_indices), plan.request_indices.data(), plan.slots * 4);
     std::memcpy(hb(ml.split_kv_tile_indices), plan.kv_tile_indices.data(), plan.slots * 4);
     reinterpret_cast<int32_t*>(hb(ml.split_kv_chunk_size))[0] = plan.chunk;
@@ -828,12 +833,12 @@ struct Model {
     return 0;
   }
   bool step_uses_oproj_form(const StepCtx& c) const {
-    return attn_status && attn_oproj && oproj_plan && c.padded == 1 && c.split && decode_mode >= 1 && !tp_comm;
+    return attn_status && attn_oproj && oproj_plan && c.padded <= pq::oproj_fused_max_batch() && c.split && decode_mode >= 1 && !tp_comm;
   }
   int step_launch(const StepCtx& c) {
     if (enable_graph && !tap_on) {
       const int bi = bucket_index(c.padded);
-      const int gv = !c.split ? 0 : (oproj_plan && attn_oproj && c.padded == 1 && !tp_comm && decode_mode >= 1 ? 2 : 1);
+      const int gv = !c.split ? 0 : (oproj_plan && attn_oproj && c.padded <= pq::oproj_fused_max_batch() && !tp_comm && decode_mode >= 1 ? 2 : 1);
       hipGraphExec_t& exec = graphs[bi][gv];
       if (!exec) {  // capture once (cuda_graph.rs:36-55), thread-local mode
         hipGraph_t graph = nullptr;
