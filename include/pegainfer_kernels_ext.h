@@ -113,6 +113,10 @@ int32_t pegainfer_fused_decode_attention(const Half* qkv, Half* output, const Ha
  * attn_proj_out [hidden], status (optional) receives 0x300 when the bounded wait for the attention rows expired.
  * Returns hipErrorInvalidValue (1) when the shape does not fit; the caller then issues the two launches. */
 int32_t pegainfer_fused_decode_attention_oproj(const Half* qkv, Half* attn_out, const Half* kv_data, int64_t k_offset_elems, int64_t v_offset_elems, const int32_t* page_indices, const int32_t* page_indptr, const int32_t* last_page_len_d, const int32_t* positions, const Half* q_norm_weight, const Half* k_norm_weight, const Half* cos_cache, const Half* sin_cache, float rms_eps, const int32_t* split_request_indices, const int32_t* split_kv_tile_indices, const int32_t* split_kv_chunk_size_ptr, const int32_t* split_o_indptr, const uint8_t* split_block_valid_mask, Half* tmp_v, float* tmp_s, int32_t num_qo_heads, int32_t num_kv_heads, int32_t head_dim, int32_t page_size, int32_t batch_size, int32_t split_slots, int32_t min_padding_slots, int64_t stride_page, float sm_scale, const int32_t* slot_desc, int32_t* merge_counters, const Half* o_proj, Half* attn_proj_out, int32_t hidden, int32_t* done_counter, uint32_t* status, pegainfer_stream_t stream);
+/* 1 when a step of batch_size (1 or 2) requests with this configuration can take pegainfer_fused_decode_attention_oproj
+ * (the launcher's own shape test, without pointers): a host runtime asks once at model creation and plans its KV chunks
+ * for the form from the first step on. */
+int32_t pegainfer_fused_decode_attention_oproj_supported(int32_t num_qo_heads, int32_t num_kv_heads, int32_t head_dim, int32_t hidden, int32_t split_slots, int32_t min_padding_slots, int32_t batch_size);
 
 /* Debug aid (not in ffi.rs): buf = device array of (workgroups per launch, <= 4096) * 8 uint64, or NULL.  Every later
  * dot2-GEMV launch stamps it with the 100 MHz wall clock per workgroup: [0] entry, [1] x staged, [2] first weight block

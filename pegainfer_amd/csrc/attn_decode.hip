@@ -560,6 +560,33 @@ int32_t pegainfer_fused_decode_attention(
 // launch (the host runtime keeps one per layer and clears them once per step).  Returns hipErrorInvalidValue when the
 // shape does not fit the form (then the caller runs the two stand-alone launches): batch_size != 1, more attention
 // workgroups than CUs, q_dim not a multiple of 2048 or > 8192, more than 10 o_proj rows per CU.
+// Shape test of the fused attention + o_proj launch, by configuration only (no pointers): a host runtime asks ONCE, at model
+// creation, whether its steps of `batch_size` requests can take the form, and plans its KV chunks accordingly from the first
+// step on (before round 5 the launcher's refusal inside the first graph capture was the only way to find out).
+static bool oproj_shape_fits(int num_qo_heads, int num_kv_heads, int head_dim, int hidden, int split_slots, int min_padding_slots,
+                             int batch_size) {
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+    return n;
+  }();
+  const int q_dim = num_qo_heads * head_dim;
+  const int grid = split_slots * num_kv_heads;
+  const int n_gemv = min_padding_slots * num_kv_heads;
+  const int group = num_kv_heads > 0 ? num_qo_heads / num_kv_heads : 0;
+  if (head_dim != 128 || batch_size < 1 || batch_size > 2 || split_slots < 1 || min_padding_slots < 1 ||
+      min_padding_slots >= split_slots || grid > cus || (q_dim % 2048) != 0 || q_dim / 2048 > 2 /* 2 K blocks per wave */ ||
+      hidden < 1 || (group != 1 && group != 2 && group != 4))
+    return false;
+  if (n_gemv < 1 || ceil_div(hidden, 2 * n_gemv) > kOprojMaxRows) return false;
+  if (batch_size == 2 && !(group == 4 && q_dim / 512 == num_kv_heads)) return false;   // two requests: per-group form only
+  return true;
+}
+int32_t pegainfer_fused_decode_attention_oproj_supported(int32_t num_qo_heads, int32_t num_kv_heads, int32_t head_dim, int32_t hidden,
+                                                         int32_t split_slots, int32_t min_padding_slots, int32_t batch_size) {
+  return oproj_shape_fits(num_qo_heads, num_kv_heads, head_dim, hidden, split_slots, min_padding_slots, batch_size) ? 1 : 0;
+}
+
 int32_t pegainfer_fused_decode_attention_oproj(
     const Half* qkv, Half* attn_out, const Half* kv_data, int64_t k_offset_elems, int64_t v_offset_elems,
     const int32_t* page_indices, const int32_t* page_indptr, const int32_t* last_page_len_d,
@@ -570,22 +597,13 @@ int32_t pegainfer_fused_decode_attention_oproj(
     int32_t head_dim, int32_t page_size, int32_t batch_size, int32_t split_slots, int32_t min_padding_slots,
     int64_t stride_page, float sm_scale, const int32_t* slot_desc, int32_t* merge_counters, const Half* o_proj,
     Half* attn_proj_out, int32_t hidden, int32_t* done_counter, uint32_t* status, pegainfer_stream_t stream) {
-  static const int cus = [] {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
-    return n;
-  }();
   const int q_dim = num_qo_heads * head_dim;
   const int grid = split_slots * num_kv_heads;
-  const int n_gemv = min_padding_slots * num_kv_heads;   // the caller's plan never leaves fewer padding slots than this
   const int group = num_kv_heads > 0 ? num_qo_heads / num_kv_heads : 0;
-  if (head_dim != 128 || batch_size < 1 || batch_size > 2 || !merge_counters || !done_counter || !o_proj || !attn_proj_out || !slot_desc ||
-      split_slots < 1 || min_padding_slots < 1 || min_padding_slots >= split_slots || grid > cus || (q_dim % 2048) != 0 ||
-      q_dim / 2048 > 2 /* 2 K blocks per wave */ || hidden < 1 || (group != 1 && group != 2 && group != 4) ||
-      !host_aligned16(qkv) || !host_aligned16(kv_data) || !host_aligned16(slot_desc) || !host_aligned16(o_proj) ||
-      !host_aligned16(attn_out))
+  if (!oproj_shape_fits(num_qo_heads, num_kv_heads, head_dim, hidden, split_slots, min_padding_slots, batch_size) ||
+      !merge_counters || !done_counter || !o_proj || !attn_proj_out || !slot_desc || !host_aligned16(qkv) ||
+      !host_aligned16(kv_data) || !host_aligned16(slot_desc) || !host_aligned16(o_proj) || !host_aligned16(attn_out))
     return static_cast<int32_t>(hipErrorInvalidValue);
-  if (n_gemv < 1 || ceil_div(hidden, 2 * n_gemv) > kOprojMaxRows) return static_cast<int32_t>(hipErrorInvalidValue);
   DecodeAttnArgs a;
   fill_args(a, nullptr, attn_out, kv_data, k_offset_elems, v_offset_elems, page_indices, page_indptr, last_page_len_d,
             split_request_indices, split_kv_tile_indices, split_kv_chunk_size_ptr, split_block_valid_mask, tmp_v, tmp_s,
@@ -596,8 +614,7 @@ int32_t pegainfer_fused_decode_attention_oproj(
   // per-head-group arrival counters (done_counter = num_kv_heads ints, kMergeCtrStride apart) when a K block of the
   // o_proj deal is one kv head group; PEGAINFER_OPROJ_GROUPWAIT=0 keeps the single counter + whole-row wait (A/B, same bits)
   static const bool gw = [] { const char* e = getenv("PEGAINFER_OPROJ_GROUPWAIT"); return !(e && e[0] == '0'); }();
-  a.done_stride = gw && group == 4 && q_dim / 512 == num_kv_heads ? kMergeCtrStride : 0;
-  if (batch_size == 2 && a.done_stride == 0) return static_cast<int32_t>(hipErrorInvalidValue);   // two requests: per-group form only
+  a.done_stride = (gw || batch_size == 2) && group == 4 && q_dim / 512 == num_kv_heads ? kMergeCtrStride : 0;
   static const int hold = [] { const char* e = getenv("PEGAINFER_ATTN_OPROJ_HOLD"); return e && *e ? atoi(e) : 0; }();
   OprojArgs g{o_proj, attn_proj_out, hidden, q_dim, split_slots, num_kv_heads * batch_size, status, hold};
   hipStream_t s = as_stream(stream);

@@ -114,7 +114,8 @@ struct Model {
   size_t kDoneInts = 0;                       // Hkv x 32 ints per layer (set in init)
   uint32_t *attn_status = nullptr, *attn_status_host = nullptr;
   bool oproj_step = false;   // the step being recorded / run uses the fused launch
-  bool oproj_shape_ok = true;   // cleared the first time the fused launcher refuses the model's shape (e.g. hidden 4096)
+  bool oproj_shape_ok = true;   // the model's shape fits the fused launch at bs 1 (asked at init; e.g. hidden 4096 does not)
+  bool oproj_shape_ok2 = true;  // ... and at bs 2
   bool oproj_plan = false;   // this step's split plan keeps the padding slots the fused launch needs (single request, <= 2304 tokens)
   int oproj_fallbacks = 0;
   // sampling scratch (ops/sampling.rs)
@@ -244,6 +245,12 @@ struct Model {
     std::memset(meta_host, 0, ml.total);
     if (dalloc(&meta_dev, ml.total)) return -1;
     PQ_HIP(hipHostMalloc(reinterpret_cast<void**>(&tokens_out_host), bs * 4, hipHostMallocDefault));
+    {  // the fused attention + o_proj form by configuration: the grid of a step is (256 / Hkv) slots x Hkv workgroups
+      const int slots1 = std::max(1, 256 / std::max(1, Hkv)), slots2 = 2 * std::max(1, 256 / std::max(1, 2 * Hkv));
+      oproj_shape_ok = pegainfer_fused_decode_attention_oproj_supported(Hq, Hkv, D, H, slots1, slots1 - pq::oproj_fused_max_chunks(), 1) == 1;
+      oproj_shape_ok2 = pq::oproj_fused_max_batch() >= 2 &&
+                        pegainfer_fused_decode_attention_oproj_supported(Hq, Hkv, D, H, slots2, slots2 - pq::oproj_fused_max_chunks(), 2) == 1;
+    }
     if (attn_oproj) {
       kDoneInts = (size_t)2 * Hkv * 32;   // one arrival counter per (request <= 2, kv head group), a cache line each
       if (dalloc(&attn_done, (size_t)L * kDoneInts) || dalloc(&attn_status, 4)) return -1;
@@ -662,7 +669,7 @@ struct Model {
             attn_proj, H, attn_done + (size_t)li * kDoneInts, attn_status, S());
         if (r2 == 0) fused_o = true;
         else if (r2 != (int)hipErrorInvalidValue) rc = r2;
-        else { oproj_step = false; oproj_shape_ok = false; }   // the shape does not fit the form: two launches from here on, and no chunk cap in later plans
+        else { oproj_step = false; oproj_shape_ok = oproj_shape_ok2 = false; }   // cannot happen after init's shape test; kept as the safe path
       }
       if (!rc && !fused_o)
         rc = pegainfer_fused_decode_attention(
@@ -791,7 +798,8 @@ struct Model {
       ri[i] = i;
       kti[i] = 0;
     }
-    const bool oproj_usable = attn_oproj && attn_done && fused_merge && !tp_comm && decode_mode >= 1 && D == 128 && oproj_shape_ok;
+    const bool oproj_usable = attn_oproj && attn_done && fused_merge && !tp_comm && decode_mode >= 1 && D == 128 &&
+                              (padded == 1 ? oproj_shape_ok : padded == 2 ? oproj_shape_ok2 : false);
     const SplitPlan plan = make_split_plan(split_policy, seq_lens, padded, Hkv, oproj_usable);
     int max_seq = 0;
     for (int v : seq_lens) max_seq = std::max(max_seq, v);

@@ -227,11 +227,15 @@ def real2():
         rng = np.random.default_rng(77)
         work = {
             "bs1": [PROMPT_1024],
-            "bs2": [PROMPT_1024, _prompt(rng, 777)],       # round 5: two requests in the fused attention + o_proj launch
+            # round 5: two requests in the fused attention + o_proj launch.  "bs2": <= 9 x 64 tokens each, where the capped
+            # plan of the fused form (9 chunks per request) and the un-capped plan of decode_mode 0 (16) cut the KV into the
+            # SAME 64-token chunks, so the two modes are comparable bit for bit; "bs2long": 128-token chunks, vs the oracle
+            "bs2": [_prompt(rng, 540), _prompt(rng, 300)],
+            "bs2long": [PROMPT_1024, _prompt(rng, 777)],
             "bs8": [_prompt(rng, n) for n in (700, 333, 129, 64, 17, 16, 5, 1)],
             "bs32": [_prompt(rng, n) for n in [600] + rng.integers(1, 97, 31).tolist()],
         }
-        steps = {"bs1": N_DECODE, "bs2": 6, "bs8": 4, "bs32": 2}
+        steps = {"bs1": N_DECODE, "bs2": 6, "bs2long": 4, "bs8": 4, "bs32": 2}
         ref = {}
         for name, prompts in work.items():
             orc = Qwen3Oracle(cfg, w, num_pages=512, rope_positions=4096)
@@ -303,7 +307,7 @@ def test_real_dims_bs1_prefill_1024_then_decode(built_libs, real2, mode, policy,
         assert np.array_equal(got.argmax(-1)[strong], want.argmax(-1)[strong])
 
 
-@pytest.mark.parametrize("name,mode,policy", [("bs2", 1, 1), ("bs2", 1, 0), ("bs8", 0, 1), ("bs8", 1, 1), ("bs8", 1, 0), ("bs32", 0, 1), ("bs32", 1, 1)])
+@pytest.mark.parametrize("name,mode,policy", [("bs2", 1, 1), ("bs2long", 1, 1), ("bs2long", 1, 0), ("bs8", 0, 1), ("bs8", 1, 1), ("bs8", 1, 0), ("bs32", 0, 1), ("bs32", 1, 1)])
 def test_real_dims_batched_prefill_and_decode(built_libs, real2, name, mode, policy):
     """bs 8 = skinny-MFMA fused decode family, bs 32 = the 7-launch mid-batch layer (decode_mode 1) or the reference
     op sequence over tiled GEMMs (decode_mode 0); ragged prompt lengths 1..700."""
@@ -334,9 +338,8 @@ def test_real_dims_fused_path_bit_identical_to_reference_sequence(built_libs, re
 def test_real_dims_two_requests_fused_attention_oproj(built_libs, real2, monkeypatch):
     """bs 2 at the real widths (round 5): attention + o_proj of BOTH requests in one launch (nine KV
     chunks each, the padding-slot workgroups hold the o_proj rows, per-(request, head group) arrival counters) must give
-    the bits of the round-4 form (two launches, PEGAINFER_OPROJ_MAX_BATCH=1 ... which a fresh engine reads at plan time
-    - so the knob is checked through its effect: the decode step got FASTER without changing a bit), of each request
-    decoded alone (batch == sequential, batch_decode.rs:505-606) and of the reference op sequence; graph and eager."""
+    the bits of the reference op sequence on the same plan (decode_mode 0) and of the eager launches; each request decoded
+    alone agrees within the bf16 bound (batch_decode.rs:505-606 is a token-level check in the reference too)."""
     _, state, ref = real2
     case = ref["bs2"]
     runs = {}
@@ -347,14 +350,18 @@ def test_real_dims_two_requests_fused_attention_oproj(built_libs, real2, monkeyp
         assert all(p == 1 for p in paths), tag          # the KV is partitioned: the fused launch's plan
         eng.close()
     assert np.array_equal(runs["fused"], runs["reference"]) and np.array_equal(runs["fused"], runs["eager"])
-    # each request alone, teacher-forced on the same tokens: the same bits as its column of the batch
+    # each request alone, teacher-forced on the same tokens: its column of the batch within the bf16 bound (NOT bitwise: a
+    # lone request is cut into 13-16 chunks of 64 tokens, in the pair into 7-8 of 128 - other partials, other roundings;
+    # bit-exact batch == single holds where the KV is not partitioned, tests/test_gpu_model.py)
+    scale = float(np.abs(case["decode"]).max())
     for col in range(2):
         eng = _engine(state, decode_mode=1, split_policy=1, max_batch_size=2)
         rid = eng.new_request()
         eng.prefill([rid], [case["prompts"][col]])
         for step in range(case["decode"].shape[0]):
             _, lg = eng.decode([rid], case["tokens"][step][col:col + 1], return_logits=True)
-            assert np.array_equal(lg[0], runs["fused"][step][col]), (col, step)
+            d = np.abs(bf16_from_bits(lg[0]) - bf16_from_bits(runs["fused"][step][col])).max()
+            assert d <= REL_MAX * scale, (col, step, float(d), scale)
         eng.close()
 
 
