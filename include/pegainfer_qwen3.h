@@ -113,8 +113,8 @@ int32_t pegainfer_qwen3_unified_step(pegainfer_qwen3_t m, int32_t n_prefill, int
 int32_t pegainfer_qwen3_decode(pegainfer_qwen3_t m, int32_t n_requests, const int32_t* request_ids,
                                const uint32_t* token_ids, int32_t* out_tokens, void* out_logits_host);
 /* n_steps GREEDY decode steps of one batch enqueued back to back with ONE host synchronisation at the end: the token of
- * step s never leaves the device (batched top-1 inside the captured graph -> a 4 * n-byte device copy into step s + 1's
- * metadata block), the per-step metadata blocks go through a ring of pinned buffers.  Same graphs and kernels, same bits
+ * step s never leaves the device (the batched top-1 inside the captured graph writes it into the token_ids slot of the
+ * device metadata block, which step s + 1's upload leaves alone), the per-step metadata blocks go through a ring of pinned buffers.  Same graphs and kernels, same bits
  * as n_steps calls of pegainfer_qwen3_decode (the reference's loop, executor.rs:541-640, synchronises and samples on the
  * host every step: 30-65 us of an MI355X's 2 ms step).  out_tokens [n_steps][n_requests].  Greedy only - temperature
  * sampling, stop tokens and logprobs need the host between steps.  The chain is validated as a whole (positions, pages)

@@ -198,6 +198,8 @@ struct OprojArgs {
   uint32_t* status;
   int hold_ticks;                  // 100 MHz ticks the o_proj workgroups hold their burst back (the attention's first
                                    // dependent loads - slot record, q row, page ids, K / V tile - go first)
+  unsigned long long wait_ticks;   // bound of the o_proj workgroups' wait for the attention rows (30 ms; PEGAINFER_OPROJ_WAIT_TICKS
+                                   // = 1 makes it expire at once: the test hook of the host's re-run path)
 };
 constexpr int kOprojMaxRows = 12;  // rows per wave quad
 
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(512) void attn_oproj_kernel(const DecodeAttnArgs a,
         for (int b = 0; b < NB; ++b)
           while (__hip_atomic_load(a.done_ctr + (size_t)(b * a.num_kv_heads + kb) * a.done_stride, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT) < 1) {
-            if (wall_clock64() - t0 > 3000000ull) { ok = 0; break; }   // 30 ms
+            if (wall_clock64() - t0 > g.wait_ticks) { ok = 0; break; }   // 30 ms
             __builtin_amdgcn_s_sleep(1);
           }
       }
@@ -307,7 +309,7 @@ __global__ __launch_bounds__(512) void attn_oproj_kernel(const DecodeAttnArgs a,
       const unsigned long long t0 = wall_clock64();
       int ok = 1;
       while (__hip_atomic_load(a.done_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < g.done_target) {
-        if (wall_clock64() - t0 > 3000000ull) { ok = 0; break; }   // 30 ms
+        if (wall_clock64() - t0 > g.wait_ticks) { ok = 0; break; }   // 30 ms
         __builtin_amdgcn_s_sleep(1);
       }
       ok_flag = ok;
@@ -616,7 +618,8 @@ int32_t pegainfer_fused_decode_attention_oproj(
   static const bool gw = [] { const char* e = getenv("PEGAINFER_OPROJ_GROUPWAIT"); return !(e && e[0] == '0'); }();
   a.done_stride = (gw || batch_size == 2) && group == 4 && q_dim / 512 == num_kv_heads ? kMergeCtrStride : 0;
   static const int hold = [] { const char* e = getenv("PEGAINFER_ATTN_OPROJ_HOLD"); return e && *e ? atoi(e) : 0; }();
-  OprojArgs g{o_proj, attn_proj_out, hidden, q_dim, split_slots, num_kv_heads * batch_size, status, hold};
+  static const unsigned long long wait_ticks = [] { const char* e = getenv("PEGAINFER_OPROJ_WAIT_TICKS"); return e && *e ? strtoull(e, nullptr, 10) : 3000000ull; }();
+  OprojArgs g{o_proj, attn_proj_out, hidden, q_dim, split_slots, num_kv_heads * batch_size, status, hold, wait_ticks};
   hipStream_t s = as_stream(stream);
   if (batch_size == 2) {
     attn_oproj_kernel<4, 2><<<grid, 512, 0, s>>>(a, g);

@@ -219,7 +219,7 @@ struct Model {
         dalloc(&mlp_act, bs * I) || dalloc(&mlp_out, bs * H) || dalloc(&hidden, bs * H) ||
         dalloc(&hidden2, bs * H) || dalloc(&qkv_out, bs * (size_t)(q_dim + 2 * kv_dim)) ||
         dalloc(&logits, bs * (size_t)V) || dalloc(&split_tmp_v, slots * q_dim) || dalloc(&split_tmp_s, slots * Hq) ||
-        dalloc(&tokens_out_d, bs) || dalloc(&top1_state, bs * 16) || dalloc(&merge_ctr, bs * (size_t)Hkv * 32) || dalloc(&probs_scratch, (size_t)V) ||
+        dalloc(&top1_state, bs * 16) || dalloc(&merge_ctr, bs * (size_t)Hkv * 32) || dalloc(&probs_scratch, (size_t)V) ||
         dalloc(&top1_value, 1) || dalloc(&row_states, 1024 * 1024) || dalloc(&valid_scratch, 1) ||
         dalloc(&sample_out_d, 1))
       return -1;
@@ -244,6 +244,10 @@ struct Model {
     PQ_HIP(hipHostMalloc(reinterpret_cast<void**>(&meta_host), ml.total, hipHostMallocDefault));
     std::memset(meta_host, 0, ml.total);
     if (dalloc(&meta_dev, ml.total)) return -1;
+    // The greedy tokens of a step are written INTO the metadata block's token_ids slot (same 4 * bs bytes, read by the
+    // embedding at the head of the step, written by the batched top-1 at its tail): a chained step needs no copy to feed
+    // the next one - its metadata upload simply starts behind that slot.
+    tokens_out_d = reinterpret_cast<int32_t*>(meta_dev + ml.token_ids);
     PQ_HIP(hipHostMalloc(reinterpret_cast<void**>(&tokens_out_host), bs * 4, hipHostMallocDefault));
     {  // the fused attention + o_proj form by configuration: the grid of a step is (256 / Hkv) slots x Hkv workgroups
       const int slots1 = std::max(1, 256 / std::max(1, Hkv)), slots2 = 2 * std::max(1, 256 / std::max(1, 2 * Hkv));
@@ -738,6 +742,8 @@ struct Model {
   // step_launch (replay - or capture - the (bucket, path) graph).  decode() runs ONE step and synchronises;
   // decode_greedy_chain() enqueues n steps back to back (below).
   struct StepCtx { int n = 0, padded = 0, plan_slots = 0; bool split = false; std::vector<KvState*> st; };
+  // token_ids == nullptr: a chained step - the previous step's greedy tokens already sit in the device block's token_ids
+  // slot, the upload starts behind it
   int step_prepare(int n, const int32_t* ids, const uint32_t* token_ids, StepCtx* c, uint8_t* host_block) {
     if (!finalized) { set_error("model not finalized"); return -1; }
     if (tp_failed) { set_error("tensor-parallel group failed in an earlier step (bounded wait expired): rebuild the model and its communicator"); return -5; }
@@ -834,8 +840,8 @@ struct Model {
         r[6] = plan.o_indptr[b]; r[7] = plan.o_indptr[b + 1];   // partial slots of this request (in-launch merge)
       }
     }
-    const size_t upload = ml.page_indices + (size_t)np * 4;
-    PQ_HIP(hipMemcpyAsync(meta_dev, host_block, upload, hipMemcpyHostToDevice, stream));
+    const size_t upload = ml.page_indices + (size_t)np * 4, from = token_ids ? 0 : ml.positions;
+    PQ_HIP(hipMemcpyAsync(meta_dev + from, host_block + from, upload - from, hipMemcpyHostToDevice, stream));
     c->n = n; c->padded = padded; c->split = plan.use_split; c->plan_slots = plan.slots;
     last_path = c->split ? 1 : 0;
     return 0;
@@ -886,6 +892,8 @@ struct Model {
     // with the same bits, so the request state the caller sees (seq_len advanced, pages held) matches the tokens it gets
     // back.  The loop runs until an attempt took no fallback (every fallback disables its cause for good), capped at 3.
     for (int attempt = 0;; ++attempt) {
+      if (attempt > 0)   // the failed attempt's top-1 wrote ITS tokens into the block's token_ids slot: put the inputs back
+        PQ_HIP(hipMemcpyAsync(meta_dev + ml.token_ids, meta_host + ml.token_ids, (size_t)c.padded * 4, hipMemcpyHostToDevice, stream));
       PQ_HIP(hipEventRecord(ev0, stream));
       const bool oproj_check = step_uses_oproj_form(c);
       if (step_launch(c)) return -1;
@@ -924,8 +932,8 @@ struct Model {
   // n_steps GREEDY decode steps of the same batch enqueued back to back, ONE host synchronisation at the end (round 5).
   // A synchronous step leaves the GPU idle from "tokens on the host" to "next graph launched" (metadata packing, two
   // runtime calls, the caller's own loop: 30-65 us of a 2 ms step).  Greedy needs no host in between: the token of step s
-  // is already on the device (batched top-1 inside the graph), so step s + 1's metadata block is uploaded and a 4 * n-byte
-  // device-to-device copy drops those tokens into its token_ids slot before the graph replays.  Metadata blocks travel
+  // is already on the device - the batched top-1 inside the graph writes it into the metadata block's token_ids slot, which
+  // step s + 1's upload leaves alone - so the next graph replays as soon as its (token-independent) metadata landed.  Metadata blocks travel
   // through a ring of pinned buffers (the upload of step s must have executed before its buffer is repacked: one event per
   // ring slot).  Same graphs, same kernels, same bits as n_steps calls of decode() (tested); sampling with temperature,
   // stop tokens and logprobs need the host between steps and keep using decode().
@@ -980,8 +988,6 @@ struct Model {
         StepCtx c;
         if (const int rc = step_prepare(n, ids, s == 0 ? first_tokens : nullptr, &c, chain_ring[slot])) return rc;
         PQ_HIP(hipEventRecord(chain_ev[slot], stream));
-        if (s > 0)   // the previous step's greedy tokens, device to device, into this step's token_ids slot
-          PQ_HIP(hipMemcpyAsync(meta_dev + ml.token_ids, tokens_out_d, (size_t)n * 4, hipMemcpyDeviceToDevice, stream));
         any_oproj = any_oproj || step_uses_oproj_form(c);
         if (step_launch(c)) return -1;
         PQ_HIP(hipMemcpyAsync(chain_tokens_host + (size_t)s * n, tokens_out_d, (size_t)n * 4, hipMemcpyDeviceToHost, stream));

@@ -12,6 +12,8 @@
 The oracle GEMM accumulates in fp32 here (ops.GEMM_ACCUM, plain sgemm - what cuBLAS COMPUTE_32F does);
 float64 copies of 1.2 G parameters per call would dominate the run time.  Tolerances are stated per test.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -402,3 +404,56 @@ def test_real_dims_short_prompt_prefill_path(built_libs, real2, monkeypatch):
     for g, ref, got in zip(groups, want, runs[1][0::2]):
         c, r = _close(bf16_from_bits(got), ref)
         assert c > COS_MIN and r <= REL_MAX, ([len(p) for p in g], c, r)
+
+
+def test_real_dims_fused_attention_oproj_expired_wait_reruns_the_step(built_libs, real2):
+    """The o_proj workgroups of the fused attention + o_proj launch wait for the attention rows with a BOUND; when it expires
+    the launch's output is void, the status word says so, and the host re-runs the step on the two stand-alone launches in the
+    same call (disabling the form).  PEGAINFER_OPROJ_WAIT_TICKS=1 makes the bound expire at once - in a subprocess, the
+    knob is read once per process - for a single decode call, for two requests, and inside a greedy chain: the tokens and
+    logits must be those of an engine that never had the form (the re-run restores the token inputs the failed attempt's
+    top-1 overwrote)."""
+    import subprocess
+    import sys
+    import tempfile
+    _, state, ref = real2
+    code = r'''
+import os, sys, numpy as np
+sys.path.insert(0, os.getcwd())
+from pegainfer_amd.qwen3 import Qwen3Engine
+cfg = %r
+st = np.load(sys.argv[1])
+state = {k: st[k] for k in st.files}
+out = {}
+for nb in (1, 2):
+    eng = Qwen3Engine(cfg, num_kv_pages=256, max_batch_size=2, decode_mode=1, split_policy=1).load_state(state)
+    prompts = [[100 + (i %% 1000) for i in range(520)], [7 + (i %% 900) for i in range(300)]][:nb]
+    rids = [eng.new_request() for _ in prompts]
+    toks = eng.prefill(rids, prompts)
+    if nb == 1:      # the bound expires inside a single decode call ...
+        toks, lg = eng.decode(rids, toks, return_logits=True)
+    else:            # ... or inside a chain (its re-run restarts the whole chain on the two launches)
+        first = eng.decode_greedy_chain(rids, toks, 3)
+        toks, lg = first[-1], first
+    msg = eng.lib.pegainfer_qwen3_last_error(eng.h).decode()
+    chain = eng.decode_greedy_chain(rids, toks, 5)
+    t2, lg2 = eng.decode(rids, chain[-1], return_logits=True)
+    out["tok%%d" %% nb], out["lg%%d" %% nb], out["chain%%d" %% nb], out["lg2_%%d" %% nb] = toks, lg, chain, lg2
+    out["msg%%d" %% nb] = np.array(msg)
+    eng.close()
+np.savez(sys.argv[2], **out)
+''' % (CFG2,)
+    with tempfile.TemporaryDirectory() as d:
+        np.savez(os.path.join(d, "state.npz"), **state)
+        res = {}
+        for tag, env in (("forced", {"PEGAINFER_OPROJ_WAIT_TICKS": "1"}), ("never", {"PEGAINFER_ATTN_OPROJ": "0"})):
+            out = os.path.join(d, tag + ".npz")
+            r = subprocess.run([sys.executable, "-c", code, os.path.join(d, "state.npz"), out], env=dict(os.environ, **env),
+                               cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            res[tag] = np.load(out)
+    for nb in (1, 2):
+        assert "bounded wait" in str(res["forced"]["msg%d" % nb]), str(res["forced"]["msg%d" % nb])      # the re-run really happened
+        # the plans differ (the form's chunk cap vs none) only beyond 9 x 64 tokens: these prompts stay below, so bit for bit
+        for k in ("tok%d", "lg%d", "chain%d", "lg2_%d"):
+            assert np.array_equal(res["forced"][k % nb], res["never"][k % nb]), (nb, k)
