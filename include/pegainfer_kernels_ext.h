@@ -143,6 +143,10 @@ pegainfer_status_t pegainfer_debug_gemm_route(int32_t M, int32_t T, int32_t K, i
  * result within bf16 rounding of the partials. */
 int32_t pegainfer_paged_attention_decode_split_kv_hd256(const Half* q, Half* output, const Half* kv_data, int64_t k_offset_elems, int64_t v_offset_elems, const int32_t* page_indices, const int32_t* page_indptr, const int32_t* last_page_len_d, const int32_t* request_indices, const int32_t* kv_tile_indices, const int32_t* kv_chunk_size_ptr, const int32_t* o_indptr, const uint8_t* block_valid_mask, Half* tmp_v, float* tmp_s, int32_t num_qo_heads, int32_t num_kv_heads, int32_t head_dim, int32_t page_size, int32_t batch_size, int32_t padded_batch_size, int64_t stride_page, float sm_scale, int32_t* merge_counters, pegainfer_stream_t stream);
 
+/* zero n_words 32-bit device words with a kernel launch (captured as a KERNEL node: see the note in elementwise.hip on
+ * hipMemsetAsync nodes inside replayed graphs) */
+pegainfer_status_t pegainfer_zero_words(void* ptr, int32_t n_words, pegainfer_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

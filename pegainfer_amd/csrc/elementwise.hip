@@ -124,7 +124,21 @@ static inline pegainfer_status_t last_error() { return static_cast<pegainfer_sta
 
 using namespace pk;
 
+// zero `n` 32-bit words (device counters at the head of a captured step).  A KERNEL on purpose: round 5 found that a
+// hipMemsetAsync node inside a replayed hipGraph is not reliably ordered against the graph's kernels once any eager
+// kernel launch has run on the stream between two replays (tools/diag_8b.py: the in-launch split-KV merge tickets were
+// zeroed mid-flight, for good) - kernel nodes of a captured stream are.
+__global__ void zero_words_kernel(uint32_t* __restrict__ p, int n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0u;
+}
+
 extern "C" {
+
+pegainfer_status_t pegainfer_zero_words(void* ptr, int32_t n_words, pegainfer_stream_t stream) {
+  if (n_words > 0)
+    zero_words_kernel<<<n_words >= 4096 ? 16 : 1, 256, 0, as_stream(stream)>>>(static_cast<uint32_t*>(ptr), n_words);
+  return last_error();
+}
 
 pegainfer_status_t add_cuda(const Half* a, const Half* b, Half* out, int32_t n, pegainfer_stream_t stream) {
   if (n <= 0) return 0;

@@ -534,7 +534,8 @@ struct Model35 {
   // ------------------------------------------------------------------ decode (batch_decode.rs:198-365)
   int decode_kernels(int bs, const std::vector<Request35*>& rs, bool split) {
     auto md = [&](size_t off) { return reinterpret_cast<int32_t*>(meta_dev + off); };
-    if (split) P35_HIP(hipMemsetAsync(merge_ctr, 0, (size_t)max_bs * Hkv * 32 * sizeof(int32_t), stream));
+    // a kernel node, not a memset node (csrc/elementwise.hip: pegainfer_zero_words)
+    if (split && pegainfer_zero_words(merge_ctr, (int32_t)((size_t)max_bs * Hkv * 32), S())) { set_error("pegainfer_zero_words failed"); return -1; }
     if (embedding_batched_cuda(embed, reinterpret_cast<uint32_t*>(meta_dev + m_tok), hidden, H, bs, S())) {
       set_error("embedding failed"); return -1;
     }
@@ -599,7 +600,8 @@ struct Model35 {
   // stacked outputs take contiguous [bs, dim] tensors in the reference ABI).
   int decode_kernels_fused1(Request35* r, bool split) {
     auto md = [&](size_t off) { return reinterpret_cast<int32_t*>(meta_dev + off); };
-    if (split) P35_HIP(hipMemsetAsync(merge_ctr, 0, (size_t)max_bs * Hkv * 32 * sizeof(int32_t), stream));
+    // a kernel node, not a memset node (csrc/elementwise.hip: pegainfer_zero_words)
+    if (split && pegainfer_zero_words(merge_ctr, (int32_t)((size_t)max_bs * Hkv * 32), S())) { set_error("pegainfer_zero_words failed"); return -1; }
     if (embedding_batched_cuda(embed, reinterpret_cast<uint32_t*>(meta_dev + m_tok), hidden, H, 1, S())) {
       set_error("embedding failed"); return -1;
     }

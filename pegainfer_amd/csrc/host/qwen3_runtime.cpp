@@ -173,6 +173,14 @@ struct Model {
   }
 
   void set_error(const std::string& s) { err = s; }
+  // device counters at the head of a captured step are zeroed by a KERNEL node (pegainfer_zero_words; elementwise.hip says
+  // why); PEGAINFER_CTR_RESET=memset restores the hipMemsetAsync node for the A/B
+  bool ctr_reset_memset = [] { const char* e = getenv("PEGAINFER_CTR_RESET"); return e && e[0] == 'm'; }();
+  int zero_ctrs(void* p, size_t words) {
+    if (ctr_reset_memset) { PQ_HIP(hipMemsetAsync(p, 0, words * 4, stream)); return 0; }
+    if (pegainfer_zero_words(p, (int32_t)words, S())) { set_error("pegainfer_zero_words failed"); return -1; }
+    return 0;
+  }
   void* S() const { return reinterpret_cast<void*>(stream); }
 
   template <typename T>
@@ -645,9 +653,9 @@ struct Model {
   // kernel.  Every fused kernel shares its arithmetic core with the reference-named op it replaces, so the
   // logits are bit-identical to decode_mode 0 (tests/test_gpu_fused.py).
   int decode_kernels_fused(int bs, bool split, int split_slots) {
-    if (fused_merge && split) PQ_HIP(hipMemsetAsync(merge_ctr, 0, (size_t)max_bs * Hkv * 32 * sizeof(int32_t), stream));
+    if (fused_merge && split && zero_ctrs(merge_ctr, (size_t)max_bs * Hkv * 32)) return -1;
     oproj_step = attn_oproj && attn_done && fused_merge && split && bs <= pq::oproj_fused_max_batch() && !tp_comm && D == 128 && oproj_plan;
-    if (oproj_step) PQ_HIP(hipMemsetAsync(attn_done, 0, (size_t)L * kDoneInts * sizeof(int32_t), stream));
+    if (oproj_step && zero_ctrs(attn_done, (size_t)L * kDoneInts)) return -1;
     if (embedding_batched_cuda(embed, md<uint32_t>(ml.token_ids), hidden, H, bs, S())) {
       set_error("embedding_batched_cuda failed");
       return -1;
@@ -718,7 +726,7 @@ struct Model {
     }
     rms_norm_batched_cuda(hidden, layers[0].ln1, normed, H, bs, eps, S());
     const bool mid = stacked_qkv(bs) && D == 128 && mid_batch_fused;
-    if (mid && fused_merge && split) PQ_HIP(hipMemsetAsync(merge_ctr, 0, (size_t)max_bs * Hkv * 32 * sizeof(int32_t), stream));
+    if (mid && fused_merge && split && zero_ctrs(merge_ctr, (size_t)max_bs * Hkv * 32)) return -1;
     for (int li = 0; li < L; ++li) {
       const Half* next_w = li + 1 < L ? layers[li + 1].ln1 : final_norm;
       if (mid) {

@@ -22,7 +22,15 @@ def rows_of(eng, sample_at=None, warm=0):
         _, lg = eng.decode([rid], [tk], return_logits=True)
         rows.append(lg[0].copy())
         if sample_at == i:
-            eng.sample(0, 0.8, 50, 0.95, 0.37)
+            kind = os.environ.get("DIAG_SAMPLE", "topk")
+            if kind == "topk":
+                eng.sample(0, 0.8, 50, 0.95, 0.37)          # sample_kernel<<<1, 1024>>> + sync + 4-byte D2H
+            elif kind == "top1":
+                eng.sample(0, 0.0, 1, 1.0, 0.37)            # top1_kernel<<<64, 256>>> + sync + 4-byte D2H
+            else:                                           # no kernel at all: sync + a row D2H + host arithmetic
+                import ctypes
+                lp = ctypes.c_float(0)
+                eng.lib.pegainfer_qwen3_logprobs(eng.h, 0, 5, 0, ctypes.addressof(lp), None, None)
     eng.drop_request(rid)
     return np.stack(rows)
 
@@ -63,9 +71,11 @@ def main():
         t = truth["first"]
         print(f"== {model} x {layers}: eager runs agree with each other:", all(np.array_equal(truth[k], t) for k in truth.files if k != "msgs"),
               "| errors:", str(truth["msgs"])[:200], flush=True)
-        for tag, kw in (("graph", {}), ("graph FUSED_MERGE=0", dict(env={"PEGAINFER_FUSED_MERGE": "0"})),
-                        ("graph ATTN_OPROJ=0", dict(env={"PEGAINFER_ATTN_OPROJ": "0"})), ("graph decode_mode 0", dict(mode=0)),
-                        ("graph GEMV_PERSIST=0", dict(env={"PEGAINFER_GEMV_PERSIST": "0"}))):
+        for tag, kw in (("graph (zero kernel)", {}), ("graph CTR_RESET=memset", dict(env={"PEGAINFER_CTR_RESET": "memset"})),
+                        ("memset, top1 sample", dict(env={"PEGAINFER_CTR_RESET": "memset", "DIAG_SAMPLE": "top1"})),
+                        ("memset, logprobs only", dict(env={"PEGAINFER_CTR_RESET": "memset", "DIAG_SAMPLE": "logprobs"})),
+                        ("zero kernel, ATTN_OPROJ=0", dict(env={"PEGAINFER_ATTN_OPROJ": "0"})),
+                        ("memset, ATTN_OPROJ=0", dict(env={"PEGAINFER_ATTN_OPROJ": "0", "PEGAINFER_CTR_RESET": "memset"}))):
             r = run(tag, model, layers, True, **kw)
             if r is None:
                 continue
