@@ -291,7 +291,7 @@ def run_qwen35(args, rank, world, local, dist, torch):
     from pegainfer_amd.qwen35 import QWEN35_4B, Qwen35Engine
     cfg = dict(QWEN35_4B)
     q35_mode = int(os.environ.get("PEGAINFER_Q35_DECODE_MODE", "1"))
-    total_ctx = args.ctx + args.warmup + args.steps + 8
+    total_ctx = args.ctx + args.warmup + args.steps + 8 + 66
     pages = (args.batch + 1) * (-(-total_ctx // 16) + 1) + 8
     eng = Qwen35Engine(cfg, num_kv_pages=pages, max_batch_size=max(args.batch, 1) + 1, enable_graph=not args.no_graph,
                        device=local, max_positions=max(4096, total_ctx + 16))
@@ -316,15 +316,28 @@ def run_qwen35(args, rank, world, local, dist, torch):
         torch.cuda.synchronize()
 
     step_ms, dev_ms = [], []
+    chain = args.chain if args.batch <= 4 else 0     # greedy steps in chains (pegainfer_qwen35_decode_greedy_chain), as in main()
+    if chain:
+        toks = eng.decode_greedy_chain(rids, toks, 2)[-1]      # allocates the pinned ring outside the timed region
     barrier()
     t_start = time.perf_counter()
-    for _ in range(args.steps):
+    done = 0
+    while done < args.steps:
         t0 = time.perf_counter()
-        toks = eng.decode(rids, toks)
-        step_ms.append((time.perf_counter() - t0) * 1e3)
-        dev_ms.append(eng.last_step_ms())
+        m = min(chain, args.steps - done) if chain else 1
+        toks = eng.decode_greedy_chain(rids, toks, m)[-1] if chain else eng.decode(rids, toks)
+        dt = (time.perf_counter() - t0) * 1e3 / m
+        step_ms.extend([dt] * m)
+        dev_ms.extend([eng.last_step_ms()] * m)
+        done += m
     barrier()
     elapsed = parallel.max_over_ranks(time.perf_counter() - t_start, device="cuda")
+    sync_ms = []
+    if chain:   # the reference's loop shape (one synchronisation per step) right after, for the per-step percentiles
+        for _ in range(min(args.steps, 64)):
+            t0 = time.perf_counter()
+            toks = eng.decode(rids, toks)
+            sync_ms.append((time.perf_counter() - t0) * 1e3)
     value = args.steps * args.batch * world / elapsed
     step_bytes = qwen35_bytes_per_token(cfg, args.ctx + args.warmup + args.steps / 2, args.batch)
     out = {
@@ -342,6 +355,10 @@ def run_qwen35(args, rank, world, local, dist, torch):
                     "min": round(float(min(ttfts)), 3), "iters": len(ttfts)},
         "tpot_ms": {"p50": round(float(np.median(step_ms)), 4), "p95": round(float(np.percentile(step_ms, 95)), 4),
                     "device_p50": round(float(np.median(dev_ms)), 4)},
+        "host_loop": ({"form": "chained", "chain_steps": chain,
+                       "sync_per_step": {"tpot_ms_p50": round(float(np.median(sync_ms)), 4),
+                                         "tok_s": round(args.batch * world * 1e3 / float(np.mean(sync_ms)), 2), "steps": len(sync_ms)}}
+                      if chain and sync_ms else {"form": "sync_per_step"}),
         "roofline": None,
         "step_roofline": {"algorithmic_bytes_per_step": int(step_bytes),
                           "achieved_GBps": round(step_bytes / (elapsed / args.steps) / 1e9, 1),
@@ -660,7 +677,9 @@ def main():
     # greedy steps are enqueued in chains (pegainfer_qwen3_decode_greedy_chain: the token of step s reaches step s + 1 on
     # the device, every step's tokens still travel to the host asynchronously, ONE host synchronisation per chain) unless
     # --chain 0; sampling with temperature needs the host between steps, tensor parallel checks its status block per step
-    chain = args.chain if (args.sampling == "greedy" and not tp) else 0
+    # (measured, profiles/r5_chain_ab*.txt: bs 1 +1.3 ... 1.7 %, bs 4 +0.9 %, bs 16 -1 % - there the per-step copies queue up on
+    # the stream behind 3.4 ms graphs and the host was never the limit - so chains are used up to 4 requests)
+    chain = args.chain if (args.sampling == "greedy" and not tp and args.batch <= 4) else 0
     n_warm_chain = min(2, args.warmup) if chain else 0      # the pinned metadata ring is allocated by the first chain
     for _ in range(args.warmup - n_warm_chain):
         toks = eng.decode(rids, toks)

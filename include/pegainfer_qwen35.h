@@ -71,6 +71,11 @@ int32_t pegainfer_qwen35_sample(pegainfer_qwen35_t m, int32_t column, float temp
                                 float random_val, int32_t* out_token);
 int32_t pegainfer_qwen35_logprobs(pegainfer_qwen35_t m, int32_t column, uint32_t token, int32_t top_k, float* out_logprob,
                                   uint32_t* out_top_ids, float* out_top_logprobs);
+/* n_steps GREEDY decode steps enqueued back to back with one host synchronisation - the twin of
+ * pegainfer_qwen3_decode_greedy_chain (include/pegainfer_qwen3.h): same graph, same kernels, same bits as n_steps calls of
+ * pegainfer_qwen35_decode; out_tokens [n_steps][n_requests] */
+int32_t pegainfer_qwen35_decode_greedy_chain(pegainfer_qwen35_t m, int32_t n_requests, const int32_t* request_ids,
+                                             const uint32_t* first_token_ids, int32_t n_steps, int32_t* out_tokens);
 float pegainfer_qwen35_last_step_ms(pegainfer_qwen35_t m);
 /* average ms per launch of one GEMV call site over the layers' real weights, hipEvents on the model stream (bench.py
  * roofline): which 0 = gate|up with the residual add + (1 + w) RMSNorm prologue and SwiGLU epilogue (the dominant kernel of

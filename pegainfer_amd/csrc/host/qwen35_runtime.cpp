@@ -229,7 +229,7 @@ struct Model35 {
         dalloc(&qkv, bs * C) || dalloc(&qkv_conv, bs * C) || dalloc(&z, bs * Z) || dalloc(&b_proj, bs * vh) ||
         dalloc(&a_proj, bs * vh) || dalloc(&gdr_out, bs * Z) || dalloc(&normed_gated, bs * Z) ||
         dalloc(&gate_out, bs * I) || dalloc(&up_out, bs * I) || dalloc(&act_out, bs * I) ||
-        dalloc(&mlp_out, bs * H) || dalloc(&logits, bs * (size_t)V) || dalloc(&tokens_out_d, bs) ||
+        dalloc(&mlp_out, bs * H) || dalloc(&logits, bs * (size_t)V) ||
         dalloc(&top1_state, bs * 16) || dalloc(&start_pos_d, 1) || dalloc(&probs_scratch, (size_t)V) || dalloc(&top1_value, 1) ||
         dalloc(&row_states, 1024 * 1024) || dalloc(&valid_scratch, 1) || dalloc(&sample_out_d, 1) ||
         dalloc(&wide, (size_t)std::max(C + Z + 2 * vh, 2 * q_dim + 2 * kv_dim)) ||
@@ -257,6 +257,7 @@ struct Model35 {
     P35_HIP(hipHostMalloc(reinterpret_cast<void**>(&meta_host), m_total, hipHostMallocDefault));
     std::memset(meta_host, 0, m_total);
     if (dalloc(&meta_dev, m_total)) return -1;
+    tokens_out_d = reinterpret_cast<int32_t*>(meta_dev + m_tok);   // greedy tokens land in the block's token slot (chained steps)
     P35_HIP(hipHostMalloc(reinterpret_cast<void**>(&tokens_out_host), bs * 4, hipHostMallocDefault));
     P35_HIP(hipStreamSynchronize(stream));
     return 0;
@@ -687,17 +688,22 @@ struct Model35 {
     return decode_kernels(n, rs, split);
   }
 
-  int decode(int n, const int32_t* ids, const uint32_t* toks, int32_t* out_tokens, void* out_logits_host) {
+  // One decode step = step_prepare (validate, advance the KvStates, pack + upload the metadata) + step_launch (replay or
+  // capture the graph keyed by the request ids).  toks == nullptr: a CHAINED step - the previous step's greedy tokens already
+  // sit in the device block's token slot (tokens_out_d aliases it), the upload starts behind it.
+  struct StepCtx35 { int n = 0; bool split = false; std::vector<Request35*> rs; std::vector<int> key; };
+  int step_prepare(int n, const int32_t* ids, const uint32_t* toks, StepCtx35* c, uint8_t* host_block) {
     if (n < 1 || n > max_bs) { set_error("decode batch size out of range"); return -1; }
-    std::vector<Request35*> rs(n);
-    std::vector<int> key(ids, ids + n);
+    std::vector<Request35*>& rs = c->rs;
+    rs.assign(n, nullptr);
+    c->key.assign(ids, ids + n);
     for (int i = 0; i < n; ++i) {
       rs[i] = req(ids[i]);
       if (!rs[i]) return -1;
       for (int j = 0; j < i; ++j)
         if (ids[j] == ids[i]) { set_error("duplicate request id in decode batch"); return -1; }
     }
-    auto mh = [&](size_t off) { return reinterpret_cast<int32_t*>(meta_host + off); };
+    auto mh = [&](size_t off) { return reinterpret_cast<int32_t*>(host_block + off); };
     // validate the whole batch before any KvState is advanced: a failed call leaves every request untouched
     int pages_short = 0;
     for (int i = 0; i < n; ++i) {
@@ -712,7 +718,7 @@ struct Model35 {
       const int pos = kv.seq_len;
       if (!kv.ensure_capacity(&pool, pos + 1, layout.page_size)) { set_error("KV pool exhausted"); return -1; }
       kv.seq_len += 1;
-      mh(m_tok)[i] = (int32_t)toks[i];
+      mh(m_tok)[i] = toks ? (int32_t)toks[i] : 0;
       mh(m_pos)[i] = pos;
       for (int32_t p : kv.pages) mh(m_pages)[np++] = p;
       mh(m_indptr)[i + 1] = np;
@@ -725,7 +731,9 @@ struct Model35 {
     const bool allow_split = split_policy != 0;
     std::vector<int> seq_lens(n);
     for (int i = 0; i < n; ++i) seq_lens[i] = rs[i]->kv.seq_len;
-    const pq::SplitPlan plan = pq::make_split_plan(1, seq_lens, n, Hkv);
+    // (a lone request keeps the 18-chunk plan it has had since round 3 - 128-token chunks from 1152 tokens on, one tile per
+    // wave of the 8-wave workgroups; batches take the un-capped plan)
+    const pq::SplitPlan plan = pq::make_split_plan(1, seq_lens, n, Hkv, n == 1);
     const bool split = allow_split && plan.use_split;
     // the launch covers exactly the slots refreshed below: plan.slots = n * (chunks per request), a function of n and
     // Hkv only, so it is constant for a captured graph (the key holds the request ids).  Launching n * 64 slots would
@@ -736,27 +744,37 @@ struct Model35 {
     std::memcpy(mh(m_skt), plan.kv_tile_indices.data(), (size_t)plan.slots * 4);
     mh(m_skc)[0] = plan.chunk;
     std::memcpy(mh(m_soi), plan.o_indptr.data(), (size_t)(n + 1) * 4);
-    std::memcpy(meta_host + m_sva, plan.valid.data(), (size_t)plan.slots);
-    key.push_back(split ? 1 : 0);
-    key.push_back(decode_mode);
-    P35_HIP(hipMemcpyAsync(meta_dev, meta_host, m_total, hipMemcpyHostToDevice, stream));
-    P35_HIP(hipEventRecord(ev0, stream));
+    std::memcpy(host_block + m_sva, plan.valid.data(), (size_t)plan.slots);
+    c->key.push_back(split ? 1 : 0);
+    c->key.push_back(decode_mode);
+    const size_t from = toks ? 0 : m_pos;   // m_tok is the first field of the block
+    P35_HIP(hipMemcpyAsync(meta_dev + from, host_block + from, m_total - from, hipMemcpyHostToDevice, stream));
+    c->n = n; c->split = split;
+    return 0;
+  }
+  int step_launch(const StepCtx35& c) {
     if (enable_graph && !tap_on) {
-      if (!graph || graph_ids != key) {
+      if (!graph || graph_ids != c.key) {
         if (graph) { P35_HIP(hipGraphExecDestroy(graph)); graph = nullptr; }
         hipGraph_t g = nullptr;
         P35_HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-        const int rc = run_decode_kernels(n, rs, split);
+        const int rc = run_decode_kernels(c.n, c.rs, c.split);
         hipError_t e = hipStreamEndCapture(stream, &g);
         if (rc || e != hipSuccess) { if (!rc) set_error("graph capture failed"); return -1; }
         P35_HIP(hipGraphInstantiate(&graph, g, nullptr, nullptr, 0));
         P35_HIP(hipGraphDestroy(g));
-        graph_ids = key;
+        graph_ids = c.key;
       }
       P35_HIP(hipGraphLaunch(graph, stream));
-    } else if (run_decode_kernels(n, rs, split)) {
-      return -1;
+      return 0;
     }
+    return run_decode_kernels(c.n, c.rs, c.split) ? -1 : 0;
+  }
+  int decode(int n, const int32_t* ids, const uint32_t* toks, int32_t* out_tokens, void* out_logits_host) {
+    StepCtx35 c;
+    if (const int rc = step_prepare(n, ids, toks, &c, meta_host)) return rc;
+    P35_HIP(hipEventRecord(ev0, stream));
+    if (step_launch(c)) return -1;
     P35_HIP(hipEventRecord(ev1, stream));
     P35_HIP(hipMemcpyAsync(tokens_out_host, tokens_out_d, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
     if (out_logits_host)
@@ -764,6 +782,65 @@ struct Model35 {
     P35_HIP(hipStreamSynchronize(stream));
     P35_HIP(hipEventElapsedTime(&last_step_ms, ev0, ev1));
     if (out_tokens) std::memcpy(out_tokens, tokens_out_host, (size_t)n * 4);
+    last_logits = logits;
+    last_rows = n;
+    return 0;
+  }
+  // n_steps GREEDY decode steps enqueued back to back, one host synchronisation (the twin of
+  // pegainfer_qwen3_decode_greedy_chain; include/pegainfer_qwen35.h).  The recurrent state and the KV append advance on the
+  // device exactly as in n_steps calls of decode(); the chain is validated as a whole before any request advances.
+  static constexpr int kChainRing = 8;
+  uint8_t* chain_ring[kChainRing] = {};
+  hipEvent_t chain_ev[kChainRing] = {};
+  int32_t* chain_tokens_host = nullptr;
+  size_t chain_tokens_cap = 0;
+  int decode_greedy_chain(int n, const int32_t* ids, const uint32_t* first_tokens, int n_steps, int32_t* out_tokens) {
+    if (n_steps <= 0) { set_error("decode_greedy_chain: n_steps must be positive"); return -1; }
+    if (tap_on) {
+      std::vector<uint32_t> tk(first_tokens, first_tokens + n);
+      for (int s = 0; s < n_steps; ++s) {
+        if (const int rc = decode(n, ids, tk.data(), out_tokens + (size_t)s * n, nullptr)) return rc;
+        for (int i = 0; i < n; ++i) tk[i] = (uint32_t)out_tokens[(size_t)s * n + i];
+      }
+      return 0;
+    }
+    if (!chain_ring[0])
+      for (int r = 0; r < kChainRing; ++r) {
+        P35_HIP(hipHostMalloc(reinterpret_cast<void**>(&chain_ring[r]), m_total, hipHostMallocDefault));
+        std::memset(chain_ring[r], 0, m_total);
+        P35_HIP(hipEventCreateWithFlags(&chain_ev[r], hipEventDisableTiming));
+      }
+    if ((size_t)n_steps * n > chain_tokens_cap) {
+      if (chain_tokens_host) P35_HIP(hipHostFree(chain_tokens_host));
+      chain_tokens_cap = (size_t)n_steps * n;
+      P35_HIP(hipHostMalloc(reinterpret_cast<void**>(&chain_tokens_host), chain_tokens_cap * 4, hipHostMallocDefault));
+    }
+    if (n < 1 || n > max_bs) { set_error("decode batch size out of range"); return -1; }
+    {
+      int pages_short = 0;
+      for (int i = 0; i < n; ++i) {
+        Request35* r = req(ids[i]);
+        if (!r) return -1;
+        if (r->kv.seq_len + n_steps > max_pos) { set_error("position beyond the RoPE table"); return -1; }
+        pages_short += r->kv.pages_short(r->kv.seq_len + n_steps, layout.page_size);
+      }
+      if (pages_short > pool.available()) { set_error("KV pool exhausted"); return -1; }
+    }
+    P35_HIP(hipEventRecord(ev0, stream));
+    for (int s = 0; s < n_steps; ++s) {
+      const int slot = s % kChainRing;
+      if (s >= kChainRing) P35_HIP(hipEventSynchronize(chain_ev[slot]));
+      StepCtx35 c;
+      if (const int rc = step_prepare(n, ids, s == 0 ? first_tokens : nullptr, &c, chain_ring[slot])) return rc;
+      P35_HIP(hipEventRecord(chain_ev[slot], stream));
+      if (step_launch(c)) return -1;
+      P35_HIP(hipMemcpyAsync(chain_tokens_host + (size_t)s * n, tokens_out_d, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
+    }
+    P35_HIP(hipEventRecord(ev1, stream));
+    P35_HIP(hipStreamSynchronize(stream));
+    P35_HIP(hipEventElapsedTime(&last_step_ms, ev0, ev1));
+    last_step_ms /= (float)n_steps;
+    std::memcpy(out_tokens, chain_tokens_host, (size_t)n_steps * n * 4);
     last_logits = logits;
     last_rows = n;
     return 0;
@@ -946,6 +1023,11 @@ struct Model35 {
     if (pf_meta_host) (void)hipHostFree(pf_meta_host);
     if (meta_host) (void)hipHostFree(meta_host);
     if (tokens_out_host) (void)hipHostFree(tokens_out_host);
+    for (int r = 0; r < kChainRing; ++r) {
+      if (chain_ring[r]) (void)hipHostFree(chain_ring[r]);
+      if (chain_ev[r]) (void)hipEventDestroy(chain_ev[r]);
+    }
+    if (chain_tokens_host) (void)hipHostFree(chain_tokens_host);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
     if (stream) (void)hipStreamDestroy(stream);
@@ -1013,6 +1095,10 @@ int32_t pegainfer_qwen35_prefill(pegainfer_qwen35_t m, int32_t request_id, int32
 int32_t pegainfer_qwen35_decode(pegainfer_qwen35_t m, int32_t n_requests, const int32_t* request_ids,
                                 const uint32_t* token_ids, int32_t* out_tokens, void* out_logits_host) {
   return M35(m)->decode(n_requests, request_ids, token_ids, out_tokens, out_logits_host);
+}
+int32_t pegainfer_qwen35_decode_greedy_chain(pegainfer_qwen35_t m, int32_t n_requests, const int32_t* request_ids,
+                                             const uint32_t* first_token_ids, int32_t n_steps, int32_t* out_tokens) {
+  return M35(m)->decode_greedy_chain(n_requests, request_ids, first_token_ids, n_steps, out_tokens);
 }
 int32_t pegainfer_qwen35_available_pages(pegainfer_qwen35_t m) { return M35(m)->pool.available(); }
 int32_t pegainfer_qwen35_capacity_pages(pegainfer_qwen35_t m) { return M35(m)->pool.capacity(); }

@@ -169,6 +169,15 @@ class Qwen35Engine:
                                                    lg.ctypes.data if want_logits else None), "decode")
         return (out, _bf16_to_f32(lg)) if want_logits else out
 
+    def decode_greedy_chain(self, rids, first_tokens, n_steps):
+        """n_steps greedy decode steps enqueued back to back, one host synchronisation -> int32 [n_steps, n_requests]"""
+        ids = np.ascontiguousarray(rids, dtype=np.int32)
+        toks = np.ascontiguousarray(first_tokens, dtype=np.uint32)
+        out = np.zeros((int(n_steps), ids.size), np.int32)
+        self._chk(self.lib.pegainfer_qwen35_decode_greedy_chain(self.h, ids.size, ids.ctypes.data, toks.ctypes.data, int(n_steps),
+                                                                out.ctypes.data), "decode_greedy_chain")
+        return out
+
     def last_step_ms(self):
         return float(self.lib.pegainfer_qwen35_last_step_ms(self.h))
 

@@ -294,3 +294,35 @@ def test_qwen35_split_kv_after_batch_shrink_equals_unsplit(built_libs, golden35)
         eng.close()
     for a, b in zip(outs[1]["rows"], outs[0]["rows"]):
         assert np.abs(a - b).max() <= 0.25, np.abs(a - b).max()
+
+
+def test_qwen35_decode_greedy_chain_equals_step_by_step(built_libs, golden35, monkeypatch):
+    """pegainfer_qwen35_decode_greedy_chain (n greedy steps back to back, the token handed over on the device, one host
+    synchronisation) == n calls of pegainfer_qwen35_decode: tokens, request state and the next step's logits, bit for bit -
+    fused bs = 1 decode and the reference-order sequence, one request and a batch of two (recurrent state + KV advance on
+    the device across the chain)."""
+    meta = golden35[0]
+    cases = meta["cases"]
+    for q35_mode in (1, 0):
+        monkeypatch.setenv("PEGAINFER_Q35_DECODE_MODE", str(q35_mode))
+        for prompts in ([cases[3]["prompt_tokens"]], [cases[2]["prompt_tokens"], cases[0]["prompt_tokens"]]):
+            outs = []
+            for chained in (False, True):
+                eng = make_engine(meta, max_batch_size=2)
+                rids = [eng.new_request() for _ in prompts]
+                toks = np.array([eng.prefill(r, p) for r, p in zip(rids, prompts)], np.int32)
+                if chained:
+                    seq = eng.decode_greedy_chain(rids, toks, 5)
+                    seq = np.concatenate([seq, eng.decode_greedy_chain(rids, seq[-1], 19)])
+                else:
+                    seq, t = [], toks
+                    for _ in range(24):
+                        t = eng.decode(rids, t)
+                        seq.append(t.copy())
+                    seq = np.stack(seq)
+                t1, l1 = eng.decode(rids, seq[-1], want_logits=True)
+                outs.append((seq, [eng.seq_len(r) for r in rids], t1, l1))
+                eng.close()
+            a, b = outs
+            assert np.array_equal(a[0], b[0]) and a[1] == b[1], (q35_mode, len(prompts))
+            assert np.array_equal(a[2], b[2]) and np.array_equal(a[3].view(np.uint32), b[3].view(np.uint32))
