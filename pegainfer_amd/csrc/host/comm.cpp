@@ -207,6 +207,10 @@ __global__ __launch_bounds__(1024) void oneshot_all_reduce_kernel(OsPeers peers,
   }
 }
 
+__global__ void os_zero_tail_kernel(unsigned char* p, int n) {
+  if ((int)threadIdx.x < n) p[threadIdx.x] = 0;
+}
+
 // One launch over an aligned, 16-byte-sized payload of at most 64 KB.
 static int oneshot_launch(Comm* c, unsigned char* data, int bytes, int elem, hipStream_t s) {
   const int wgs = (bytes + kOsSeg - 1) / kOsSeg;
@@ -253,7 +257,9 @@ static int oneshot_all_reduce(Comm* c, void* data, int64_t n, int elem, hipStrea
       }
       c->os_stage_stream = s;
       c->os_stage_used = true;
-      if (padded != piece && hipMemsetAsync(c->os_stage + piece, 0, (size_t)(padded - piece), s) != hipSuccess) return -1;
+      // the <= 15 pad bytes are zeroed by a KERNEL: a hipMemsetAsync node inside a replayed hipGraph stops taking effect
+      // after an eager kernel launch between two replays (round 5, csrc/elementwise.hip: pegainfer_zero_words)
+      if (padded != piece) os_zero_tail_kernel<<<1, 64, 0, s>>>(c->os_stage + piece, padded - piece);
       if (hipMemcpyAsync(c->os_stage, p + off, (size_t)piece, hipMemcpyDeviceToDevice, s) != hipSuccess) return -1;
       if (oneshot_launch(c, c->os_stage, padded, elem, s)) return -1;
       if (hipMemcpyAsync(p + off, c->os_stage, (size_t)piece, hipMemcpyDeviceToDevice, s) != hipSuccess) return -1;
