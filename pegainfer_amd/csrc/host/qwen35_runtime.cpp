@@ -812,7 +812,7 @@ struct Model35 {
       }
     if ((size_t)n_steps * n > chain_tokens_cap) {
       if (chain_tokens_host) P35_HIP(hipHostFree(chain_tokens_host));
-      chain_tokens_cap = (size_t)n_steps * n;
+      chain_tokens_cap = std::max<size_t>((size_t)n_steps * n, 4096);   // grow-only, never inside a short timed chain
       P35_HIP(hipHostMalloc(reinterpret_cast<void**>(&chain_tokens_host), chain_tokens_cap * 4, hipHostMallocDefault));
     }
     if (n < 1 || n > max_bs) { set_error("decode batch size out of range"); return -1; }

@@ -971,7 +971,7 @@ struct Model {
     }
     if ((size_t)n_steps * n > chain_tokens_cap) {
       if (chain_tokens_host) PQ_HIP(hipHostFree(chain_tokens_host));
-      chain_tokens_cap = (size_t)n_steps * n;
+      chain_tokens_cap = std::max<size_t>((size_t)n_steps * n, 4096);   // grow-only, never inside a short timed chain
       PQ_HIP(hipHostMalloc(reinterpret_cast<void**>(&chain_tokens_host), chain_tokens_cap * 4, hipHostMallocDefault));
     }
     // a chain must be admissible as a whole before any request is advanced: positions and pages of ALL its steps
