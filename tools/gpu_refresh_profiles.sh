@@ -29,13 +29,12 @@ if [ $part = a ] || [ $part = all ]; then
   pmc ${R}_fused_pmc_sq "$SQ" --steps 8 --ttft-iters 2 --profile-iters 0 --ttft10k-iters 0
   pmc ${R}_ctx10000_pmc_sq "$SQ" --ctx 10000 --steps 4 --ttft-iters 1 --profile-iters 0 --ttft10k-iters 0
   cd $repo
-  timeout 300 python bench.py > $out/${R}_bench_default_run.json 2>/dev/null
+  timeout 400 python bench.py > $out/${R}_bench_default_run.json 2>/dev/null
   timeout 200 python tools/attn_probe.py --ctx 1024 2>&1 | grep -v amdgpu.ids > $out/${R}_attn_phase_trace.txt
   timeout 200 python tools/attn_probe.py --ctx 1024 --batch 16 2>&1 | grep -v amdgpu.ids >> $out/${R}_attn_phase_trace.txt
   timeout 200 python tools/gemv_probe.py --sites 6 1 5 3 7 2>&1 | grep -v amdgpu.ids > $out/${R}_gemv_phase_trace.txt
-  for p in 1 0 1 0; do
-    PEGAINFER_GEMV_PERSIST=$p timeout 200 python bench.py --steps 96 --cpu-steps 0 --ttft-iters 1 --profile-iters 0 --ttft10k-iters 0 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('gemv persistent grid $p: tok/s', d['value'], 'device_ms', d['tpot_ms']['device_p50'])"
-  done > $out/${R}_gemv_persist_ab.txt
+  timeout 200 python tools/attn_probe.py --ctx 4096 2>&1 | grep -v amdgpu.ids >> $out/${R}_attn_phase_trace.txt
+  timeout 200 python tools/attn_probe.py --ctx 10000 2>&1 | grep -v amdgpu.ids >> $out/${R}_attn_phase_trace.txt
 fi
 if [ $part = b ] || [ $part = all ]; then
   cd $repo
@@ -47,7 +46,7 @@ if [ $part = b ] || [ $part = all ]; then
   done > $out/${R}_context_sweep.txt
   timeout 250 python bench.py --model qwen3-8b --steps 64 --cpu-steps 0 --profile-iters 0 --ttft10k-iters 0 2>/dev/null | tail -1 > $out/${R}_qwen3_8b_greedy.json
   timeout 250 python bench.py --model qwen3-8b --sampling topk_topp --steps 64 --cpu-steps 0 --ttft-iters 1 --profile-iters 0 --ttft10k-iters 0 2>/dev/null | tail -1 > $out/${R}_qwen3_8b_topk_topp.json
-  timeout 250 python bench.py --model qwen3.5-4b 2>/dev/null | tail -1 > $out/${R}_qwen35_4b_bench.json
+  timeout 250 python bench.py --model qwen3.5-4b --cpu-steps 0 2>/dev/null | tail -1 > $out/${R}_qwen35_4b_chained_bench.json
   cd /tmp
   kt ${R}_batch16 --batch 16 --steps 32 --cpu-steps 0 --ttft-iters 1 --profile-iters 0 --ttft10k-iters 0
   kt ${R}_batch32 --batch 32 --steps 32 --cpu-steps 0 --ttft-iters 1 --profile-iters 0 --ttft10k-iters 0
