@@ -201,7 +201,7 @@ struct OprojArgs {
   unsigned long long wait_ticks;   // bound of the o_proj workgroups' wait for the attention rows (30 ms; PEGAINFER_OPROJ_WAIT_TICKS
                                    // = 1 makes it expire at once: the test hook of the host's re-run path)
 };
-constexpr int kOprojMaxRows = 12;  // rows per wave quad
+constexpr int kOprojMaxRows = 14;  // rows per wave quad (12 until round 5; 14 admits 20 KV chunks = 96 o_proj workgroups for hidden 2560)
 
 template <int GROUP, int NB>   // NB = requests of the step (1, or 2 since round 5: VERDICT r4 item 4a)
 __global__ __launch_bounds__(512) void attn_oproj_kernel(const DecodeAttnArgs a, const OprojArgs g) {
