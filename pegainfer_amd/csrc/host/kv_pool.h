@@ -106,7 +106,7 @@ struct SplitPlan {
 // workgroups towards >= 256 (256 CUs): chunks/request = clamp(ceil(256/(bs*kv_heads)), 1, 64),
 // chunk = max(64, round_up16(ceil(L/chunks))); 64 tokens = one 16-token tile per wave, i.e. a workgroup's
 // whole K/V fetch is a single round trip.
-constexpr int kSplitChunkAlignDefault = 16;   // 128 = whole rounds of an 8-wave workgroup (measured: see make_split_plan)
+constexpr int kSplitChunkAlignDefault = 128;  // whole rounds of an 8-wave workgroup (16 = the round-4 plan; measured: see make_split_plan)
 constexpr int kOprojFusedMaxSeqDefault = 12288;   // measured: ctx 4096 2.213 -> 2.166 ms per step, ctx 10 000 2.422 -> 2.409 (profiles/r4_oproj_maxseq_ab.txt)
 // longest single request whose decode step keeps the fused attention + o_proj launch (18 chunks; PEGAINFER_OPROJ_MAX_SEQ
 // is the A/B knob: beyond 2304 tokens a chunk is more than one tile per wave, so the scan gets longer while the o_proj
@@ -123,7 +123,9 @@ inline int oproj_fused_max_batch() {
 }
 // chunks the requests of such a step are cut into, all together (PEGAINFER_OPROJ_CHUNKS, A/B knob)
 inline int oproj_fused_max_chunks() {
-  static const int c = [] { const char* e = getenv("PEGAINFER_OPROJ_CHUNKS"); const int v = e && *e ? atoi(e) : 18; return v < 2 ? 2 : (v > 30 ? 30 : v); }();
+  // 20 since round 5 (18 before): 10 000 tokens = 20 x 512 = four balanced tile rounds per workgroup; the 12 padding slots left
+  // give 96 o_proj workgroups x 14 rows per wave quad for hidden 2560 (kOprojMaxRows)
+  static const int c = [] { const char* e = getenv("PEGAINFER_OPROJ_CHUNKS"); const int v = e && *e ? atoi(e) : 20; return v < 2 ? 2 : (v > 30 ? 30 : v); }();
   return c;
 }
 // fused_oproj_usable: the caller can run the fused attention + o_proj launch on this step (single GPU, form enabled, shape
@@ -161,7 +163,9 @@ inline SplitPlan make_split_plan(int policy, const std::vector<int>& seq_lens, i
     // Chunks of more than one tile per wave (an 8-wave workgroup scans 128 tokens per round of its waves) are rounded up to
     // whole rounds when the fused form's plan applies: a 560-token chunk is 35 tiles dealt to 8 waves - three waves scan 5,
     // five scan 4 - and the workgroup's merge waits for the slowest (the "publish" phase of the in-kernel stamps grows from
-    // 2.4 us at 1 k to 5.7 us at 10 k tokens, profiles/r5_attn_phase_trace.txt).  PEGAINFER_SPLIT_CHUNK_ALIGN is the A/B knob.
+    // 2.4 us at 1 k to 5.7 us at 10 k tokens, profiles/r5_attn_phase_trace.txt).  Same-box A/B (profiles/r5_long_ctx_chunks_ab.txt):
+    // ctx 4096 +0.35 %, ctx 10 000 with 20 chunks of 512 tokens +0.55 % (18 chunks of 640: -2 %), ctx 2048 unchanged.
+    // PEGAINFER_SPLIT_CHUNK_ALIGN / PEGAINFER_OPROJ_CHUNKS are the A/B knobs.
     static const int align_env = [] { const char* e = getenv("PEGAINFER_SPLIT_CHUNK_ALIGN"); return e && *e ? atoi(e) : 0; }();
     const int align = align_env > 0 ? align_env : kSplitChunkAlignDefault;
     if (fused_oproj_usable && pairs <= oproj_fused_max_batch() * num_kv_heads && chunk > 128 && align > 16 && target_env <= 0)
