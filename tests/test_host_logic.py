@@ -89,6 +89,29 @@ def test_mi355x_split_policy_invariants(H, lens, padded):
     assert va[:oi[len(lens)]].all() and not va[oi[len(lens)]:].any()
 
 
+@pytest.mark.parametrize("lens,padded,chunk,chunks", [
+    ([1024], 1, 64, [16]),            # 64-token chunks (the floor): unchanged by round 5
+    ([2000], 1, 112, [18]),           # 2000 / 20 = 100 -> 112: one round of the 8 waves, 16-aligned as before
+    ([4096], 1, 256, [16]),           # 4096 / 20 = 205 -> 208 -> whole rounds of 8 waves: 256
+    ([10000], 1, 512, [20]),          # 10 000 / 20 = 500 -> 512: four balanced rounds (18 x 560 before)
+    ([1030, 777], 2, 112, [10, 7]),   # two requests share the budget: 10 chunks each at most
+    ([540, 300], 2, 64, [9, 5]),      # ... and below 10 x 64 tokens the chunks are the un-capped plan's 64
+])
+def test_mi355x_fused_form_plan_of_round_5(H, lens, padded, chunk, chunks):
+    """the fused attention + o_proj plan (pegainfer_split_kv_plan's default): at most 20 chunks shared by <= 2 requests,
+    chunks above 128 tokens rounded up to whole rounds of the 8-wave workgroup (profiles/r5_long_ctx_chunks_ab.txt)"""
+    slots = padded * 64
+    ri, kt = np.zeros(slots, np.int32), np.zeros(slots, np.int32)
+    oi, va = np.zeros(padded + 1, np.int32), np.zeros(slots, np.uint8)
+    c, use = np.zeros(1, np.int32), np.zeros(1, np.int32)
+    L = np.asarray(lens, np.int32)
+    n = H.pegainfer_split_kv_plan(1, len(lens), L.ctypes.data, padded, 8, ri.ctypes.data, kt.ctypes.data,
+                                  oi.ctypes.data, va.ctypes.data, c.ctypes.data, use.ctypes.data)
+    got = [int(oi[r + 1] - oi[r]) for r in range(len(lens))]
+    assert int(c[0]) == chunk and got == chunks, (int(c[0]), got)
+    assert sum(got) <= 20 and n == padded * (32 // padded) and use[0] == 1
+
+
 def test_native_safetensors_reader_matches_python(tmp_path):
     """The C++ mmap reader (csrc/host/safetensors_loader.h: JSON header parser, single file / HF directory with
     model.safetensors.index.json shards) sees the same tensors, shapes, dtypes and bytes as a Python parse."""
