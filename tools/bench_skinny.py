@@ -40,7 +40,8 @@ def main():
     eng.close()
     # bit-equality across variants (and a sanity bound against fp32 torch) on seeded products
     g = torch.Generator(device="cpu").manual_seed(11)
-    for name, M, K in [("o", 2560, 4096), ("down", 2560, 9728), ("qkv", 6144, 2560), ("ragged", 1000, 2560)]:
+    for name, M, K in [("o", 2560, 4096), ("down", 2560, 9728), ("qkv", 6144, 2560), ("ragged", 1000, 2560),
+                       ("gate_up", 19456, 2560), ("tall_ragged", 12300, 4096)]:
         W = (torch.randn(M, K, generator=g) * 0.05).to(torch.bfloat16).to(dev)
         for T in (5, 16, 32, 64):
             X = torch.randn(T, K, generator=g).to(torch.bfloat16).to(dev)
