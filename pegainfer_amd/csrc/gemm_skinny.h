@@ -388,12 +388,17 @@ __global__ __launch_bounds__(kSkinnyThreads) void skinny_resident_kernel(const G
   const int pitch = K >> 3;
   u32x4* xs = reinterpret_cast<u32x4*>(smem_raw);
   const int xs_bytes = (T * K * 2 + 15) & ~15;
-  // [8][NW][NB][64], twice in the one-barrier flush form (a.variant bit 0): row block n's partials go to buffer n & 1
+  // [8][NW][NB][64] per buffer.  One buffer in the two-barrier flush form; two in the one-barrier form (a.variant bit 0: row
+  // block n's partials go to buffer n & 1); a ring of 2..4 in the ticket form (bit 2, ring size in bits 4..7: block n -> buffer n % ring)
   f32x4* red = reinterpret_cast<f32x4*>(smem_raw + xs_bytes);
   constexpr int kRedQuads = 8 * NW * NB * 64;
   const bool flush1 = (a.variant & 1) != 0;
-  float* sm_inv = reinterpret_cast<float*>(smem_raw + xs_bytes + (flush1 ? 2 : 1) * kRedQuads * 16);  // [64]
+  const bool ticket = (a.variant & 4) != 0;
+  const int ring = ticket ? (a.variant >> 4) & 15 : (flush1 ? 2 : 1);
+  float* sm_inv = reinterpret_cast<float*>(smem_raw + xs_bytes + ring * kRedQuads * 16);  // [64]
+  int* sm_cnt = reinterpret_cast<int*>(sm_inv + 64);   // ticket form: [ring] arrivals, [ring] finished reductions (monotonic)
   const SkinnyLane L;
+  if (ticket && threadIdx.x < 2 * ring) sm_cnt[threadIdx.x] = 0;   // every prologue form below has a barrier before the K loop
   const int tid = threadIdx.x;
   const int rows_total = EPI == kEpiSilu ? a.I : a.M;
   const int rpb = a.rpb ? a.rpb : 16;          // rows per row block (launcher: skinny_pick_rpb)
@@ -536,22 +541,46 @@ __global__ __launch_bounds__(kSkinnyThreads) void skinny_resident_kernel(const G
   };
   zero();
 
-  // Combine the 8 waves (fixed order), store, reset.  Two forms, same arithmetic per element:
+  // Combine the 8 waves (fixed order), store, reset.  Three forms, same arithmetic per element:
   //  * two barriers around a reduction by the first NB waves (rounds 1-4);
   //  * one barrier (round 5): the partials of row block n go to buffer n & 1 and wave n & 7 ALONE adds and stores them
   //    while the other seven walk on into block n + 1.  Buffer n & 1 is written again for block n + 2, i.e. after
   //    barrier n + 1, which the reducing wave reaches only after its reduction of block n.
+  //  * no barrier (ticket form): a ring of buffers, block n -> buffer n % ring, its u-th use (u = n / ring).  A wave waits
+  //    until the buffer's previous use has been reduced (done == u), writes its partial and adds 1 to the buffer's arrival
+  //    count; wave n & 7 alone then waits for 8 (u + 1) arrivals, adds and stores, and publishes done = u + 1.  LDS executes
+  //    a wave's instructions in order, so the count is added after the partial is written and a reader that has seen the
+  //    count reads the partials behind it; no fence (a workgroup-scope fence would also drain the weight loads in flight).
+  //    The earliest unreduced block's writers wait only for blocks before it: no cycle.
   auto flush = [&](int rbi) {
-    f32x4* rb = flush1 ? red + (rbi & 1) * kRedQuads : red;
+    const int buf = ticket ? rbi % ring : (flush1 ? rbi & 1 : 0);
+    const int use = ticket ? rbi / ring : 0;
+    f32x4* rb = red + buf * kRedQuads;
+    if (ticket && use > 0)
+      while (__hip_atomic_load(&sm_cnt[ring + buf], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < use) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
 #pragma unroll
     for (int w = 0; w < NW; ++w)
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) rb[((L.wave * NW + w) * NB + nb) * 64 + L.lane] = skinny_fold(acc[w][nb]);
     zero();
     if (a.variant & 2) return;   // timing probe (PEGAINFER_SKINNY_FLUSH=2/3): no barrier, nothing stored
-    __syncthreads();
     const int blk0 = ((int)blockIdx.x + rbi * (int)gridDim.x) * rpb;
     const int lim = blk0 + rpb < rows_total ? blk0 + rpb : rows_total;
+    if (ticket) {
+      asm volatile("" ::: "memory");
+      if (L.lane == 0) (void)__hip_atomic_fetch_add(&sm_cnt[buf], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (L.wave == (rbi & 7)) {
+        while (__hip_atomic_load(&sm_cnt[buf], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < kSkinnyWaves * (use + 1))
+          __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+        skinny_reduce_store<NB, EPI>(a, rb, blk0, lim, L.lane, 64);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reduction's LDS reads have returned
+        if (L.lane == 0) __hip_atomic_store(&sm_cnt[ring + buf], use + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      return;
+    }
+    __syncthreads();
     if (flush1) {
       if (L.wave == (rbi & 7)) skinny_reduce_store<NB, EPI>(a, rb, blk0, lim, L.lane, 64);
     } else {
@@ -815,9 +844,10 @@ inline int skinny_pick_rpb(int rows) {
   return h < 1 ? 1 : (h > 16 ? 16 : h);
 }
 
-// PEGAINFER_SKINNY_FLUSH: 0 = two-barrier flush, 1 = one-barrier flush; +2 = timing probe without barriers and stores
+// PEGAINFER_SKINNY_FLUSH: 0 = two-barrier flush, 1 = one-barrier flush, 4 = ticket form (no barrier); +2 = timing probe
+// without barriers and stores
 inline int skinny_flush_mode() {
-  static const int v = [] { const char* e = getenv("PEGAINFER_SKINNY_FLUSH"); return e && *e ? atoi(e) & 3 : kSkinnyFlushDefault; }();
+  static const int v = [] { const char* e = getenv("PEGAINFER_SKINNY_FLUSH"); return e && *e ? atoi(e) & 7 : kSkinnyFlushDefault; }();
   return v;
 }
 
@@ -830,8 +860,14 @@ inline void skinny_launch_resident(GemvFusedArgs a, hipStream_t s) {
   const int nrb = ceil_div(rows, a.rpb);
   const int xs_bytes = (a.T * a.K * 2 + 15) & ~15, red_bytes = 8 * NW * NB * 64 * 16;
   a.variant = skinny_flush_mode();
-  if ((a.variant & 1) && xs_bytes + 2 * red_bytes + 64 * 4 > 160 * 1024) a.variant &= ~1;   // no room for the second buffer
-  const int lds = xs_bytes + ((a.variant & 1) ? 2 : 1) * red_bytes + 64 * 4;
+  const int room = (160 * 1024 - xs_bytes - 64 * 4 - 64) / red_bytes;   // buffers that fit beside x
+  int bufs = 1;
+  if (a.variant & 4) {
+    if (room >= 2) { bufs = room > 4 ? 4 : room; a.variant = (a.variant & 7) | (bufs << 4); }
+    else a.variant = (a.variant & 2) | 1;                               // no room for a ring: the one-barrier form ...
+  }
+  if ((a.variant & 5) == 1) { if (room >= 2) bufs = 2; else a.variant &= ~1; }   // ... or the two-barrier form
+  const int lds = xs_bytes + bufs * red_bytes + 64 * 4 + 64;
   auto kern = &skinny_resident_kernel<NB, EPI>;
   static const bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);

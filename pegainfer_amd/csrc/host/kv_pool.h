@@ -108,7 +108,7 @@ struct SplitPlan {
 // whole K/V fetch is a single round trip.
 constexpr int kSplitChunkAlignDefault = 128;  // whole rounds of an 8-wave workgroup (16 = the round-4 plan; measured: see make_split_plan)
 constexpr int kOprojFusedMaxSeqDefault = 12288;   // measured: ctx 4096 2.213 -> 2.166 ms per step, ctx 10 000 2.422 -> 2.409 (profiles/r4_oproj_maxseq_ab.txt)
-// longest single request whose decode step keeps the fused attention + o_proj launch (18 chunks; PEGAINFER_OPROJ_MAX_SEQ
+// longest single request whose decode step keeps the fused attention + o_proj launch (20 chunks; PEGAINFER_OPROJ_MAX_SEQ
 // is the A/B knob: beyond 2304 tokens a chunk is more than one tile per wave, so the scan gets longer while the o_proj
 // launch it hides stays 6 us)
 inline int oproj_fused_max_seq() {
@@ -155,7 +155,7 @@ inline SplitPlan make_split_plan(int policy, const std::vector<int>& seq_lens, i
     // tokens in one tile per wave) - the other slots of the launch grid stay
     // padding, and the fused attention + o_proj launch gives their workgroups the o_proj rows (attn_oproj_kernel)
     const int grid_slots = want;   // the launch grid keeps its one-workgroup-per-CU size
-    // (round 5) two requests share the same budget: 18 / 2 = 9 chunks each, the launch grid stays 2 x 16 slots x kv heads
+    // (round 5) two requests share the same budget: 20 / 2 = 10 chunks each, the launch grid stays 2 x 16 slots x kv heads
     if (fused_oproj_usable && pairs <= oproj_fused_max_batch() * num_kv_heads && max_seq <= oproj_fused_max_seq() && target_env <= 0)
       want = std::min(want, std::max(1, oproj_fused_max_chunks() / std::max(1, padded_bs)));
     int chunk = (max_seq + want - 1) / want;

@@ -230,8 +230,9 @@ def real2():
         work = {
             "bs1": [PROMPT_1024],
             # round 5: two requests in the fused attention + o_proj launch.  "bs2": <= 9 x 64 tokens each, where the capped
-            # plan of the fused form (9 chunks per request) and the un-capped plan of decode_mode 0 (16) cut the KV into the
-            # SAME 64-token chunks, so the two modes are comparable bit for bit; "bs2long": 128-token chunks, vs the oracle
+            # plan of the fused form (10 of the launch's 20 chunks per request) and the un-capped plan of decode_mode 0
+            # (16) cut the KV into the SAME 64-token chunks, so the two modes are comparable bit for bit; "bs2long":
+            # 128-token chunks, vs the oracle
             "bs2": [_prompt(rng, 540), _prompt(rng, 300)],
             "bs2long": [PROMPT_1024, _prompt(rng, 777)],
             "bs8": [_prompt(rng, n) for n in (700, 333, 129, 64, 17, 16, 5, 1)],
