@@ -377,7 +377,6 @@ skinny_tiles_done:
 // Same pair -> wave mapping and the same per-wave accumulation order as the tiled kernel: bit-identical.
 // ---------------------------------------------------------------------------------------------------
 constexpr int kSkinnyResidentBytes = 128 * 1024;   // o_proj at 16 columns (16 x 4096 x 2 B) is the largest resident x
-constexpr int kSkinnyFlushDefault = 0;
 
 template <int NB, int EPI>
 __global__ __launch_bounds__(kSkinnyThreads) void skinny_resident_kernel(const GemvFusedArgs a) {
@@ -567,6 +566,19 @@ __global__ __launch_bounds__(kSkinnyThreads) void skinny_resident_kernel(const G
     if (a.variant & 2) return;   // timing probe (PEGAINFER_SKINNY_FLUSH=2/3): no barrier, nothing stored
     const int blk0 = ((int)blockIdx.x + rbi * (int)gridDim.x) * rpb;
     const int lim = blk0 + rpb < rows_total ? blk0 + rpb : rows_total;
+    if (ticket && (a.variant & 8)) {   // last arriver reduces: nobody waits for the slowest wave, the slowest wave adds
+      asm volatile("" ::: "memory");
+      int old = 0;
+      if (L.lane == 0) old = __hip_atomic_fetch_add(&sm_cnt[buf], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      old = __builtin_amdgcn_readfirstlane(old);
+      asm volatile("" ::: "memory");
+      if (old == kSkinnyWaves * (use + 1) - 1) {
+        skinny_reduce_store<NB, EPI>(a, rb, blk0, lim, L.lane, 64);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reduction's LDS reads have returned
+        if (L.lane == 0) __hip_atomic_store(&sm_cnt[ring + buf], use + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      return;
+    }
     if (ticket) {
       asm volatile("" ::: "memory");
       if (L.lane == 0) (void)__hip_atomic_fetch_add(&sm_cnt[buf], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -625,212 +637,6 @@ __global__ __launch_bounds__(kSkinnyThreads) void skinny_resident_kernel(const G
   }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// Row-wave variant (round 5; T <= 16, x resident, tall matrices - gate_up, lm_head): every WAVE owns whole row blocks of
-// <= 8 rows and walks the full K of each, so there is no cross-wave reduction and no barrier after the x prologue (the
-// resident kernel above deals a block's K pairs onto its 8 waves and pays a barrier pair - and the wait for the slowest
-// wave - per row block, three times per workgroup for gate_up).  Row block b belongs to workgroup b % G, wave (b / G) % 8;
-// a block is ONE 8-row register per weight set, so a wave's load instruction fetches rpb (<= 8) distinct rows x 128 B (the
-// rows past rpb are clamped duplicates: same lines).  NS register sets of CH pairs are in flight per wave.
-// Per-element K order: pairs ascending into the two parity accumulators, added at the end - it differs from the 8-wave
-// kernels' (different bits, same bound), does not depend on T, rpb or the grid, and is the same for the store and the
-// SwiGLU form: a shape routed here is routed here in every form (skinny_rowwave_ok).
-// ---------------------------------------------------------------------------------------------------
-template <int EPI>
-__global__ __launch_bounds__(kSkinnyThreads) void skinny_rowwave_kernel(const GemvFusedArgs a) {
-  constexpr int NW = EPI == kEpiSilu ? 2 : 1;
-  constexpr int CH = NW == 1 ? 8 : 4;   // pairs per register set: 8 loads of 1 KB
-  constexpr int NS = 4;                 // register sets in flight (32 loads per wave)
-  constexpr int LPS = CH * NW;          // loads per set
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int K = a.K, T = a.T;
-  const int pitch = K >> 3;
-  u32x4* xs = reinterpret_cast<u32x4*>(smem_raw);
-  const int xs_bytes = (T * K * 2 + 15) & ~15;
-  float* sm_inv = reinterpret_cast<float*>(smem_raw + xs_bytes);   // [64]
-  const SkinnyLane L;
-  const int rows_total = EPI == kEpiSilu ? a.I : a.M;
-  const int rpb = a.rpb;                       // 1..8 (launcher: skinny_rowwave_rpb)
-  const int nrb = (rows_total + rpb - 1) / rpb;
-  const int np = K >> 6;                       // 64-wide K pairs (K % 64 == 0)
-  const int wave_u = __builtin_amdgcn_readfirstlane(L.wave);     // wave-uniform: the index arithmetic below stays scalar
-  const int first = (int)blockIdx.x + (int)gridDim.x * wave_u;   // this wave's first row block
-  const int stride = (int)gridDim.x * kSkinnyWaves;
-  const int my_nb = first < nrb ? (nrb - first + stride - 1) / stride : 0;
-  const int total = my_nb * np;                // this wave's work items (row block, pair); 0: the wave only helps stage x
-
-  // Work items are issued and multiplied strictly in order, so each side keeps a (row block, pair) cursor instead of
-  // dividing an item number by np.
-  u32x4 av[NS][NW][CH];
-  int ib = 0, ip = 0;                          // next item to load
-  auto issue = [&](u32x4 (&v)[NW][CH]) {       // total > 0
-#pragma unroll
-    for (int c = 0; c < CH; ++c) {
-      const bool live = ib < my_nb;            // past the end: clamped load of a valid address; not multiplied
-      const int bi = live ? ib : my_nb - 1, pair = live ? ip : np - 1;
-      if (++ip == np) { ip = 0; ++ib; }
-      const int blk0 = (first + bi * stride) * rpb;
-      const int lim = blk0 + rpb < rows_total ? blk0 + rpb : rows_total;
-      int row = blk0 + L.prow;
-      row = row < lim ? row : lim - 1;
-#pragma unroll
-      for (int w = 0; w < NW; ++w)
-        v[w][c] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(
-            a.W + ((size_t)row + (size_t)w * a.I) * K + pair * 64 + L.pchunk * 8));
-    }
-  };
-  // ---- prologue + one-time staging of x: the three forms of skinny_resident_kernel (x side first, the first two weight
-  //      sets behind it), same arithmetic ----
-  const bool round_sum = (a.flags & kGemvRoundSum) != 0;
-  constexpr int XV = 5;
-  const int nvec_row = K >> 3;
-  const bool early_plain = !a.norm_w && (K & 511) == 0;
-  const bool early_norm = a.norm_w && nvec_row <= 64 * XV && T <= 2 * kSkinnyWaves;
-  if (early_plain) {
-    typedef __attribute__((address_space(3))) void* lds_ptr_t;
-    const uint32_t xs_lds = (uint32_t)(uintptr_t)(lds_ptr_t)xs;
-    const int pieces = K >> 9;
-    for (int t = L.wave; t < T; t += kSkinnyWaves)
-      for (int q = 0; q < pieces; ++q) {
-        const Half* src = a.X + (size_t)t * K + (size_t)(((q << 6) + L.lane) ^ (t & 15)) * 8;
-        const uint32_t dst = xs_lds + (uint32_t)(t * pitch + (q << 6)) * 16u;
-        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
-                     :: "v"(src), "s"(__builtin_amdgcn_readfirstlane(dst)) : "memory", "m0");
-      }
-    if (total > 0) issue(av[0]);
-    if (total > CH) issue(av[1]);
-    if (total > CH) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * LPS) : "memory");
-    else if (total > 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LPS) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  } else if (early_norm) {
-    u32x4 hx[2][XV], rx[2][XV], gx[XV];
-#pragma unroll
-    for (int j = 0; j < XV; ++j) {
-      const int c = L.lane + 64 * j;
-      if (c < nvec_row) {
-        gx[j] = reinterpret_cast<const u32x4*>(a.norm_w)[c];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int t = L.wave + u * kSkinnyWaves;
-          if (t < T) {
-            hx[u][j] = reinterpret_cast<const u32x4*>(a.X + (size_t)t * K)[c];
-            if (a.residual) rx[u][j] = reinterpret_cast<const u32x4*>(a.residual + (size_t)t * K)[c];
-          }
-        }
-      }
-    }
-    asm volatile("" ::: "memory");   // the x-side loads stay in front of the weight loads
-    if (total > 0) issue(av[0]);
-    if (total > CH) issue(av[1]);
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int t = L.wave + u * kSkinnyWaves;
-      if (t >= T) continue;
-      float ss = 0.f;
-#pragma unroll
-      for (int j = 0; j < XV; ++j) {
-        if (L.lane + 64 * j < nvec_row) {
-          if (a.residual && round_sum) add_round_sq8(hx[u][j], rx[u][j], ss);
-          else if (a.residual) add_sq8(hx[u][j], rx[u][j], ss);
-          else sq8(hx[u][j], ss);
-        }
-      }
-      ss = wave_sum(ss);
-      const float inv = rsqrtf(__fadd_rn(ss / (float)K, a.eps));
-#pragma unroll
-      for (int j = 0; j < XV; ++j) {
-        const int c = L.lane + 64 * j;
-        if (c < nvec_row) {
-          u32x4 v;
-          if (a.residual) {
-            u32x4 nh;
-            v = norm_scale8(hx[u][j], &rx[u][j], gx[j], inv, 0.f, &nh, round_sum);
-            if (blockIdx.x == 0) reinterpret_cast<u32x4*>(a.hidden_out + (size_t)t * K)[c] = nh;
-          } else {
-            v = norm_scale8(hx[u][j], nullptr, gx[j], inv, 0.f, nullptr);
-          }
-          xs[t * pitch + (c ^ (t & 15))] = v;
-        }
-      }
-    }
-    __syncthreads();
-  } else {
-    if (total > 0) issue(av[0]);
-    if (total > CH) issue(av[1]);
-    if (a.norm_w) {
-      for (int t = L.wave; t < T; t += kSkinnyWaves) {
-        const float v = wave_row_inv_rms(a.X + (size_t)t * K, a.residual ? a.residual + (size_t)t * K : nullptr, K, a.eps,
-                                         round_sum);
-        if (L.lane == 0) sm_inv[t] = v;
-      }
-      __syncthreads();
-    }
-    skinny_stage_x<1>(a, xs, sm_inv, pitch, 0, K, L.wave, L.lane);
-    __syncthreads();
-  }
-  if (total == 0) return;                      // no barrier below this line
-#pragma unroll
-  for (int s = 2; s < NS; ++s)
-    if (total > s * CH) issue(av[s]);
-
-  f32x4 acc[NW][2];                            // [weight set][chunk parity] of the wave's current row block
-  auto zero = [&]() {
-#pragma unroll
-    for (int w = 0; w < NW; ++w) { acc[w][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[w][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-  };
-  zero();
-  // D layout of the parity trick (header): real row 2 g + e of the register = acc[.][0][2 e] + acc[.][1][2 e + 1], token l15
-  int cb = 0, cp = 0;                          // next item to multiply
-  auto store = [&](int bi) {
-    const int blk0 = (first + bi * stride) * rpb;
-    const int lim = blk0 + rpb < rows_total ? blk0 + rpb : rows_total;
-    if (L.l15 < T) {
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const int r = blk0 + 2 * L.g + e;
-        if (r >= lim) continue;
-        const float v0 = acc[0][0][2 * e] + acc[0][1][2 * e + 1];
-        if (EPI == kEpiSilu) {
-          const float gt = bf16_round_f(v0), up = bf16_round_f(acc[NW - 1][0][2 * e] + acc[NW - 1][1][2 * e + 1]);
-          a.Y[(size_t)L.l15 * a.I + r] = f2bf(silu_f(gt) * up);
-        } else {
-          a.Y[(size_t)L.l15 * a.M + r] = f2bf(v0);
-        }
-      }
-    }
-    zero();
-  };
-  const int tx = L.l15 < T ? L.l15 : T - 1;   // absent token columns re-read a staged row; their results are never stored
-  auto compute = [&](const u32x4 (&v)[NW][CH]) {
-#pragma unroll
-    for (int c = 0; c < CH; ++c) {
-      if (cb < my_nb) {
-        const int bi = cb, pair = cp;
-        if (++cp == np) { cp = 0; ++cb; }
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const bf16x8_t b = __builtin_bit_cast(bf16x8_t, xs[tx * pitch + ((pair * 8 + 2 * L.g + h) ^ L.l15)]);
-#pragma unroll
-          for (int w = 0; w < NW; ++w)
-            acc[w][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, v[w][c]), b, acc[w][h], 0, 0, 0);
-        }
-        if (pair == np - 1) store(bi);
-      }
-    }
-  };
-  for (int base = 0; base < total; base += NS * CH) {   // a register set is refilled as soon as it is consumed
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      const int it = base + s * CH;
-      if (it < total) {
-        compute(av[s]);
-        if (it + NS * CH < total) issue(av[s]);
-      }
-    }
-  }
-}
-
 // Row-block height (<= 16) that deals the row blocks evenly onto the CUs: k = the rounds 16-row blocks would need,
 // height = ceil(rows / (k * CUs)).  2560 rows -> 10 (256 blocks), 6144 -> 12 (512), 9728 -> 13 (749 of 768), 4096 -> 16.
 // PEGAINFER_SKINNY_RPB=0 keeps 16-row blocks (A/B); a positive value forces that height.
@@ -844,11 +650,16 @@ inline int skinny_pick_rpb(int rows) {
   return h < 1 ? 1 : (h > 16 ? 16 : h);
 }
 
-// PEGAINFER_SKINNY_FLUSH: 0 = two-barrier flush, 1 = one-barrier flush, 4 = ticket form (no barrier); +2 = timing probe
-// without barriers and stores
-inline int skinny_flush_mode() {
-  static const int v = [] { const char* e = getenv("PEGAINFER_SKINNY_FLUSH"); return e && *e ? atoi(e) & 7 : kSkinnyFlushDefault; }();
-  return v;
+// How the resident kernel combines its 8 waves per row block (bit-identical forms, profiles/r5_skinny_flush_ab.txt, T = 4 / 8 /
+// 16, cold weights): two barriers (rounds 1-4) -> gate_up 21.5-21.9 us, lm_head 131-143; one barrier -> 21.0-21.1, 129-142;
+// tickets -> 20.2-20.7, 121-133, but qkv / o_proj (two / one row block per workgroup: nothing to overlap) +0.1 us.  A probe
+// without barriers and stores (FLUSH=2) measured 18.2 us: what is left is the reducing wave's own wait and the stores.
+// Default: tickets where a workgroup walks more than two row blocks, else the one-barrier form.
+// PEGAINFER_SKINNY_FLUSH: 0 = two barriers, 1 = one barrier, 4 = tickets; +2 = the timing probe (nothing stored).
+inline int skinny_flush_mode(int nrb) {
+  static const int env = [] { const char* e = getenv("PEGAINFER_SKINNY_FLUSH"); return e && *e ? atoi(e) & 15 : -1; }();
+  if (env >= 0) return env;
+  return nrb > 2 * device_cus() ? 4 : 1;
 }
 
 template <int NB, int EPI>
@@ -859,11 +670,11 @@ inline void skinny_launch_resident(GemvFusedArgs a, hipStream_t s) {
   a.rpb = skinny_pick_rpb(rows);
   const int nrb = ceil_div(rows, a.rpb);
   const int xs_bytes = (a.T * a.K * 2 + 15) & ~15, red_bytes = 8 * NW * NB * 64 * 16;
-  a.variant = skinny_flush_mode();
+  a.variant = skinny_flush_mode(nrb);
   const int room = (160 * 1024 - xs_bytes - 64 * 4 - 64) / red_bytes;   // buffers that fit beside x
   int bufs = 1;
   if (a.variant & 4) {
-    if (room >= 2) { bufs = room > 4 ? 4 : room; a.variant = (a.variant & 7) | (bufs << 4); }
+    if (room >= 2) { bufs = room > 4 ? 4 : room; a.variant = (a.variant & 15) | (bufs << 4); }
     else a.variant = (a.variant & 2) | 1;                               // no room for a ring: the one-barrier form ...
   }
   if ((a.variant & 5) == 1) { if (room >= 2) bufs = 2; else a.variant &= ~1; }   // ... or the two-barrier form
@@ -920,32 +731,6 @@ inline void skinny_launch(GemvFusedArgs a, hipStream_t s) {
   }
 }
 
-// Row-wave routing, by shape only (so that the plain and the SwiGLU launch over the same matrix take the same kernel):
-// <= 16 token columns, x resident, at least kRowwaveMinRows weight rows streamed (gate_up: 2 I; lm_head).
-// PEGAINFER_SKINNY_ROWWAVE=0/1 switches it, PEGAINFER_SKINNY_ROWWAVE_RPB forces the rows per wave block (1..8).
-constexpr int kRowwaveMinRows = 12288;
-constexpr int kRowwaveDefault = 0;
-inline bool skinny_rowwave_ok(int rows_streamed, int T, int K) {
-  static const bool on = [] { const char* e = getenv("PEGAINFER_SKINNY_ROWWAVE"); return e && *e ? atoi(e) != 0 : kRowwaveDefault != 0; }();
-  return on && T >= 2 && T <= 16 && (K & 63) == 0 && (long)T * K * 2 <= kSkinnyResidentBytes && rows_streamed >= kRowwaveMinRows;
-}
-inline int skinny_rowwave_rpb(int rows) {
-  static const int env = [] { const char* e = getenv("PEGAINFER_SKINNY_ROWWAVE_RPB"); return e && *e ? atoi(e) : 0; }();
-  int h = env > 0 ? env : ceil_div(rows, device_cus() * kSkinnyWaves);
-  return h < 1 ? 1 : (h > 8 ? 8 : h);
-}
-template <int EPI>
-inline void skinny_launch_rowwave(GemvFusedArgs a, hipStream_t s) {
-  a.KT = a.K;
-  a.rpb = skinny_rowwave_rpb(EPI == kEpiSilu ? a.I : a.M);
-  const int lds = ((a.T * a.K * 2 + 15) & ~15) + 64 * 4;
-  auto kern = &skinny_rowwave_kernel<EPI>;
-  static const bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
-  (void)once;
-  kern<<<device_cus(), kSkinnyThreads, lds, s>>>(a);
-}
-
 // 2 <= T <= 64, K % 64 == 0
 template <int EPI>
 inline bool skinny_dispatch(const GemvFusedArgs& a, hipStream_t s) {
@@ -954,7 +739,6 @@ inline bool skinny_dispatch(const GemvFusedArgs& a, hipStream_t s) {
   const int nb = a.T <= 16 ? 1 : a.T <= 32 ? 2 : 4;
   const bool resident = (long)a.T * a.K * 2 <= kSkinnyResidentBytes &&
                         (long)a.T * a.K * 2 + 8 * NW * nb * 64 * 16 + 256 <= 160 * 1024;
-  if (skinny_rowwave_ok(EPI == kEpiSilu ? 2 * a.I : a.M, a.T, a.K)) { skinny_launch_rowwave<EPI>(a, s); return true; }
   if (a.T <= 16) { if (resident) skinny_launch_resident<1, EPI>(a, s); else skinny_launch<1, EPI>(a, s); }
   else if (a.T <= 32) { if (resident) skinny_launch_resident<2, EPI>(a, s); else skinny_launch<2, EPI>(a, s); }
   else { if (resident) skinny_launch_resident<4, EPI>(a, s); else skinny_launch<4, EPI>(a, s); }

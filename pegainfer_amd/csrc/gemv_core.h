@@ -54,7 +54,8 @@ struct GemvFusedArgs {
   int flags;              // kGemvNormOffset | kGemvRoundSum | kGemvSiluRound (dot2 GEMV path only)
   unsigned long long* trace;  // debug (pegainfer_debug_gemv_trace): 8 wall-clock stamps per workgroup, else null
   int rpb;                // skinny kernels: W rows per row block (0 = 16); set by the launcher (skinny_pick_rpb)
-  int variant;            // skinny resident kernel: bit 0 = one-barrier flush (launcher: skinny_flush_mode), bit 1 = timing probe
+  int variant;            // skinny resident kernel (launcher: skinny_flush_mode): bit 0 one-barrier flush, bit 2 ticket flush with
+                          // the ring size in bits 4..7, bit 1 timing probe
 };
 // process-wide debug hook, defined in linear.hip; copied into the launch arguments by gemv_launch_one
 extern unsigned long long* g_gemv_trace;
