@@ -566,19 +566,6 @@ __global__ __launch_bounds__(kSkinnyThreads) void skinny_resident_kernel(const G
     if (a.variant & 2) return;   // timing probe (PEGAINFER_SKINNY_FLUSH=2/3): no barrier, nothing stored
     const int blk0 = ((int)blockIdx.x + rbi * (int)gridDim.x) * rpb;
     const int lim = blk0 + rpb < rows_total ? blk0 + rpb : rows_total;
-    if (ticket && (a.variant & 8)) {   // last arriver reduces: nobody waits for the slowest wave, the slowest wave adds
-      asm volatile("" ::: "memory");
-      int old = 0;
-      if (L.lane == 0) old = __hip_atomic_fetch_add(&sm_cnt[buf], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      old = __builtin_amdgcn_readfirstlane(old);
-      asm volatile("" ::: "memory");
-      if (old == kSkinnyWaves * (use + 1) - 1) {
-        skinny_reduce_store<NB, EPI>(a, rb, blk0, lim, L.lane, 64);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reduction's LDS reads have returned
-        if (L.lane == 0) __hip_atomic_store(&sm_cnt[ring + buf], use + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
-      return;
-    }
     if (ticket) {
       asm volatile("" ::: "memory");
       if (L.lane == 0) (void)__hip_atomic_fetch_add(&sm_cnt[buf], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -654,10 +641,13 @@ inline int skinny_pick_rpb(int rows) {
 // 16, cold weights): two barriers (rounds 1-4) -> gate_up 21.5-21.9 us, lm_head 131-143; one barrier -> 21.0-21.1, 129-142;
 // tickets -> 20.2-20.7, 121-133, but qkv / o_proj (two / one row block per workgroup: nothing to overlap) +0.1 us.  A probe
 // without barriers and stores (FLUSH=2) measured 18.2 us: what is left is the reducing wave's own wait and the stores.
+// A ticket form in which the LAST ARRIVER adds (nobody waits; the slowest wave gets the extra work) measured worse than the
+// designated wave: gate_up 21.8-22.2 us (profiles/r5_skinny_flush_ab2.txt).  In the pipeline (bench.py --batch, same box,
+// alternating, two-barrier form vs this default): bs 4 2.68 / 2.67 -> 2.59 / 2.60 ms per step, bs 16 3.564 / 3.567 -> 3.464 / 3.490.
 // Default: tickets where a workgroup walks more than two row blocks, else the one-barrier form.
 // PEGAINFER_SKINNY_FLUSH: 0 = two barriers, 1 = one barrier, 4 = tickets; +2 = the timing probe (nothing stored).
 inline int skinny_flush_mode(int nrb) {
-  static const int env = [] { const char* e = getenv("PEGAINFER_SKINNY_FLUSH"); return e && *e ? atoi(e) & 15 : -1; }();
+  static const int env = [] { const char* e = getenv("PEGAINFER_SKINNY_FLUSH"); return e && *e ? atoi(e) & 7 : -1; }();
   if (env >= 0) return env;
   return nrb > 2 * device_cus() ? 4 : 1;
 }
@@ -674,7 +664,7 @@ inline void skinny_launch_resident(GemvFusedArgs a, hipStream_t s) {
   const int room = (160 * 1024 - xs_bytes - 64 * 4 - 64) / red_bytes;   // buffers that fit beside x
   int bufs = 1;
   if (a.variant & 4) {
-    if (room >= 2) { bufs = room > 4 ? 4 : room; a.variant = (a.variant & 15) | (bufs << 4); }
+    if (room >= 2) { bufs = room > 4 ? 4 : room; a.variant = (a.variant & 7) | (bufs << 4); }
     else a.variant = (a.variant & 2) | 1;                               // no room for a ring: the one-barrier form ...
   }
   if ((a.variant & 5) == 1) { if (room >= 2) bufs = 2; else a.variant &= ~1; }   // ... or the two-barrier form
