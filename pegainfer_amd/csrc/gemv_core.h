@@ -36,15 +36,11 @@ __host__ __device__ inline int gemv_xs_bytes(int K, int KT) {
   const int kt = K < KT ? K : KT;
   return (NT * kt * 2 + 15) & ~15;
 }
-constexpr int kGemvPartRing = 4;
-constexpr bool kGemvTicketDefault = false;
 template <int NT, int RPW, int KSPLIT, int EPI>
 inline int gemv_lds_bytes(int K, int KT, bool residual) {
   constexpr int NW = EPI == kEpiSilu ? 2 : 1;
   // x tile (+ the raw residual rows of the early prologue) + K-split partials + 16 floats: inv_rms per token
-  // K-split forms: a ring of kGemvPartRing partial buffers + 2 x kGemvPartRing counters behind them (ticket form)
-  return gemv_xs_bytes<NT>(K, KT) * (residual && NT <= 2 ? 2 : 1) +
-         ((KSPLIT == 1 ? 0 : kGemvPartRing * 4 * NW * RPW * NT + 2 * kGemvPartRing) + 16) * 4;
+  return gemv_xs_bytes<NT>(K, KT) * (residual && NT <= 2 ? 2 : 1) + ((KSPLIT == 1 ? 0 : 4 * NW * RPW * NT) + 16) * 4;
 }
 
 struct GemvFusedArgs {
@@ -76,8 +72,8 @@ constexpr int kGemvNormAllWaves = 32;   // launcher-only bit (PEGAINFER_GEMV_NOR
 // U = K blocks a wave keeps in flight per row (U*NW*RPW loads of 1 KB).  The launcher picks U = 5 when that covers a
 // whole row (K = 2560: 5 blocks; K = 9728 dealt to 4 waves: 5, 5, 5, 4), so a row group needs ONE memory round trip
 // instead of "four blocks, then a dependent fifth"; the per-(row, token) block order is the same for every U.
-template <int NT, int RPW, int KSPLIT, int EPI, int U = 4, bool TICKET = false>
-__global__ __launch_bounds__(256, TICKET && NT == 1 ? 4 : 1) void gemv_fused_kernel(const GemvFusedArgs a) {
+template <int NT, int RPW, int KSPLIT, int EPI, int U = 4>
+__global__ __launch_bounds__(256) void gemv_fused_kernel(const GemvFusedArgs a) {
   const int KT = a.KT;
   constexpr int NW = EPI == kEpiSilu ? 2 : 1;  // weight row sets streamed together
   constexpr int ROWS_PER_GROUP = (KSPLIT == 1 ? 4 : 1) * RPW;
@@ -88,12 +84,7 @@ __global__ __launch_bounds__(256, TICKET && NT == 1 ? 4 : 1) void gemv_fused_ker
   const int xs_bytes = gemv_xs_bytes<NT>(a.K, a.KT);
   u32x4* rs = reinterpret_cast<u32x4*>(smem_raw + xs_bytes);   // raw residual rows (early prologue), when given
   float* part = reinterpret_cast<float*>(smem_raw + xs_bytes * (a.residual && NT <= 2 ? 2 : 1));
-  constexpr int kPartFloats = 4 * NW * RPW * NT;   // one buffer of K-split partials: [4 waves][NW][RPW][NT]
-  float* red = part + (KSPLIT == 1 ? 0 : kGemvPartRing * kPartFloats + 2 * kGemvPartRing);
-  int* tk = reinterpret_cast<int*>(part + kGemvPartRing * kPartFloats);   // K-split ticket form: [ring] arrivals, [ring] reductions done
-  constexpr bool ticket = KSPLIT > 1 && TICKET;   // its own instantiation: the barrier form keeps its 128 VGPRs (4 workgroups per CU)
-  if (ticket && threadIdx.x < 2 * kGemvPartRing) tk[threadIdx.x] = 0;   // every prologue form has a barrier before the first group ends
-  int git = 0;                                      // groups this workgroup has finished
+  float* red = part + (KSPLIT == 1 ? 0 : 4 * NW * RPW * NT);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int K = a.K, T = a.T;
   const int pitch = (K < KT ? K : KT) >> 3;  // 16-byte vectors per token row of the x tile
@@ -376,43 +367,6 @@ __global__ __launch_bounds__(256, TICKET && NT == 1 ? 4 : 1) void gemv_fused_ker
 #pragma unroll
           for (int t = 0; t < NT; ++t) emit(r, t, acc[0][r][t], acc[NW - 1][r][t]);
       }
-    } else if constexpr (ticket) {
-      // No barrier (round 5, as skinny_resident_kernel's ticket flush): group n's partials go to buffer n % ring, wave n & 3
-      // alone waits for the four arrivals and adds them in wave order (same sum as below); a buffer is rewritten only after
-      // its previous reduction was published.  LDS executes a wave's instructions in order: no fence.
-      const int slot = git % kGemvPartRing, use = git / kGemvPartRing;
-      float* pb = part + slot * kPartFloats;
-      if (lane == 0) {
-        if (use > 0)
-          while (__hip_atomic_load(&tk[kGemvPartRing + slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < use) __builtin_amdgcn_s_sleep(1);
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int s = 0; s < NW; ++s)
-#pragma unroll
-          for (int r = 0; r < RPW; ++r)
-#pragma unroll
-            for (int t = 0; t < NT; ++t) pb[((wave * NW + s) * RPW + r) * NT + t] = acc[s][r][t];
-        asm volatile("" ::: "memory");
-        (void)__hip_atomic_fetch_add(&tk[slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
-      if (wave == (git & 3) && lane < RPW * NT) {
-        while (__hip_atomic_load(&tk[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4 * (use + 1)) __builtin_amdgcn_s_sleep(1);
-        asm volatile("" ::: "memory");
-        const int r = lane / NT, t = lane - r * NT;
-        float tot[NW];
-#pragma unroll
-        for (int s = 0; s < NW; ++s) {
-          float v = pb[((0 * NW + s) * RPW + r) * NT + t];
-          v += pb[((1 * NW + s) * RPW + r) * NT + t];
-          v += pb[((2 * NW + s) * RPW + r) * NT + t];
-          v += pb[((3 * NW + s) * RPW + r) * NT + t];
-          tot[s] = v;
-        }
-        emit(r, t, tot[0], tot[NW - 1]);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the partials have been read
-        if (lane == 0) __hip_atomic_store(&tk[kGemvPartRing + slot], use + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
-      ++git;
     } else {
       if (lane == 0) {
 #pragma unroll
@@ -452,17 +406,13 @@ __global__ __launch_bounds__(256, TICKET && NT == 1 ? 4 : 1) void gemv_fused_ker
 // Grid sizing: every workgroup should be co-resident (no second, half-empty scheduling round) and all of them
 // should walk the same number of row groups.  capacity = occupancy(kernel, lds) x CU count; rounds =
 // ceil(ngroups / capacity); grid = ceil(ngroups / rounds).  K > KT (multi-tile x) needs one group per workgroup.
-template <int NT, int RPW, int KSPLIT, int EPI, int U = 4, bool TICKET = false>
+template <int NT, int RPW, int KSPLIT, int EPI, int U = 4>
 inline void gemv_launch_one(const GemvFusedArgs& a, hipStream_t s) {
-  if constexpr (KSPLIT > 1 && NT == 1 && !TICKET) {   // PEGAINFER_GEMV_TICKET (single column): the K-split partials meet without a barrier
-    static const bool ticket = [] { const char* e = getenv("PEGAINFER_GEMV_TICKET"); return e && *e ? *e != '0' : kGemvTicketDefault; }();
-    if (ticket) { gemv_launch_one<NT, RPW, KSPLIT, EPI, U, true>(a, s); return; }
-  }
   constexpr int ROWS_PER_GROUP = (KSPLIT == 1 ? 4 : 1) * RPW;
   const int rows = EPI == kEpiSilu ? a.I : a.M;
   const int ngroups = ceil_div(rows, ROWS_PER_GROUP);
   const int lds = gemv_lds_bytes<NT, RPW, KSPLIT, EPI>(a.K, a.KT, a.residual != nullptr);
-  auto kern = &gemv_fused_kernel<NT, RPW, KSPLIT, EPI, U, TICKET>;
+  auto kern = &gemv_fused_kernel<NT, RPW, KSPLIT, EPI, U>;
   static const bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
   (void)once;
