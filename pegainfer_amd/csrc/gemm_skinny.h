@@ -269,55 +269,6 @@ __global__ __launch_bounds__(kSkinnyThreads) void skinny_mfma_kernel(const GemvF
   // are counted: x(k) has landed when at most W(k) [+ x(k+1) + W(k+1)] are outstanding.
   constexpr bool kDmaForm = kPipe && NB == 1 && RB == 1 && NW == 1;
   constexpr int kDmaPerTile = 2 * 4;   // 2 token rows per wave x 4 pieces of 1 KiB
-  // Same shapes, x straight into the B-operand registers (round 5, a.variant bit 8): with ONE row block per workgroup every x
-  // element is used once, by the wave that owns its K pair - so each wave loads exactly the fragments it multiplies
-  // (lane (token, k group g): 16 bytes at chunk 2 g + h of its pairs; L2 hits), behind nothing and in front of the same
-  // tile's weights.  No LDS image of x, no barrier in the K loop; accumulation order as in compute_b: same bits.
-  if constexpr (kDmaForm) {
-    if ((a.variant & 0x100) && !a.norm_w && KT == 2048 && T <= 2 * kSkinnyWaves) {
-      u32x4 xA[JP][2], xB[JP][2];
-      const int tx = L.l15 < T ? L.l15 : T - 1;   // absent token columns re-read a valid row; never stored
-      const Half* xrow = a.X + (size_t)tx * K + L.g * 16;
-      auto issue_x = [&](int k0, u32x4 (&xv)[JP][2]) {
-        const int kt = (K - k0) < KT ? (K - k0) : KT;
-        const int npairs = kt >> 6;
-#pragma unroll
-        for (int j = 0; j < JP; ++j) {
-          int p = L.wave + kSkinnyWaves * j;
-          p = p < npairs ? p : npairs - 1;
-#pragma unroll
-          for (int h = 0; h < 2; ++h) xv[j][h] = *reinterpret_cast<const u32x4*>(xrow + k0 + p * 64 + h * 8);
-        }
-      };
-      auto compute_x = [&](int k0, const u32x4 (&av)[NW][RB][JP][2], const u32x4 (&xv)[JP][2]) {
-        const int kt = (K - k0) < KT ? (K - k0) : KT;
-        const int npairs = kt >> 6;
-#pragma unroll
-        for (int j = 0; j < JP; ++j) {
-          const int p = L.wave + kSkinnyWaves * j;
-          if (p < npairs) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-              for (int rh = 0; rh < 2; ++rh)
-                acc[0][0][0][rh][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                    __builtin_bit_cast(bf16x8_t, av[0][0][j][rh]), __builtin_bit_cast(bf16x8_t, xv[j][h]), acc[0][0][0][rh][h], 0, 0, 0);
-          }
-        }
-      };
-      issue_x(0, xA);
-      issue(0, avA);
-      if (KT < K) { issue_x(KT, xB); issue(KT, avB); }
-      for (int k0 = 0; k0 < K; k0 += 2 * KT) {
-        compute_x(k0, avA, xA);
-        if (k0 + 2 * KT < K) { issue_x(k0 + 2 * KT, xA); issue(k0 + 2 * KT, avA); }
-        if (k0 + KT >= K) break;
-        compute_x(k0 + KT, avB, xB);
-        if (k0 + 3 * KT < K) { issue_x(k0 + 3 * KT, xB); issue(k0 + 3 * KT, avB); }
-      }
-      goto skinny_tiles_done;
-    }
-  }
   if constexpr (kDmaForm) {
     if (!a.norm_w && KT == 2048 && (K & 511) == 0 && T <= 2 * kSkinnyWaves) {   // launcher doubled the tile region
       typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -425,7 +376,6 @@ skinny_tiles_done:
 // weight loads (CH pairs = 2*CH KB per weight set) in flight - no per-tile barrier, no re-staging.
 // Same pair -> wave mapping and the same per-wave accumulation order as the tiled kernel: bit-identical.
 // ---------------------------------------------------------------------------------------------------
-constexpr bool kSkinnyXDirectDefault = false;
 constexpr int kSkinnyResidentBytes = 128 * 1024;   // o_proj at 16 columns (16 x 4096 x 2 B) is the largest resident x
 
 template <int NB, int EPI>
@@ -742,9 +692,6 @@ inline void skinny_launch_rb(GemvFusedArgs a, hipStream_t s) {
   a.rpb = RB == 1 ? skinny_pick_rpb(rows) : 16;
   // the LDS-DMA form of the kernel (plain x, <= 16 columns, 2048-wide tiles) keeps two x tile buffers
   const bool dma_form = NB == 1 && RB == 1 && EPI != kEpiSilu && !a.norm_w && a.KT == 2048 && (a.K & 511) == 0 && a.T <= 16;
-  // PEGAINFER_SKINNY_XDIRECT: x fragments straight into registers on the same shapes (see the kernel)
-  static const bool xdirect = [] { const char* e = getenv("PEGAINFER_SKINNY_XDIRECT"); return e && *e ? *e != '0' : kSkinnyXDirectDefault; }();
-  a.variant = dma_form && xdirect ? 0x100 : 0;
   const int lds = skinny_xs_bytes(NB, a.T, a.KT) * (dma_form ? 2 : 1) + (64 + 4) * 4;
   auto kern = &skinny_mfma_kernel<NB, EPI, RB>;
   static const bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
