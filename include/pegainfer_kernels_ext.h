@@ -123,6 +123,12 @@ int32_t pegainfer_fused_decode_attention_oproj_supported(int32_t num_qo_heads, i
  * consumed, [3] K loop of the last row group done, [4] exit, [5] XCC id.  tools/gemv_probe.py prints the breakdown. */
 void pegainfer_debug_gemv_trace(uint64_t* buf);
 
+/* Debug / test hook (not in ffi.rs), no device work: force how the batched-decode GEMM at 3..16 token columns
+ * (skinny_resident_kernel) combines its 8 waves' partial sums per row block: 0 = two barriers, 1 = one barrier,
+ * 4 = LDS tickets without a barrier; -1 = the launcher's own choice (tickets where a workgroup walks more than two row
+ * blocks).  The forms produce the same bits; the hook exists so that a test can show it inside one process. */
+void pegainfer_debug_skinny_flush(int32_t mode);
+
 /* Debug aid (not in ffi.rs): buf = device array of slots * num_kv_heads * 8 uint64, or NULL to switch off.  Every later
  * fused decode-attention launch stamps it with the 100 MHz wall clock at its phase boundaries: [0] entry, [1] slot
  * record read, [2] q prologue done, [3] KV scan done, [4] partials published, [5] ticket drawn, [6] merge done,

@@ -646,8 +646,10 @@ inline int skinny_pick_rpb(int rows) {
 // alternating, two-barrier form vs this default): bs 4 2.68 / 2.67 -> 2.59 / 2.60 ms per step, bs 16 3.564 / 3.567 -> 3.464 / 3.490.
 // Default: tickets where a workgroup walks more than two row blocks, else the one-barrier form.
 // PEGAINFER_SKINNY_FLUSH: 0 = two barriers, 1 = one barrier, 4 = tickets; +2 = the timing probe (nothing stored).
+extern int g_skinny_flush_override;   // linear.hip: pegainfer_debug_skinny_flush (tests compare the forms in one process); -1 = none
 inline int skinny_flush_mode(int nrb) {
   static const int env = [] { const char* e = getenv("PEGAINFER_SKINNY_FLUSH"); return e && *e ? atoi(e) & 7 : -1; }();
+  if (g_skinny_flush_override >= 0) return g_skinny_flush_override & 7;
   if (env >= 0) return env;
   return nrb > 2 * device_cus() ? 4 : 1;
 }

@@ -476,6 +476,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_add_kernel(const float* __r
 // Split-K workspace (64 MB): created by cublas_init() (the reference's handles own a 32 MB cuBLAS workspace the same way,
 // csrc/linear.cu:14-42), per thread = per GPU rank.  Without it the split-K route is simply not taken.
 constexpr size_t kSplitKWorkspaceBytes = 64u << 20;
+int g_skinny_flush_override = -1;
 static thread_local float* g_splitk_ws = nullptr;
 
 static bool glds_gemm_ok(const Half* W, const Half* X, const Half* Y, int M, int K) {
@@ -808,6 +809,9 @@ extern "C" {
 // 100 MHz wall clock: [0] entry, [1] x staged, [2] first weight block consumed, [3] last row group's K loop done,
 // [4] exit, [5] XCC id; nullptr switches it off (tools/gemv_probe.py).  Not part of the reference ABI.
 void pegainfer_debug_gemv_trace(uint64_t* buf) { pk::g_gemv_trace = reinterpret_cast<unsigned long long*>(buf); }
+// Debug / test hook: force how skinny_resident_kernel's 8 waves meet per row block (0 two barriers, 1 one barrier, 4 tickets;
+// -1 = back to the launcher's choice).  The forms are bit-identical; tests/test_gpu_ops.py compares them in one process.
+void pegainfer_debug_skinny_flush(int32_t mode) { pk::g_skinny_flush_override = mode < 0 ? -1 : (mode & 7); }
 
 
 int32_t cuda_set_device(int32_t device_ordinal) { return static_cast<int32_t>(hipSetDevice(device_ordinal)); }

@@ -68,6 +68,47 @@ def test_gemv_fused_silu_epilogue_matches_unfused(built_libs, T, I, K):
     assert np.array_equal(bf16_bits(from_dev(out)), bf16_bits(from_dev(ref)))
 
 
+@pytest.mark.parametrize("T", [3, 8, 16])
+def test_skinny_flush_forms_are_bit_identical(built_libs, T):
+    """Round 5: skinny_resident_kernel combines its 8 waves' partial sums per row block with two barriers, one barrier, or
+    LDS tickets without a barrier (the launcher's choice where a workgroup walks more than two row blocks).  Same bits in all
+    three, on shapes whose workgroups walk 1, 2, 3-5 and ~40 row blocks (the last two re-use the ticket ring's buffers), for
+    the plain store and for the add + RMSNorm prologue with the SwiGLU epilogue."""
+    import torch
+    from pegainfer_amd import ffi
+    L = ffi.lib()
+    s = torch.cuda.current_stream().cuda_stream
+    rng = np.random.default_rng(100 + T)
+    try:
+        for M, K in [(2560, 4096), (6144, 2560), (19456, 2560), (12300, 4096), (151936 // 4, 2560)]:
+            W, X = rnd(rng, M, K, scale=0.05), rnd(rng, T, K)
+            Wd, Xd = to_dev(W), to_dev(X)
+            outs = {}
+            for mode in (0, 1, 4, -1):
+                L.pegainfer_debug_skinny_flush(mode)
+                y = torch.zeros((T, M), dtype=torch.bfloat16, device="cuda")
+                assert L.pegainfer_gemv_fused(Wd.data_ptr(), Xd.data_ptr(), y.data_ptr(), M, T, K, None, None, None, 0.0, 0, s) == 0
+                outs[mode] = bf16_bits(from_dev(y))
+            assert all(np.array_equal(outs[0], outs[m]) for m in (1, 4, -1)), (M, K)
+            ref = X.astype(np.float64) @ W.astype(np.float64).T
+            assert np.abs(from_dev(y) - ref).max() <= 2.0 ** -6 * max(1.0, np.abs(ref).max())
+        I, K = 9728, 2560
+        W, X, R, g = rnd(rng, 2 * I, K, scale=0.06), rnd(rng, T, K), rnd(rng, T, K), rnd(rng, K)
+        Wd, Xd, Rd, gd = to_dev(W), to_dev(X), to_dev(R), to_dev(g)
+        outs = {}
+        for mode in (0, 1, 4, -1):
+            L.pegainfer_debug_skinny_flush(mode)
+            y = torch.zeros((T, I), dtype=torch.bfloat16, device="cuda")
+            h = torch.zeros((T, K), dtype=torch.bfloat16, device="cuda")
+            assert L.pegainfer_gemv_fused(Wd.data_ptr(), Xd.data_ptr(), y.data_ptr(), 2 * I, T, K, Rd.data_ptr(), gd.data_ptr(),
+                                          h.data_ptr(), 1e-6, I, s) == 0
+            outs[mode] = (bf16_bits(from_dev(y)), bf16_bits(from_dev(h)))
+        for m in (1, 4, -1):
+            assert np.array_equal(outs[0][0], outs[m][0]) and np.array_equal(outs[0][1], outs[m][1])
+    finally:
+        L.pegainfer_debug_skinny_flush(-1)
+
+
 def test_gemv_fused_rejects_unsupported_shapes(built_libs):
     import torch
     from pegainfer_amd import ffi
