@@ -1,15 +1,14 @@
 #!/bin/bash
-# One gpurun call (round 5): ticket flush with a designated reducer (4) against the last-arriver form (12) and the two-barrier
-# form (0) at the call sites; then the batch sweep points with the two-barrier form against the default (auto) in the pipeline.
+# One gpurun call (round 5): ticket flush with a designated reducer (4) against the two-barrier form (0) at the call sites (the
+# run archived as profiles/r5_skinny_flush_ab2.txt also had a last-arriver ticket form, 12, measured slower and removed since); then the batch sweep points with the two-barrier form against the default (auto) in the pipeline.
 mkdir -p gpurun_out
 out=gpurun_out/r5_skinny_flush_ab2.txt
 : > $out
 run() { env "$@" timeout 150 python tools/bench_skinny.py ${SKINNY_TS:-4 16} 2>&1 | grep -v "amdgpu.ids" >> $out || echo "variant $* failed" >> $out; }
-run PEGAINFER_SKINNY_FLUSH=12
 run PEGAINFER_SKINNY_FLUSH=4
 run PEGAINFER_SKINNY_FLUSH=0
-run PEGAINFER_SKINNY_FLUSH=12
 run PEGAINFER_SKINNY_FLUSH=4
+run PEGAINFER_SKINNY_FLUSH=0
 grep layer4 $out
 python - <<'PY'
 import re, collections
