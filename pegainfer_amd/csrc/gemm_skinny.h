@@ -540,7 +540,7 @@ __global__ __launch_bounds__(kSkinnyThreads) void skinny_resident_kernel(const G
   };
   zero();
 
-  // Combine the 8 waves (fixed order), store, reset.  Three forms, same arithmetic per element:
+  // Combine the 8 waves (fixed order), store, reset.  Four forms, same arithmetic per element:
   //  * two barriers around a reduction by the first NB waves (rounds 1-4);
   //  * one barrier (round 5): the partials of row block n go to buffer n & 1 and wave n & 7 ALONE adds and stores them
   //    while the other seven walk on into block n + 1.  Buffer n & 1 is written again for block n + 2, i.e. after
@@ -551,34 +551,60 @@ __global__ __launch_bounds__(kSkinnyThreads) void skinny_resident_kernel(const G
   //    a wave's instructions in order, so the count is added after the partial is written and a reader that has seen the
   //    count reads the partials behind it; no fence (a workgroup-scope fence would also drain the weight loads in flight).
   //    The earliest unreduced block's writers wait only for blocks before it: no cycle.
+  //  * lazy tickets (bits 0 + 2): as above, but wave n & 7 does not wait at all: it remembers that it owes block n and adds
+  //    it up at one of its later flushes once the count is complete - at the latest when buffer n % ring is needed again
+  //    (block n + ring, by which time every wave has written block n... or it waits for that) or after its last item.  A wave
+  //    owes at most one block at a time (its blocks are 8 apart, the ring is <= 4 deep), and a wave at block r has added up
+  //    everything it owed up to r - ring, so the earliest unreduced block never waits on a later one.
+  const int wave_u = __builtin_amdgcn_readfirstlane(L.wave);
+  const bool lazy = ticket && flush1;
+  int pend = -1;                                  // lazy form: the row block this wave still has to add up
+  auto complete = [&](int p) {
+    return __hip_atomic_load(&sm_cnt[p % ring], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= kSkinnyWaves * (p / ring + 1);
+  };
+  auto reduce_blk = [&](int p) {                  // ticket forms: this wave alone adds block p's partials and stores
+    const int b0 = ((int)blockIdx.x + p * (int)gridDim.x) * rpb;
+    asm volatile("" ::: "memory");
+    skinny_reduce_store<NB, EPI>(a, red + (p % ring) * kRedQuads, b0, b0 + rpb < rows_total ? b0 + rpb : rows_total, L.lane, 64);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reduction's LDS reads have returned
+    if (L.lane == 0) __hip_atomic_store(&sm_cnt[ring + p % ring], p / ring + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
   auto flush = [&](int rbi) {
     const int buf = ticket ? rbi % ring : (flush1 ? rbi & 1 : 0);
     const int use = ticket ? rbi / ring : 0;
     f32x4* rb = red + buf * kRedQuads;
-    if (ticket && use > 0)
-      while (__hip_atomic_load(&sm_cnt[ring + buf], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < use) __builtin_amdgcn_s_sleep(1);
+    if (lazy && pend >= 0 && pend != rbi - ring && complete(pend)) { reduce_blk(pend); pend = -1; }
+    if (ticket && use > 0) {
+      if (lazy && pend == rbi - ring) {           // this buffer's previous block is the one this wave owes
+        while (!complete(pend)) __builtin_amdgcn_s_sleep(1);
+        reduce_blk(pend);
+        pend = -1;
+      } else {
+        while (__hip_atomic_load(&sm_cnt[ring + buf], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < use) __builtin_amdgcn_s_sleep(1);
+      }
+    }
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int w = 0; w < NW; ++w)
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) rb[((L.wave * NW + w) * NB + nb) * 64 + L.lane] = skinny_fold(acc[w][nb]);
     zero();
-    if (a.variant & 2) return;   // timing probe (PEGAINFER_SKINNY_FLUSH=2/3): no barrier, nothing stored
-    const int blk0 = ((int)blockIdx.x + rbi * (int)gridDim.x) * rpb;
-    const int lim = blk0 + rpb < rows_total ? blk0 + rpb : rows_total;
+    if (a.variant & 2) return;   // timing probe (PEGAINFER_SKINNY_FLUSH=2): no barrier, nothing stored
     if (ticket) {
       asm volatile("" ::: "memory");
       if (L.lane == 0) (void)__hip_atomic_fetch_add(&sm_cnt[buf], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      if (L.wave == (rbi & 7)) {
-        while (__hip_atomic_load(&sm_cnt[buf], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < kSkinnyWaves * (use + 1))
-          __builtin_amdgcn_s_sleep(1);
-        asm volatile("" ::: "memory");
-        skinny_reduce_store<NB, EPI>(a, rb, blk0, lim, L.lane, 64);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reduction's LDS reads have returned
-        if (L.lane == 0) __hip_atomic_store(&sm_cnt[ring + buf], use + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (wave_u == (rbi & 7)) {
+        if (lazy) {
+          pend = rbi;
+        } else {
+          while (!complete(rbi)) __builtin_amdgcn_s_sleep(1);
+          reduce_blk(rbi);
+        }
       }
       return;
     }
+    const int blk0 = ((int)blockIdx.x + rbi * (int)gridDim.x) * rpb;
+    const int lim = blk0 + rpb < rows_total ? blk0 + rpb : rows_total;
     __syncthreads();
     if (flush1) {
       if (L.wave == (rbi & 7)) skinny_reduce_store<NB, EPI>(a, rb, blk0, lim, L.lane, 64);
@@ -621,6 +647,10 @@ __global__ __launch_bounds__(kSkinnyThreads) void skinny_resident_kernel(const G
     if (item0 + CH >= total) break;
     compute(item0 + CH, avB);
     if (item0 + 3 * CH < total) issue(item0 + 3 * CH, avB);
+  }
+  if (pend >= 0) {                                // lazy tickets: the block this wave still owes
+    while (!complete(pend)) __builtin_amdgcn_s_sleep(1);
+    reduce_blk(pend);
   }
 }
 

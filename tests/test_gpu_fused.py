@@ -84,26 +84,26 @@ def test_skinny_flush_forms_are_bit_identical(built_libs, T):
             W, X = rnd(rng, M, K, scale=0.05), rnd(rng, T, K)
             Wd, Xd = to_dev(W), to_dev(X)
             outs = {}
-            for mode in (0, 1, 4, -1):
+            for mode in (0, 1, 4, 5, -1):
                 L.pegainfer_debug_skinny_flush(mode)
                 y = torch.zeros((T, M), dtype=torch.bfloat16, device="cuda")
                 assert L.pegainfer_gemv_fused(Wd.data_ptr(), Xd.data_ptr(), y.data_ptr(), M, T, K, None, None, None, 0.0, 0, s) == 0
                 outs[mode] = bf16_bits(from_dev(y))
-            assert all(np.array_equal(outs[0], outs[m]) for m in (1, 4, -1)), (M, K)
+            assert all(np.array_equal(outs[0], outs[m]) for m in (1, 4, 5, -1)), (M, K)
             ref = X.astype(np.float64) @ W.astype(np.float64).T
             assert np.abs(from_dev(y) - ref).max() <= 2.0 ** -6 * max(1.0, np.abs(ref).max())
         I, K = 9728, 2560
         W, X, R, g = rnd(rng, 2 * I, K, scale=0.06), rnd(rng, T, K), rnd(rng, T, K), rnd(rng, K)
         Wd, Xd, Rd, gd = to_dev(W), to_dev(X), to_dev(R), to_dev(g)
         outs = {}
-        for mode in (0, 1, 4, -1):
+        for mode in (0, 1, 4, 5, -1):
             L.pegainfer_debug_skinny_flush(mode)
             y = torch.zeros((T, I), dtype=torch.bfloat16, device="cuda")
             h = torch.zeros((T, K), dtype=torch.bfloat16, device="cuda")
             assert L.pegainfer_gemv_fused(Wd.data_ptr(), Xd.data_ptr(), y.data_ptr(), 2 * I, T, K, Rd.data_ptr(), gd.data_ptr(),
                                           h.data_ptr(), 1e-6, I, s) == 0
             outs[mode] = (bf16_bits(from_dev(y)), bf16_bits(from_dev(h)))
-        for m in (1, 4, -1):
+        for m in (1, 4, 5, -1):
             assert np.array_equal(outs[0][0], outs[m][0]) and np.array_equal(outs[0][1], outs[m][1])
     finally:
         L.pegainfer_debug_skinny_flush(-1)
