@@ -674,14 +674,17 @@ inline int skinny_pick_rpb(int rows) {
 // A ticket form in which the LAST ARRIVER adds (nobody waits; the slowest wave gets the extra work) measured worse than the
 // designated wave: gate_up 21.8-22.2 us (profiles/r5_skinny_flush_ab2.txt).  In the pipeline (bench.py --batch, same box,
 // alternating, two-barrier form vs this default): bs 4 2.68 / 2.67 -> 2.59 / 2.60 ms per step, bs 16 3.564 / 3.567 -> 3.464 / 3.490.
-// Default: tickets where a workgroup walks more than two row blocks, else the one-barrier form.
-// PEGAINFER_SKINNY_FLUSH: 0 = two barriers, 1 = one barrier, 4 = tickets; +2 = the timing probe (nothing stored).
+// Lazy tickets (5: the designated wave does not wait either - it adds a block up at one of its later flushes, once the count
+// is complete): gate_up 19.9-20.2 us against 20.7-21.1 with waiting tickets, the fused form 22.3 / 24.1-24.7 against 22.7 /
+// 25.4-25.6, lm_head 122-131 against 127-137 (profiles/r5_skinny_flush_ab3.txt).
+// Default: lazy tickets where a workgroup walks more than two row blocks, else the one-barrier form.
+// PEGAINFER_SKINNY_FLUSH: 0 = two barriers, 1 = one barrier, 4 = tickets, 5 = lazy tickets; 2 = the timing probe (nothing stored).
 extern int g_skinny_flush_override;   // linear.hip: pegainfer_debug_skinny_flush (tests compare the forms in one process); -1 = none
 inline int skinny_flush_mode(int nrb) {
   static const int env = [] { const char* e = getenv("PEGAINFER_SKINNY_FLUSH"); return e && *e ? atoi(e) & 7 : -1; }();
   if (g_skinny_flush_override >= 0) return g_skinny_flush_override & 7;
   if (env >= 0) return env;
-  return nrb > 2 * device_cus() ? 4 : 1;
+  return nrb > 2 * device_cus() ? 5 : 1;
 }
 
 template <int NB, int EPI>
