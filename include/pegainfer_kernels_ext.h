@@ -125,8 +125,9 @@ void pegainfer_debug_gemv_trace(uint64_t* buf);
 
 /* Debug / test hook (not in ffi.rs), no device work: force how the batched-decode GEMM at 3..16 token columns
  * (skinny_resident_kernel) combines its 8 waves' partial sums per row block: 0 = two barriers, 1 = one barrier,
- * 4 = LDS tickets without a barrier; -1 = the launcher's own choice (tickets where a workgroup walks more than two row
- * blocks).  The forms produce the same bits; the hook exists so that a test can show it inside one process. */
+ * 4 = LDS tickets without a barrier, 5 = lazy tickets (no waiting wave either); -1 = the launcher's own choice (lazy
+ * tickets where a workgroup walks more than two row blocks).  The forms produce the same bits; the hook exists so that a
+ * test can show it inside one process. */
 void pegainfer_debug_skinny_flush(int32_t mode);
 
 /* Debug aid (not in ffi.rs): buf = device array of slots * num_kv_heads * 8 uint64, or NULL to switch off.  Every later

@@ -809,7 +809,7 @@ extern "C" {
 // 100 MHz wall clock: [0] entry, [1] x staged, [2] first weight block consumed, [3] last row group's K loop done,
 // [4] exit, [5] XCC id; nullptr switches it off (tools/gemv_probe.py).  Not part of the reference ABI.
 void pegainfer_debug_gemv_trace(uint64_t* buf) { pk::g_gemv_trace = reinterpret_cast<unsigned long long*>(buf); }
-// Debug / test hook: force how skinny_resident_kernel's 8 waves meet per row block (0 two barriers, 1 one barrier, 4 tickets;
+// Debug / test hook: force how skinny_resident_kernel's 8 waves meet per row block (0 two barriers, 1 one barrier, 4 tickets, 5 lazy tickets;
 // -1 = back to the launcher's choice).  The forms are bit-identical; tests/test_gpu_ops.py compares them in one process.
 void pegainfer_debug_skinny_flush(int32_t mode) { pk::g_skinny_flush_override = mode < 0 ? -1 : (mode & 7); }
 

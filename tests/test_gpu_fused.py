@@ -71,7 +71,7 @@ def test_gemv_fused_silu_epilogue_matches_unfused(built_libs, T, I, K):
 @pytest.mark.parametrize("T", [3, 8, 16])
 def test_skinny_flush_forms_are_bit_identical(built_libs, T):
     """Round 5: skinny_resident_kernel combines its 8 waves' partial sums per row block with two barriers, one barrier, or
-    LDS tickets without a barrier (the launcher's choice where a workgroup walks more than two row blocks).  Same bits in all
+    LDS tickets without a barrier - waiting or lazy (the launcher's choice where a workgroup walks more than two row blocks).  Same bits in all
     three, on shapes whose workgroups walk 1, 2, 3-5 and ~40 row blocks (the last two re-use the ticket ring's buffers), for
     the plain store and for the add + RMSNorm prologue with the SwiGLU epilogue."""
     import torch
