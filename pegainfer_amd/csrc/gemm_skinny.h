@@ -392,7 +392,7 @@ __global__ __launch_bounds__(kSkinnyThreads) void skinny_resident_kernel(const G
   f32x4* red = reinterpret_cast<f32x4*>(smem_raw + xs_bytes);
   constexpr int kRedQuads = 8 * NW * NB * 64;
   const bool flush1 = (a.variant & 1) != 0;
-  const bool ticket = (a.variant & 4) != 0;
+  const bool ticket = NB == 1 && (a.variant & 4) != 0;   // <= 16 columns only (the launcher never asks for it above: registers)
   const int ring = ticket ? (a.variant >> 4) & 15 : (flush1 ? 2 : 1);
   float* sm_inv = reinterpret_cast<float*>(smem_raw + xs_bytes + ring * kRedQuads * 16);  // [64]
   int* sm_cnt = reinterpret_cast<int*>(sm_inv + 64);   // ticket form: [ring] arrivals, [ring] finished reductions (monotonic)
@@ -696,6 +696,7 @@ inline void skinny_launch_resident(GemvFusedArgs a, hipStream_t s) {
   const int nrb = ceil_div(rows, a.rpb);
   const int xs_bytes = (a.T * a.K * 2 + 15) & ~15, red_bytes = 8 * NW * NB * 64 * 16;
   a.variant = skinny_flush_mode(nrb);
+  if (NB > 1 && (a.variant & 4)) a.variant = (a.variant & 2) | 1;          // wider tiles: the one-barrier form
   const int room = (160 * 1024 - xs_bytes - 64 * 4 - 64) / red_bytes;   // buffers that fit beside x
   int bufs = 1;
   if (a.variant & 4) {
