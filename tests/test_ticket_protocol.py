@@ -1,0 +1,208 @@
+"""The barrier-free cross-wave hand-off of skinny_resident_kernel (pegainfer_amd/csrc/gemm_skinny.h, `flush`, round 5)
+restated as a state machine and run under random wave schedules on the CPU.
+
+On the GPU the protocol is exercised by a handful of launch shapes and whatever interleavings the hardware happens to
+produce; here every wave is a coroutine that yields at each LDS operation, a seeded scheduler picks who moves next, and
+the invariants the kernel's comment block claims are asserted on every step:
+
+  * a row block is added up exactly once, by wave n & 7, and only after all 8 partials of THAT block are in its buffer;
+  * a buffer is never overwritten before the block it holds has been added up (ring re-use);
+  * nobody waits for ever: the earliest block that is not added up never depends on a later one (no cycle), also when
+    waves run arbitrarily far apart, and every wave leaves with nothing owed.
+
+Forms: waiting tickets (PEGAINFER_SKINNY_FLUSH=4: the designated wave spins until the count is complete) and lazy
+tickets (=5, the default for tall matrices: it remembers the block and adds it up at a later flush, at the latest when the
+buffer is needed again or after its last item).  Ring sizes 2..4 as the launcher can pick them (LDS room beside x).
+"""
+import random
+
+import pytest
+
+WAVES = 8
+
+
+class Lds:
+    def __init__(self, ring):
+        self.ring = ring
+        self.cnt = [0] * ring            # sm_cnt[buf]: arrivals, monotonic
+        self.done = [0] * ring           # sm_cnt[ring + buf]: reductions published, monotonic
+        self.part = [[None] * WAVES for _ in range(ring)]   # (block, wave) tag of the partial each wave last wrote
+        self.reduced = {}                # block -> wave that added it up
+
+
+def wave_program(w, lds, nblocks, lazy, log):
+    """One wave of the kernel: for every row block, `flush(rbi)`; then the tail.  Yields "spin" when it re-reads a counter
+    that has not reached the value it needs, "step" after any other LDS operation."""
+    ring = lds.ring
+    pend = -1
+
+    def complete(p):
+        return lds.cnt[p % ring] >= WAVES * (p // ring + 1)
+
+    def reduce_blk(p):
+        buf = p % ring
+        assert p not in lds.reduced, f"block {p} added up twice"
+        assert all(tag == (p, v) for v, tag in enumerate(lds.part[buf])), \
+            f"wave {w} adds up block {p} but buffer {buf} holds {lds.part[buf]}"
+        lds.reduced[p] = w
+        lds.done[buf] = p // ring + 1
+        log.append(("reduce", w, p))
+
+    for rbi in range(nblocks):
+        yield "step"                                   # the wave's K items of this block (any amount of time)
+        buf, use = rbi % ring, rbi // ring
+        if lazy and pend >= 0 and pend != rbi - ring and complete(pend):
+            reduce_blk(pend)
+            pend = -1
+            yield "step"
+        if use > 0:
+            if lazy and pend == rbi - ring:
+                while not complete(pend):
+                    log.append(("spin", w, pend))
+                    yield "spin"
+                reduce_blk(pend)
+                pend = -1
+                yield "step"
+            else:
+                while lds.done[buf] < use:
+                    log.append(("spin", w, rbi))
+                    yield "spin"
+        # the buffer's previous block (rbi - ring) has been added up: writing is safe
+        prev = lds.part[buf][w]
+        assert prev is None or prev[0] in lds.reduced, f"wave {w} overwrites the partial of block {prev[0]} before it was added up"
+        lds.part[buf][w] = (rbi, w)
+        yield "step"
+        lds.cnt[buf] += 1                              # ds_add behind the partial (LDS executes a wave's ops in order)
+        yield "step"
+        if w == (rbi & 7):
+            if lazy:
+                assert pend < 0, f"wave {w} owes two blocks at once ({pend}, {rbi})"
+                pend = rbi
+            else:
+                while not complete(rbi):
+                    log.append(("spin", w, rbi))
+                    yield "spin"
+                reduce_blk(rbi)
+                yield "step"
+    log.append(("tail", w, nblocks))
+    if pend >= 0:                                      # the tail of the kernel
+        while not complete(pend):
+            log.append(("spin", w, pend))
+            yield "spin"
+        reduce_blk(pend)
+
+
+def run(ring, nblocks, lazy, seed, bias=None):
+    rng = random.Random(seed)
+    lds, log = Lds(ring), []
+    waves = {w: wave_program(w, lds, nblocks, lazy, log) for w in range(WAVES)}
+    weight = {w: 1.0 for w in waves}
+    if bias == "straggler":                            # one wave gets a hundredth of the others' turns
+        weight[rng.randrange(WAVES)] = 0.01
+    elif bias == "sprinter":                           # one wave runs as far ahead as the protocol lets it
+        weight = {w: 0.02 for w in waves}
+        weight[rng.randrange(WAVES)] = 1.0
+    spinning = set()
+    steps = 0
+    while waves:
+        steps += 1
+        assert steps < 400000, "no progress"
+        ids = list(waves)
+        w = rng.choices(ids, [weight[i] for i in ids])[0]
+        try:
+            what = next(waves[w])
+        except StopIteration:
+            del waves[w]
+            spinning.discard(w)
+            continue
+        if what == "spin":
+            spinning.add(w)
+            # deadlock = every live wave is spinning and a full sweep over them changes nothing
+            if spinning >= set(waves):
+                before = (list(lds.cnt), list(lds.done), dict(lds.reduced))
+                for v in list(waves):
+                    try:
+                        if next(waves[v]) != "spin":
+                            spinning.discard(v)
+                    except StopIteration:
+                        del waves[v]
+                        spinning.discard(v)
+                assert (list(lds.cnt), list(lds.done), dict(lds.reduced)) != before or not (spinning >= set(waves)) or not waves, \
+                    f"deadlock: ring {ring}, blocks {nblocks}, lazy {lazy}, seed {seed}: cnt {lds.cnt} done {lds.done}"
+        else:
+            spinning.discard(w)
+    assert sorted(lds.reduced) == list(range(nblocks)), "a block was never added up"
+    assert all(lds.reduced[b] == (b & 7) for b in lds.reduced), "added up by the wrong wave"
+    return log
+
+
+@pytest.mark.parametrize("lazy", [False, True])
+@pytest.mark.parametrize("ring", [2, 3, 4])
+def test_every_block_is_added_up_once_and_nobody_waits_for_ever(ring, lazy):
+    for nblocks in (1, 2, 3, 4, 5, 8, 9, 17, 46):     # o_proj 1, qkv 2, gate_up 3 (5 plain), lm_head ~46 per workgroup
+        for seed in range(12):
+            run(ring, nblocks, lazy, seed)
+
+
+@pytest.mark.parametrize("lazy", [False, True])
+@pytest.mark.parametrize("bias", ["straggler", "sprinter"])
+def test_waves_far_apart(bias, lazy):
+    """A wave a ring's length ahead of the others must stop at the buffer it would overwrite; a straggler must not strand the
+    blocks it owes."""
+    for ring in (2, 3, 4):
+        for seed in range(8):
+            run(ring, 20, lazy, 1000 + seed, bias)
+
+
+def test_lazy_form_defers_the_sum_instead_of_waiting():
+    """What the lazy form is for: with three blocks per workgroup and a ring of four (gate_up at 16 columns) no wave ever
+    spins before its last item - the sums of blocks 0 and 1 happen at a later flush or in the tail."""
+    for seed in range(20):
+        log = run(4, 3, True, seed)
+        in_tail = set()
+        for kind, w, _ in log:
+            if kind == "tail":
+                in_tail.add(w)
+            assert kind != "spin" or w in in_tail, f"seed {seed}: wave {w} waited before its last item"
+        assert sorted(e[2] for e in log if e[0] == "reduce") == [0, 1, 2]
+        # the waiting form does make the designated waves wait inside the K loop (that is the 0.8 us it costs on gate_up)
+    waited = 0
+    for seed in range(20):
+        log, in_tail = run(4, 3, False, seed), set()
+        for kind, w, _ in log:
+            if kind == "tail":
+                in_tail.add(w)
+            waited += kind == "spin" and w not in in_tail
+    assert waited > 0
+
+
+def test_the_checker_sees_a_broken_protocol():
+    """The invariants above are not vacuous: a ring re-used without waiting for `done` is caught."""
+    class NoWait(Lds):
+        pass
+
+    def broken(w, lds, nblocks, log):
+        ring = lds.ring
+        for rbi in range(nblocks):
+            yield "step"
+            buf = rbi % ring
+            prev = lds.part[buf][w]
+            assert prev is None or prev[0] in lds.reduced, "overwrite"
+            lds.part[buf][w] = (rbi, w)
+            lds.cnt[buf] += 1
+            yield "step"
+            if w == (rbi & 7):
+                while lds.cnt[buf] < WAVES * (rbi // ring + 1):
+                    yield "spin"
+                lds.reduced[rbi] = w
+    with pytest.raises(AssertionError, match="overwrite"):
+        for seed in range(50):
+            rng = random.Random(seed)
+            lds = NoWait(2)
+            waves = {w: broken(w, lds, 12, []) for w in range(WAVES)}
+            while waves:
+                w = rng.choice(list(waves))
+                try:
+                    next(waves[w])
+                except StopIteration:
+                    del waves[w]
