@@ -687,23 +687,36 @@ inline int skinny_flush_mode(int nrb) {
   return nrb > 2 * device_cus() ? 5 : 1;
 }
 
+// The flush form a resident launch takes and the partial buffers it needs (one function for the launcher and for
+// pegainfer_debug_gemm_route, which tests/test_gemm_routing.py pins on the CPU): nw weight sets, nb 16-token blocks.
+struct SkinnyFlushPlan { int variant, bufs, rpb, nrb; };
+inline SkinnyFlushPlan skinny_flush_plan(int nw, int nb, int T, int K, int rows) {
+  SkinnyFlushPlan p;
+  p.rpb = skinny_pick_rpb(rows);
+  p.nrb = ceil_div(rows, p.rpb);
+  const int xs_bytes = (T * K * 2 + 15) & ~15, red_bytes = 8 * nw * nb * 64 * 16;
+  p.variant = skinny_flush_mode(p.nrb);
+  if (nb > 1 && (p.variant & 4)) p.variant = (p.variant & 2) | 1;          // wider tiles: the one-barrier form
+  const int room = (160 * 1024 - xs_bytes - 64 * 4 - 64) / red_bytes;   // buffers that fit beside x
+  p.bufs = 1;
+  if (p.variant & 4) {
+    if (room >= 2) { p.bufs = room > 4 ? 4 : room; p.variant = (p.variant & 7) | (p.bufs << 4); }
+    else p.variant = (p.variant & 2) | 1;                               // no room for a ring: the one-barrier form ...
+  }
+  if ((p.variant & 5) == 1) { if (room >= 2) p.bufs = 2; else p.variant &= ~1; }   // ... or the two-barrier form
+  return p;
+}
+
 template <int NB, int EPI>
 inline void skinny_launch_resident(GemvFusedArgs a, hipStream_t s) {
   constexpr int NW = EPI == kEpiSilu ? 2 : 1;
   a.KT = a.K;
   const int rows = EPI == kEpiSilu ? a.I : a.M;
-  a.rpb = skinny_pick_rpb(rows);
-  const int nrb = ceil_div(rows, a.rpb);
+  const SkinnyFlushPlan fp = skinny_flush_plan(NW, NB, a.T, a.K, rows);
+  a.rpb = fp.rpb;
+  a.variant = fp.variant;
+  const int nrb = fp.nrb, bufs = fp.bufs;
   const int xs_bytes = (a.T * a.K * 2 + 15) & ~15, red_bytes = 8 * NW * NB * 64 * 16;
-  a.variant = skinny_flush_mode(nrb);
-  if (NB > 1 && (a.variant & 4)) a.variant = (a.variant & 2) | 1;          // wider tiles: the one-barrier form
-  const int room = (160 * 1024 - xs_bytes - 64 * 4 - 64) / red_bytes;   // buffers that fit beside x
-  int bufs = 1;
-  if (a.variant & 4) {
-    if (room >= 2) { bufs = room > 4 ? 4 : room; a.variant = (a.variant & 7) | (bufs << 4); }
-    else a.variant = (a.variant & 2) | 1;                               // no room for a ring: the one-barrier form ...
-  }
-  if ((a.variant & 5) == 1) { if (room >= 2) bufs = 2; else a.variant &= ~1; }   // ... or the two-barrier form
   const int lds = xs_bytes + bufs * red_bytes + 64 * 4 + 64;
   auto kern = &skinny_resident_kernel<NB, EPI>;
   static const bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -757,14 +770,16 @@ inline void skinny_launch(GemvFusedArgs a, hipStream_t s) {
   }
 }
 
+inline bool skinny_is_resident(int nw, int T, int K) {
+  const int nb = T <= 16 ? 1 : T <= 32 ? 2 : 4;
+  return (long)T * K * 2 <= kSkinnyResidentBytes && (long)T * K * 2 + 8 * nw * nb * 64 * 16 + 256 <= 160 * 1024;
+}
 // 2 <= T <= 64, K % 64 == 0
 template <int EPI>
 inline bool skinny_dispatch(const GemvFusedArgs& a, hipStream_t s) {
   if (a.T < 2 || a.T > 64 || (a.K & 63) != 0) return false;
   constexpr int NW = EPI == kEpiSilu ? 2 : 1;
-  const int nb = a.T <= 16 ? 1 : a.T <= 32 ? 2 : 4;
-  const bool resident = (long)a.T * a.K * 2 <= kSkinnyResidentBytes &&
-                        (long)a.T * a.K * 2 + 8 * NW * nb * 64 * 16 + 256 <= 160 * 1024;
+  const bool resident = skinny_is_resident(NW, a.T, a.K);
   if (a.T <= 16) { if (resident) skinny_launch_resident<1, EPI>(a, s); else skinny_launch<1, EPI>(a, s); }
   else if (a.T <= 32) { if (resident) skinny_launch_resident<2, EPI>(a, s); else skinny_launch<2, EPI>(a, s); }
   else { if (resident) skinny_launch_resident<4, EPI>(a, s); else skinny_launch<4, EPI>(a, s); }

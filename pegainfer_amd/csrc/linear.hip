@@ -976,7 +976,19 @@ pegainfer_status_t pegainfer_debug_gemm_route(int32_t M, int32_t T, int32_t K, i
   using namespace pk;
   if (!out || T <= 0 || K <= 0 || (silu_I <= 0 && M <= 0)) return (pegainfer_status_t)hipErrorInvalidValue;
   out[0] = 0; out[1] = 1; out[2] = 0;
-  if (T <= 16) return 0;
+  if (T <= 16) {
+    // 3..16 columns on the resident-x skinny kernel: out[1] = how its 8 waves meet per row block (0 two barriers, 1 one
+    // barrier, 4 tickets, 5 lazy tickets), out[2] = partial buffers * 100 + rows per row block; out[1] = -1: another kernel
+    // of the family (dot2 GEMV at 1-2 columns, the tiled skinny kernel when x does not fit in LDS)
+    out[1] = -1;
+    const int nw = silu_I > 0 ? 2 : 1;
+    if (T >= 3 && (K & 63) == 0 && skinny_is_resident(nw, T, K)) {
+      const SkinnyFlushPlan fp = skinny_flush_plan(nw, 1, T, K, silu_I > 0 ? silu_I : M);
+      out[1] = fp.variant & 7;
+      out[2] = fp.bufs * 100 + fp.rpb;
+    }
+    return 0;
+  }
   // the K-split pairs whose GEMM half runs on the stream kernel (glds_splitk_launch): same slices, row tiles of rt blocks
   auto split_kind = [&](const SplitKPlan& pl) {
     const StreamPlan sp = stream_splitk_plan(M, pl.ksplit);

@@ -73,3 +73,41 @@ def test_invalid_arguments(route):
     out = (ctypes.c_int32 * 3)()
     assert ffi.lib().pegainfer_debug_gemm_route(0, 128, 2560, 0, out) != 0
     assert ffi.lib().pegainfer_debug_gemm_route(2560, 128, 2560, 0, None) != 0
+
+
+@pytest.mark.parametrize("T", [3, 4, 8, 16])
+def test_how_the_waves_of_the_3_to_16_column_gemm_meet(route, T):
+    """Round 5 (gemm_skinny.h, skinny_flush_plan): on the resident-x kernel the 8 waves of a workgroup combine their partial
+    sums per row block through lazy LDS tickets where a workgroup walks more than two row blocks (gate_up in both forms,
+    lm_head) and with one barrier where it walks one or two (qkv, o_proj); down_proj's x (16 x 9728) does not fit in LDS from
+    7 columns on and takes the tiled kernel.  out[1] = form, out[2] = partial buffers x 100 + rows per row block."""
+    assert route(0, T, 2560, I)[:2] == (0, 5) and route(0, T, 2560, I)[2] == 413           # 749 row blocks of 13, ring of 4
+    assert route(2 * I, T, 2560)[:2] == (0, 5) and route(2 * I, T, 2560)[2] == 416         # the unfused stacked launch
+    assert route(151936, T, 2560)[:2] == (0, 5)                                            # lm_head
+    assert route(*((QKV[0], T, QKV[1])))[1:] == (1, 212)                                   # 512 row blocks of 12: two per workgroup
+    assert route(O[0], T, O[1])[1:] == (1, 210)                                            # 256 row blocks of 10: one per workgroup
+    if T * DOWN[1] * 2 <= 128 * 1024:
+        assert route(DOWN[0], T, DOWN[1])[1:] == (1, 210)
+    else:
+        assert route(DOWN[0], T, DOWN[1])[1] == -1                                         # tiled kernel
+    # Qwen3-8B widths (hidden 4096): up to 15 columns a ring fits beside x; at 16 columns x is 128 KB and not even the second
+    # 16 KB buffer (two weight sets) of the one-barrier form does: gate_up keeps the two-barrier form there, o_proj-like
+    # single-set launches (8 KB buffers) get a ring of 3
+    assert route(0, T, 4096, 12288)[1:] == ((5, 416) if T < 16 else (0, 116))
+    assert route(40000, 16, 4096)[1:] == (5, 316)
+    assert route(1, 1, 2560)[1] == -1 and route(6144, 2, 2560)[1] == -1                    # dot2 GEMV
+
+
+def test_flush_form_override_hook(route):
+    from pegainfer_amd import ffi
+    lib = ffi.lib()
+    try:
+        for mode in (0, 1, 4, 5):
+            lib.pegainfer_debug_skinny_flush(mode)
+            assert route(0, 16, 2560, I)[1] == mode
+        lib.pegainfer_debug_skinny_flush(4)
+        assert route(0, 16, 4096, 12288)[1:] == (0, 116)       # no room for a ring nor for a second buffer: two barriers
+        assert route(0, 15, 4096, 12288)[1:] == (4, 216)       # a ring of 2
+    finally:
+        lib.pegainfer_debug_skinny_flush(-1)
+    assert route(0, 16, 2560, I)[1] == 5
