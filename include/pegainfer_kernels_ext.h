@@ -135,12 +135,15 @@ void pegainfer_debug_skinny_flush(int32_t mode);
  * record read, [2] q prologue done, [3] KV scan done, [4] partials published, [5] ticket drawn, [6] merge done,
  * [7] = 1 for the workgroup that merged.  tools/attn_probe.py prints the per-phase means. */
 void pegainfer_debug_attn_trace(uint64_t* buf);
-/* Debug / test hook, no device work: which kernel a GEMM of this shape with T > 16 token columns takes.  silu_I > 0 asks
+/* Debug / test hook, no device work: which kernel a GEMM of this shape takes.  silu_I > 0 asks
  * for the SwiGLU form.  out[0] = kind (0 GEMV / skinny family; 12 / 13 / 22 / 23 128-row LDS-DMA kernel; 256 / 257 the
  * 256 x 256 kernel / its SwiGLU form with the thin last round on the 128-row kernel; 1280 / 1281 the 128 x 256 kernel
  * plain / SwiGLU; 3000 + rt the weight-streaming kernel on rt x 16-row tiles; 1000 + tt a K-split plan on tt = 64 / 128
  * (128-row), 129 (128 x 256), 256 (256 x 256) tiles; 2000 + rt a tt = 64 plan whose GEMM half runs on the streaming
- * kernel), out[1] = K slices, out[2] = K tiles per slice (kind 257: activation-column tiles of the head). */
+ * kernel), out[1] = K slices, out[2] = K tiles per slice (kind 257: activation-column tiles of the head).
+ * T <= 16 (kind 0): out[1] = how the resident-x skinny kernel's waves meet per row block (0 two barriers, 1 one barrier,
+ * 4 tickets, 5 lazy tickets; -1 = the dot2 GEMV at 1-2 columns or the tiled skinny kernel), out[2] = partial buffers * 100
+ * + rows per row block. */
 pegainfer_status_t pegainfer_debug_gemm_route(int32_t M, int32_t T, int32_t K, int32_t silu_I, int32_t* out);
 
 /* Partition-KV decode attention at head_dim 256 (Qwen3.5 full-attention layers).  No counterpart in ffi.rs (its
