@@ -320,7 +320,7 @@ def paged_attention_decode_split_kv(q, kv_data, layout, layer, page_indices, pag
 
 
 def batch_prefill_paged(q, kv_data, layout, layer, page_indices, page_indptr, last_page_len,
-                        q_indptr, num_q_heads, sm_scale, row_block=1024):
+                        q_indptr, num_q_heads, sm_scale, row_block=1024, causal_shift=0):
     """Causal varlen GQA prefill over the paged cache (wrapper
     csrc/paged_attention.cu:399-535 -> FlashInfer BatchPrefillWithPagedKVCacheDispatched,
     MaskMode::kCausal): query row i of a request with qo_len rows and kv_len cached
@@ -351,6 +351,8 @@ def batch_prefill_paged(q, kv_data, layout, layer, page_indices, page_indptr, la
             for r0 in range(0, qo_len, row_block):
                 r1 = min(qo_len, r0 + row_block)
                 hi = np.arange(r0, r1) + (kv_len - qo_len) + 1            # kv positions < hi are visible
+                if causal_shift:   # fault injection of tests/test_depth_harness.py only: an off-by-one mask
+                    hi = np.clip(hi + causal_shift, 1, kv_len)
                 top = int(hi[-1])
                 Qg = Qb[r0:r1, kh * g:(kh + 1) * g, :].astype(np.float64)  # [rows, g, D]
                 S = (Qg.reshape(-1, D) @ Kh[:top].T) * np.float64(sm_scale)
