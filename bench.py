@@ -69,7 +69,8 @@ def gpu_parity_run(eng, prompt, steps):
     return toks, np.stack(rows)
 
 
-def cpu_legs(cfg, bits, prompt, gpu_tokens, gpu_rows_bits, steps, threads, hf_repeats=3, hf_new_tokens=33, hf_threads=None):
+def cpu_legs(cfg, bits, prompt, gpu_tokens, gpu_rows_bits, steps, threads, hf_repeats=3, hf_new_tokens=33, hf_threads=None,
+             batch_rows=None):
     """bench.py's CPU side, on the host cores of the GPU box, on the SAME checkpoint and the SAME prompt as the GPU leg
     (rank 0, N = 1 only; a bounded sample).  Two engines:
 
@@ -177,6 +178,21 @@ def cpu_legs(cfg, bits, prompt, gpu_tokens, gpu_rows_bits, steps, threads, hf_re
                              "what": "RMS logit error of the engine against the fp32-activation pass of the oracle, over that of "
                                      "the bf16 oracle against the same pass, per step and pooled (oracle/parity.py)"}
         del mt
+        # the batch sweep's columns (every request of a bs-N step carries the bench prompt and is teacher-forced on the same
+        # tokens, so ONE oracle / truth stream referees all of them): the derived ratio per batch size
+        if batch_rows:
+            T_ = np.stack(trows)
+            parity["batch"] = {}
+            for label, rb in batch_rows.items():
+                got = bf16_from_bits(rb)                                  # [bs, 1 + steps, V]
+                m_ = min(got.shape[1], len(R))
+                bd = par.derived(got[:, :m_], np.broadcast_to(R[:m_], got[:, :m_].shape), np.broadcast_to(T_[:m_], got[:, :m_].shape))
+                b_ok, b_agree, _, _ = par.near_tie_ok(got[:, :m_], R[:m_][None], R[:m_][None])
+                parity["batch"][label] = {"ratio_pooled": round(bd["ratio_pooled"], 4), "ratio_max": round(bd["ratio_max"], 4),
+                                          "within_bar": bool(bd["ratio_pooled"] <= par.AGG_MAX and bd["ratio_max"] <= par.STEP_MAX),
+                                          "cos_engine_vs_oracle_min": round(bd["cos_engine_vs_oracle_min"], 6),
+                                          "tokens_equal": [int(b_agree.sum()), int(b_agree.size)],
+                                          "tokens_differing_away_from_a_near_tie": int((~b_ok).sum())}
     except Exception as e:  # noqa: BLE001
         parity["derived"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     parity.update({"cos_min": round(float(cs.min()), 6), "max_dlogit": round(float(dl.max()), 4),
@@ -197,16 +213,37 @@ def traffic_probe_main(model, bs):
     """`bench.py --traffic-probe` (run UNDER rocprofv3 --pmc by measure_traffic): a 2-layer engine of the benchmarked
     shape launches the dominant kernel - the gate_up GEMV with its add + RMSNorm prologue and SwiGLU epilogue - 40
     times over cold weights.  No torch, no timing: the counters are the product."""
+    if model == "qwen3.5-4b":   # configs[3]: the gate|up GEMV of the hybrid model ((1 + w) norm prologue, SwiGLU epilogue)
+        from pegainfer_amd.qwen35 import QWEN35_4B, Qwen35Engine
+        cfg = dict(QWEN35_4B, num_hidden_layers=4, layer_types=QWEN35_4B["layer_types"][:4])
+        eng = Qwen35Engine(cfg, num_kv_pages=8, max_batch_size=1, max_positions=4096)
+        eng.fill_synthetic(seed=42, std=0.02)
+        eng.bench_gemv(0, PROBE_LAUNCHES - 3)
+        eng.close()
+        return 0
     from pegainfer_amd.qwen3 import QWEN3_4B, QWEN3_8B, Qwen3Engine
     cfg = dict(QWEN3_4B if model == "qwen3-4b" else QWEN3_8B, num_hidden_layers=2)
     eng = Qwen3Engine(cfg, num_kv_pages=8, max_batch_size=max(bs, 1), decode_mode=1, max_positions=4096)
     eng.fill_synthetic(seed=42, std=0.02)
-    eng.bench_gemv(5, 40, bs)
+    eng.bench_gemv(5, PROBE_LAUNCHES - 3, bs)
     eng.close()
     return 0
 
 
-def measure_traffic(model, bs, kernel_prefix="gemv_fused_kernel<1, 1, 1, 1"):
+PROBE_LAUNCHES = 43   # bench_gemv(5, 40, bs): 3 warm-up + 40 timed launches of the gate_up call site
+
+
+def pick_call_site_kernel(per_kernel, launches=PROBE_LAUNCHES):
+    """per_kernel: {kernel name: (sum, count)} of one counter pass over the traffic probe.  The dominant GEMV is whatever
+    kernel the gate_up call site dispatched - a dot2 instantiation for Qwen3-4B, another one for hidden 4096, the skinny MFMA
+    kernel at bs >= 3 - so it is identified by the probe's launch count (the only kernel launched exactly `launches` times
+    whose name says GEMV / GEMM; the largest mean value wins a tie), not by a template-argument prefix."""
+    cand = [(tot / n, k) for k, (tot, n) in per_kernel.items()
+            if n == launches and any(t in k for t in ("gemv", "skinny", "gemm"))]
+    return max(cand)[1] if cand else None
+
+
+def measure_traffic(model, bs, kernel_prefix=None):
     """HBM bytes per launch of the dominant kernel from the PMC counters, measured NOW: FETCH_SIZE and WRITE_SIZE in their
     own rocprofv3 passes (they do not fit one pass: MI355X_MICROARCH.md 'rocprofv3 PMC slots'), --kernel-trace only, KiB
     per dispatch, FETCH_SIZE x 2 (the guide's gfx950 correction: a wide coalesced stream is reported at half).  Returns
@@ -236,19 +273,58 @@ def measure_traffic(model, bs, kernel_prefix="gemv_fused_kernel<1, 1, 1, 1"):
             kname = "kernel_name" if "kernel_name" in cols else [c for c in cols if "name" in c and "kernel" in c][0]
             cname = "counter_name" if "counter_name" in cols else [c for c in cols if "counter" in c and "name" in c][0]
             vname = "value" if "value" in cols else [c for c in cols if "value" in c][0]
-            tot, n = 0.0, 0
+            per = {}
             for k, c, v in db.execute(f"select {kname}, {cname}, {vname} from counters_collection"):
-                if c == counter and kernel_prefix in k.replace("void ", "").replace("pk::", ""):
-                    tot += float(v)
-                    n += 1
+                if c == counter:
+                    k = k.replace("void ", "").replace("pk::", "")
+                    t_, n_ = per.get(k, (0.0, 0))
+                    per[k] = (t_ + float(v), n_ + 1)
             db.close()
-            if n == 0:
+            if kernel_prefix is None:
+                kernel_prefix = pick_call_site_kernel(per)
+                if kernel_prefix is None:
+                    return None, f"no kernel with {PROBE_LAUNCHES} dispatches in the {counter} pass: " + str(sorted((n_, k[:40]) for k, (_, n_) in per.items())[-4:])
+            hit = [(t_, n_) for k, (t_, n_) in per.items() if kernel_prefix in k]
+            if not hit:
                 return None, f"no {kernel_prefix} dispatch in the {counter} pass"
-            vals[counter] = (tot / n, n)
+            vals[counter] = (sum(t_ for t_, _ in hit) / sum(n_ for _, n_ in hit), sum(n_ for _, n_ in hit))
+            vals["kernel"] = kernel_prefix
     traffic = int(2 * vals["FETCH_SIZE"][0] * 1024 + vals["WRITE_SIZE"][0] * 1024)
-    return traffic, ("measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) "
+    return traffic, (f"kernel {vals['kernel'][:60]} (found by the probe's launch count); "
+                     "measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) "
                      f"over {vals['FETCH_SIZE'][1]} dispatches of the kernel on cold weights; KiB per dispatch, FETCH_SIZE x 2 "
                      "(gfx950 correction, MI355X_MICROARCH.md)")
+
+
+def run_tp_leg(make_engine, prompt, steps, warmup, world, full_cfg, fence, max_over_ranks):
+    """The sharded leg of an N > 1 bench line: ONE request through the tensor-parallel engine of every rank, timed by the
+    contract's protocol (warm-up, `steps` decode steps between two fences = barrier + device sync, MAX over ranks).
+    make_engine() -> an attached TP engine; host-only logic, so tests/test_parallel_gloo.py runs it at world 2 over gloo with
+    a stand-in engine."""
+    e = make_engine()
+    r_ = e.new_request()
+    fence()
+    t0 = time.perf_counter()
+    tk = e.prefill([r_], [prompt])
+    ttft = max_over_ranks(time.perf_counter() - t0) * 1e3
+    for _ in range(warmup):
+        tk = e.decode([r_], tk)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tk = e.decode([r_], tk)
+    fence()
+    el = max_over_ranks(time.perf_counter() - t0)
+    dev = e.last_step_ms()
+    e.close()
+    ctx = len(prompt) + warmup + steps / 2
+    b = algorithmic_bytes_per_token(full_cfg, ctx, 1)
+    return {"tok_s": round(steps / el, 2), "ms_per_step": round(el / steps * 1e3, 4), "device_ms_last_step": round(float(dev), 4),
+            "ttft_ms": round(ttft, 3), "scaling": "strong", "parallelism": "tp%d" % world, "steps": steps, "warmup": warmup,
+            "all_reduces_per_step": 2 * full_cfg["num_hidden_layers"],
+            "frac_of_aggregate_8TBps": round(b / (el / steps) / 1e9 / (HBM_PEAK_GBS * world), 4),
+            "what": "ONE request sharded over the ranks (q/k/v/gate/up by rows, o/down by columns, weights.rs:121-291), sum "
+                    "all-reduce of [hidden] bf16 after o_proj and down_proj inside the captured graph"}
 
 
 MFMA_PEAK_TFLOPS = 2500.0  # MI355X dense bf16 (MI355X_MICROARCH.md); never the 2:1-sparsity figure
@@ -353,8 +429,14 @@ def run_qwen35(args, rank, world, local, dist, torch):
                    "parallelism": "replicas%d" % world if world > 1 else "single"},
         "ttft_ms": {"prompt_tokens": args.ctx, "p50": round(float(np.median(ttfts)), 3),
                     "min": round(float(min(ttfts)), 3), "iters": len(ttfts)},
-        "tpot_ms": {"p50": round(float(np.median(step_ms)), 4), "p95": round(float(np.percentile(step_ms, 95)), 4),
-                    "device_p50": round(float(np.median(dev_ms)), 4)},
+        "tpot_ms": ({"p50": round(float(np.median(sync_ms)), 4), "p95": round(float(np.percentile(sync_ms, 95)), 4),
+                     "percentiles_from": f"{len(sync_ms)} steps of the sync-per-step loop after the timed region",
+                     "device_p50": round(float(np.median(dev_ms)), 4), "mean": round(elapsed / args.steps * 1e3, 4),
+                     "mean_is": f"timed region: chains of {chain} greedy steps, one host synchronisation per chain"}
+                    if chain and sync_ms else
+                    {"p50": round(float(np.median(step_ms)), 4), "p95": round(float(np.percentile(step_ms, 95)), 4),
+                     "percentiles_from": "the timed region (one host synchronisation per step)",
+                     "device_p50": round(float(np.median(dev_ms)), 4)}),
         "host_loop": ({"form": "chained", "chain_steps": chain,
                        "sync_per_step": {"tpot_ms_p50": round(float(np.median(sync_ms)), 4),
                                          "tok_s": round(args.batch * world * 1e3 / float(np.mean(sync_ms)), 2), "steps": len(sync_ms)}}
@@ -379,6 +461,8 @@ def run_qwen35(args, rank, world, local, dist, torch):
                                "frac": round(kbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                "step_frac": out["step_roofline"]["frac_of_8TBps"], "traffic": None,
                                "bytes_per_launch": kbytes, "avg_launch_us": round(ms * 1e3, 2)}
+            if world == 1 and os.environ.get("PEGAINFER_BENCH_TRAFFIC", "1") != "0":
+                out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measure_traffic("qwen3.5-4b", 1)
         else:
             out["roofline"] = {"bound": "hbm", "kernel": "whole decode step (graph)", "achieved": out["step_roofline"]["achieved_GBps"],
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": out["step_roofline"]["frac_of_8TBps"],
@@ -819,26 +903,75 @@ def main():
         th.join(timeout=deadline)
         mp8_hung = th.is_alive()
         mp8 = {"error": f"collective microbench did not finish within {deadline:.0f} s; abandoned"} if mp8_hung else box.get("mp8")
+    # the SHARDED config next to the replicas value: north_star asks for tokens/s "at 2/4/8 GPUs for the
+    # sharded config", and the driver's scaling run passes no flag - so every N > 1 line also carries the reference's Qwen3
+    # tensor parallel (weights.rs:121-291; two sum all-reduces per layer inside the captured graph) as `tp`, timed by the same
+    # protocol (warm-up, K steps between barriers, MAX over ranks).  One request, strong scaling.  Same watchdog as above.
+    tp_leg, tp_hung = None, False
+    if (world > 1 and not tp and not mp8_hung and os.environ.get("PEGAINFER_BENCH_TP_LEG", "1") != "0"
+            and full_cfg["num_key_value_heads"] % world == 0):
+        import threading
+        tbox = {}
+
+        def tp_side():
+            try:
+                torch.cuda.set_device(local)
+                n_ctx = args.ctx + args.warmup + args.steps + 16
+
+                def make_engine():
+                    e = Qwen3Engine(parallel.tp_local_config(full_cfg, world), num_kv_pages=-(-n_ctx // 16) + 9, max_batch_size=1,
+                                    enable_graph=not args.no_graph, decode_mode=args.decode_mode, split_policy=args.split_policy,
+                                    device=local, max_positions=max(4096, n_ctx + 16))
+                    e.fill_synthetic(seed=42, std=0.02)            # replicated tensors must agree across the ranks
+                    parallel.attach_tp(e)
+                    return e
+
+                def fence():
+                    dist.barrier()
+                    torch.cuda.synchronize()
+                tbox["tp"] = run_tp_leg(make_engine, prompt, args.steps, args.warmup, world, full_cfg, fence,
+                                        lambda x: parallel.max_over_ranks(x, device="cuda"))
+            except Exception as e_:  # noqa: BLE001
+                tbox["tp"] = {"error": f"{type(e_).__name__}: {e_}"[:300]}
+
+        th = threading.Thread(target=tp_side, daemon=True)
+        th.start()
+        th.join(timeout=float(os.environ.get("PEGAINFER_BENCH_TP_TIMEOUT", "240")))
+        tp_hung = th.is_alive()
+        tp_leg = {"error": "tensor-parallel leg did not finish within its deadline; abandoned"} if tp_hung else tbox.get("tp")
+        if tp_leg and "error" not in tp_leg and isinstance(mp8, dict) and "all_reduce_small" in mp8:
+            tp_leg["all_reduce_us"] = mp8["all_reduce_small"].get("bf16_5KB")   # the payload of a decode step's all-reduce
+        mp8_hung = mp8_hung or tp_hung
     ctx_mid = args.ctx + args.warmup + args.steps / 2
     step_bytes = algorithmic_bytes_per_token(full_cfg, ctx_mid, args.batch)
 
+    sampling_name = {"greedy": "greedy", "topk_topp": "top-k/top-p sampling (T 0.8, k 50, p 0.95)",
+                     "topp": "top-p sampling (T 0.8, p 0.9)"}[args.sampling]
     out = {
-        "metric": "decode tokens/sec + TTFT, Qwen3-4B bf16 greedy, 1xMI355X" if args.model == "qwen3-4b"
-                  else "decode tokens/sec + TTFT, Qwen3-8B bf16 greedy, 1xMI355X",
+        "metric": "decode tokens/sec + TTFT, %s bf16 %s, 1xMI355X" % ("Qwen3-4B" if args.model == "qwen3-4b" else "Qwen3-8B", sampling_name),
         "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "rccl_ranks": (dist.get_world_size() if world > 1 else 1), "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(mean_ms, 4), "higher_is_better": True,
         "scaling": "strong" if tp else "weak",
         "vs_baseline": None, "dtype": "bf16", "data": data,
-        "config": {"workload": f"{args.model} greedy decode, hipGraph {'off' if args.no_graph else 'on'}, "
+        "config": {"workload": f"{args.model} {sampling_name} decode, hipGraph {'off' if args.no_graph else 'on'}, "
                                f"bs={args.batch}/GPU, ctx {args.ctx}->{args.ctx + args.warmup + args.steps} "
                                f"(reference decode_heavy: synthetic prompt 100+(i%1000))",
                    "batch_per_gpu": args.batch, "ctx": args.ctx, "decode_mode": args.decode_mode,
                    "sampling": args.sampling, "split_policy": args.split_policy, "parallelism": ("tp%d" % world if tp else "replicas%d" % world) if world > 1 else "single"},
         "ttft_ms": {"prompt_tokens": args.ctx, "p50": round(float(np.median(ttfts)), 3),
                     "min": round(float(min(ttfts)), 3), "iters": len(ttfts)},
-        "tpot_ms": {"p50": round(p50_ms, 4), "p95": round(float(np.percentile(step_ms, 95)), 4),
-                    "device_p50": round(float(np.median(dev_ms)), 4), "mean": round(mean_ms, 4),
-                    "mean_over_p50": round(mean_ms / p50_ms, 4)},
+        # per-step percentiles come from PER-STEP samples only: with chained steps the timed region yields one
+        # average per chain, so p50 / p95 are taken from the sync-per-step loop run right after it on the same requests and
+        # the chained figure is labelled a mean
+        "tpot_ms": ({"p50": round(float(np.median(sync_ms)), 4), "p95": round(float(np.percentile(sync_ms, 95)), 4),
+                     "percentiles_from": f"{len(sync_ms)} steps of the sync-per-step loop after the timed region",
+                     "device_p50": round(float(np.median(dev_ms)), 4), "mean": round(mean_ms, 4),
+                     "mean_is": f"timed region: chains of {chain} greedy steps, one host synchronisation per chain",
+                     "chain_mean_p50": round(p50_ms, 4)} if chain and sync_ms else
+                    {"p50": round(p50_ms, 4), "p95": round(float(np.percentile(step_ms, 95)), 4),
+                     "percentiles_from": "the timed region (one host synchronisation per step)",
+                     "device_p50": round(float(np.median(dev_ms)), 4), "mean": round(mean_ms, 4),
+                     "mean_over_p50": round(mean_ms / p50_ms, 4)}),
         # how the timed steps were driven: chains of `chain_steps` greedy steps with the token handed over on the device and
         # one host synchronisation per chain (every step's tokens are still copied to the host, asynchronously), or the
         # reference's loop shape - a host synchronisation per step; `sync_per_step` is the second form measured right after
@@ -851,6 +984,10 @@ def main():
         "ttft_ms_10000": ttft10k,
         "ttft_ms_short": ttft_short,
         "mp8_collectives_us": mp8,
+        # N > 1: `value` is the replicas leg (independent requests, weak scaling); `tp` is the sharded leg (one request, strong)
+        "tp": tp_leg,
+        "scaling_legs": ({"value": "strong (tensor parallel)" if tp else "weak (replicas: one independent request stream per GPU)",
+                          "tp": "strong (one request over all ranks)"} if world > 1 else None),
         "prefill_roofline": prefill_roofline(full_cfg, args.ctx, float(np.median(ttfts)), world if tp else 1),
         # the whole step against the HBM roofline, from the DRIVER-TIMED ms_per_step (wall clock of the contract's timed
         # region: metadata upload, graph replay, token D2H, host loop - what `value` is made of); the graph's own device time
@@ -916,7 +1053,7 @@ def main():
             per_site[name] = {"us": round(t * 1e3, 2), "GBps": round(M * K * 2 / (t * 1e-3) / 1e9, 1)}
         out["gemv_sites"] = per_site
     # ---- CPU side (rank 0, N = 1): parity of the benchmarked model + the reference's CPU path as the baseline ----
-    cpu_inputs = None
+    cpu_inputs, batch_rows = None, None
     if rank == 0 and args.cpu_steps > 0 and world == 1 and not mp8_hung:
         try:
             gtoks, grows = gpu_parity_run(eng, prompt, args.cpu_steps)
@@ -948,9 +1085,22 @@ def main():
                 e.drop_request(i)
             b = algorithmic_bytes_per_token(full_cfg, args.ctx + 5 + args.sweep_steps / 2, bs)
             return {"ms_per_step": round(dt * 1e3, 4), "tok_s": round(bs / dt, 1), "frac_of_8TBps": round(b / dt / 1e9 / HBM_PEAK_GBS, 4)}
+        def forced_rows(e, bs, feed):
+            """every column = the bench prompt teacher-forced on the bs-1 parity run's tokens -> bf16 bits [bs, 1 + len(feed), V]"""
+            ids = [e.new_request() for _ in range(bs)]
+            _, lg = e.prefill(ids, [prompt] * bs, return_logits=True)
+            rows = [lg.copy()]
+            for tk in feed:
+                _, lg = e.decode(ids, [tk] * bs, return_logits=True)
+                rows.append(lg.copy())
+            for i in ids:
+                e.drop_request(i)
+            return np.stack(rows, axis=1)
         try:
             e2 = side_engine(args.decode_mode, 16)
             out["batch_sweep"] = {"ctx": args.ctx, "steps": args.sweep_steps, **{str(bs): rate(e2, bs) for bs in (2, 4, 8, 16)}}
+            if cpu_inputs is not None:   # parity of the batched steps, refereed by the bs-1 oracle / truth streams (cpu_legs)
+                batch_rows = {str(bs): forced_rows(e2, bs, cpu_inputs[1][:-1]) for bs in (2, 4, 8, 16)}
             e2.close()
             if args.decode_mode >= 1:
                 e3 = side_engine(0, 1)
@@ -970,7 +1120,10 @@ def main():
             hf_threads = int(os.environ.get("PEGAINFER_CPU_THREADS", "0")) or min(32, threads)
             try:
                 out["cpu_baseline"], out["parity"] = cpu_legs(cfg, cpu_inputs[0], prompt, cpu_inputs[1], cpu_inputs[2],
-                                                              args.cpu_steps, threads, hf_threads=hf_threads)
+                                                              args.cpu_steps, threads, hf_threads=hf_threads, batch_rows=batch_rows)
+                for label, pb in (out["parity"].pop("batch", None) or {}).items():
+                    if isinstance(out.get("batch_sweep"), dict) and label in out["batch_sweep"]:
+                        out["batch_sweep"][label]["parity"] = pb
             except MemoryError:
                 out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": threads, "kind": "port",
                                        "sample": "skipped: host RAM too small for the fp32 oracle weights"}

@@ -170,7 +170,7 @@ def gemm(W, X):
     (csrc/linear.cu:45-75; cublasGemmEx COMPUTE_32F — reduction order is cuBLAS
     internal, so this oracle accumulates in float64 and parity is by tolerance)."""
     if GEMM_ACCUM is np.float32:
-        return bf16_round(X.astype(F32) @ W.T)
+        return bf16_round(np.asarray(X, dtype=F32) @ W.T)
     y = X.astype(np.float64) @ W.astype(np.float64).T
     return bf16_round(y.astype(F32))
 

