@@ -212,7 +212,7 @@ def main():
     import pytest
     t = os.path.join(ROOT, "tests")
     argv = [os.path.join(t, "test_gpu_full_depth.py"), os.path.join(t, "test_gpu_full_depth_qwen35.py"),
-            os.path.join(t, "test_gpu_full_depth_8b.py"), "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider", "--durations=12"]
+            os.path.join(t, "test_gpu_full_depth_8b.py"), os.path.join(t, "test_gpu_full_depth_batch.py"), "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider", "--durations=12"]
     if args.k:
         argv += ["-k", args.k]
     rc = pytest.main(argv)
