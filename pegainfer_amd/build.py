@@ -48,8 +48,8 @@ def _run(cmd):
     return r.stdout
 
 
-def _compile(src, extra, headers):
-    obj = os.path.join(OBJDIR, os.path.basename(src) + ".o")
+def _compile(src, extra, headers, objdir=None):
+    obj = os.path.join(objdir or OBJDIR, os.path.basename(src) + ".o")
     if _newer([src] + headers, obj):
         _run([_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall",
               "-Wno-unused-function", "-I", os.path.join(ROOT, "include"), "-I", CSRC] + extra +
@@ -57,12 +57,19 @@ def _compile(src, extra, headers):
     return obj
 
 
-def build(verbose=False, force=False):
-    os.makedirs(LIBDIR, exist_ok=True)
-    os.makedirs(OBJDIR, exist_ok=True)
+def build(verbose=False, force=False, variant=None, extra_flags=()):
+    """variant: build the same sources with `extra_flags` into pegainfer_amd/lib_<variant> (objects in build_<variant>) for a
+    same-box A/B against the default build (PEGAINFER_LIB_DIR selects it at load time); the default build takes no flags."""
+    libdir = LIBDIR if not variant else os.path.join(PKG, "lib_" + variant)
+    objdir = OBJDIR if not variant else os.path.join(PKG, "build_" + variant)
+    kernel_lib, host_lib = os.path.join(libdir, os.path.basename(KERNEL_LIB)), os.path.join(libdir, os.path.basename(HOST_LIB))
+    extra_flags = list(extra_flags) if variant else []
+    os.makedirs(libdir, exist_ok=True)
+    os.makedirs(objdir, exist_ok=True)
     if force:
-        for f in os.listdir(OBJDIR):
-            os.remove(os.path.join(OBJDIR, f))
+        for f in os.listdir(objdir):
+            if os.path.isfile(os.path.join(objdir, f)):
+                os.remove(os.path.join(objdir, f))
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers += [os.path.join(ROOT, "include", f) for f in os.listdir(os.path.join(ROOT, "include"))]
     ksrcs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
@@ -71,20 +78,27 @@ def build(verbose=False, force=False):
         hsrcs = sorted(os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".cpp"))
         hheaders = [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".h")]
     with cf.ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 4)) as ex:
-        kfut = [ex.submit(_compile, s, [], headers) for s in ksrcs]
-        hfut = [ex.submit(_compile, s, ["-x", "hip", "-I", HOST], headers + hheaders) for s in hsrcs]
+        kfut = [ex.submit(_compile, s, extra_flags, headers, objdir) for s in ksrcs]
+        hfut = [ex.submit(_compile, s, ["-x", "hip", "-I", HOST] + extra_flags, headers + hheaders, objdir) for s in hsrcs]
         kobjs = [f.result() for f in kfut]
         hobjs = [f.result() for f in hfut]
-    if _newer(kobjs, KERNEL_LIB):
-        _run([_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", KERNEL_LIB] + kobjs)
-    if hobjs and _newer(hobjs + [KERNEL_LIB], HOST_LIB):
-        _run([_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", HOST_LIB] + hobjs +
-             ["-L", LIBDIR, "-lpegainfer_kernels_hip", "-L", "/opt/rocm/lib", "-lrccl", "-Wl,-rpath,$ORIGIN",
+    if _newer(kobjs, kernel_lib):
+        _run([_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", kernel_lib] + kobjs)
+    if hobjs and _newer(hobjs + [kernel_lib], host_lib):
+        _run([_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", host_lib] + hobjs +
+             ["-L", libdir, "-lpegainfer_kernels_hip", "-L", "/opt/rocm/lib", "-lrccl", "-Wl,-rpath,$ORIGIN",
               "-Wl,-rpath,/opt/rocm/lib"])
     if verbose:
-        print("built", KERNEL_LIB, HOST_LIB if hobjs else "")
-    return KERNEL_LIB, (HOST_LIB if hobjs else None)
+        print("built", kernel_lib, host_lib if hobjs else "")
+    return kernel_lib, (host_lib if hobjs else None)
 
 
 if __name__ == "__main__":
-    build(verbose=True, force="--force" in sys.argv)
+    # python -m pegainfer_amd.build [--force] [--variant NAME -- extra hipcc flags ...]
+    argv = sys.argv[1:]
+    var, flags = None, []
+    if "--variant" in argv:
+        i = argv.index("--variant")
+        var = argv[i + 1]
+        flags = argv[argv.index("--") + 1:] if "--" in argv else []
+    build(verbose=True, force="--force" in argv, variant=var, extra_flags=flags)

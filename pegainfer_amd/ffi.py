@@ -12,7 +12,9 @@ import re
 PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 INCLUDE = os.path.join(ROOT, "include")
-LIBDIR = os.path.join(PKG, "lib")
+# PEGAINFER_LIB_DIR: an alternative build of the two libraries (python -m pegainfer_amd.build --variant NAME -> pegainfer_amd/lib_NAME:
+# same sources, extra hipcc flags) for same-box A/B runs; default pegainfer_amd/lib
+LIBDIR = os.environ.get("PEGAINFER_LIB_DIR") or os.path.join(PKG, "lib")
 
 _SCALARS = {
     "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "uint32_t": ctypes.c_uint32,

@@ -13,7 +13,7 @@ from pegainfer_amd.qwen3 import QWEN3_4B, Qwen3Engine  # noqa: E402
 
 lens = [int(a) for a in sys.argv[1:]] or [4, 8, 16, 32, 64, 128]
 tag = " ".join(f"{k[10:]}={v}" for k, v in sorted(os.environ.items()) if k.startswith("PEGAINFER_PREFILL")) or "default"
-eng = Qwen3Engine(dict(QWEN3_4B), num_kv_pages=max(lens) // 16 + 8, max_batch_size=2, decode_mode=1, max_positions=4096)
+eng = Qwen3Engine(dict(QWEN3_4B), num_kv_pages=max(lens) // 16 + 8, max_batch_size=2, decode_mode=1, max_positions=max(4096, max(lens) + 16))
 eng.fill_synthetic(seed=1, std=0.02)
 for n in lens:
     p, ts = [100 + (i % 1000) for i in range(n)], []
