@@ -313,6 +313,316 @@ inline void gemm256_splitk_launch(const Half* W, const Half* X, int M, int T, in
       SplitOut{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0, t_tiles == 1 && weights_nt_on()}, part, nk_slice);
 }
 
+// ---- stream-K form of the 256 x 256 kernel (round 6) --------------------------------------------------------------------
+// The data-parallel launch above pays for tile quantisation: 304 tiles (gate_up at 1024 tokens) are one full round of the
+// 256 CUs plus 48 tiles that cost a second full tile time; 152 tiles (512 tokens) leave 104 CUs idle.  Here the launch is
+// PERSISTENT - one workgroup per CU - and the work is the linear sequence of (tile, K-tile pair) units, tile-major, dealt in
+// equal contiguous ranges: workgroup position p owns units [U p / G, U (p + 1) / G).  A range is cut at tile boundaries into
+// segments; each segment runs the 8-phase main loop over its K range and then
+//   * covers the whole tile            -> the ordinary epilogue;
+//   * starts inside a tile             -> (only ever a workgroup's FIRST segment) the fp32 accumulators go to the workgroup's
+//                                         256 KiB slot of the split-K workspace, lane-contiguous, write-through (sc1) stores,
+//                                         drained, then flag[p] = 1: published EARLY in the workgroup's timeline, no waiting;
+//   * starts a tile but ends inside it -> (only ever its LAST segment) the workgroup OWNS the tile: it takes the partials of
+//                                         positions p + 1, p + 2, ... up to the one that holds the tile's last unit, in that
+//                                         order (= ascending K), adds them to its accumulators, clears their flags, and runs
+//                                         the epilogue.  Those partials were published a whole range ago.
+// So the sum over K is taken in a FIXED order that depends on (M, T, K, G) only: deterministic, rerun- and graph-stable, but
+// not the K order of the data-parallel kernels - the cross-route bit identity of rounds 1-5 is given up for prefill GEMMs at
+// these sizes; the oracle comparison under the derived bar referees.  No deadlock: a publisher never waits,
+// an owner waits only for publishers, and all G <= CU-count workgroups are co-resident (one per CU by LDS).  Positions follow
+// the XCD-aware order of the other kernels (block b runs on XCD b % 8): neighbours in the unit order share an XCD's L2 except
+// at seven seams, so most partials are re-read from the L2 they were written through.
+constexpr int kG256SlotFloats = 256 * 256;   // one workgroup's accumulators: 8 x 4 f32x4 per thread x 512 threads
+template <bool SILU>
+__global__ __launch_bounds__(512) void mfma_gemm256_streamk_kernel(const Half* __restrict__ W, const Half* __restrict__ X,
+                                                                   Half* __restrict__ Y, int M, int T, int K, int m_tiles,
+                                                                   int t_tiles, SplitOut so, float* __restrict__ part,
+                                                                   uint32_t* __restrict__ flags) {
+  extern __shared__ __attribute__((aligned(16))) u32x4 g256_smem[];
+  const int ntiles = m_tiles * t_tiles;
+  const int G = gridDim.x;
+  int pos = blockIdx.x;
+  {  // XCD-aware position: the workgroups of one XCD are neighbours in the unit order
+    const int q = G / 8, r = G % 8, xcd = pos % 8, idx = pos / 8;
+    pos = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int KP = K / (2 * G256_BK);                       // K-tile pairs per tile
+  const long U = (long)ntiles * KP;
+  auto range_begin = [&](int p) { return U * p / G; };
+  const long u_begin = range_begin(pos), u_end = range_begin(pos + 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int l15 = lane & 15, g = lane >> 4;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)&g256_smem[0];
+  auto half_ptr = [&](int par, int which) { return g256_smem + (size_t)(par * 4 + which) * (kG256HalfBytes / 16); };
+
+  f32x4 acc[8][4];
+  bf16x8_t a[4][2], b[2][2];
+  auto read_a = [&](int par, int which) {
+    const u32x4* h = half_ptr(par, which);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        a[i][ks] = __builtin_bit_cast(bf16x8_t, h[lds_slot(wr * 64 + i * 16 + l15, ks * 4 + g)]);
+  };
+  auto read_b = [&](int par, int which) {
+    const u32x4* h = half_ptr(par, which);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        b[j][ks] = __builtin_bit_cast(bf16x8_t, h[lds_slot(wc * 32 + j * 16 + l15, ks * 4 + g)]);
+  };
+  auto quad = [&](int ih, int jh) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[ih * 4 + i][jh * 2 + j] =
+              __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][ks], b[j][ks], acc[ih * 4 + i][jh * 2 + j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  long u = u_begin;
+  while (u < u_end) {
+    const int tile = (int)(u / KP), kp0 = (int)(u - (long)tile * KP);
+    const int kp1 = (long)(KP - kp0) < u_end - u ? KP : kp0 + (int)(u_end - u);
+    const int mt = tile / t_tiles, tt = tile - mt * t_tiles;
+    const int m0 = mt * G256_BM, t0 = tt * G256_BT;
+    const int nk = 2 * (kp1 - kp0);
+    // ---- DMA sources of this tile (as in the data-parallel kernel), advanced to the segment's first K tile ----
+    const Half* src[4][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int p = (j * 8 + wave) * 64 + lane, hrow = p >> 3, cs = (p & 7) ^ (hrow & 7);
+      {
+        const int wr_ = hrow >> 6, r = hrow & 63;
+#pragma unroll
+        for (int hi = 0; hi < 2; ++hi) {
+          int row;
+          if (SILU) {
+            int gr = so.silu_c0 + mt * 128 + wr_ * 64 + r;
+            gr = gr < silu_cols_end(so) ? gr : silu_cols_end(so) - 1;
+            row = gr + (hi ? so.silu_I : 0);
+          } else {
+            row = m0 + wr_ * 128 + hi * 64 + r;
+            row = row < M ? row : M - 1;
+          }
+          src[hi ? kHalfAhi : kHalfAlo][j] = W + (size_t)row * K + cs * 8 + (size_t)kp0 * 2 * G256_BK;
+        }
+      }
+      {
+        const int wc_ = hrow >> 5, r = hrow & 31;
+#pragma unroll
+        for (int hi = 0; hi < 2; ++hi) {
+          int tr = t0 + wc_ * 64 + hi * 32 + r;
+          tr = tr < T ? tr : T - 1;
+          src[hi ? kHalfBhi : kHalfBlo][j] = X + (size_t)tr * K + cs * 8 + (size_t)kp0 * 2 * G256_BK;
+        }
+      }
+    }
+    auto stage = [&](int which, int kt) {
+      const int ktc = kt < nk ? kt : nk - 1;
+      const uint32_t slot = lds0 + (uint32_t)(((kt & 1) * 4 + which) * kG256HalfBytes);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(slot + (uint32_t)(j * 8 + wave) * 1024u);
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                     :: "v"(src[which][j] + (size_t)ktc * G256_BK), "s"(dst) : "memory", "m0");
+      }
+    };
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- the 8-phase main loop over K tiles [2 kp0, 2 kp1) ----
+    stage(kHalfAlo, 0); stage(kHalfBlo, 0); stage(kHalfBhi, 0); stage(kHalfAhi, 0);
+    stage(kHalfAlo, 1); stage(kHalfBhi, 1);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();
+    auto ktile = [&](int kt, int par) {
+      read_b(par, kHalfBlo);
+      __builtin_amdgcn_sched_barrier(0);
+      read_a(par, kHalfAlo);
+      stage(kHalfAhi, kt + 1);
+      __builtin_amdgcn_s_barrier();
+      quad(0, 0);
+      __builtin_amdgcn_s_barrier();
+      read_b(par, kHalfBhi);
+      stage(kHalfBlo, kt + 1);
+      __builtin_amdgcn_s_barrier();
+      quad(0, 1);
+      __builtin_amdgcn_s_barrier();
+      read_a(par, kHalfAhi);
+      stage(kHalfAlo, kt + 2);
+      __builtin_amdgcn_s_barrier();
+      quad(1, 1);
+      __builtin_amdgcn_s_barrier();
+      read_b(par, kHalfBlo);
+      stage(kHalfBhi, kt + 2);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      quad(1, 0);
+      __builtin_amdgcn_s_barrier();
+    };
+    for (int kt = 0; kt < nk; kt += 2) {
+      ktile(kt, 0);
+      ktile(kt + 1, 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (wr == 0) __builtin_amdgcn_s_barrier();   // both wave rows are level again: the LDS may be re-staged
+
+    if (kp0 != 0) {
+      // ---- publish: lane-contiguous write-through stores (one 1 KiB line per wave and instruction), drain, flag ----
+      float* slot = part + (size_t)pos * kG256SlotFloats + (size_t)threadIdx.x * 4;
+      asm volatile("" : "+v"(slot));   // opaque: keeps the 32 loop-invariant store addresses from being hoisted (and spilled)
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(slot + (size_t)(i * 4 + j) * 2048), "v"(acc[i][j]) : "memory");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (threadIdx.x == 0) __hip_atomic_store(flags + pos, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      if (kp1 != KP) {
+        // ---- own the tile: add the later K ranges in ascending order ----
+        const long need = (long)(tile + 1) * KP;
+        long covered = u_end;
+        for (int p = pos + 1; covered < need; ++p) {
+          if (threadIdx.x == 0)
+            while (__hip_atomic_load(flags + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(2);
+          __syncthreads();
+          const float* slot = part + (size_t)p * kG256SlotFloats + (size_t)threadIdx.x * 4;
+          asm volatile("" : "+v"(slot));
+#pragma unroll
+          for (int qt = 0; qt < 4; ++qt) {   // four batches of eight 16-byte loads: 32 registers next to the 128 accumulators
+            f32x4 tmp[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+              asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(tmp[q]) : "v"(slot + (size_t)(qt * 8 + q) * 2048) : "memory");
+            // the waitcnt is tied to the loaded registers so that no use can be scheduled in front of it
+            asm volatile("s_waitcnt vmcnt(0)"
+                         : "+v"(tmp[0]), "+v"(tmp[1]), "+v"(tmp[2]), "+v"(tmp[3]), "+v"(tmp[4]), "+v"(tmp[5]), "+v"(tmp[6]), "+v"(tmp[7])
+                         :: "memory");
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc[(qt * 8 + q) >> 2][(qt * 8 + q) & 3] += tmp[q];
+          }
+          __syncthreads();   // every wave has taken its part of the slot
+          if (threadIdx.x == 0) __hip_atomic_store(flags + p, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          covered = range_begin(p + 1);
+        }
+      }
+      // ---- epilogue (the data-parallel kernel's): lane holds rows m = .. + g*4 + e of token t = .. + l15 ----
+      if (SILU) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int t = t0 + wc * 64 + j * 16 + l15;
+          if (t >= T) continue;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int m = so.silu_c0 + mt * 128 + wr * 64 + i * 16 + g * 4;
+            float r[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float sg = silu_f(bf16_round_f(acc[i][j][e]));
+              r[e] = (so.silu_round ? bf16_round_f(sg) : sg) * bf16_round_f(acc[i + 4][j][e]);
+            }
+            if (m + 3 < silu_cols_end(so)) {
+              u32x2 o;
+              o.x = pack_bf2(r[0], r[1]);
+              o.y = pack_bf2(r[2], r[3]);
+              *reinterpret_cast<u32x2*>(Y + (size_t)t * so.silu_I + m) = o;
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (m + e < silu_cols_end(so)) Y[(size_t)t * so.silu_I + m + e] = f2bf(r[e]);
+            }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int t = t0 + wc * 64 + j * 16 + l15;
+          if (t >= T) continue;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int m = m0 + wr * 128 + i * 16 + g * 4;
+            Half* dst = Y;
+            int ld = M, mm = m, mlim = M;
+            if (so.Y1) {
+              const int b1 = so.M0 + so.M1, b2 = b1 + so.M2;
+              if (m < so.M0) { ld = mlim = so.M0; }
+              else if (m < b1) { dst = so.Y1; ld = mlim = so.M1; mm = m - so.M0; }
+              else if (m < b2) { dst = so.Y2; ld = mlim = so.M2; mm = m - b1; }
+              else { dst = so.Y3; ld = mlim = M - b2; mm = m - b2; }
+            }
+            if (mm + 3 < mlim) {
+              u32x2 o;
+              o.x = pack_bf2(acc[i][j][0], acc[i][j][1]);
+              o.y = pack_bf2(acc[i][j][2], acc[i][j][3]);
+              *reinterpret_cast<u32x2*>(dst + (size_t)t * ld + mm) = o;
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (mm + e < mlim) dst[(size_t)t * ld + mm + e] = f2bf(acc[i][j][e]);
+            }
+          }
+        }
+      }
+    }
+    u += kp1 - kp0;
+  }
+}
+
+// Stream-K plan, by shape and CU count only (the launcher and pegainfer_debug_gemm_route share it): taken when a round of
+// 256 x 256 tiles would leave more than `min_waste_pct` % of the CU-rounds idle and the K range of a workgroup is long
+// enough to amortise a pipeline fill (>= 4 K-tile pairs).  PEGAINFER_STREAMK=0 switches it off (A/B knob).
+inline bool gemm256_streamk_on() {
+  static const bool v = [] { const char* e = getenv("PEGAINFER_STREAMK"); return !(e && e[0] == '0'); }();
+  return v;
+}
+inline bool gemm256_streamk_plan(long tiles256, int K, int cus) {
+  static const int min_waste = [] { const char* e = getenv("PEGAINFER_STREAMK_MIN_WASTE"); return e && *e ? atoi(e) : 8; }();
+  if (!gemm256_streamk_on() || cus < 8 || tiles256 <= 0) return false;
+  const long rounds = (tiles256 + cus - 1) / cus;
+  const long waste_pct = 100 - 100 * tiles256 / (rounds * cus);
+  const long units = tiles256 * (K / (2 * G256_BK));
+  return waste_pct >= min_waste && units / cus >= 4;
+}
+
+inline void gemm256_streamk_launch(const Half* W, const Half* X, Half* Y, int M, int T, int K, SplitOut so, float* part,
+                                   uint32_t* flags, int cus, hipStream_t s) {
+  const bool silu = so.silu_I > 0;
+  const int m_tiles = silu ? ceil_div(silu_cols_end(so) - so.silu_c0, 128) : ceil_div(M, G256_BM), t_tiles = ceil_div(T, G256_BT);
+  so.w_nt = 0;
+  if (silu) {
+    static const bool once = [] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_gemm256_streamk_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kG256LdsBytes);
+      return true;
+    }();
+    (void)once;
+    mfma_gemm256_streamk_kernel<true><<<cus, 512, kG256LdsBytes, s>>>(W, X, Y, M, T, K, m_tiles, t_tiles, so, part, flags);
+  } else {
+    static const bool once = [] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_gemm256_streamk_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kG256LdsBytes);
+      return true;
+    }();
+    (void)once;
+    mfma_gemm256_streamk_kernel<false><<<cus, 512, kG256LdsBytes, s>>>(W, X, Y, M, T, K, m_tiles, t_tiles, so, part, flags);
+  }
+}
+
 // ---- 128 x 256 tiles: the same machinery for matrices with too few 256-row tiles to fill the chip (qkv / o_proj /
 // down_proj at ~0.5-2 k tokens: 2560 rows are 10 tiles of 256 but 20 of 128).  8 waves as 2 x 4, wave (wr, wc) owns
 // 64 W rows x 64 token rows = 4 x 4 MFMA tiles (64 accumulator VGPRs).  A K tile is THREE 16 KiB half-tiles - A (all 128

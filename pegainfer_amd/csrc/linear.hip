@@ -476,8 +476,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_add_kernel(const float* __r
 // Split-K workspace (64 MB): created by cublas_init() (the reference's handles own a 32 MB cuBLAS workspace the same way,
 // csrc/linear.cu:14-42), per thread = per GPU rank.  Without it the split-K route is simply not taken.
 constexpr size_t kSplitKWorkspaceBytes = 64u << 20;
+constexpr size_t kStreamKFlagBytes = 64u << 10;   // behind the workspace: one 32-bit flag per stream-K workgroup, zeroed once
 int g_skinny_flush_override = -1;
 static thread_local float* g_splitk_ws = nullptr;
+static thread_local uint32_t* g_streamk_flags = nullptr;
 
 static bool glds_gemm_ok(const Half* W, const Half* X, const Half* Y, int M, int K) {
   return (K & 7) == 0 && host_aligned16(W) && host_aligned16(X) && (K % BK) == 0 && (M & 3) == 0 &&
@@ -628,7 +630,7 @@ static void glds_splitk_launch(const Half* W, const Half* X, Half* Y, int M, int
 // 1281 = the 128 x 256 kernel, plain / SwiGLU.  One function for the launcher and for pegainfer_debug_gemm_route (the
 // routing table is pinned by a CPU test: a threshold edit must not silently change what the GPU tests exercise).
 struct TiledRoute { int kind, m_head; };
-static TiledRoute tiled_route(int M, int T, int K, const SplitOut& so) {
+static TiledRoute tiled_route(int M, int T, int K, const SplitOut& so, bool assume_ws = false) {
   // long prompts: 256 x 256 tiles on the 8-phase schedule once they give every CU work (PEGAINFER_GEMM256 = 0 never,
   // 1 whenever the shape allows, N = from N tiles on; A/B probe knob)
   // from 128 tiles on (half the CUs): one partly filled round of 256 x 256 tiles still beats the smaller tilings -
@@ -638,6 +640,14 @@ static TiledRoute tiled_route(int M, int T, int K, const SplitOut& so) {
   if (g256_min > 0 && gemm256_ok(M, T, K)) {
     const int mt256 = so.silu_I > 0 ? ceil_div(so.silu_I, 128) : ceil_div(M, G256_BM), tt256 = ceil_div(T, G256_BT);
     const long tiles256 = (long)mt256 * tt256;
+    // (round 6) stream-K: a PERSISTENT one-workgroup-per-CU launch over the (tile, K-tile pair) units whenever a round of
+    // 256 x 256 tiles would leave >= 8 % of the CU-rounds idle - gate_up at 512 / 1024 / 2048 tokens: 152 / 304 / 608 tiles on
+    // 256 CUs.  kind 258.  Fixed K order per (M, T, K, CU count); not the order of the data-parallel kernels (gemm256.h).
+    static const int sk_min = [] { const char* e = getenv("PEGAINFER_STREAMK_MIN_TILES"); return e && *e ? atoi(e) : 128; }();
+    if (tiles256 >= sk_min && (g_splitk_ws || assume_ws) && so.silu_c1 == 0 &&
+        (size_t)device_cus() * kG256SlotFloats * 4 <= kSplitKWorkspaceBytes && (size_t)device_cus() * 4 <= kStreamKFlagBytes &&
+        gemm256_streamk_plan(tiles256, K, device_cus()))
+      return {258, 0};
     if (tiles256 >= g256_min) {
       // A thin last round: 304 tiles (gate_up at 1024 tokens) are one full round of the 256 CUs plus 48 tiles that
       // cost a second full tile time (127 us for 102 GFLOP).  The SwiGLU form can hand the activation columns of
@@ -693,6 +703,7 @@ static void glds_gemm_launch(const Half* W, const Half* X, Half* Y, int M, int T
       glds_gemm_launch_t<128, 2>(W, X, Y, M, T, K, tail, s);
       return;
     }
+    if (r.kind == 258) { gemm256_streamk_launch(W, X, Y, M, T, K, so, g_splitk_ws, g_streamk_flags, device_cus(), s); return; }
     if (r.kind == 256) { gemm256_launch(W, X, Y, M, T, K, so, s); return; }
     if (r.kind == 1280 || r.kind == 1281) { gemm128x256_launch(W, X, Y, M, T, K, so, nullptr, 1, 0, s); return; }
     // the plan said a 128-token stream tile exists; should a future plan / route change make the launcher refuse, fall
@@ -824,14 +835,20 @@ static thread_local int g_blas_inits = 0;
 void cublas_init(void) {
   if (g_blas_inits++ == 0 && !pk::g_splitk_ws) {
     void* p = nullptr;
-    if (hipMalloc(&p, pk::kSplitKWorkspaceBytes) == hipSuccess) pk::g_splitk_ws = static_cast<float*>(p);
-    else (void)hipGetLastError();   // no device / no memory: the split-K route is skipped
+    if (hipMalloc(&p, pk::kSplitKWorkspaceBytes + pk::kStreamKFlagBytes) == hipSuccess) {
+      pk::g_splitk_ws = static_cast<float*>(p);
+      pk::g_streamk_flags = reinterpret_cast<uint32_t*>(static_cast<char*>(p) + pk::kSplitKWorkspaceBytes);
+      (void)hipMemset(pk::g_streamk_flags, 0, pk::kStreamKFlagBytes);   // owners clear what publishers set: zero between launches
+    } else {
+      (void)hipGetLastError();   // no device / no memory: the split-K and stream-K routes are skipped
+    }
   }
 }
 void cublas_destroy(void) {
   if (g_blas_inits > 0 && --g_blas_inits == 0 && pk::g_splitk_ws) {
     (void)hipFree(pk::g_splitk_ws);
     pk::g_splitk_ws = nullptr;
+    pk::g_streamk_flags = nullptr;
   }
 }
 
@@ -969,7 +986,7 @@ pegainfer_status_t pegainfer_gemm_silu_rounded(const Half* W, const Half* X, Hal
 // silu_I > 0 asks for the SwiGLU form (M is then ignored, the matrix has 2 * silu_I rows).  out[0] = kind, out[1] = K
 // slices (1 = un-split), out[2] = K tiles per slice or, for kind 257, the activation-column tiles of the 256 x 256 head.
 // kind: 0 = GEMV / skinny family (T <= 16, or a 17..64-column shape the tiled kernels do not take); the TiledRoute kinds (12,
-// 13, 22, 23, 256, 257, 1280, 1281, 3000 + row blocks of the stream kernel); 1000 + tt for the K-split plans (tt = 64 / 128:
+// 13, 22, 23, 256, 257, 258 = stream-K over 256 x 256 tiles, 1280, 1281, 3000 + row blocks of the stream kernel); 1000 + tt for the K-split plans (tt = 64 / 128:
 // 128-row kernel, 129: 128 x 256 kernel, 256: 256 x 256 kernel), 2000 + row blocks where the GEMM half of a tt = 64 plan
 // runs on the stream kernel (<= 128 tokens).  Assumes the split-K workspace of cublas_init() exists.
 pegainfer_status_t pegainfer_debug_gemm_route(int32_t M, int32_t T, int32_t K, int32_t silu_I, int32_t* out) {
@@ -1010,7 +1027,7 @@ pegainfer_status_t pegainfer_debug_gemm_route(int32_t M, int32_t T, int32_t K, i
     if (pl.nk_slice > 0) { out[0] = split_kind(pl); out[1] = pl.ksplit; out[2] = pl.nk_slice; return 0; }
   }
   SplitOut so{nullptr, nullptr, nullptr, 0, 0, 0, silu_I > 0 ? silu_I : 0, 0, 0, 0};
-  const TiledRoute r = tiled_route(silu_I > 0 ? 2 * silu_I : M, T, K, so);
+  const TiledRoute r = tiled_route(silu_I > 0 ? 2 * silu_I : M, T, K, so, true);
   out[0] = r.kind; out[2] = r.m_head;
   return 0;
 }

@@ -286,7 +286,18 @@ def test_gemm_silu_epilogue_equals_gemm_then_silu_mul_fused(P, T, I, K):
     P.silu_mul_fused_batch_into(P.gemm(Wd, Xd), ref)
     out = torch.zeros_like(ref)
     P.gemm_silu_into(Wd, Xd, out)
-    assert np.array_equal(bf16_bits(from_dev(out)), bf16_bits(from_dev(ref)))
+    from pegainfer_amd import ffi
+    kind = np.zeros(3, np.int32)
+    ffi.lib().pegainfer_debug_gemm_route(0, T, K, I, kind.ctypes.data)
+    if kind[0] == 258:
+        # round 6: the stream-K route sums K in a fixed order of ITS OWN per (tile count, K, CU count) - and a 128 + 128-row SwiGLU
+        # tile and a 256-row plain tile cut K at different units - so fused == pair holds to the GEMM tolerance there, not to
+        # the bit (cross-route bit identity of prefill GEMMs given up; tests/test_gpu_real_dims.py pins the
+        # route against float64 and its own rerun determinism)
+        d = np.abs(from_dev(out) - from_dev(ref))
+        assert d.max() <= 2.0 ** -6 * max(1.0, np.abs(from_dev(ref)).max()) and (d > 0).mean() < 0.2
+    else:
+        assert np.array_equal(bf16_bits(from_dev(out)), bf16_bits(from_dev(ref)))
     exp = O.silu_mul_fused(O.gemm(W, X), I)
     assert np.abs(from_dev(out) - exp).max() <= 2.0 ** -6 * max(1.0, np.abs(exp).max())
 

@@ -458,3 +458,88 @@ np.savez(sys.argv[2], **out)
         # the plans differ (the form's chunk cap vs none) only beyond 9 x 64 tokens: these prompts stay below, so bit for bit
         for k in ("tok%d", "lg%d", "chain%d", "lg2_%d"):
             assert np.array_equal(res["forced"][k % nb], res["never"][k % nb]), (nb, k)
+
+
+# ------------------------------------------------------------------ (d) stream-K over 256 x 256 tiles (round 6)
+def _route(M, T, K, silu_I=0):
+    from pegainfer_amd import ffi
+    out = np.zeros(3, np.int32)
+    assert ffi.lib().pegainfer_debug_gemm_route(M, T, K, silu_I, out.ctypes.data) == 0
+    return int(out[0])
+
+
+@pytest.mark.parametrize("M,K,T", [(19456, 2560, 512), (19456, 2560, 1024), (19456, 2560, 1100), (19456, 2560, 2048),
+                                   (6144, 2560, 2048), (24576, 4096, 768), (18432, 2560, 1024)])
+def test_streamk_gemm_against_float64(P, M, K, T):
+    """The persistent stream-K launch (kind 258: one workgroup per CU over the (tile, K-tile pair) units, fp32 partials
+    published through the split-K workspace, the owner adds them in ascending K): every shape whose 256 x 256 tiling
+    leaves >= 8 % of a CU round idle - gate_up of the three configs at 512 ... 2048 tokens (ragged T too), the stacked
+    qkv at 2048 - against float64 on 1536 seeded rows, the GEMM envelope of the other routes; twice (same bits: the
+    K order is fixed per shape), with another stream-K shape in between (owners clear the flags they consumed)."""
+    assert _route(M, T, K) == 258, _route(M, T, K)
+    rng = np.random.default_rng(M + T + K)
+    W, X = rnd(rng, M, K, scale=0.05), rnd(rng, T, K)
+    Wd, Xd = to_dev(W), to_dev(X)
+    got = from_dev(P.gemm(Wd, Xd))
+    rows = np.sort(rng.choice(M, size=1536, replace=False))
+    Wr, X64 = W[rows].astype(np.float64), X.astype(np.float64)
+    ref, env = X64 @ Wr.T, np.abs(X64) @ np.abs(Wr).T
+    tol = env * 2.0 ** -7 * 0.05 + np.abs(ref) * 2.0 ** -8 + 1e-6
+    err = np.abs(got[:, rows] - ref)
+    assert np.all(err <= tol), (M, T, K, float((err / tol).max()))
+    assert np.isfinite(got).all()
+    other = P.gemm(to_dev(rnd(rng, 19456, 2560, scale=0.05)), to_dev(rnd(rng, 600, 2560)))     # 3 x 76 = 228 tiles: stream-K
+    assert np.isfinite(from_dev(other)).all()
+    again = from_dev(P.gemm(Wd, Xd))
+    assert np.array_equal(bf16_bits(again), bf16_bits(got))
+
+
+@pytest.mark.parametrize("I,K,T,rounded", [(9728, 2560, 1024, False), (9728, 2560, 520, False), (12288, 4096, 1024, False),
+                                           (9216, 2560, 1024, True)])
+def test_streamk_swiglu_gemm_against_the_pair(P, I, K, T, rounded):
+    """gate_up GEMM with SwiGLU in the epilogue on the stream-K route against the oracle's pair gemm -> silu_mul on float64
+    sums: gate and up rounded to bf16 before the activation (fused_proj.cu:57-62; the Qwen3.5 form rounds silu too).  A gate
+    / up value may differ from the float64-rounded one by one bf16 step (fp32 accumulation order), so the bar is the
+    activation evaluated over those one-step neighbourhoods plus one output rounding."""
+    import torch
+    from pegainfer_amd import ffi
+    assert _route(0, T, K, I) == 258
+    rng = np.random.default_rng(I + T)
+    W, X = rnd(rng, 2 * I, K, scale=0.03), rnd(rng, T, K)
+    Wd, Xd = to_dev(W), to_dev(X)
+    out = torch.empty((T, I), dtype=torch.bfloat16, device="cuda")
+    fn = ffi.lib().pegainfer_gemm_silu_rounded if rounded else ffi.lib().pegainfer_gemm_silu
+    s = torch.cuda.current_stream().cuda_stream
+    assert fn(Wd.data_ptr(), Xd.data_ptr(), out.data_ptr(), None, I, T, K, s) == 0
+    got = from_dev(out)
+    cols = np.sort(rng.choice(I, size=1024, replace=False))
+    X64 = X.astype(np.float64)
+    gate, up = X64 @ W[cols].astype(np.float64).T, X64 @ W[I + cols].astype(np.float64).T
+    env_g, env_u = np.abs(X64) @ np.abs(W[cols]).astype(np.float64).T, np.abs(X64) @ np.abs(W[I + cols]).astype(np.float64).T
+    silu = lambda g: g / (1.0 + np.exp(-g))
+    ref = silu(gate) * up
+    # first-order error propagation of the two GEMM envelopes through silu(g) * u, plus bf16 roundings of g, u, (silu,) out
+    dg = env_g * 2.0 ** -7 * 0.05 + np.abs(gate) * 2.0 ** -8
+    du = env_u * 2.0 ** -7 * 0.05 + np.abs(up) * 2.0 ** -8
+    dsilu = np.abs(silu(gate + 1e-3) - silu(gate - 1e-3)) / 2e-3          # |silu'|
+    tol = dsilu * dg * np.abs(up) + np.abs(silu(gate)) * (du + (2.0 ** -8 * np.abs(up) if rounded else 0)) + np.abs(ref) * 2.0 ** -7 + 1e-5
+    err = np.abs(got[:, cols] - ref)
+    assert np.all(err <= 1.5 * tol), (I, T, float((err / tol).max()))
+    out2 = torch.empty_like(out)
+    assert fn(Wd.data_ptr(), Xd.data_ptr(), out2.data_ptr(), None, I, T, K, s) == 0
+    assert torch.equal(out, out2)
+
+
+def test_streamk_split3_outputs(P):
+    """the stacked q | k | v projection at 2048 tokens (24 x 8 = 192 tiles: stream-K) writes its three buffers"""
+    import torch
+    rng = np.random.default_rng(77)
+    T, K = 2048, 2560
+    W, X = rnd(rng, 6144, K, scale=0.05), rnd(rng, T, K)
+    q = torch.empty((T, 4096), dtype=torch.bfloat16, device="cuda")
+    k = torch.empty((T, 1024), dtype=torch.bfloat16, device="cuda")
+    v = torch.empty((T, 1024), dtype=torch.bfloat16, device="cuda")
+    Wd, Xd = to_dev(W), to_dev(X)
+    P.gemm_split3_into(Wd, Xd, q, k, v)
+    full = from_dev(P.gemm(Wd, Xd))
+    assert np.array_equal(bf16_bits(np.concatenate([from_dev(q), from_dev(k), from_dev(v)], axis=1)), bf16_bits(full))
