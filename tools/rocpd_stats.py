@@ -1,6 +1,10 @@
 #!/usr/bin/env python3
 """Summarise a rocprofv3 rocpd sqlite database (ROCm 7.2 default output of
-`rocprofv3 --kernel-trace --stats`) as a per-kernel table: calls, total/avg/min/max duration.
+`rocprofv3 --kernel-trace --stats`) as a per-kernel table: calls, total/avg/min/max duration - and, since round 6, the
+kernel's share of the TIMELINE: avg_step_us = mean of end(k) - max(end(previous kernel), start(k)) ... i.e. how much later
+the stream's "last kernel finished" mark moves because of this kernel.  Back-to-back dependent kernels of a replayed graph
+get their START stamp while the predecessor is still draining, so `avg_us` of a trivial row kernel reads 4-5 us where its
+real cost is a ~1.5-2 us boundary plus its work; the sum of avg_step_us over a step IS the step's busy time.
 Usage: python tools/rocpd_stats.py <results.db> [out.csv]"""
 import csv
 import re
@@ -18,18 +22,26 @@ def main():
     db = sqlite3.connect(sys.argv[1])
     cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
     namec = "name" if "name" in cols else [c for c in cols if "name" in c][0]
-    rows = db.execute(f"select {namec}, start, end from kernels").fetchall()
+    rows = db.execute(f"select {namec}, start, end from kernels order by end").fetchall()
     agg = {}
+    prev_end = None
     for name, s, e in rows:
-        a = agg.setdefault(short(name), [0, 0, 10 ** 18, 0])
+        a = agg.setdefault(short(name), [0, 0, 10 ** 18, 0, 0, 0])
         d = e - s
         a[0] += 1; a[1] += d; a[2] = min(a[2], d); a[3] = max(a[3], d)
+        # timeline share: from the previous kernel's end (or this kernel's own start, if the stream was idle in between:
+        # gaps > 20 us are host time, not counted) to this kernel's end
+        if prev_end is not None and s - prev_end < 20000:
+            a[4] += e - max(prev_end, min(s, prev_end)); a[5] += 1
+        else:
+            a[4] += d; a[5] += 1
+        prev_end = e
     total = sum(a[1] for a in agg.values()) or 1
     table = sorted(agg.items(), key=lambda kv: -kv[1][1])
-    out = [("kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "pct")]
-    for k, (n, t, mn, mx) in table:
+    out = [("kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "pct", "avg_step_us")]
+    for k, (n, t, mn, mx, st, sn) in table:
         out.append((k, n, round(t / 1e3, 1), round(t / n / 1e3, 2), round(mn / 1e3, 2), round(mx / 1e3, 2),
-                    round(100.0 * t / total, 2)))
+                    round(100.0 * t / total, 2), round(st / max(sn, 1) / 1e3, 2)))
     w = csv.writer(open(sys.argv[2], "w", newline="") if len(sys.argv) > 2 else sys.stdout)
     w.writerows(out)
 
