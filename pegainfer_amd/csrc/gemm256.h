@@ -340,7 +340,6 @@ __global__ __launch_bounds__(512) void mfma_gemm256_streamk_kernel(const Half* _
                                                                    int t_tiles, SplitOut so, float* __restrict__ part,
                                                                    uint32_t* __restrict__ flags) {
   extern __shared__ __attribute__((aligned(16))) u32x4 g256_smem[];
-  const int ntiles = m_tiles * t_tiles;
   const int G = gridDim.x;
   int pos = blockIdx.x;
   {  // XCD-aware position: the workgroups of one XCD are neighbours in the unit order
@@ -348,9 +347,20 @@ __global__ __launch_bounds__(512) void mfma_gemm256_streamk_kernel(const Half* _
     pos = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
   const int KP = K / (2 * G256_BK);                       // K-tile pairs per tile
-  const long U = (long)ntiles * KP;
-  auto range_begin = [&](int p) { return U * p / G; };
-  const long u_begin = range_begin(pos), u_end = range_begin(pos + 1);
+  // TEAMS (second form, same round): the first form dealt the (tile, K pair) units tile-major to single workgroups and LOST
+  // (gate_up at 1024 tokens 154 us against 136-140 data-parallel, profiles/r6_streamk_gemm_ab.txt): neighbours in the unit
+  // order then sit at K offsets a third of a tile apart, no two workgroups ever want the same W K-tile at the same time, and
+  // the 4-fold W re-use the data-parallel order gets from an XCD's L2 (the t_tiles token tiles of one row tile run side by
+  // side) is gone.  So the unit is a ROW tile's K pair, dealt to TEAMS of t_tiles workgroups - consecutive positions, one
+  // XCD - whose member tt computes token tile tt of every unit of the team's range: the members walk the same W K-tiles in
+  // step, exactly the sharing pattern of the data-parallel launch.  A member's partner for the hand-off is the same member
+  // of the next team (position + t_tiles).
+  const int nteams = G / t_tiles;
+  if (pos >= nteams * t_tiles) return;                    // G % t_tiles left-over workgroups
+  const int team = pos / t_tiles, tt = pos - team * t_tiles;
+  const long U = (long)m_tiles * KP;
+  auto range_begin = [&](int tm) { return U * tm / nteams; };
+  const long u_begin = range_begin(team), u_end = range_begin(team + 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int wr = wave >> 2, wc = wave & 3;
   const int l15 = lane & 15, g = lane >> 4;
@@ -391,9 +401,8 @@ __global__ __launch_bounds__(512) void mfma_gemm256_streamk_kernel(const Half* _
 
   long u = u_begin;
   while (u < u_end) {
-    const int tile = (int)(u / KP), kp0 = (int)(u - (long)tile * KP);
+    const int mt = (int)(u / KP), kp0 = (int)(u - (long)mt * KP);
     const int kp1 = (long)(KP - kp0) < u_end - u ? KP : kp0 + (int)(u_end - u);
-    const int mt = tile / t_tiles, tt = tile - mt * t_tiles;
     const int m0 = mt * G256_BM, t0 = tt * G256_BT;
     const int nk = 2 * (kp1 - kp0);
     // ---- DMA sources of this tile (as in the data-parallel kernel), advanced to the segment's first K tile ----
@@ -495,9 +504,10 @@ __global__ __launch_bounds__(512) void mfma_gemm256_streamk_kernel(const Half* _
     } else {
       if (kp1 != KP) {
         // ---- own the tile: add the later K ranges in ascending order ----
-        const long need = (long)(tile + 1) * KP;
+        const long need = (long)(mt + 1) * KP;
         long covered = u_end;
-        for (int p = pos + 1; covered < need; ++p) {
+        int tm = team;
+        for (int p = pos + t_tiles; covered < need; p += t_tiles) {
           if (threadIdx.x == 0)
             while (__hip_atomic_load(flags + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(2);
           __syncthreads();
@@ -518,7 +528,8 @@ __global__ __launch_bounds__(512) void mfma_gemm256_streamk_kernel(const Half* _
           }
           __syncthreads();   // every wave has taken its part of the slot
           if (threadIdx.x == 0) __hip_atomic_store(flags + p, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          covered = range_begin(p + 1);
+          tm += 1;
+          covered = range_begin(tm + 1);
         }
       }
       // ---- epilogue (the data-parallel kernel's): lane holds rows m = .. + g*4 + e of token t = .. + l15 ----
@@ -590,13 +601,14 @@ inline bool gemm256_streamk_on() {
   static const bool v = [] { const char* e = getenv("PEGAINFER_STREAMK"); return !(e && e[0] == '0'); }();
   return v;
 }
-inline bool gemm256_streamk_plan(long tiles256, int K, int cus) {
+inline bool gemm256_streamk_plan(long tiles256, int K, int cus, int t_tiles) {
   static const int min_waste = [] { const char* e = getenv("PEGAINFER_STREAMK_MIN_WASTE"); return e && *e ? atoi(e) : 8; }();
-  if (!gemm256_streamk_on() || cus < 8 || tiles256 <= 0) return false;
+  if (!gemm256_streamk_on() || cus < 8 || tiles256 <= 0 || t_tiles < 1 || t_tiles > cus / 8) return false;   // a team fits an XCD
   const long rounds = (tiles256 + cus - 1) / cus;
   const long waste_pct = 100 - 100 * tiles256 / (rounds * cus);
-  const long units = tiles256 * (K / (2 * G256_BK));
-  return waste_pct >= min_waste && units / cus >= 4;
+  const long nteams = cus / t_tiles, row_units = tiles256 / t_tiles * (K / (2 * G256_BK));
+  const long idle_pct = 100 - 100 * nteams * t_tiles / cus;             // workgroups that fit no team
+  return waste_pct >= min_waste + idle_pct && row_units / nteams >= 4;
 }
 
 inline void gemm256_streamk_launch(const Half* W, const Half* X, Half* Y, int M, int T, int K, SplitOut so, float* part,

@@ -646,7 +646,7 @@ static TiledRoute tiled_route(int M, int T, int K, const SplitOut& so, bool assu
     static const int sk_min = [] { const char* e = getenv("PEGAINFER_STREAMK_MIN_TILES"); return e && *e ? atoi(e) : 128; }();
     if (tiles256 >= sk_min && (g_splitk_ws || assume_ws) && so.silu_c1 == 0 &&
         (size_t)device_cus() * kG256SlotFloats * 4 <= kSplitKWorkspaceBytes && (size_t)device_cus() * 4 <= kStreamKFlagBytes &&
-        gemm256_streamk_plan(tiles256, K, device_cus()))
+        gemm256_streamk_plan(tiles256, K, device_cus(), tt256))
       return {258, 0};
     if (tiles256 >= g256_min) {
       // A thin last round: 304 tiles (gate_up at 1024 tokens) are one full round of the 256 CUs plus 48 tiles that

@@ -42,7 +42,7 @@ def test_decode_family_is_not_routed_here(route):
     (1024, (1280, 1, 0), (1129, 3, 22), (1129, 3, 51), (258, 1, 0)),    # the headline TTFT shape: 304 tiles (1.19 rounds)
     (2048, (258, 1, 0), (1256, 3, 22), (1256, 3, 52), (258, 1, 0)),     # qkv 192 tiles, gate_up 608 (2.4 rounds)
     (4096, (258, 1, 0), (258, 1, 0), (258, 1, 0), (256, 1, 0)),         # qkv 384 (1.5 rounds), o / down 160; gate_up 1216 = 4.75
-    (10000, (256, 1, 0), (258, 1, 0), (258, 1, 0), (256, 1, 0)),        # o / down 400 tiles (1.56 rounds); qkv 960, gate_up 3040
+    (10000, (256, 1, 0), (256, 1, 0), (256, 1, 0), (256, 1, 0)),        # 40 token tiles: a team would not fit an XCD (32 CUs)
 ])
 def test_qwen3_4b_projection_routes(route, T, qkv, o, down, gate_up):
     assert route(*QKV[:1], T, QKV[1]) == qkv
