@@ -30,6 +30,8 @@
 // partial sums meet in LDS and are added in fixed wave order.
 #pragma once
 
+#include <cstdio>
+
 #include <cstdlib>
 
 #include "common.h"
@@ -680,10 +682,22 @@ inline int skinny_pick_rpb(int rows) {
 // Default: lazy tickets where a workgroup walks more than two row blocks, else the one-barrier form.
 // PEGAINFER_SKINNY_FLUSH: 0 = two barriers, 1 = one barrier, 4 = tickets, 5 = lazy tickets; 2 = the timing probe (nothing stored).
 extern int g_skinny_flush_override;   // linear.hip: pegainfer_debug_skinny_flush (tests compare the forms in one process); -1 = none
+// The timing probe (bit 1: partials written, nothing reduced or stored) exists only WITHOUT the ticket bit: with tickets its
+// early return would skip the arrival / done counters and every later use of a ring buffer would spin for ever on them - a GPU
+// hang, not garbage.  Modes 6 / 7 are therefore folded to 2; the probe is announced on stderr once.
+inline int skinny_flush_sanitise(int mode) {
+  mode &= 7;
+  if ((mode & 2) && (mode & 4)) mode = 2;
+  if (mode & 2) {
+    static const bool said = (fprintf(stderr, "pegainfer: PEGAINFER_SKINNY_FLUSH probe mode - the resident skinny GEMMs store NOTHING\n"), true);
+    (void)said;
+  }
+  return mode;
+}
 inline int skinny_flush_mode(int nrb) {
   static const int env = [] { const char* e = getenv("PEGAINFER_SKINNY_FLUSH"); return e && *e ? atoi(e) & 7 : -1; }();
-  if (g_skinny_flush_override >= 0) return g_skinny_flush_override & 7;
-  if (env >= 0) return env;
+  if (g_skinny_flush_override >= 0) return skinny_flush_sanitise(g_skinny_flush_override);
+  if (env >= 0) return skinny_flush_sanitise(env);
   return nrb > 2 * device_cus() ? 5 : 1;
 }
 

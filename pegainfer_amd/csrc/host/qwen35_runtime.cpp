@@ -121,6 +121,7 @@ struct Model35 {
   int32_t* merge_ctr = nullptr;  // in-launch split-KV merge tickets, zeroed at the head of every step
   hipGraphExec_t graph = nullptr;
   std::vector<int> graph_ids;   // request ids of the captured step, then the attention path
+  std::vector<std::pair<std::vector<int>, hipGraphExec_t>> graph_cache;   // parked execs of other keys (<= 8)
   // debug tap (include/pegainfer_qwen35.h, accuracy-parity-playbook.md:15-24): the residual stream leaving every layer
   Half* tap = nullptr;
   bool tap_on = false;
@@ -755,7 +756,24 @@ struct Model35 {
   int step_launch(const StepCtx35& c) {
     if (enable_graph && !tap_on) {
       if (!graph || graph_ids != c.key) {
-        if (graph) { P35_HIP(hipGraphExecDestroy(graph)); graph = nullptr; }
+        // a small cache of execs per key: inside a greedy chain the key flips when the attention path toggles, and
+        // destroying an exec whose earlier replays are still in flight on the stream is not known to be safe on ROCm 7.2.  The
+        // current exec is parked, a parked one with the wanted key is revived; when the cache is full the stream is drained
+        // before the oldest exec is destroyed.
+        if (graph) { graph_cache.emplace_back(graph_ids, graph); graph = nullptr; }
+        for (size_t i = 0; i < graph_cache.size(); ++i)
+          if (graph_cache[i].first == c.key) {
+            graph = graph_cache[i].second;
+            graph_ids = c.key;
+            graph_cache.erase(graph_cache.begin() + i);
+            break;
+          }
+        if (graph) { P35_HIP(hipGraphLaunch(graph, stream)); return 0; }
+        if (graph_cache.size() >= 8) {
+          P35_HIP(hipStreamSynchronize(stream));
+          P35_HIP(hipGraphExecDestroy(graph_cache.front().second));
+          graph_cache.erase(graph_cache.begin());
+        }
         hipGraph_t g = nullptr;
         P35_HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
         const int rc = run_decode_kernels(c.n, c.rs, c.split);
@@ -796,6 +814,10 @@ struct Model35 {
   size_t chain_tokens_cap = 0;
   int decode_greedy_chain(int n, const int32_t* ids, const uint32_t* first_tokens, int n_steps, int32_t* out_tokens) {
     if (n_steps <= 0) { set_error("decode_greedy_chain: n_steps must be positive"); return -1; }
+    if (n < 1 || n > max_bs) { set_error("decode batch size out of range"); return -1; }   // before first_tokens is touched
+    for (int i = 0; i < n; ++i)
+      for (int j = 0; j < i; ++j)
+        if (ids[i] == ids[j]) { set_error("decode_greedy_chain: duplicate request id"); return -1; }
     if (tap_on) {
       std::vector<uint32_t> tk(first_tokens, first_tokens + n);
       for (int s = 0; s < n_steps; ++s) {
@@ -831,9 +853,17 @@ struct Model35 {
       const int slot = s % kChainRing;
       if (s >= kChainRing) P35_HIP(hipEventSynchronize(chain_ev[slot]));
       StepCtx35 c;
-      if (const int rc = step_prepare(n, ids, s == 0 ? first_tokens : nullptr, &c, chain_ring[slot])) return rc;
+      // a failure at step s > 0 leaves steps 0 .. s - 1 in flight; the recurrent state they advanced cannot be rolled back, so
+      // they are drained, their tokens are handed out, and the error says how far the requests have moved
+      auto abort_chain = [&](int rc) {
+        (void)hipStreamSynchronize(stream);
+        if (s > 0) std::memcpy(out_tokens, chain_tokens_host, (size_t)s * n * 4);
+        set_error(err + " (decode_greedy_chain: " + std::to_string(s) + " of " + std::to_string(n_steps) + " steps completed; the requests stand there)");
+        return rc;
+      };
+      if (const int rc = step_prepare(n, ids, s == 0 ? first_tokens : nullptr, &c, chain_ring[slot])) return abort_chain(rc);
       P35_HIP(hipEventRecord(chain_ev[slot], stream));
-      if (step_launch(c)) return -1;
+      if (step_launch(c)) return abort_chain(-1);
       P35_HIP(hipMemcpyAsync(chain_tokens_host + (size_t)s * n, tokens_out_d, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
     }
     P35_HIP(hipEventRecord(ev1, stream));
@@ -1017,6 +1047,7 @@ struct Model35 {
     (void)hipSetDevice(device);
     if (stream) (void)hipStreamSynchronize(stream);
     if (graph) (void)hipGraphExecDestroy(graph);
+    for (auto& ge : graph_cache) (void)hipGraphExecDestroy(ge.second);
     for (void* p : owned) (void)hipFree(p);
     for (void* p : pf_owned) (void)hipFree(p);
     if (pf_meta_dev) (void)hipFree(pf_meta_dev);

@@ -954,6 +954,11 @@ struct Model {
   size_t chain_tokens_cap = 0;
   int decode_greedy_chain(int n, const int32_t* ids, const uint32_t* first_tokens, int n_steps, int32_t* out_tokens) {
     if (n_steps <= 0) { set_error("decode_greedy_chain: n_steps must be positive"); return -1; }
+    // everything that can be refused is refused BEFORE the first step and before first_tokens is touched
+    if (n < 1 || n > max_bs || bucket_for(n) < 0) { set_error("decode batch size out of range"); return -1; }
+    for (int i = 0; i < n; ++i)
+      for (int j = 0; j < i; ++j)
+        if (ids[i] == ids[j]) { set_error("decode_greedy_chain: duplicate request id"); return -1; }
     if (tp_comm || tap_on) {   // step by step: the one-shot status / the taps are per step
       std::vector<uint32_t> tk(first_tokens, first_tokens + n);
       for (int s = 0; s < n_steps; ++s) {
@@ -994,10 +999,18 @@ struct Model {
         const int slot = s % kChainRing;
         if (s >= kChainRing) PQ_HIP(hipEventSynchronize(chain_ev[slot]));   // its upload has executed: safe to repack
         StepCtx c;
-        if (const int rc = step_prepare(n, ids, s == 0 ? first_tokens : nullptr, &c, chain_ring[slot])) return rc;
+        // a failure at step s > 0 (graph capture, page race) leaves steps 0 .. s - 1 in flight: drain them, put the requests
+        // back where the chain found them (their KV appends are simply overwritten later) and only then report - the next
+        // call must not repack pinned ring slots whose uploads have not executed
+        auto abort_chain = [&](int rc) {
+          (void)hipStreamSynchronize(stream);
+          for (int i = 0; i < n; ++i) req(ids[i])->seq_len = start_len[i];
+          return rc;
+        };
+        if (const int rc = step_prepare(n, ids, s == 0 ? first_tokens : nullptr, &c, chain_ring[slot])) return abort_chain(rc);
         PQ_HIP(hipEventRecord(chain_ev[slot], stream));
         any_oproj = any_oproj || step_uses_oproj_form(c);
-        if (step_launch(c)) return -1;
+        if (step_launch(c)) return abort_chain(-1);
         PQ_HIP(hipMemcpyAsync(chain_tokens_host + (size_t)s * n, tokens_out_d, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
       }
       PQ_HIP(hipEventRecord(ev1, stream));
