@@ -146,6 +146,11 @@ void pegainfer_debug_attn_trace(uint64_t* buf);
  * + rows per row block. */
 pegainfer_status_t pegainfer_debug_gemm_route(int32_t M, int32_t T, int32_t K, int32_t silu_I, int32_t* out);
 
+/* Debug / test hook: 1 = prefill GEMMs whose 256 x 256 tiling leaves >= 8 % of a CU round idle take the persistent stream-K
+ * launch (kind 258 of pegainfer_debug_gemm_route), 0 = never, -1 = the environment decides (PEGAINFER_STREAMK=1; default off:
+ * measured slower than the data-parallel launch, profiles/r6_streamk_*).  Process-wide. */
+void pegainfer_debug_streamk(int32_t on);
+
 /* Partition-KV decode attention at head_dim 256 (Qwen3.5 full-attention layers).  No counterpart in ffi.rs (its
  * hd256 decode symbol is non-partition only, ffi.rs:1286-1306); arguments and scratch contract are exactly those of
  * paged_attention_decode_split_kv_cuda, plus the optional merge_counters of pegainfer_fused_decode_attention

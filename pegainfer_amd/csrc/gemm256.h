@@ -594,12 +594,18 @@ __global__ __launch_bounds__(512) void mfma_gemm256_streamk_kernel(const Half* _
   }
 }
 
-// Stream-K plan, by shape and CU count only (the launcher and pegainfer_debug_gemm_route share it): taken when a round of
-// 256 x 256 tiles would leave more than `min_waste_pct` % of the CU-rounds idle and the K range of a workgroup is long
-// enough to amortise a pipeline fill (>= 4 K-tile pairs).  PEGAINFER_STREAMK=0 switches it off (A/B knob).
+// Stream-K plan, by shape and CU count only (the launcher and pegainfer_debug_gemm_route share it): taken - when switched
+// on - where a round of 256 x 256 tiles would leave more than `min_waste_pct` % of the CU-rounds idle and the K range of a
+// team is long enough to amortise a pipeline fill (>= 4 K-tile pairs).
+// OFF by default: measured SLOWER than the data-parallel launch + tail at every shape it applies to (profiles/r6_streamk_*:
+// gate_up 512 / 1024 / 2048 tokens 91 / 151 / 265 us against 71 / 137 / 230; TTFT(1024) 11.7 against 10.9 ms) - every
+// workgroup publishes and re-reads a 256 KiB fp32 tile at the same moment, 64 MB each way through the fabric with nothing
+// to overlap it, which costs more than the idle CU-rounds it removes.  PEGAINFER_STREAMK=1 / pegainfer_debug_streamk(1)
+// switch it on (the GPU tests do: the kernel stays correct and deterministic).
+extern int g_streamk_override;   // linear.hip: pegainfer_debug_streamk; -1 = the environment decides
 inline bool gemm256_streamk_on() {
-  static const bool v = [] { const char* e = getenv("PEGAINFER_STREAMK"); return !(e && e[0] == '0'); }();
-  return v;
+  static const bool v = [] { const char* e = getenv("PEGAINFER_STREAMK"); return e && e[0] == '1'; }();
+  return g_streamk_override >= 0 ? g_streamk_override != 0 : v;
 }
 inline bool gemm256_streamk_plan(long tiles256, int K, int cus, int t_tiles) {
   static const int min_waste = [] { const char* e = getenv("PEGAINFER_STREAMK_MIN_WASTE"); return e && *e ? atoi(e) : 8; }();

@@ -478,6 +478,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_add_kernel(const float* __r
 constexpr size_t kSplitKWorkspaceBytes = 64u << 20;
 constexpr size_t kStreamKFlagBytes = 64u << 10;   // behind the workspace: one 32-bit flag per stream-K workgroup, zeroed once
 int g_skinny_flush_override = -1;
+int g_streamk_override = -1;
 static thread_local float* g_splitk_ws = nullptr;
 static thread_local uint32_t* g_streamk_flags = nullptr;
 
@@ -640,9 +641,9 @@ static TiledRoute tiled_route(int M, int T, int K, const SplitOut& so, bool assu
   if (g256_min > 0 && gemm256_ok(M, T, K)) {
     const int mt256 = so.silu_I > 0 ? ceil_div(so.silu_I, 128) : ceil_div(M, G256_BM), tt256 = ceil_div(T, G256_BT);
     const long tiles256 = (long)mt256 * tt256;
-    // (round 6) stream-K: a PERSISTENT one-workgroup-per-CU launch over the (tile, K-tile pair) units whenever a round of
-    // 256 x 256 tiles would leave >= 8 % of the CU-rounds idle - gate_up at 512 / 1024 / 2048 tokens: 152 / 304 / 608 tiles on
-    // 256 CUs.  kind 258.  Fixed K order per (M, T, K, CU count); not the order of the data-parallel kernels (gemm256.h).
+    // (round 6) stream-K, kind 258, OFF unless PEGAINFER_STREAMK=1: a PERSISTENT one-workgroup-per-CU launch over (row tile, K-tile
+    // pair) units for shapes whose round of 256 x 256 tiles would leave >= 8 % of the CU-rounds idle (gate_up at 512 / 1024 /
+    // 2048 tokens: 152 / 304 / 608 tiles on 256 CUs).  Built, correct, deterministic - and measured slower (gemm256.h).
     static const int sk_min = [] { const char* e = getenv("PEGAINFER_STREAMK_MIN_TILES"); return e && *e ? atoi(e) : 128; }();
     if (tiles256 >= sk_min && (g_splitk_ws || assume_ws) && so.silu_c1 == 0 &&
         (size_t)device_cus() * kG256SlotFloats * 4 <= kSplitKWorkspaceBytes && (size_t)device_cus() * 4 <= kStreamKFlagBytes &&
@@ -823,6 +824,9 @@ void pegainfer_debug_gemv_trace(uint64_t* buf) { pk::g_gemv_trace = reinterpret_
 // Debug / test hook: force how skinny_resident_kernel's 8 waves meet per row block (0 two barriers, 1 one barrier, 4 tickets, 5 lazy tickets;
 // -1 = back to the launcher's choice).  The forms are bit-identical; tests/test_gpu_ops.py compares them in one process.
 void pegainfer_debug_skinny_flush(int32_t mode) { pk::g_skinny_flush_override = mode < 0 ? -1 : (mode & 7); }
+// Debug / test hook: 1 routes the shapes of gemm256_streamk_plan to the stream-K launch (kind 258), 0 never, -1 = the
+// environment (PEGAINFER_STREAMK, default off: measured slower - gemm256.h).
+void pegainfer_debug_streamk(int32_t on) { pk::g_streamk_override = on < 0 ? -1 : (on != 0); }
 
 
 int32_t cuda_set_device(int32_t device_ordinal) { return static_cast<int32_t>(hipSetDevice(device_ordinal)); }
