@@ -410,10 +410,17 @@ __global__ __launch_bounds__(512) void splitk_reduce_add_norm_kernel(const float
                                                                      const Half* __restrict__ w, Half* __restrict__ out,
                                                                      int d, int T, int ksplit, float eps, bool round_sum) {
   extern __shared__ __attribute__((aligned(16))) unsigned char rn_smem[];
-  u32x4* rrow = reinterpret_cast<u32x4*>(rn_smem);              // [d / 8] bf16x8
-  float* sm_inv = reinterpret_cast<float*>(rn_smem + (size_t)d * 2);
+  u32x4* rrow = reinterpret_cast<u32x4*>(rn_smem);              // [d / 8] bf16x8: the slice sum r
+  u32x4* hrow = reinterpret_cast<u32x4*>(rn_smem + (size_t)d * 2);   // [d / 8] bf16x8: the residual row (round 6)
+  float* sm_inv = reinterpret_cast<float*>(rn_smem + (size_t)d * 4);
   const int t = blockIdx.x, nvec = d >> 3;
-  for (int i = threadIdx.x; i < nvec; i += 512) {
+  const Half* hin = hidden_in + (size_t)t * d;
+  Half* hr = hidden + (size_t)t * d;
+  Half* orow = out + (size_t)t * d;
+  // (round 6) ONE memory round trip per thread instead of three dependent ones: the residual row and the norm weight leave
+  // with the partials; wave 0's canonical sum of squares reads both rows from LDS (same values, same order: same bits) and the
+  // scale pass works from registers.  Rows of more than 512 vectors (d > 4096) keep the reloading loop for their tail.
+  auto slice_sum = [&](int i) {
     const float* p = part + (size_t)t * d + i * 8;
     f32x4 pa[8], pb[8];   // ksplit <= 8: every slice's loads leave before the first add (slice order is kept)
 #pragma unroll
@@ -429,23 +436,40 @@ __global__ __launch_bounds__(512) void splitk_reduce_add_norm_kernel(const float
       if (z < ksplit) { a += pa[z]; b += pb[z]; }
     u32x4 r;
     r.x = pack_bf2(a[0], a[1]); r.y = pack_bf2(a[2], a[3]); r.z = pack_bf2(b[0], b[1]); r.w = pack_bf2(b[2], b[3]);
-    rrow[i] = r;
+    return r;
+  };
+  // the thread's first vector stays in registers; further ones (d > 4096) go through LDS / a reload
+  const int i0 = threadIdx.x;
+  const bool have0 = i0 < nvec;
+  u32x4 h0 = {0u, 0u, 0u, 0u}, w0 = {0u, 0u, 0u, 0u}, r0 = {0u, 0u, 0u, 0u};
+  if (have0) {
+    h0 = reinterpret_cast<const u32x4*>(hin)[i0];
+    w0 = reinterpret_cast<const u32x4*>(w)[i0];
+    r0 = slice_sum(i0);
+    rrow[i0] = r0;
+    hrow[i0] = h0;
+  }
+  for (int i = i0 + 512; i < nvec; i += 512) {
+    hrow[i] = reinterpret_cast<const u32x4*>(hin)[i];
+    rrow[i] = slice_sum(i);
   }
   __syncthreads();
-  const Half* hin = hidden_in + (size_t)t * d;
-  Half* hr = hidden + (size_t)t * d;
   if (threadIdx.x < 64) {
-    const float inv = wave_row_inv_rms(hin, reinterpret_cast<const Half*>(rrow), d, eps, round_sum);
+    const float inv = wave_row_inv_rms(reinterpret_cast<const Half*>(hrow), reinterpret_cast<const Half*>(rrow), d, eps, round_sum);
     if (threadIdx.x == 0) *sm_inv = inv;
   }
   __syncthreads();
   const float inv = *sm_inv;
-  Half* orow = out + (size_t)t * d;
-  for (int i = threadIdx.x; i < nvec; i += 512) {
+  if (have0) {
+    u32x4 nh;
+    const u32x4 o = norm_scale8(h0, &r0, w0, inv, 0.f, &nh, round_sum);
+    reinterpret_cast<u32x4*>(hr)[i0] = nh;
+    reinterpret_cast<u32x4*>(orow)[i0] = o;
+  }
+  for (int i = i0 + 512; i < nvec; i += 512) {
     const u32x4 r = rrow[i];
     u32x4 nh;
-    const u32x4 o = norm_scale8(reinterpret_cast<const u32x4*>(hin)[i], &r, reinterpret_cast<const u32x4*>(w)[i], inv,
-                                0.f, &nh, round_sum);
+    const u32x4 o = norm_scale8(hrow[i], &r, reinterpret_cast<const u32x4*>(w)[i], inv, 0.f, &nh, round_sum);
     reinterpret_cast<u32x4*>(hr)[i] = nh;
     reinterpret_cast<u32x4*>(orow)[i] = o;
   }
@@ -701,7 +725,11 @@ static void glds_gemm_launch(const Half* W, const Half* X, Half* Y, int M, int T
       head.silu_c0 = 0; head.silu_c1 = r.m_head * 128;
       tail.silu_c0 = r.m_head * 128; tail.silu_c1 = so.silu_I;
       gemm256_launch(W, X, Y, M, T, K, head, s);
-      glds_gemm_launch_t<128, 2>(W, X, Y, M, T, K, tail, s);
+      // the thin tail: 128-token tiles with a 2-deep ring (192 workgroups at 1024 tokens), or - PEGAINFER_GEMM256_TAIL_TT=64, A/B
+      // knob - 64-token tiles with a 3-deep ring (384 workgroups, two per CU, all resident)
+      static const int tail_tt = [] { const char* e = getenv("PEGAINFER_GEMM256_TAIL_TT"); return e && *e ? atoi(e) : 128; }();
+      if (tail_tt == 64) glds_gemm_launch_t<64, 3>(W, X, Y, M, T, K, tail, s);
+      else glds_gemm_launch_t<128, 2>(W, X, Y, M, T, K, tail, s);
       return;
     }
     if (r.kind == 258) { gemm256_streamk_launch(W, X, Y, M, T, K, so, g_splitk_ws, g_streamk_flags, device_cus(), s); return; }
@@ -1055,13 +1083,13 @@ pegainfer_status_t pegainfer_gemm_add_rms_norm(const Half* W, const Half* X, Hal
     return (pegainfer_status_t)hipErrorInvalidValue;
   hipStream_t s = as_stream(stream);
   const bool vec = (M & 7) == 0 && host_aligned16(hidden) && host_aligned16(norm_weight) && host_aligned16(normed_out) &&
-                   (size_t)M * 2 + 16 <= 64 * 1024;
+                   (size_t)M * 4 + 16 <= 64 * 1024;
   const bool split = glds_gemm_ok(W, X, y_scratch, M, K) &&
                      (T > 64 ? splitk_plan(M, T, K).nk_slice > 0 : mid_batch_route(W, X, y_scratch, M, T, K) == 2);
   if (vec && split) {
     const SplitKPlan pl = splitk_plan(M, T, K);
     glds_splitk_launch(W, X, y_scratch, M, T, K, SplitOut{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0}, pl, s, false);
-    splitk_reduce_add_norm_kernel<<<T, 512, (size_t)M * 2 + 16, s>>>(g_splitk_ws, hidden, hidden, norm_weight, normed_out,
+    splitk_reduce_add_norm_kernel<<<T, 512, (size_t)M * 4 + 16, s>>>(g_splitk_ws, hidden, hidden, norm_weight, normed_out,
                                                                     M, T, pl.ksplit, eps, false);
     return (pegainfer_status_t)hipGetLastError();
   }
@@ -1104,13 +1132,13 @@ pegainfer_status_t pegainfer_gemm_add_then_rms_norm(const Half* W, const Half* X
     return (pegainfer_status_t)hipErrorInvalidValue;
   hipStream_t s = as_stream(stream);
   const bool vec = (M & 7) == 0 && host_aligned16(a) && host_aligned16(out) && host_aligned16(norm_weight) &&
-                   host_aligned16(normed_out) && (size_t)M * 2 + 16 <= 64 * 1024;
+                   host_aligned16(normed_out) && (size_t)M * 4 + 16 <= 64 * 1024;
   const bool split = glds_gemm_ok(W, X, y_scratch, M, K) &&
                      (T > 64 ? splitk_plan(M, T, K).nk_slice > 0 : mid_batch_route(W, X, y_scratch, M, T, K) == 2);
   if (vec && split) {
     const SplitKPlan pl = splitk_plan(M, T, K);
     glds_splitk_launch(W, X, y_scratch, M, T, K, SplitOut{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0}, pl, s, false);
-    splitk_reduce_add_norm_kernel<<<T, 512, (size_t)M * 2 + 16, s>>>(g_splitk_ws, a, out, norm_weight, normed_out, M, T,
+    splitk_reduce_add_norm_kernel<<<T, 512, (size_t)M * 4 + 16, s>>>(g_splitk_ws, a, out, norm_weight, normed_out, M, T,
                                                                     pl.ksplit, eps, true);
     return (pegainfer_status_t)hipGetLastError();
   }
