@@ -115,6 +115,19 @@ def cpu_legs(cfg, bits, prompt, gpu_tokens, gpu_rows_bits, steps, threads, hf_re
                 hf_tokens, hf_logits = toks, lg
             ttfts.append(stamps[1] - t0)
             rates.append((len(stamps) - 2) / (stamps[-1] - stamps[1]))
+        # ... and HF teacher-forced on the ENGINE's own tokens (the free-running comparison ends at the first near-tie -
+        # two steps on the driver's box): every step of the parity run compared, whatever the greedy choices did
+        try:
+            tf = hf_engine.teacher_forced_logits(model, prompt, gpu_tokens[:-1])
+            m_tf = min(len(tf), len(gpu_rows))
+            d_tf = np.abs(gpu_rows[:m_tf] - tf[:m_tf]).max(-1)
+            srt_tf = np.sort(tf[:m_tf], axis=-1)
+            agree_tf = gpu_rows[:m_tf].argmax(-1) == tf[:m_tf].argmax(-1)
+            hf_forced = {"steps_compared": int(m_tf), "cos_min": round(float(cos_rows(gpu_rows[:m_tf], tf[:m_tf]).min()), 6),
+                         "max_dlogit": round(float(d_tf.max()), 4), "argmax_equal": int(agree_tf.sum()),
+                         "argmax_differing_away_from_a_near_tie": int((~agree_tf & ((srt_tf[:, -1] - srt_tf[:, -2]) > 2 * d_tf)).sum())}
+        except Exception as e:  # noqa: BLE001
+            hf_forced = {"error": f"{type(e).__name__}: {e}"[:200]}
         del model
         n = min(len(gpu_tokens), len(hf_tokens))
         first_diff = next((i for i in range(n) if gpu_tokens[i] != hf_tokens[i]), None)
@@ -126,7 +139,8 @@ def cpu_legs(cfg, bits, prompt, gpu_tokens, gpu_rows_bits, steps, threads, hf_re
                         "tokens": hf_tokens[:n], "tokens_equal_prefix": n if first_diff is None else first_diff,
                         "first_diff_step": first_diff, "steps_compared": m, "cos_min": round(float(cs.min()), 6),
                         "max_dlogit": round(float(np.abs(gpu_rows[:m] - hf_logits[:m]).max()), 4),
-                        "hf_top1_margin": [round(float(x), 4) for x in (srt[:, -1] - srt[:, -2])[:m]]}
+                        "hf_top1_margin": [round(float(x), 4) for x in (srt[:, -1] - srt[:, -2])[:m]],
+                        "teacher_forced_on_engine_tokens": hf_forced}
         baseline = {"value": round(float(np.median(rates)), 3), "unit": "tokens/s", "cores": int(hf_threads),
                     "kind": "reference", "engine": "hf-transformers " + __import__("transformers").__version__,
                     "spread": {"min": round(float(min(rates)), 3), "max": round(float(max(rates)), 3), "repeats": hf_repeats},

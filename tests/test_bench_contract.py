@@ -151,6 +151,9 @@ def test_cpu_legs_run_on_a_tiny_checkpoint():
     assert base["kind"] == "reference" and base["value"] > 0 and base["port"]["kind"] == "port"
     assert par["cos_min"] == 1.0 and par["max_dlogit"] == 0.0 and par["tokens_equal"] == 5
     assert par["hf"]["cos_min"] > 0.999 and par["hf"]["steps_compared"] >= 1
+    # HF teacher-forced on the 'GPU' tokens: all 5 rows compared whatever the free-running streams did
+    tf = par["hf"]["teacher_forced_on_engine_tokens"]
+    assert tf["steps_compared"] == 5 and tf["cos_min"] > 0.999 and tf["argmax_differing_away_from_a_near_tie"] == 0
 
 
 def test_cpu_leg_qwen35_runs_on_the_tiny_golden_checkpoint():
