@@ -13,6 +13,14 @@ the invariants the kernel's comment block claims are asserted on every step:
 Forms: waiting tickets (PEGAINFER_SKINNY_FLUSH=4: the designated wave spins until the count is complete) and lazy
 tickets (=5, the default for tall matrices: it remembers the block and adds it up at a later flush, at the latest when the
 buffer is needed again or after its last item).  Ring sizes 2..4 as the launcher can pick them (LDS room beside x).
+
+WHAT THIS IS NOT: it model-checks a PYTHON RESTATEMENT of the protocol, not the kernel's instructions.  Two
+things it cannot see are argued, not proven, in docs/lab-notes/round-5.md section 9 and rest on the GPU tests instead:
+that LDS executes one wave's `ds_write` / `ds_add_u32` / `ds_read` in program order (so "write the partial, then bump the
+count" needs a compiler barrier only, no fence), and that the kernel's code IS this state machine.  The GPU-side evidence is
+tests/test_gpu_ops.py::test_skinny_flush_forms_are_bit_identical (all forms against each other at a handful of shapes) plus
+every batched-decode test running on the lazy form - since round 6 also bs 4 / 16 at 36 layers
+(tests/test_gpu_full_depth_batch.py).
 """
 import random
 
