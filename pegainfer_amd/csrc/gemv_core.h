@@ -68,6 +68,8 @@ extern unsigned long long* g_gemv_trace;
 enum { kGemvNormOffset = 1, kGemvRoundSum = 2, kGemvSiluRound = 4 };
 constexpr int kGemvProloguePrio = 64;   // launcher-only bit (PEGAINFER_GEMV_PRIO=0 clears it): see the prologue
 constexpr int kGemvNormAllWaves = 32;   // launcher-only bit (PEGAINFER_GEMV_NORM1W=0): every wave sums the squares (A/B probe)
+constexpr int kGemvTraceProlog = 128;   // launcher-only bit (PEGAINFER_GEMV_TRACE_PROLOGUE=1, with pegainfer_debug_gemv_trace): stamps
+                                        // 2 / 3 mark "sum of squares done" / "inverse RMS seen by every wave" instead of the K loop's marks
 
 // U = K blocks a wave keeps in flight per row (U*NW*RPW loads of 1 KB).  The launcher picks U = 5 when that covers a
 // whole row (K = 2560: 5 blocks; K = 9728 dealt to 4 waves: 5, 5, 5, 4), so a row group needs ONE memory round trip
@@ -229,8 +231,10 @@ __global__ __launch_bounds__(256) void gemv_fused_kernel(const GemvFusedArgs a) 
         ss = wave_sum(ss);
         inv[t] = rsqrtf(__fadd_rn(ss / (float)K, a.eps));
         if (!all_waves && lane == 0) red[t] = inv[t];
+        if (a.trace && (a.flags & kGemvTraceProlog) && lane == 0 && t == 0) a.trace[(size_t)blockIdx.x * 8 + 2] = wall_clock64();
       }
       __syncthreads();  // the raw rows have been read; the inverse RMS values are in LDS
+      if (a.flags & kGemvTraceProlog) PK_GEMV_STAMP(a, 3);
       if (!all_waves) {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
@@ -315,7 +319,7 @@ __global__ __launch_bounds__(256) void gemv_fused_kernel(const GemvFusedArgs a) 
     {
       const int nblk = (kt0 + 511) >> 9;
       consume(kt0, nblk, bfirst);
-      if (first_group) { PK_GEMV_STAMP(a, 2); first_group = false; }
+      if (first_group) { if (!(a.flags & kGemvTraceProlog)) PK_GEMV_STAMP(a, 2); first_group = false; }
       for (int b0 = bfirst + U * KSPLIT; b0 < nblk; b0 += U * KSPLIT) {
         issue(0, kt0, b0);
         consume(kt0, nblk, b0);
@@ -335,7 +339,7 @@ __global__ __launch_bounds__(256) void gemv_fused_kernel(const GemvFusedArgs a) 
     }
     const int g_next = g + gridDim.x;
     const bool has_next = g_next < ngroups;
-    if (!has_next) PK_GEMV_STAMP(a, 3);
+    if (!has_next && !(a.flags & kGemvTraceProlog)) PK_GEMV_STAMP(a, 3);
     const int row0 = (KSPLIT == 1 ? g * 4 + wave : g) * RPW;  // rows of the group being finished
     if (has_next) {
       set_rows(g_next);
@@ -458,6 +462,8 @@ inline void gemv_launch_one(const GemvFusedArgs& a, hipStream_t s) {
   if (!norm1w) b.flags |= kGemvNormAllWaves;
   static const bool prio = [] { const char* e = getenv("PEGAINFER_GEMV_PRIO"); return !(e && *e == '0'); }();
   if (prio) b.flags |= kGemvProloguePrio;
+  static const bool tprol = [] { const char* e = getenv("PEGAINFER_GEMV_TRACE_PROLOGUE"); return e && *e == '1'; }();
+  if (tprol) b.flags |= kGemvTraceProlog;
   kern<<<grid, 256, lds, s>>>(b);
 }
 

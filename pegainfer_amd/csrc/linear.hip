@@ -727,7 +727,11 @@ static void glds_gemm_launch(const Half* W, const Half* X, Half* Y, int M, int T
       gemm256_launch(W, X, Y, M, T, K, head, s);
       // the thin tail: 128-token tiles with a 2-deep ring (192 workgroups at 1024 tokens), or - PEGAINFER_GEMM256_TAIL_TT=64, A/B
       // knob - 64-token tiles with a 3-deep ring (384 workgroups, two per CU, all resident)
-      static const int tail_tt = [] { const char* e = getenv("PEGAINFER_GEMM256_TAIL_TT"); return e && *e ? atoi(e) : 128; }();
+      // (round 6, same-box A/B profiles/r6_reduce_and_tail_ttft.txt: TTFT(1024) 10.53 -> 10.33 ms, TTFT(2048) 18.25 -> 18.40):
+      // 64-token tiles exactly when the 128-token tiling would give the tail fewer tiles than there are CUs
+      static const int tail_env = [] { const char* e = getenv("PEGAINFER_GEMM256_TAIL_TT"); return e && *e ? atoi(e) : 0; }();
+      const long tail_tiles128 = (long)ceil_div(so.silu_I - r.m_head * 128, 64) * ceil_div(T, 128);
+      const int tail_tt = tail_env ? tail_env : (tail_tiles128 < device_cus() ? 64 : 128);
       if (tail_tt == 64) glds_gemm_launch_t<64, 3>(W, X, Y, M, T, K, tail, s);
       else glds_gemm_launch_t<128, 2>(W, X, Y, M, T, K, tail, s);
       return;
