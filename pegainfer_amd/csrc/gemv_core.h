@@ -221,21 +221,15 @@ __global__ __launch_bounds__(256) void gemv_fused_kernel(const GemvFusedArgs a) 
       for (int t = 0; t < NT; ++t) {
         if (t >= T || !(all_waves || wave == ((w0 + t) & 3))) continue;
         float ss = 0.f;
-        // (round 6) the LDS reads of vector j + 64 are issued before vector j's chain of fmas: the loop paid one LDS round
-        // trip per iteration in front of every chain (0.9 us for the five vectors of a 2560-wide row, in-kernel stamps
-        // profiles/r6_gemv_prologue_split.txt).  Same order of additions: same bits.
-        const bool has_r = a.residual != nullptr;
-        u32x4 hv = xs[t * pitch + (lane < nvec_row ? lane : 0)], rv = hv;
-        if (has_r) rv = rs[t * pitch + (lane < nvec_row ? lane : 0)];
-        for (int j = lane; j < nvec_row; j += 64) {
-          const int jn = j + 64 < nvec_row ? j + 64 : j;
-          const u32x4 hn = xs[t * pitch + jn];
-          u32x4 rn = hn;
-          if (has_r) rn = rs[t * pitch + jn];
-          if (has_r && round_sum) add_round_sq8(hv, rv, ss);
-          else if (has_r) add_sq8(hv, rv, ss);
-          else sq8(hv, ss);
-          hv = hn; rv = rn;
+        // (round 6: a software-pipelined form - the LDS reads of vector j + 64 issued before vector j's chain of fmas - was
+        // measured SLOWER, sum phase 0.89 -> 1.32-1.40 us by the in-kernel stamps, profiles/r6_gemv_prologue_split*.txt, and
+        // removed: this plain loop is what the compiler schedules best)
+        if (a.residual && round_sum) {
+          for (int j = lane; j < nvec_row; j += 64) add_round_sq8(xs[t * pitch + j], rs[t * pitch + j], ss);
+        } else if (a.residual) {
+          for (int j = lane; j < nvec_row; j += 64) add_sq8(xs[t * pitch + j], rs[t * pitch + j], ss);
+        } else {
+          for (int j = lane; j < nvec_row; j += 64) sq8(xs[t * pitch + j], ss);
         }
         ss = wave_sum(ss);
         inv[t] = rsqrtf(__fadd_rn(ss / (float)K, a.eps));

@@ -159,11 +159,15 @@ __global__ __launch_bounds__(256) void rms_norm_gated_kernel(const Half* __restr
   }
 }
 
+static bool norm_reg_on() {   // PEGAINFER_NORM_REG=0: the looping form for every launch (A/B knob)
+  static const bool v = [] { const char* e = getenv("PEGAINFER_NORM_REG"); return !(e && e[0] == '0'); }();
+  return v;
+}
 template <bool OFFSET>
 static void launch_rms(const Half* x, const Half* w, Half* out, int d, int rows, float eps, hipStream_t s) {
   if (d <= 0 || rows <= 0) return;
   const bool vec = (d & 7) == 0 && host_aligned16(x) && host_aligned16(w) && host_aligned16(out);
-  const bool reg = vec && (d >> 3) <= 64 * kNormRegVecs && ceil_div(rows, kNormWaves) <= device_cus();
+  const bool reg = vec && norm_reg_on() && (d >> 3) <= 64 * kNormRegVecs && ceil_div(rows, kNormWaves) <= device_cus();
   if (reg) rms_norm_vec_kernel<OFFSET, true><<<ceil_div(rows, kNormWaves), kNormBlock, 0, s>>>(x, w, out, d, rows, eps);
   else if (vec) rms_norm_vec_kernel<OFFSET, false><<<ceil_div(rows, kNormWaves), kNormBlock, 0, s>>>(x, w, out, d, rows, eps);
   else rms_norm_scalar_kernel<OFFSET><<<rows, kNormBlock, 0, s>>>(x, w, out, d, eps);
@@ -174,7 +178,7 @@ static void launch_fused(Half* hidden, const Half* residual, const Half* w, Half
   if (d <= 0 || rows <= 0) return;
   const bool vec = (d & 7) == 0 && host_aligned16(hidden) && host_aligned16(residual) &&
                    host_aligned16(w) && host_aligned16(out);
-  const bool reg = vec && (d >> 3) <= 64 * kNormRegVecs && ceil_div(rows, kNormWaves) <= device_cus();
+  const bool reg = vec && norm_reg_on() && (d >> 3) <= 64 * kNormRegVecs && ceil_div(rows, kNormWaves) <= device_cus();
   if (reg)
     fused_add_rms_norm_vec_kernel<false, true><<<ceil_div(rows, kNormWaves), kNormBlock, 0, s>>>(hidden, residual, w, out, d,
                                                                                                 rows, eps);
