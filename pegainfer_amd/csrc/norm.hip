@@ -13,10 +13,7 @@
 namespace pk {
 
 // VEC kernels: one wave per row, 4 rows per 256-thread block.  Scalar fallback (d % 8 != 0): one block per row.
-// REG (round 6): the row lives in registers - one memory round trip instead of ten dependent ones; taken for FEW rows (one
-// workgroup per CU at most: decode steps, short prompts), where the launch is latency-bound.  Many rows (long prefills) keep the
-// looping form: its 30-odd registers let eight workgroups share a CU, which is what a bandwidth-bound launch needs.
-template <bool OFFSET, bool REG>
+template <bool OFFSET>
 __global__ __launch_bounds__(kNormBlock) void rms_norm_vec_kernel(const Half* __restrict__ x,
                                                                   const Half* __restrict__ w,
                                                                   Half* __restrict__ out, int d, int rows, float eps) {
@@ -26,22 +23,8 @@ __global__ __launch_bounds__(kNormBlock) void rms_norm_vec_kernel(const Half* __
   const Half* xr = x + (size_t)row * d;
   Half* orow = out + (size_t)row * d;
   const float bias = OFFSET ? 1.0f : 0.0f;
-  const int nvec = d >> 3;
-  if constexpr (REG) {   // the row lives in registers: ONE memory round trip (norm_core.h), same bits
-    NormRow row;
-    norm_row_load(row, xr, nullptr, d);
-    u32x4 g[kNormRegVecs];
-#pragma unroll
-    for (int k = 0; k < kNormRegVecs; ++k)
-      if (lane + k * 64 < nvec) g[k] = reinterpret_cast<const u32x4*>(w)[lane + k * 64];
-    const float inv = norm_row_inv_rms(row, false, d, eps);
-#pragma unroll
-    for (int k = 0; k < kNormRegVecs; ++k)
-      if (lane + k * 64 < nvec)
-        reinterpret_cast<u32x4*>(orow)[lane + k * 64] = norm_scale8(row.h[k], nullptr, g[k], inv, bias, nullptr);
-    return;
-  }
   const float inv = wave_row_inv_rms(xr, nullptr, d, eps);
+  const int nvec = d >> 3;
   for (int i = lane; i < nvec; i += 64)
     reinterpret_cast<u32x4*>(orow)[i] = norm_scale8(reinterpret_cast<const u32x4*>(xr)[i], nullptr,
                                                     reinterpret_cast<const u32x4*>(w)[i], inv, bias, nullptr);
@@ -67,7 +50,7 @@ __global__ __launch_bounds__(kNormBlock) void rms_norm_scalar_kernel(const Half*
 
 // hidden = bf16(h + r); out = bf16((h + r)_fp32 * inv * w): the sum of squares uses the UNROUNDED fp32 sum and is
 // taken before hidden is modified; each lane then re-reads exactly the elements it overwrites.
-template <bool OFFSET, bool REG>
+template <bool OFFSET>
 __global__ __launch_bounds__(kNormBlock) void fused_add_rms_norm_vec_kernel(Half* __restrict__ hidden,
                                                                             const Half* __restrict__ residual,
                                                                             const Half* __restrict__ w,
@@ -80,26 +63,8 @@ __global__ __launch_bounds__(kNormBlock) void fused_add_rms_norm_vec_kernel(Half
   const Half* rr = residual + (size_t)row * d;
   Half* orow = out + (size_t)row * d;
   const float bias = OFFSET ? 1.0f : 0.0f;
-  const int nvec = d >> 3;
-  if constexpr (REG) {   // the two rows live in registers: ONE memory round trip (norm_core.h), same bits
-    NormRow row;
-    norm_row_load(row, hr, rr, d);
-    u32x4 g[kNormRegVecs];
-#pragma unroll
-    for (int k = 0; k < kNormRegVecs; ++k)
-      if (lane + k * 64 < nvec) g[k] = reinterpret_cast<const u32x4*>(w)[lane + k * 64];
-    const float inv = norm_row_inv_rms(row, true, d, eps);
-#pragma unroll
-    for (int k = 0; k < kNormRegVecs; ++k)
-      if (lane + k * 64 < nvec) {
-        u32x4 nh;
-        const u32x4 o = norm_scale8(row.h[k], &row.r[k], g[k], inv, bias, &nh);
-        reinterpret_cast<u32x4*>(hr)[lane + k * 64] = nh;
-        reinterpret_cast<u32x4*>(orow)[lane + k * 64] = o;
-      }
-    return;
-  }
   const float inv = wave_row_inv_rms(hr, rr, d, eps);
+  const int nvec = d >> 3;
   for (int i = lane; i < nvec; i += 64) {
     const u32x4 r = reinterpret_cast<const u32x4*>(rr)[i];
     u32x4 nh;
@@ -159,17 +124,11 @@ __global__ __launch_bounds__(256) void rms_norm_gated_kernel(const Half* __restr
   }
 }
 
-static bool norm_reg_on() {   // PEGAINFER_NORM_REG=0: the looping form for every launch (A/B knob)
-  static const bool v = [] { const char* e = getenv("PEGAINFER_NORM_REG"); return !(e && e[0] == '0'); }();
-  return v;
-}
 template <bool OFFSET>
 static void launch_rms(const Half* x, const Half* w, Half* out, int d, int rows, float eps, hipStream_t s) {
   if (d <= 0 || rows <= 0) return;
   const bool vec = (d & 7) == 0 && host_aligned16(x) && host_aligned16(w) && host_aligned16(out);
-  const bool reg = vec && norm_reg_on() && (d >> 3) <= 64 * kNormRegVecs && ceil_div(rows, kNormWaves) <= device_cus();
-  if (reg) rms_norm_vec_kernel<OFFSET, true><<<ceil_div(rows, kNormWaves), kNormBlock, 0, s>>>(x, w, out, d, rows, eps);
-  else if (vec) rms_norm_vec_kernel<OFFSET, false><<<ceil_div(rows, kNormWaves), kNormBlock, 0, s>>>(x, w, out, d, rows, eps);
+  if (vec) rms_norm_vec_kernel<OFFSET><<<ceil_div(rows, kNormWaves), kNormBlock, 0, s>>>(x, w, out, d, rows, eps);
   else rms_norm_scalar_kernel<OFFSET><<<rows, kNormBlock, 0, s>>>(x, w, out, d, eps);
 }
 
@@ -178,13 +137,9 @@ static void launch_fused(Half* hidden, const Half* residual, const Half* w, Half
   if (d <= 0 || rows <= 0) return;
   const bool vec = (d & 7) == 0 && host_aligned16(hidden) && host_aligned16(residual) &&
                    host_aligned16(w) && host_aligned16(out);
-  const bool reg = vec && norm_reg_on() && (d >> 3) <= 64 * kNormRegVecs && ceil_div(rows, kNormWaves) <= device_cus();
-  if (reg)
-    fused_add_rms_norm_vec_kernel<false, true><<<ceil_div(rows, kNormWaves), kNormBlock, 0, s>>>(hidden, residual, w, out, d,
-                                                                                                rows, eps);
-  else if (vec)
-    fused_add_rms_norm_vec_kernel<false, false><<<ceil_div(rows, kNormWaves), kNormBlock, 0, s>>>(hidden, residual, w, out, d,
-                                                                                                 rows, eps);
+  if (vec)
+    fused_add_rms_norm_vec_kernel<false><<<ceil_div(rows, kNormWaves), kNormBlock, 0, s>>>(hidden, residual, w, out, d,
+                                                                                          rows, eps);
   else fused_add_rms_norm_scalar_kernel<false><<<rows, kNormBlock, 0, s>>>(hidden, residual, w, out, d, eps);
 }
 

@@ -37,44 +37,6 @@ __device__ __forceinline__ void add_round_sq8(const u32x4& h, const u32x4& r, fl
   a = bf16_round_f(bf_lo(h.w) + bf_lo(r.w)); ss = fmaf(a, a, ss); a = bf16_round_f(bf_hi(h.w) + bf_hi(r.w)); ss = fmaf(a, a, ss);
 }
 
-// The same row kept in registers (round 6): up to kNormRegVecs 16-byte vectors per lane = rows of <= 4096 elements.  The
-// looping form below pays one memory round trip PER ITERATION (the loads of iteration i + 1 are not issued before iteration
-// i's sum is taken: 5 dependent round trips for a 2560-wide row, then 5 more in the caller's scale loop - most of the 5 us a
-// one-row norm launch cost on the strict-ABI decode path); here every load of the row leaves first, the canonical chain
-// (lane l folds vectors l, l + 64, ... in order) runs over registers, and the caller scales from the same registers.
-constexpr int kNormRegVecs = 8;
-struct NormRow {
-  u32x4 h[kNormRegVecs], r[kNormRegVecs];
-  int n;   // vectors this lane holds
-};
-// loads (and keeps) the lane's vectors of the row; rr may be null.  d % 8 == 0 and d <= 64 * 8 * kNormRegVecs.
-__device__ __forceinline__ void norm_row_load(NormRow& row, const Half* __restrict__ hr, const Half* __restrict__ rr, int d) {
-  const int nvec = d >> 3, lane = threadIdx.x & 63;
-  row.n = 0;
-#pragma unroll
-  for (int k = 0; k < kNormRegVecs; ++k) {
-    const int i = lane + k * 64;
-    if (i < nvec) {
-      row.h[k] = reinterpret_cast<const u32x4*>(hr)[i];
-      if (rr) row.r[k] = reinterpret_cast<const u32x4*>(rr)[i];
-      row.n = k + 1;
-    }
-  }
-}
-// the canonical sum of squares over the registers: bit-identical to wave_row_inv_rms on the same row
-__device__ __forceinline__ float norm_row_inv_rms(const NormRow& row, bool has_r, int d, float eps, bool round_sum = false) {
-  float ss = 0.f;
-#pragma unroll
-  for (int k = 0; k < kNormRegVecs; ++k) {
-    if (k >= row.n) break;
-    if (has_r && round_sum) add_round_sq8(row.h[k], row.r[k], ss);
-    else if (has_r) add_sq8(row.h[k], row.r[k], ss);
-    else sq8(row.h[k], ss);
-  }
-  ss = wave_sum(ss);
-  return rsqrtf(__fadd_rn(ss / (float)d, eps));
-}
-
 // inv_rms of row `hr` (+ `rr` when non-null), d % 8 == 0; call from ALL 64 lanes of one wave.
 __device__ __forceinline__ float wave_row_inv_rms(const Half* __restrict__ hr, const Half* __restrict__ rr, int d,
                                                   float eps, bool round_sum = false) {
