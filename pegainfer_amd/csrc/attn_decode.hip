@@ -58,12 +58,17 @@ __device__ __forceinline__ void decode_attn_body(const DecodeAttnArgs& a, const 
   PK_ATTN_STAMP(a, slot, kvh, 3);
   // merge the workgroup's NPART partial states
   st.store_state(sm_m, sm_l, sm_o, wave * Scan::TPI + lane / Scan::LPT, lane);
+  // two-stage merge (round 6, attn_decode_core.h): every wave folds its own TPI lane-row states (no barrier: own slots), then
+  // one thread per (head, 8 output dims) merges the NW folds.  PEGAINFER_ATTN_FOLD=0 at build time is not offered: one
+  // arithmetic for every form.
+  static_assert(64 % (D / 8) == 0, "an element sweep of 64 lanes must cover whole heads");
+  for (int e = lane; e < GROUP * (D / 8); e += 64) attn_fold_wave<D, GROUP, Scan::TPI>(sm_m, sm_l, sm_o, wave, e);
   __syncthreads();
   // one thread per (head, 8 output dims): 16-byte stores.  With merge_counters the partials are published
   // write-through (sc1): they are read by a workgroup on another XCD later in this same launch.
   const bool publish = PARTITION && a.merge_counters != nullptr;
   for (int e = threadIdx.x; e < GROUP * (D / 8); e += NW * 64)
-    attn_finish_part<D, GROUP, PARTITION>(a, ci.b, slot, kvh, e, NPART, sm_m, sm_l, sm_o, publish);
+    attn_finish_part<D, GROUP, PARTITION>(a, ci.b, slot, kvh, e, NW, sm_m, sm_l, sm_o, publish, false, Scan::TPI);
   if (publish) {
     // "last workgroup done" merge without cache-wide fences (guide: sc1 payload -> vmcnt(0) -> counter; the
     // reader uses sc1 loads): every chunk's partials are write-through, the ticket is a relaxed agent atomic,

@@ -246,22 +246,60 @@ struct AttnScan {
   }
 };
 
-// Merge of the workgroup's NPART partial states for element e = (head h, 8 output dims d0) and the store: one thread
+// Stage 1 of the in-workgroup merge (round 6).  Until round 5 ONE wave merged all NW x TPI lane-row states: two dependent
+// loops of 32 LDS round trips (the running maximum, then the weighted sums) while seven waves waited - most of the 2.4 us
+// "publish" phase of the in-kernel stamps.  Now every wave first folds ITS OWN TPI lane-row states of element e = (head, 8
+// output dims) into the first of its slots (p = q * TPI), un-normalised - M = max m_p, L = sum l_p 2^(m_p - M),
+// O = sum o_p 2^(m_p - M) - and the final merge walks NW entries.  No barrier in front of it: a wave reads only slots its own
+// lanes wrote (LDS serves one wave's instructions in order).  Same formulas, another association: new bits for every decode
+// attention form at once (they all come through here), fused == unfused and batch == single untouched.
+template <int D, int GROUP, int TPI>
+__device__ __forceinline__ void attn_fold_wave(float* sm_m, float* sm_l, float* sm_o, int q, int e) {
+  const int h = e / (D / 8), d0 = (e - h * (D / 8)) * 8;
+  const int p0 = q * TPI;
+  float mp[TPI], M = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < TPI; ++i) {
+    mp[i] = sm_m[(p0 + i) * GROUP + h];
+    M = fmaxf(M, mp[i]);
+  }
+  float L = 0.f, O[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) O[i] = 0.f;
+  if (M != -INFINITY) {
+#pragma unroll
+    for (int i = 0; i < TPI; ++i) {
+      const float w = exp2f(mp[i] - M);
+      L = fmaf(sm_l[(p0 + i) * GROUP + h], w, L);
+      const f32x4 x0 = *reinterpret_cast<const f32x4*>(&sm_o[((size_t)(p0 + i) * GROUP + h) * D + d0]);
+      const f32x4 x1 = *reinterpret_cast<const f32x4*>(&sm_o[((size_t)(p0 + i) * GROUP + h) * D + d0 + 4]);
+      O[0] = fmaf(x0[0], w, O[0]); O[1] = fmaf(x0[1], w, O[1]); O[2] = fmaf(x0[2], w, O[2]); O[3] = fmaf(x0[3], w, O[3]);
+      O[4] = fmaf(x1[0], w, O[4]); O[5] = fmaf(x1[1], w, O[5]); O[6] = fmaf(x1[2], w, O[6]); O[7] = fmaf(x1[3], w, O[7]);
+    }
+  }
+  asm volatile("" ::: "memory");   // every read of the wave's slots is issued before the fold is written over slot p0
+  *reinterpret_cast<f32x4*>(&sm_o[((size_t)p0 * GROUP + h) * D + d0]) = f32x4{O[0], O[1], O[2], O[3]};
+  *reinterpret_cast<f32x4*>(&sm_o[((size_t)p0 * GROUP + h) * D + d0 + 4]) = f32x4{O[4], O[5], O[6], O[7]};
+  if (d0 == 0) { sm_m[p0 * GROUP + h] = M; sm_l[p0 * GROUP + h] = L; }
+}
+
+// Merge of the workgroup's partial states (entries p * pstride, p < npart) for element e = (head h, 8 output dims d0) and the store: one thread
 // per e.  PARTITION writes a normalised bf16 partial + fp32 log2-sum-exp to tmp_v / tmp_s (write-through when
 // `publish`: they are read by another workgroup later in this launch); otherwise the output row of request b
 // (`coherent_out`: also write-through - the engine hands it to the o_proj phase of other workgroups).
 template <int D, int GROUP, bool PARTITION>
 __device__ __forceinline__ void attn_finish_part(const DecodeAttnArgs& a, int b, int slot, int kvh, int e, int npart,
                                                  const float* sm_m, const float* sm_l, const float* sm_o, bool publish,
-                                                 bool coherent_out = false) {
+                                                 bool coherent_out = false, int pstride = 1) {
   const int h = e / (D / 8), d0 = (e - h * (D / 8)) * 8;
   float M = -INFINITY;
-  for (int p = 0; p < npart; ++p) M = fmaxf(M, sm_m[p * GROUP + h]);
+  for (int pi = 0; pi < npart; ++pi) M = fmaxf(M, sm_m[pi * pstride * GROUP + h]);
   float L = 0.f, O[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) O[i] = 0.f;
   if (M != -INFINITY) {
-    for (int p = 0; p < npart; ++p) {
+    for (int pi = 0; pi < npart; ++pi) {
+      const int p = pi * pstride;
       const float w = exp2f(sm_m[p * GROUP + h] - M);
       L = fmaf(sm_l[p * GROUP + h], w, L);
       const f32x4 x0 = *reinterpret_cast<const f32x4*>(&sm_o[((size_t)p * GROUP + h) * D + d0]);

@@ -68,8 +68,11 @@ extern unsigned long long* g_gemv_trace;
 enum { kGemvNormOffset = 1, kGemvRoundSum = 2, kGemvSiluRound = 4 };
 constexpr int kGemvProloguePrio = 64;   // launcher-only bit (PEGAINFER_GEMV_PRIO=0 clears it): see the prologue
 constexpr int kGemvNormAllWaves = 32;   // launcher-only bit (PEGAINFER_GEMV_NORM1W=0): every wave sums the squares (A/B probe)
-constexpr int kGemvTraceProlog = 128;   // launcher-only bit (PEGAINFER_GEMV_TRACE_PROLOGUE=1, with pegainfer_debug_gemv_trace): stamps
-                                        // 2 / 3 mark "sum of squares done" / "inverse RMS seen by every wave" instead of the K loop's marks
+// NOTE (round 6): this kernel's code generation is FRAGILE.  Two extra debug stamps inside the norm prologue (a launcher-only
+// flag bit, dead at run time) cost the K = 4096 KSPLIT forms 10 % (Qwen3-8B gate_up 33.8 -> 37.2 us, 323.5 -> 304.5 tok/s) and
+// the K = 2560 forms 0.9 %, same box, same hour (profiles/r6_libs_ab_*.txt) - at unchanged VGPR counts.  They were removed
+// again; the split they measured is in profiles/r6_gemv_prologue_split.txt.  Any edit here needs a same-box A/B of BOTH models
+// (python -m pegainfer_amd.build --variant NAME + PEGAINFER_LIB_DIR).
 
 // U = K blocks a wave keeps in flight per row (U*NW*RPW loads of 1 KB).  The launcher picks U = 5 when that covers a
 // whole row (K = 2560: 5 blocks; K = 9728 dealt to 4 waves: 5, 5, 5, 4), so a row group needs ONE memory round trip
@@ -221,9 +224,6 @@ __global__ __launch_bounds__(256) void gemv_fused_kernel(const GemvFusedArgs a) 
       for (int t = 0; t < NT; ++t) {
         if (t >= T || !(all_waves || wave == ((w0 + t) & 3))) continue;
         float ss = 0.f;
-        // (round 6: a software-pipelined form - the LDS reads of vector j + 64 issued before vector j's chain of fmas - was
-        // measured SLOWER, sum phase 0.89 -> 1.32-1.40 us by the in-kernel stamps, profiles/r6_gemv_prologue_split*.txt, and
-        // removed: this plain loop is what the compiler schedules best)
         if (a.residual && round_sum) {
           for (int j = lane; j < nvec_row; j += 64) add_round_sq8(xs[t * pitch + j], rs[t * pitch + j], ss);
         } else if (a.residual) {
@@ -234,10 +234,8 @@ __global__ __launch_bounds__(256) void gemv_fused_kernel(const GemvFusedArgs a) 
         ss = wave_sum(ss);
         inv[t] = rsqrtf(__fadd_rn(ss / (float)K, a.eps));
         if (!all_waves && lane == 0) red[t] = inv[t];
-        if (a.trace && (a.flags & kGemvTraceProlog) && lane == 0 && t == 0) a.trace[(size_t)blockIdx.x * 8 + 2] = wall_clock64();
       }
       __syncthreads();  // the raw rows have been read; the inverse RMS values are in LDS
-      if (a.flags & kGemvTraceProlog) PK_GEMV_STAMP(a, 3);
       if (!all_waves) {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
@@ -322,7 +320,7 @@ __global__ __launch_bounds__(256) void gemv_fused_kernel(const GemvFusedArgs a) 
     {
       const int nblk = (kt0 + 511) >> 9;
       consume(kt0, nblk, bfirst);
-      if (first_group) { if (!(a.flags & kGemvTraceProlog)) PK_GEMV_STAMP(a, 2); first_group = false; }
+      if (first_group) { PK_GEMV_STAMP(a, 2); first_group = false; }
       for (int b0 = bfirst + U * KSPLIT; b0 < nblk; b0 += U * KSPLIT) {
         issue(0, kt0, b0);
         consume(kt0, nblk, b0);
@@ -342,7 +340,7 @@ __global__ __launch_bounds__(256) void gemv_fused_kernel(const GemvFusedArgs a) 
     }
     const int g_next = g + gridDim.x;
     const bool has_next = g_next < ngroups;
-    if (!has_next && !(a.flags & kGemvTraceProlog)) PK_GEMV_STAMP(a, 3);
+    if (!has_next) PK_GEMV_STAMP(a, 3);
     const int row0 = (KSPLIT == 1 ? g * 4 + wave : g) * RPW;  // rows of the group being finished
     if (has_next) {
       set_rows(g_next);
@@ -465,8 +463,6 @@ inline void gemv_launch_one(const GemvFusedArgs& a, hipStream_t s) {
   if (!norm1w) b.flags |= kGemvNormAllWaves;
   static const bool prio = [] { const char* e = getenv("PEGAINFER_GEMV_PRIO"); return !(e && *e == '0'); }();
   if (prio) b.flags |= kGemvProloguePrio;
-  static const bool tprol = [] { const char* e = getenv("PEGAINFER_GEMV_TRACE_PROLOGUE"); return e && *e == '1'; }();
-  if (tprol) b.flags |= kGemvTraceProlog;
   kern<<<grid, 256, lds, s>>>(b);
 }
 

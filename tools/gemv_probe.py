@@ -57,11 +57,6 @@ def main():
             print(f"   prologue: wave 0's x-side loads landed at {us(t[:, 6].mean() - t0):.2f} (max {us(t[:, 6].max() - t0):.2f}) | "
                   f"all waves' at {us(t[:, 7].mean() - t0):.2f} (max {us(t[:, 7].max() - t0):.2f}) | norm arithmetic + barriers "
                   f"{us((t[:, 1] - t[:, 7]).mean()):.2f} (max {us((t[:, 1] - t[:, 7]).max()):.2f})")
-        if os.environ.get("PEGAINFER_GEMV_TRACE_PROLOGUE") == "1" and (t[:, 2] > 0).all():
-            # stamps 2 / 3 re-purposed: the summing wave has the inverse RMS / every wave has passed the barrier behind it
-            print(f"   norm prologue split: rows in LDS -> sum of squares done {us((t[:, 2] - t[:, 7]).mean()):.2f} (max "
-                  f"{us((t[:, 2] - t[:, 7]).max()):.2f}) | -> barrier passed {us((t[:, 3] - t[:, 2]).mean()):.2f} | -> scaled + "
-                  f"barrier {us((t[:, 1] - t[:, 3]).mean()):.2f} (max {us((t[:, 1] - t[:, 3]).max()):.2f})")
         per_xcc = [us(t[t[:, 5] == x][:, 4].max() - t0) for x in range(8) if (t[:, 5] == x).any()]
         print("   last exit per XCC:", " ".join(f"{v:.2f}" for v in per_xcc))
     eng.close()
