@@ -29,10 +29,14 @@ def exact_activations():
         _EXACT[0] = old
 
 
-_TORCH_MIN = 1 << 18   # elements from which the multi-threaded conversion pays
-
-
-def _bf16_round_numpy(x):
+def bf16_round(x):
+    """float32 -> nearest-even bf16, returned as float32 (``__float2bfloat16``).  Plain single-thread numpy on purpose: round 6
+    tried torch's multi-threaded float -> bfloat16 -> float conversion (5 x faster on the 8-core build container, but the
+    full-depth oracle passes got 30-75 % SLOWER on the 256-core GPU hosts: a 256-thread pool next to numpy's BLAS threads) and
+    a chunked numpy thread pool (no faster: the conversion is memory-bound)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    if _EXACT[0]:
+        return x
     u = x.view(np.uint32)
     bias = np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))
     r = ((u + bias) & np.uint32(0xFFFF0000)).astype(np.uint32)
@@ -40,24 +44,6 @@ def _bf16_round_numpy(x):
     if nan.any():
         r = np.where(nan, np.uint32(0x7FC00000), r)
     return r.view(np.float32).reshape(x.shape)
-
-
-def bf16_round(x):
-    """float32 -> nearest-even bf16, returned as float32 (``__float2bfloat16``).  Large arrays (a full-depth oracle pass
-    spends half its time here: 40 M-element GEMM outputs, one thread) go through torch's multi-threaded float -> bfloat16 ->
-    float conversion - the same round-to-nearest-even, NaNs canonicalised afterwards to the numpy form's 0x7FC0;
-    tests/test_oracle_kats.py pins the two forms against each other on random bit patterns."""
-    x = np.ascontiguousarray(x, dtype=np.float32)
-    if _EXACT[0]:
-        return x
-    if x.size >= _TORCH_MIN:
-        import torch
-        r = torch.from_numpy(x.reshape(-1)).to(torch.bfloat16).to(torch.float32).numpy()
-        nan = np.isnan(r)
-        if nan.any():
-            r[nan] = np.uint32(0x7FC00000).view(np.float32)
-        return r.reshape(x.shape)
-    return _bf16_round_numpy(x)
 
 
 def bf16_bits(x):
