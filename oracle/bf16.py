@@ -29,14 +29,30 @@ def exact_activations():
         _EXACT[0] = old
 
 
-def bf16_round(x):
-    """float32 -> nearest-even bf16, returned as float32 (``__float2bfloat16``).  Plain single-thread numpy on purpose: round 6
-    tried torch's multi-threaded float -> bfloat16 -> float conversion (5 x faster on the 8-core build container, but the
-    full-depth oracle passes got 30-75 % SLOWER on the 256-core GPU hosts: a 256-thread pool next to numpy's BLAS threads) and
-    a chunked numpy thread pool (no faster: the conversion is memory-bound)."""
-    x = np.ascontiguousarray(x, dtype=np.float32)
-    if _EXACT[0]:
-        return x
+_NATIVE = [None, False]   # (ctypes function or None, looked for already)
+_NATIVE_MIN = 1 << 16     # elements from which the C helper pays
+
+
+def _native_round():
+    """oracle/_native/libpegainfer_oracle.so (oracle/bf16_round.c, built by `make -C oracle`): one-pass, 16-thread rounding.
+    Absent library -> None (the numpy statement below is then used for every size)."""
+    if not _NATIVE[1]:
+        _NATIVE[1] = True
+        import ctypes
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_native", "libpegainfer_oracle.so")
+        if os.path.exists(path):
+            try:
+                fn = ctypes.CDLL(path).pegainfer_oracle_bf16_round
+                fn.restype = None
+                fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+                _NATIVE[0] = (fn, max(1, min(16, os.cpu_count() or 1)))
+            except (OSError, AttributeError):
+                _NATIVE[0] = None
+    return _NATIVE[0]
+
+
+def _bf16_round_numpy(x):
     u = x.view(np.uint32)
     bias = np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))
     r = ((u + bias) & np.uint32(0xFFFF0000)).astype(np.uint32)
@@ -44,6 +60,24 @@ def bf16_round(x):
     if nan.any():
         r = np.where(nan, np.uint32(0x7FC00000), r)
     return r.view(np.float32).reshape(x.shape)
+
+
+def bf16_round(x):
+    """float32 -> nearest-even bf16, returned as float32 (``__float2bfloat16``).  The statement is `_bf16_round_numpy`; arrays
+    of >= 64 K elements go through the one-pass C helper (oracle/bf16_round.c, same arithmetic, pinned against the numpy form
+    by tests/test_oracle_kats.py) when it has been built - a full-depth oracle pass rounds ~3 G elements.  (Round 6 first tried
+    torch's threaded conversion: 5 x faster on 8 cores, 30-75 % SLOWER passes on the 256-core GPU hosts; and a chunked numpy
+    thread pool: no faster, the five numpy passes are memory-bound.)"""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    if _EXACT[0]:
+        return x
+    if x.size >= _NATIVE_MIN:
+        nat = _native_round()
+        if nat is not None:
+            out = np.empty_like(x)
+            nat[0](x.ctypes.data, out.ctypes.data, x.size, nat[1])
+            return out
+    return _bf16_round_numpy(x)
 
 
 def bf16_bits(x):

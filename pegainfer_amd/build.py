@@ -88,6 +88,12 @@ def build(verbose=False, force=False, variant=None, extra_flags=()):
         _run([_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", host_lib] + hobjs +
              ["-L", libdir, "-lpegainfer_kernels_hip", "-L", "/opt/rocm/lib", "-lrccl", "-Wl,-rpath,$ORIGIN",
               "-Wl,-rpath,/opt/rocm/lib"])
+    # the oracle's C helper (checker only - nothing in pegainfer_amd/ loads it): oracle/Makefile, plain gcc; building the checker
+    # is not using it, and a missing gcc only means the oracle rounds in numpy
+    if not variant and os.path.exists(os.path.join(ROOT, "oracle", "Makefile")) and shutil.which("make") and shutil.which("gcc"):
+        r = subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0 and verbose:
+            print("oracle helper not built:", r.stdout[-300:])
     if verbose:
         print("built", kernel_lib, host_lib if hobjs else "")
     return kernel_lib, (host_lib if hobjs else None)

@@ -159,3 +159,17 @@ def test_vectorised_prefill_attention_equals_rowwise_restatement():
     assert bf16_ulp_diff(a, b_) <= 1
     assert (bf16_bits(a) == bf16_bits(b_)).mean() > 0.999
 
+
+def test_bf16_round_c_helper_equals_the_numpy_statement():
+    """oracle/bf16_round.c (one pass, OpenMP; used for arrays >= 64 K elements when built) == the numpy statement of
+    __float2bfloat16 on random bit patterns, ties, infinities, NaNs of both signs and denormals."""
+    from oracle import bf16 as B
+    if B._native_round() is None:
+        pytest.skip("oracle/_native/libpegainfer_oracle.so not built (make -C oracle)")
+    rng = np.random.default_rng(3)
+    u = rng.integers(0, 2 ** 32, B._NATIVE_MIN * 8, dtype=np.uint64).astype(np.uint32)
+    u[:8] = [0x3F808000, 0x3F818000, 0x7F800000, 0xFF800000, 0x7FC12345, 0xFFC00001, 0x00000001, 0x80008000]
+    x = u.view(np.float32)
+    a, b = B.bf16_round(x), B._bf16_round_numpy(x)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert np.array_equal(B.bf16_round(x[:1000]).view(np.uint32), b[:1000].view(np.uint32))       # small arrays: numpy path
