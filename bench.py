@@ -554,8 +554,7 @@ def cpu_leg_qwen35(cfg, tensors, prompt, gpu_tokens, gpu_rows, hf_threads, cores
         w = {k: (v if v.dtype == np.float32 else bf16_from_bits(v)) for k, v in tensors.items()}
         feed = gpu_tokens[:-1]
         t0 = time.perf_counter()
-        R = par.qwen35_pass(oc, w, prompt, feed, exact=False, max_pos=len(prompt) + len(feed) + 16)
-        T_ = par.qwen35_pass(oc, w, prompt, feed, exact=True, max_pos=len(prompt) + len(feed) + 16)
+        R, T_ = par.qwen35_pass_pair(oc, w, prompt, feed, max_pos=len(prompt) + len(feed) + 16)   # both passes side by side
         dv = par.derived(gpu_rows[:len(R)], R, T_)
         ok, agree, margin, dmax = par.near_tie_ok(gpu_rows[:len(R)], R, R)
         parity["oracle"] = {"engine": "oracle/qwen35_ref.py teacher-forced on the GPU's greedy tokens (prefill + every decode step)",

@@ -10,23 +10,29 @@ import contextlib
 
 import numpy as np
 
-_EXACT = [False]
+import threading
+
+_EXACT = threading.local()   # per THREAD (round 6): the bf16 and the fp32-truth pass of one model run side by side (oracle/parity.py)
+
+
+def _exact_on():
+    return getattr(_EXACT, "on", False)
 
 
 @contextlib.contextmanager
 def exact_activations():
-    """The "fp32 truth" pass of the parity tests: inside this context ``bf16_round`` is the identity,
-    so an oracle built AND run here evaluates the same DAG on the same bf16 weights with no activation rounding at all
-    (fp32 storage, fp32 / fp64 accumulation, unrounded RoPE tables).  It is what both the bf16 oracle and the HIP path
+    """The "fp32 truth" pass of the parity tests: inside this context - in THIS thread - ``bf16_round`` is
+    the identity, so an oracle built AND run here evaluates the same DAG on the same bf16 weights with no activation rounding at
+    all (fp32 storage, fp32 / fp64 accumulation, unrounded RoPE tables).  It is what both the bf16 oracle and the HIP path
     approximate; ``err(engine vs truth) <= c * err(bf16 oracle vs truth)`` separates summation-order noise (c ~ 1) from a
     wrong or missing rounding point / a wrong kernel route (c >> 1) without a hand-picked tolerance.  Checkpoints must be
     generated OUTSIDE the context (weights stay bf16-valued)."""
-    old = _EXACT[0]
-    _EXACT[0] = True
+    old = _exact_on()
+    _EXACT.on = True
     try:
         yield
     finally:
-        _EXACT[0] = old
+        _EXACT.on = old
 
 
 _NATIVE = [None, False]   # (ctypes function or None, looked for already)
@@ -69,7 +75,7 @@ def bf16_round(x):
     torch's threaded conversion: 5 x faster on 8 cores, 30-75 % SLOWER passes on the 256-core GPU hosts; and a chunked numpy
     thread pool: no faster, the five numpy passes are memory-bound.)"""
     x = np.ascontiguousarray(x, dtype=np.float32)
-    if _EXACT[0]:
+    if _exact_on():
         return x
     if x.size >= _NATIVE_MIN:
         nat = _native_round()

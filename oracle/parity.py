@@ -81,13 +81,20 @@ def oracle_mode(exact):
         O.GEMM_ACCUM = old
 
 
-def qwen3_pass(cfg, w, prompts, feeds, exact, taps=False, max_pos=4096):
+@contextlib.contextmanager
+def _thread_mode(exact):
+    """inside a concurrent pair: only the per-thread part of oracle_mode (the shared GEMM_ACCUM is set by the pair's caller)"""
+    with (exact_activations() if exact else contextlib.nullcontext()):
+        yield
+
+
+def qwen3_pass(cfg, w, prompts, feeds, exact, taps=False, max_pos=4096, _set_mode=True):
     """Qwen3 oracle / truth pass: prompts (list of token lists) prefilled as ONE batch, then len(feeds[0]) decode steps
     teacher-forced on feeds[r][s].  -> rows [n_req, 1 + steps, V] (and, with taps, a list per step of [L, n_req, H])"""
     from .qwen3_ref import KvState, Qwen3Oracle
     n, steps = len(prompts), len(feeds[0]) if feeds else 0
     pages = sum(-(-(len(p) + steps) // 16) for p in prompts) + 8
-    with oracle_mode(exact):
+    with (oracle_mode(exact) if _set_mode else _thread_mode(exact)):
         orc = Qwen3Oracle(cfg, w, num_pages=pages, rope_positions=max_pos)
         sts = [KvState() for _ in prompts]
         tap_steps = []
@@ -106,10 +113,36 @@ def qwen3_pass(cfg, w, prompts, feeds, exact, taps=False, max_pos=4096):
     return (out, tap_steps) if taps else out
 
 
-def qwen35_pass(cfg, w, prompt, feed, exact, taps=False, max_pos=2048):
+def _pair(fn):
+    """bf16 pass and fp32-truth pass of the same model SIDE BY SIDE on two threads (round 6): `exact_activations` is per thread,
+    GEMM_ACCUM is the same for both (set once around the pair), numpy releases the GIL inside BLAS and its large element-wise
+    kernels - on the pool's 256-core hosts the two ~75 s passes of a 36-layer model then cost the wall time of one.  Same
+    functions, same arguments: the same bits as two calls in a row (tests/test_depth_harness.py compares)."""
+    from concurrent.futures import ThreadPoolExecutor
+    old = O.GEMM_ACCUM
+    O.GEMM_ACCUM = np.float32
+    try:
+        with ThreadPoolExecutor(max_workers=2) as ex:
+            fo, ft = ex.submit(fn, False), ex.submit(fn, True)
+            return fo.result(), ft.result()
+    finally:
+        O.GEMM_ACCUM = old
+
+
+def qwen3_pass_pair(cfg, w, prompts, feeds, taps=False, max_pos=4096):
+    """(oracle result, truth result) of qwen3_pass, computed concurrently"""
+    return _pair(lambda exact: qwen3_pass(cfg, w, prompts, feeds, exact, taps=taps, max_pos=max_pos, _set_mode=False))
+
+
+def qwen35_pass_pair(cfg, w, prompt, feed, taps=False, max_pos=2048):
+    """(oracle result, truth result) of qwen35_pass, computed concurrently"""
+    return _pair(lambda exact: qwen35_pass(cfg, w, prompt, feed, exact, taps=taps, max_pos=max_pos, _set_mode=False))
+
+
+def qwen35_pass(cfg, w, prompt, feed, exact, taps=False, max_pos=2048, _set_mode=True):
     """Qwen3.5 oracle / truth pass on one request -> rows [1 + steps, V] (and taps: per step [L, 1, H])"""
     from .qwen35_ref import Qwen35Oracle
-    with oracle_mode(exact):
+    with (oracle_mode(exact) if _set_mode else _thread_mode(exact)):
         orc = Qwen35Oracle(cfg, w, num_pages=(len(prompt) + len(feed)) // 16 + 8, rope_positions=max_pos)
         st = orc.new_request()
         tap_steps = []

@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 from oracle.parity import (AGG_MAX, STEP_MAX, assert_derived, cos_rows, derived, layer_curve, near_tie_ok,  # noqa: F401
-                           oracle_mode, qwen3_pass, qwen35_pass, rms_rows)
+                           oracle_mode, qwen3_pass, qwen3_pass_pair, qwen35_pass, qwen35_pass_pair, rms_rows)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 

@@ -310,3 +310,15 @@ def test_a_sharp_attention_fixture_is_chaotic_not_sharp_eyed(sharp1024):
     for name in ("causal mask +1 (one future token visible)", "KV page of another request in the table"):
         d = dc.derived(_faulty(s, FAULTS[name]), s["oracle"], s["truth"])
         assert d["ratio_pooled"] < 1.5, (name, d["ratio_pooled"])
+
+
+def test_concurrent_pass_pair_equals_two_passes_in_a_row(small):
+    """oracle/parity.py runs the bf16 pass and the fp32-truth pass of a model side by side on two threads (the exact-activation
+    switch is per thread): same rows and taps, bit for bit, as the two calls one after the other."""
+    s = small
+    (orc, otaps), (tru, ttaps) = dc.qwen3_pass_pair(s["cfg"], s["w"], s["prompts"], s["feeds"], taps=True)
+    assert np.array_equal(orc, s["oracle"]) and np.array_equal(tru, s["truth"])
+    assert all(np.array_equal(a, b) for a, b in zip(otaps, s["otaps"])) and all(np.array_equal(a, b) for a, b in zip(ttaps, s["ttaps"]))
+    assert not np.array_equal(orc, tru)
+    x = np.float32([1.0 + 2.0 ** -10])
+    assert not np.array_equal(bf16_round(x), x)          # the caller's thread is back in bf16 mode

@@ -162,11 +162,9 @@ def oracle36(ckpt36, engine36):
     prompts = [d["prompt"]] + [d["short"][n] for n in dc.SHORT_LENS] + [d["short"][n] for n in dc.SHORT_HF]
     feeds = ([d["meta"]["hf_tokens"][:N_STEPS]] + [engine36["short_tokens"][n][:N_STEPS] for n in dc.SHORT_LENS] +
              [d["short_meta"]["cases"][str(n)]["hf_tokens"][:N_STEPS] for n in dc.SHORT_HF])
-    orc, otaps = dc.qwen3_pass(d["cfg"], d["w"], prompts, feeds, exact=False, taps=True)
-    _timed("oracle36_bf16", t0)
-    t0 = time.time()
-    tru, ttaps = dc.qwen3_pass(d["cfg"], d["w"], prompts, feeds, exact=True, taps=True)
-    _timed("oracle36_truth", t0)
+    # the bf16 pass and the fp32-truth pass run side by side on two threads (oracle/parity.py: same bits as one after the other)
+    (orc, otaps), (tru, ttaps) = dc.qwen3_pass_pair(d["cfg"], d["w"], prompts, feeds, taps=True)
+    _timed("oracle36_pair", t0)
     col = {"p1024": 0}
     col.update({("short", n): 1 + i for i, n in enumerate(dc.SHORT_LENS)})
     col.update({("hf", n): 1 + len(dc.SHORT_LENS) + i for i, n in enumerate(dc.SHORT_HF)})

@@ -104,11 +104,9 @@ def test_qwen3_8b_full_depth_greedy_and_topk_topp_sampling(built_libs):
         w = dict(zip(names, pool.map(lambda k: bf16_from_bits(bits[k]), names)))
     del bits
     cfg = Qwen3Config(**CFG8)
-    ref = dc.qwen3_pass(cfg, w, [prompt], [toks[:N_STEPS8]], exact=False)[0]
-    _timed("oracle8b_bf16", t0)
-    t0 = time.time()
-    tru = dc.qwen3_pass(cfg, w, [prompt], [toks[:N_STEPS8]], exact=True)[0]
-    _timed("oracle8b_truth", t0)
+    ref, tru = dc.qwen3_pass_pair(cfg, w, [prompt], [toks[:N_STEPS8]])      # both passes side by side on two threads
+    ref, tru = ref[0], tru[0]
+    _timed("oracle8b_pair", t0)
     runs = {"A": rows_a, "B": rows_b, "C": rows_c, "E_no_oproj_attempt": rows_e}
     got = bf16_from_bits(rows_b)
     dv = dc.derived(got, ref, tru)

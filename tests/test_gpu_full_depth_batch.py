@@ -108,11 +108,8 @@ def oracle_rows(ckpt):
     t0 = time.time()
     d = ckpt
     prompts, feeds = [d["prompts"][n] for n in LENS], [d["feeds"][n] for n in LENS]
-    orc = dc.qwen3_pass(d["cfg"], d["w"], prompts, feeds, exact=False)
-    _timed("batch_oracle36_bf16", t0)
-    t0 = time.time()
-    tru = dc.qwen3_pass(d["cfg"], d["w"], prompts, feeds, exact=True)
-    _timed("batch_oracle36_truth", t0)
+    orc, tru = dc.qwen3_pass_pair(d["cfg"], d["w"], prompts, feeds)     # both passes side by side on two threads
+    _timed("batch_oracle36_pair", t0)
     return dict(oracle=orc, truth=tru)                 # [16, 1 + STEPS, V] each
 
 

@@ -86,11 +86,8 @@ def depth35(built_libs):
         eng.close()
     _timed("engine35", t0)
     t0 = time.time()
-    out["oracle"], out["otaps"] = dc.qwen35_pass(cfg, w, prompt, feed, exact=False, taps=True)
-    _timed("oracle35_bf16", t0)
-    t0 = time.time()
-    out["truth"], out["ttaps"] = dc.qwen35_pass(cfg, w, prompt, feed, exact=True, taps=True)
-    _timed("oracle35_truth", t0)
+    (out["oracle"], out["otaps"]), (out["truth"], out["ttaps"]) = dc.qwen35_pass_pair(cfg, w, prompt, feed, taps=True)   # side by side
+    _timed("oracle35_pair", t0)
     return out
 
 
