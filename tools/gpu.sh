@@ -61,6 +61,7 @@ case $verb in
     ;;
   kt)
     name=$1; shift
+    export PEGAINFER_BENCH_TRAFFIC=0     # no nested rocprofv3 (bench.py's live traffic probe) under the tracer
     cd /tmp && export TMPDIR=/tmp
     rm -rf /tmp/prof_$name
     (cd $repo && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_$name -o run -- python "$@" > /tmp/prof_$name.log 2>&1)
@@ -72,6 +73,7 @@ case $verb in
   pmc)
     name=$1; ctr=$2; shift 2
     [ "$ctr" = SQ ] && ctr=$SQ
+    export PEGAINFER_BENCH_TRAFFIC=0
     cd /tmp && export TMPDIR=/tmp
     rm -rf /tmp/pmc_$name
     (cd $repo && timeout 600 rocprofv3 --pmc $ctr --kernel-trace -d /tmp/pmc_$name -o run -- python "$@" > /tmp/pmc_$name.log 2>&1)
