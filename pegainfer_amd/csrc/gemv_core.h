@@ -77,11 +77,7 @@ constexpr int kGemvNormAllWaves = 32;   // launcher-only bit (PEGAINFER_GEMV_NOR
 // U = K blocks a wave keeps in flight per row (U*NW*RPW loads of 1 KB).  The launcher picks U = 5 when that covers a
 // whole row (K = 2560: 5 blocks; K = 9728 dealt to 4 waves: 5, 5, 5, 4), so a row group needs ONE memory round trip
 // instead of "four blocks, then a dependent fifth"; the per-(row, token) block order is the same for every U.
-// PRO = 1 (round 6, norm sites at 1-2 columns only; a.norm_w != null guaranteed by the launcher): the wave that sums a token
-// row's squares takes that row (and the residual row) STRAIGHT INTO REGISTERS, issued next to the LDS-DMAs, and sums from
-// registers as soon as its loads have landed - no LDS read round trips in front of the fma chains, no barrier in front of the
-// sum (the first barrier now also waits for the sum).  Same canonical order (lane l: vectors l, l + 64, ...): same bits.
-template <int NT, int RPW, int KSPLIT, int EPI, int U = 4, int PRO = 0>
+template <int NT, int RPW, int KSPLIT, int EPI, int U = 4>
 __global__ __launch_bounds__(256) void gemv_fused_kernel(const GemvFusedArgs a) {
   const int KT = a.KT;
   constexpr int NW = EPI == kEpiSilu ? 2 : 1;  // weight row sets streamed together
@@ -216,67 +212,6 @@ __global__ __launch_bounds__(256) void gemv_fused_kernel(const GemvFusedArgs a) 
         }
       }
     }
-    if constexpr (PRO == 1) {
-      constexpr int XV = 8;                       // 64 x 8 vectors: rows of <= 4096 elements (the launcher checks)
-      u32x4 hx[XV], rx[XV];
-      int myt = -1;                               // the token row this wave sums (NT <= 2 of the 4 waves sum)
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-        if (t < T && wave == ((w0 + t) & 3)) myt = t;
-      if (myt >= 0) {
-        const u32x4* xr = reinterpret_cast<const u32x4*>(a.X + (size_t)myt * K);
-        const u32x4* rr = reinterpret_cast<const u32x4*>(a.residual ? a.residual + (size_t)myt * K : a.X + (size_t)myt * K);
-#pragma unroll
-        for (int k = 0; k < XV; ++k) {
-          const int c = lane + 64 * k;
-          if (c < nvec_row) { hx[k] = xr[c]; rx[k] = rr[c]; }
-        }
-      }
-      issue(0, kt0, bfirst);
-      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(U * NW * RPW) : "memory");   // everything older than the weight group has landed
-      PK_GEMV_STAMP(a, 6);
-      if (myt >= 0) {
-        float ss = 0.f;
-#pragma unroll
-        for (int k = 0; k < XV; ++k) {
-          if (lane + 64 * k < nvec_row) {
-            if (a.residual && round_sum) add_round_sq8(hx[k], rx[k], ss);
-            else if (a.residual) add_sq8(hx[k], rx[k], ss);
-            else sq8(hx[k], ss);
-          }
-        }
-        ss = wave_sum(ss);
-        const float v = rsqrtf(__fadd_rn(ss / (float)K, a.eps));
-        if (lane == 0) red[myt] = v;
-      }
-      __syncthreads();       // every wave's DMAs have landed AND the inverse RMS values are in LDS
-      PK_GEMV_STAMP(a, 7);
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-        if (t < T) inv[t] = red[t];
-#pragma unroll
-      for (int i = 0; i < XP; ++i) {
-        const int c = cvec[i];
-        if (c < nvec_row) {
-#pragma unroll
-          for (int t = 0; t < NT; ++t) {
-            if (t >= T) continue;
-            const u32x4 h = xs[t * pitch + c];
-            u32x4 v;
-            if (a.residual) {
-              const u32x4 r = rs[t * pitch + c];
-              u32x4 nh;
-              v = norm_scale8(h, &r, gx[i], inv[t], nbias, &nh, round_sum);
-              if (blockIdx.x == 0) reinterpret_cast<u32x4*>(a.hidden_out + (size_t)t * K)[c] = nh;
-            } else {
-              v = norm_scale8(h, nullptr, gx[i], inv[t], nbias, nullptr);
-            }
-            xs[t * pitch + c] = v;
-          }
-        }
-      }
-      __syncthreads();
-    } else {
     issue(0, kt0, bfirst);
     // the U * NW * RPW weight loads issued last may stay in flight; everything older (the DMAs) has landed
     asm volatile("s_waitcnt vmcnt(%0)" :: "n"(U * NW * RPW) : "memory");
@@ -329,7 +264,6 @@ __global__ __launch_bounds__(256) void gemv_fused_kernel(const GemvFusedArgs a) 
       }
       __syncthreads();
     }
-    }   // PRO == 0
   } else {
   issue(0, kt0, bfirst);  // weights first; the x-side loads queue behind them (wide-batch / tiled-x forms)
   // per-token inverse RMS (canonical one-wave-per-row order), only when a norm weight is given:
@@ -477,13 +411,13 @@ __global__ __launch_bounds__(256) void gemv_fused_kernel(const GemvFusedArgs a) 
 // Grid sizing: every workgroup should be co-resident (no second, half-empty scheduling round) and all of them
 // should walk the same number of row groups.  capacity = occupancy(kernel, lds) x CU count; rounds =
 // ceil(ngroups / capacity); grid = ceil(ngroups / rounds).  K > KT (multi-tile x) needs one group per workgroup.
-template <int NT, int RPW, int KSPLIT, int EPI, int U = 4, int PRO = 0>
+template <int NT, int RPW, int KSPLIT, int EPI, int U = 4>
 inline void gemv_launch_one(const GemvFusedArgs& a, hipStream_t s) {
   constexpr int ROWS_PER_GROUP = (KSPLIT == 1 ? 4 : 1) * RPW;
   const int rows = EPI == kEpiSilu ? a.I : a.M;
   const int ngroups = ceil_div(rows, ROWS_PER_GROUP);
   const int lds = gemv_lds_bytes<NT, RPW, KSPLIT, EPI>(a.K, a.KT, a.residual != nullptr);
-  auto kern = &gemv_fused_kernel<NT, RPW, KSPLIT, EPI, U, PRO>;
+  auto kern = &gemv_fused_kernel<NT, RPW, KSPLIT, EPI, U>;
   static const bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
   (void)once;
@@ -541,21 +475,6 @@ inline void gemv_launch_nt(const GemvFusedArgs& a, hipStream_t s) {
   // (PEGAINFER_GEMV_U5=0: the four-then-one form, for A/B runs); wider batches keep U = 4 (register budget)
   static const bool u5 = [] { const char* e = getenv("PEGAINFER_GEMV_U5"); return !(e && *e == '0'); }();
   const int nblk = (a.K + 511) >> 9;
-  // (round 6) norm sites at 1-2 columns whose x block is resident: the register-sum prologue (PRO = 1; PEGAINFER_GEMV_REGSUM=0: A/B)
-  static const bool regsum = [] { const char* e = getenv("PEGAINFER_GEMV_REGSUM"); return !(e && *e == '0'); }();
-  const bool pro = NT <= 2 && regsum && a.norm_w && a.K <= a.KT && (a.K & 511) == 0 && (a.K >> 3) <= 512;
-  if constexpr (NT <= 2) {
-    if (pro) {
-      if (a.K >= 4096) {
-        if (u5 && (nblk + 3) / 4 == 5) gemv_launch_one<NT, RPW, 4, EPI, 5, 1>(a, s);
-        else gemv_launch_one<NT, RPW, 4, EPI, 4, 1>(a, s);
-      } else {
-        if (u5 && nblk == 5) gemv_launch_one<NT, RPW, 1, EPI, 5, 1>(a, s);
-        else gemv_launch_one<NT, RPW, 1, EPI, 4, 1>(a, s);
-      }
-      return;
-    }
-  }
   if (a.K >= 4096) {
     if (NT <= 2 && u5 && a.K <= a.KT && (nblk + 3) / 4 == 5) gemv_launch_one<NT, RPW, 4, EPI, (NT <= 2 ? 5 : 4)>(a, s);
     else gemv_launch_one<NT, RPW, 4, EPI>(a, s);
