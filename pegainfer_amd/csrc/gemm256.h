@@ -663,7 +663,10 @@ enum { kG128A = 0, kG128Blo = 1, kG128Bhi = 2 };
 // wave-row-0 wave; the eight compute waves issue none.  A DMA instruction costs its wave ~133 cycles of issue slot
 // (tools/probes/ingest_probe) - six per wave and K tile were 800 cycles next to 32 MFMAs = 512.  159 VGPRs: three waves
 // per SIMD fit.  NF = 0: the round-3 form (every wave stages its share), kept for the A/B (PEGAINFER_GEMM128X256_FEED=0).
-template <bool SILU, int NF>
+// MT (round 6) = 16-row MFMA tiles per wave row: 4 = the 128-row tile; 3 = a 96-row tile (plain NF = 4 form only) for
+// matrices whose 128-row tiling leaves CUs idle - the stacked qkv at 768 / 1024 tokens: 144 / 192 tiles of 128 rows, 192 / 256
+// of 96.  Same per-element K order: same bits.
+template <bool SILU, int NF, int MT = 4>
 __global__ __launch_bounds__(512 + NF * 64) void mfma_gemm128x256_kernel(const Half* __restrict__ W, const Half* __restrict__ X,
                                                                Half* __restrict__ Y, int M, int T, int K, int m_tiles,
                                                                int t_tiles, SplitOut so, float* __restrict__ part,
@@ -676,13 +679,17 @@ __global__ __launch_bounds__(512 + NF * 64) void mfma_gemm128x256_kernel(const H
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
   const int mt = tile / t_tiles, tt = tile - mt * t_tiles;
-  const int m0 = mt * G128_BM, t0 = tt * G256_BT;
+  constexpr int BMT = 32 * MT;            // W rows per tile
+  const int m0 = mt * BMT, t0 = tt * G256_BT;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int wr = wave >> 2, wc = wave & 3;
   const int l15 = lane & 15, g = lane >> 4;
 
   constexpr int NI = NF ? NF : 8;           // waves that issue DMAs
   constexpr int PPW = 16 / NI;              // 1 KiB pieces per issuing wave and half-tile
+  constexpr int PPA = 4 * MT / NI;          // ... of the A half-tile (32 * MT rows = 4 * MT pieces)
+  constexpr int HT = MT / 2;                // SwiGLU form: gate m-tiles per wave row (their up rows are the wave row's other half)
+  static_assert((4 * MT) % NI == 0 && (MT % 2 == 0 || !SILU), "the SwiGLU form pairs m-tiles: an even count per wave row");
   const bool feeder = NF && wave >= 8;
   const int wi = NF ? wave - 8 : wave;      // index among the issuing waves (compute waves of the NF form: negative, unused)
   const Half* src[3][PPW];
@@ -690,12 +697,13 @@ __global__ __launch_bounds__(512 + NF * 64) void mfma_gemm128x256_kernel(const H
   for (int j = 0; j < PPW; ++j) {
     const int p = (j * NI + (wi < 0 ? 0 : wi)) * 64 + lane, hrow = p >> 3, cs = (p & 7) ^ (hrow & 7);
     int row;
-    if (SILU) {   // a wave row's m-tiles 0, 1 are 32 gate rows, 2, 3 their 32 up rows: gate and up of an element meet in one lane
-      int gr = so.silu_c0 + mt * 64 + (hrow >> 6) * 32 + ((hrow >> 4) & 1) * 16 + (hrow & 15);
+    if (SILU) {   // a wave row's m-tiles 0 .. HT-1 are 16 * HT gate rows, HT .. MT-1 their up rows: gate and up of an element meet in one lane
+      const int hr = hrow < BMT ? hrow : BMT - 1, wrow = hr / (16 * MT), ti = (hr >> 4) - wrow * MT, up = ti >= HT;
+      int gr = so.silu_c0 + mt * (16 * MT) + wrow * (16 * HT) + (ti - (up ? HT : 0)) * 16 + (hr & 15);
       gr = gr < silu_cols_end(so) ? gr : silu_cols_end(so) - 1;
-      row = gr + (((hrow >> 4) & 2) ? so.silu_I : 0);
+      row = gr + (up ? so.silu_I : 0);
     } else {
-      row = m0 + hrow;
+      row = m0 + (hrow < BMT ? hrow : BMT - 1);
       row = row < M ? row : M - 1;
     }
     src[kG128A][j] = W + (size_t)row * K + cs * 8;
@@ -723,6 +731,7 @@ __global__ __launch_bounds__(512 + NF * 64) void mfma_gemm128x256_kernel(const H
     const uint32_t slot = lds0 + (uint32_t)((ring * 3 + which) * kG256HalfBytes);
 #pragma unroll
     for (int j = 0; j < PPW; ++j) {
+      if (which == kG128A && j >= PPA) break;
       const uint32_t dst = __builtin_amdgcn_readfirstlane(slot + (uint32_t)(j * NI + wi) * 1024u);
       if (which == kG128A && so.w_nt)   // a single token tile: W bytes have one reader (SplitOut::w_nt)
         asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt"
@@ -734,19 +743,19 @@ __global__ __launch_bounds__(512 + NF * 64) void mfma_gemm128x256_kernel(const H
   };
   auto half_ptr = [&](int ring, int which) { return g256_smem + (size_t)(ring * 3 + which) * (kG256HalfBytes / 16); };
 
-  f32x4 acc[4][4];
+  f32x4 acc[MT][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  bf16x8_t a[4][2], b[2][2];
+  bf16x8_t a[MT][2], b[2][2];
   auto read_a = [&](int ring) {
     const u32x4* h = half_ptr(ring, kG128A);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
-        a[i][ks] = __builtin_bit_cast(bf16x8_t, h[lds_slot(wr * 64 + i * 16 + l15, ks * 4 + g)]);
+        a[i][ks] = __builtin_bit_cast(bf16x8_t, h[lds_slot(wr * (16 * MT) + i * 16 + l15, ks * 4 + g)]);
   };
   auto read_b = [&](int ring, int which) {
     const u32x4* h = half_ptr(ring, which);
@@ -761,14 +770,14 @@ __global__ __launch_bounds__(512 + NF * 64) void mfma_gemm128x256_kernel(const H
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           acc[i][jh * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][ks], b[j][ks], acc[i][jh * 2 + j], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
   };
 
-  constexpr int kTileDmas = 3 * PPW;        // DMAs per issuing wave and K tile: the counted wait leaves one tile in flight
+  constexpr int kTileDmas = PPA + 2 * PPW;  // DMAs per issuing wave and K tile: the counted wait leaves one tile in flight
   if (feeder) {
     // the whole staging side, in the barrier rhythm of a wave-row-0 wave (the EARLIEST any wave of the round-3 form touched
     // a ring slot, so the hazards are the ones argued above): A + B_lo of tile kt + 2 in phase 1, B_hi in phase 2
@@ -833,19 +842,19 @@ __global__ __launch_bounds__(512 + NF * 64) void mfma_gemm128x256_kernel(const H
   if constexpr (NF == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail loads must not outlive the workgroup's LDS
   if (wr == 0) __builtin_amdgcn_s_barrier();
 
-  if (SILU) {
+  if constexpr (SILU) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int t = t0 + wc * 64 + j * 16 + l15;
       if (t >= T) continue;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int m = so.silu_c0 + mt * 64 + wr * 32 + i * 16 + g * 4;
+      for (int i = 0; i < HT; ++i) {
+        const int m = so.silu_c0 + mt * (16 * MT) + wr * (16 * HT) + i * 16 + g * 4;
         float r[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {  // the GEMM output is bf16 before SwiGLU (fused_proj.cu:57-62)
           const float sg = silu_f(bf16_round_f(acc[i][j][e]));
-          r[e] = (so.silu_round ? bf16_round_f(sg) : sg) * bf16_round_f(acc[i + 2][j][e]);
+          r[e] = (so.silu_round ? bf16_round_f(sg) : sg) * bf16_round_f(acc[i + HT][j][e]);
         }
         if (m + 3 < silu_cols_end(so)) {
           u32x2 o;
@@ -868,8 +877,8 @@ __global__ __launch_bounds__(512 + NF * 64) void mfma_gemm128x256_kernel(const H
       const int t = t0 + wc * 64 + j * 16 + l15;
       if (t >= T) continue;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wr * 64 + i * 16 + g * 4;
+      for (int i = 0; i < MT; ++i) {
+        const int m = m0 + wr * (16 * MT) + i * 16 + g * 4;
         if (m + 3 < M) {
           *reinterpret_cast<f32x4*>(pz + (size_t)t * M + m) = acc[i][j];
         } else {
@@ -886,8 +895,8 @@ __global__ __launch_bounds__(512 + NF * 64) void mfma_gemm128x256_kernel(const H
     const int t = t0 + wc * 64 + j * 16 + l15;
     if (t >= T) continue;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = m0 + wr * 64 + i * 16 + g * 4;
+    for (int i = 0; i < MT; ++i) {
+      const int m = m0 + wr * (16 * MT) + i * 16 + g * 4;
       Half* dst = Y;
       int ld = M, mm = m, mlim = M;
       if (so.Y1) {
@@ -918,17 +927,29 @@ inline bool gemm128x256_feed_on() {
   static const bool v = [] { const char* e = getenv("PEGAINFER_GEMM128X256_FEED"); return !(e && e[0] == '0'); }();
   return v;
 }
-template <bool SILU, int NF>
+template <bool SILU, int NF, int MT = 4>
 inline void gemm128x256_launch_nf(const Half* W, const Half* X, Half* Y, int M, int T, int K, const SplitOut& so, float* part,
                                   int ksplit, int nk_slice, int m_tiles, int t_tiles, hipStream_t s) {
   static const bool once = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_gemm128x256_kernel<SILU, NF>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_gemm128x256_kernel<SILU, NF, MT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, kG128LdsBytes);
     return true;
   }();
   (void)once;
-  mfma_gemm128x256_kernel<SILU, NF><<<dim3(m_tiles * t_tiles, part ? ksplit : 1), 512 + NF * 64, kG128LdsBytes, s>>>(
+  mfma_gemm128x256_kernel<SILU, NF, MT><<<dim3(m_tiles * t_tiles, part ? ksplit : 1), 512 + NF * 64, kG128LdsBytes, s>>>(
       W, X, Y, M, T, K, m_tiles, t_tiles, so, part, nk_slice);
+}
+// 96-row tiles (MT = 3), plain un-split feeder form: see the kernel's header
+inline void gemm96x256_launch(const Half* W, const Half* X, Half* Y, int M, int T, int K, SplitOut so, hipStream_t s) {
+  const int t_tiles = ceil_div(T, G256_BT);
+  so.w_nt = t_tiles == 1 && weights_nt_on();
+  gemm128x256_launch_nf<false, 4, 3>(W, X, Y, M, T, K, so, nullptr, 1, 0, ceil_div(M, 96), t_tiles, s);
+}
+// SwiGLU form on 64-row tiles (MT = 2: 16 gate rows + their 16 up rows per wave row): the thin tail behind the 256 x 256 round
+inline void gemm64x256_silu_launch(const Half* W, const Half* X, Half* Y, int M, int T, int K, SplitOut so, hipStream_t s) {
+  const int t_tiles = ceil_div(T, G256_BT);
+  so.w_nt = t_tiles == 1 && weights_nt_on();
+  gemm128x256_launch_nf<true, 4, 2>(W, X, Y, M, T, K, so, nullptr, 1, 0, ceil_div(silu_cols_end(so) - so.silu_c0, 32), t_tiles, s);
 }
 inline void gemm128x256_launch(const Half* W, const Half* X, Half* Y, int M, int T, int K, SplitOut so, float* part,
                                int ksplit, int nk_slice, hipStream_t s) {

@@ -547,6 +547,22 @@ static bool gemm128x256_on() {
   static const bool v = [] { const char* e = getenv("PEGAINFER_GEMM128X256"); return !(e && e[0] == '0'); }();
   return v;
 }
+// (round 6) Plain prefill GEMMs of >= 512 tokens WITHOUT a K-split plan whose 128 x 256 tiling is ONE partly filled round: 1283 = the
+// same round on 96 x 256 tiles (feeder kernel, gemm256.h) when those fill more of the chip, 0 = no.  The stacked qkv at 768 / 1024
+// tokens is 144 / 192 tiles of 128 rows, 192 / 256 of 96: 35.9 -> 31.5 / 37.8 -> 33.9 us, same bits; TTFT(768 / 1024) 7.90 -> 7.77 /
+// 9.85 -> 9.75 ms same-box (profiles/r6_gemm96_ab.txt, r6_small_tiles_ttft_ab2.txt).  PEGAINFER_GEMM_SMALL_TILES=0 switches it off.
+// Two wider forms of the rule were measured and NOT kept - both look 10-30 % faster per GEMM with L2-hot weights
+// (tools/bench_prefill_gemm.py at 1 weight copy, profiles/r6_gemm_force_sweep.txt) and are slower in the model, where weights come
+// from HBM: (a) over the K-split plans of o_proj / down_proj at 1536 .. 3072 tokens (whose slice sum also carries the residual add +
+// RMSNorm): TTFT(1536 / 2048) +1 / +3 % (r6_small_tiles_ttft_ab.txt); (b) several rounds of small tiles instead of 1.1-1.5 rounds
+// of 256 x 256 (qkv at 3072 / 4096 tokens): TTFT +2.7 / +1.7 % (r6_small_tiles_ttft_ab2.txt).
+static int small_tile_unsplit(int M, int T, int K) {
+  static const bool on = [] { const char* e = getenv("PEGAINFER_GEMM_SMALL_TILES"); return !(e && e[0] == '0'); }();
+  if (!on || !gemm128x256_on() || !gemm128x256_feed_on() || !gemm128x256_ok(M, T, K) || T < 512) return 0;
+  const int cus = device_cus(), tt = ceil_div(T, G256_BT);
+  const long t96 = (long)ceil_div(M, 96) * tt, t128 = (long)ceil_div(M, G128_BM) * tt;
+  return t128 > 128 && t128 <= 256 && t96 <= cus && t96 > t128 ? 1283 : 0;
+}
 constexpr int kSplitKMaxRows = 16384;   // below this (< 128 row tiles) the 17..64-column GEMM splits K
 struct SplitKPlan { int ksplit, nk_slice, tt; };
 static SplitKPlan splitk_plan(int M, int T, int K, bool assume_ws = false) {
@@ -656,6 +672,14 @@ static void glds_splitk_launch(const Half* W, const Half* X, Half* Y, int M, int
 // routing table is pinned by a CPU test: a threshold edit must not silently change what the GPU tests exercise).
 struct TiledRoute { int kind, m_head; };
 static TiledRoute tiled_route(int M, int T, int K, const SplitOut& so, bool assume_ws = false) {
+  // PEGAINFER_GEMM_FORCE=256 | 1280 | 1283 (A/B probe only): that un-split kernel for every plain GEMM it accepts
+  static const int force = [] { const char* e = getenv("PEGAINFER_GEMM_FORCE"); return e && *e ? atoi(e) : 0; }();
+  if (force && so.silu_I == 0 && T > 64) {
+    if (force == 256 && gemm256_ok(M, T, K)) return {256, 0};
+    if ((force == 1280 || force == 1283) && gemm128x256_ok(M, T, K)) return {force, 0};
+  }
+  if (so.silu_I == 0 && !force)
+    if (const int kind = small_tile_unsplit(M, T, K)) return {kind, 0};
   // long prompts: 256 x 256 tiles on the 8-phase schedule once they give every CU work (PEGAINFER_GEMM256 = 0 never,
   // 1 whenever the shape allows, N = from N tiles on; A/B probe knob)
   // from 128 tiles on (half the CUs): one partly filled round of 256 x 256 tiles still beats the smaller tilings -
@@ -731,13 +755,21 @@ static void glds_gemm_launch(const Half* W, const Half* X, Half* Y, int M, int T
       // 64-token tiles exactly when the 128-token tiling would give the tail fewer tiles than there are CUs
       static const int tail_env = [] { const char* e = getenv("PEGAINFER_GEMM256_TAIL_TT"); return e && *e ? atoi(e) : 0; }();
       const long tail_tiles128 = (long)ceil_div(so.silu_I - r.m_head * 128, 64) * ceil_div(T, 128);
-      const int tail_tt = tail_env ? tail_env : (tail_tiles128 < device_cus() ? 64 : 128);
-      if (tail_tt == 64) glds_gemm_launch_t<64, 3>(W, X, Y, M, T, K, tail, s);
+      // (round 6, profiles/r6_tail_feeder_ab.txt) the feeder form of the 128 x 256 kernel takes the tail: (64 + 64)-row SwiGLU
+      // tiles (tail_tt 4), or (32 + 32)-row ones (tail_tt 2) while those still fit one round - TTFT(1024) 9.99 -> 9.76 ms (192
+      // tiles of 64 rows), TTFT(2048) 17.82 -> 17.24 (192 tiles of 128 rows); 64 / 128 = the round-5 kernels, kept for the A/B
+      const long tail_tiles4 = (long)ceil_div(so.silu_I - r.m_head * 128, 64) * ceil_div(T, G256_BT);
+      const int tail_feeder = !gemm128x256_on() || !gemm128x256_feed_on() ? 0 : tail_tiles4 * 2 <= device_cus() ? 2 : 4;
+      const int tail_tt = tail_env ? tail_env : tail_feeder ? tail_feeder : (tail_tiles128 < device_cus() ? 64 : 128);
+      if (tail_tt == 2) gemm64x256_silu_launch(W, X, Y, M, T, K, tail, s);
+      else if (tail_tt == 4) gemm128x256_launch(W, X, Y, M, T, K, tail, nullptr, 1, 0, s);
+      else if (tail_tt == 64) glds_gemm_launch_t<64, 3>(W, X, Y, M, T, K, tail, s);
       else glds_gemm_launch_t<128, 2>(W, X, Y, M, T, K, tail, s);
       return;
     }
     if (r.kind == 258) { gemm256_streamk_launch(W, X, Y, M, T, K, so, g_splitk_ws, g_streamk_flags, device_cus(), s); return; }
     if (r.kind == 256) { gemm256_launch(W, X, Y, M, T, K, so, s); return; }
+    if (r.kind == 1283) { gemm96x256_launch(W, X, Y, M, T, K, so, s); return; }
     if (r.kind == 1280 || r.kind == 1281) { gemm128x256_launch(W, X, Y, M, T, K, so, nullptr, 1, 0, s); return; }
     // the plan said a 128-token stream tile exists; should a future plan / route change make the launcher refuse, fall
     // through to the 128-row kernel (same per-element K order) instead of leaving Y unwritten

@@ -37,8 +37,10 @@ def test_decode_family_is_not_routed_here(route):
     (129, (1064, 3, 14), (1064, 8, 8), (1064, 8, 19), (1281, 1, 0)),    # from 129 tokens on: the round-3 kernels
     (256, (23, 1, 0), (1064, 6, 11), (1064, 6, 26), (1281, 1, 0)),      # gate_up: SwiGLU form of the 128 x 256 kernel
     (512, (1129, 2, 20), (1129, 6, 11), (1129, 6, 26), (256, 1, 0)),    # gate_up: 152 tiles of 256 x 256, one round
-    (1024, (1280, 1, 0), (1129, 3, 22), (1129, 3, 51), (257, 1, 64)),   # the headline TTFT shape
+    (1024, (1283, 1, 0), (1129, 3, 22), (1129, 3, 51), (257, 1, 64)),   # the headline TTFT shape; qkv: 256 tiles of 96 x 256 (round 6)
     (2048, (256, 1, 0), (1256, 3, 22), (1256, 3, 52), (257, 1, 64)),
+    (768, (1283, 1, 0), (1129, 4, 16), (1129, 4, 38), (256, 1, 0)),     # round 6: qkv 192 tiles of 96 x 256 instead of 144 of 128 x 256
+    (3072, (256, 1, 0), (1256, 2, 32), (1256, 2, 76), (256, 1, 0)),
     (4096, (256, 1, 0), (256, 1, 0), (256, 1, 0), (256, 1, 0)),
     (10000, (256, 1, 0), (256, 1, 0), (256, 1, 0), (256, 1, 0)),
 ])
@@ -53,7 +55,7 @@ def test_qwen3_4b_projection_routes(route, T, qkv, o, down, gate_up):
     # round 6, behind pegainfer_debug_streamk(1) / PEGAINFER_STREAMK=1 (default OFF: measured slower, gemm256.h): kind 258 = stream-K
     # over the 256 x 256 tiles wherever a round of tiles would leave >= 8 % of the CU-rounds idle and a team of t_tiles fits an XCD
     (512, (1129, 2, 20), (1129, 6, 11), (1129, 6, 26), (258, 1, 0)),    # gate_up: 152 tiles for 256 CUs
-    (1024, (1280, 1, 0), (1129, 3, 22), (1129, 3, 51), (258, 1, 0)),    # 304 tiles (1.19 rounds)
+    (1024, (1283, 1, 0), (1129, 3, 22), (1129, 3, 51), (258, 1, 0)),    # 304 tiles (1.19 rounds)
     (2048, (258, 1, 0), (1256, 3, 22), (1256, 3, 52), (258, 1, 0)),     # qkv 192 tiles, gate_up 608 (2.4 rounds)
     (4096, (258, 1, 0), (258, 1, 0), (258, 1, 0), (256, 1, 0)),         # qkv 384 (1.5 rounds), o / down 160; gate_up 1216 = 4.75
     (10000, (256, 1, 0), (256, 1, 0), (256, 1, 0), (256, 1, 0)),        # 40 token tiles: a team would not fit an XCD (32 CUs)

@@ -75,8 +75,11 @@ def test_decode_gemv_and_gemm_kernels_keep_their_occupancy():
     # prefill: 8-wave 256 x 256 tiles need two waves per SIMD; the 128-tile LDS-DMA kernels two workgroups per CU
     check(md, r"mfma_gemm256_kernel<(true|false)>", 256, at_least=2)
     # round 3: 128 x 256 tiles (plain / split-K and SwiGLU forms), 8 waves = two per SIMD, 64 accumulators
-    check(md, r"mfma_gemm128x256_kernel<(true|false), 0>", 256, at_least=2)
-    check(md, r"mfma_gemm128x256_kernel<(true|false), 4>", 168, at_least=2)    # 8 compute + 4 feeder waves: three per SIMD
+    check(md, r"mfma_gemm128x256_kernel<(true|false), 0, 4>", 256, at_least=2)
+    check(md, r"mfma_gemm128x256_kernel<(true|false), 4, 4>", 168, at_least=2)    # 8 compute + 4 feeder waves: three per SIMD
+    # round 6: 96-row plain tiles (qkv at 768 / 1024 tokens) and (32 + 32)-row SwiGLU tiles (the gate_up tail), feeder form
+    check(md, r"mfma_gemm128x256_kernel<false, 4, 3>", 168)
+    check(md, r"mfma_gemm128x256_kernel<true, 4, 2>", 168)
     check(md, r"mfma_gemm_glds_kernel<\d+, \d, (true|false)>", 256, at_least=6)
     check(md, r"splitk_reduce\w*kernel", 256, at_least=3)
     # round 4: the weight-streaming GEMM (one workgroup per CU: 4 compute + 3..6 feeder waves; 64- / 128-token tiles): spill-free

@@ -17,6 +17,8 @@ from pegainfer_amd import ops  # noqa: E402
 
 SHAPES = [("qkv", 6144, 2560), ("o", 2560, 4096), ("gate_up", 19456, 2560), ("down", 2560, 9728),
           ("ragged", 1000, 2560)]
+if os.environ.get("PEGAINFER_PROBE_MODEL") == "8b":     # the Qwen3-8B projections
+    SHAPES = [("qkv", 6144, 4096), ("o", 4096, 4096), ("gate_up", 24576, 4096), ("down", 4096, 12288)]
 
 
 def main():
