@@ -397,6 +397,28 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   *reinterpret_cast<u32x2*>(dst + (size_t)t * ld + mm) = o;
 }
 
+// (round 6) un-split shapes of pegainfer_gemm_add_then_rms_norm: out = bf16(a + y), normed = rms_norm(out) * w in ONE pass over
+// the rows instead of add_cuda + rms_norm_batched_cuda (10 000 tokens: 25 + 22 us and 256 MB -> one launch, 205 MB).  One wave per
+// row, the canonical order of norm_core.h over the ROUNDED sum: the same bits as the two calls.  out may alias a.
+__global__ __launch_bounds__(256) void add_then_rms_norm_vec_kernel(const Half* a, const Half* __restrict__ y,
+                                                                    const Half* __restrict__ w, Half* out,
+                                                                    Half* __restrict__ normed, int d, int rows, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const Half* ar = a + (size_t)row * d;
+  const Half* yr = y + (size_t)row * d;
+  const float inv = wave_row_inv_rms(ar, yr, d, eps, true);
+  const int nvec = d >> 3;
+  for (int i = lane; i < nvec; i += 64) {
+    const u32x4 r = reinterpret_cast<const u32x4*>(yr)[i];
+    u32x4 nh;
+    const u32x4 o = norm_scale8(reinterpret_cast<const u32x4*>(ar)[i], &r, reinterpret_cast<const u32x4*>(w)[i], inv, 0.f, &nh, true);
+    reinterpret_cast<u32x4*>(out + (size_t)row * d)[i] = nh;
+    reinterpret_cast<u32x4*>(normed + (size_t)row * d)[i] = o;
+  }
+}
+
 // splitk_reduce_kernel + fused_add_rms_norm_batched_cuda in one launch, one workgroup per token row (d = M):
 //   r = bf16(sum_z part[z][t][:])  (what the reduce kernel would have stored),  hidden = bf16(hidden + r),
 //   out = bf16((hidden + r)_fp32 * inv_rms * w).  All 512 threads build r in LDS; wave 0 then takes the row's sum of
@@ -1176,6 +1198,12 @@ pegainfer_status_t pegainfer_gemm_add_then_rms_norm(const Half* W, const Half* X
     glds_splitk_launch(W, X, y_scratch, M, T, K, SplitOut{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0}, pl, s, false);
     splitk_reduce_add_norm_kernel<<<T, 512, (size_t)M * 4 + 16, s>>>(g_splitk_ws, a, out, norm_weight, normed_out, M, T,
                                                                     pl.ksplit, eps, true);
+    return (pegainfer_status_t)hipGetLastError();
+  }
+  static const bool fuse_rows = [] { const char* e = getenv("PEGAINFER_ADD_THEN_NORM_FUSED"); return !(e && e[0] == '0'); }();
+  if (vec && !split && fuse_rows && T > 16 && host_aligned16(y_scratch)) {
+    gemm_dispatch(W, X, y_scratch, M, T, K, s);
+    add_then_rms_norm_vec_kernel<<<ceil_div(T, 4), 256, 0, s>>>(a, y_scratch, norm_weight, out, normed_out, M, T, eps);
     return (pegainfer_status_t)hipGetLastError();
   }
   const pegainfer_status_t rc = pegainfer_gemm_add(W, X, y_scratch, a, out, M, T, K, stream);

@@ -282,7 +282,7 @@ def test_model_mid_batch_fused_layer_bitwise_equals_reference_sequence(built_lib
 
 
 # ------------------------------------------------------------------ prefill launch fusions (round 3)
-@pytest.mark.parametrize("T", [1024, 333, 40, 5])
+@pytest.mark.parametrize("T", [1024, 333, 40, 5, 4100])   # 4100 tokens: un-split 256 x 256 tiles + the one-pass add-then-norm rows kernel
 def test_gemm_add_then_rms_norm_matches_the_three_calls(built_libs, T):
     """pegainfer_gemm_add_then_rms_norm (down_proj + residual add + the next layer's input RMSNorm; on split-K shapes
     the slice sum, the add and the norm are one launch) == gemm_cuda -> add_cuda -> rms_norm_batched_cuda, every bit of
