@@ -151,6 +151,16 @@ pegainfer_status_t pegainfer_debug_gemm_route(int32_t M, int32_t T, int32_t K, i
  * measured slower than the data-parallel launch, profiles/r6_streamk_*).  Process-wide. */
 void pegainfer_debug_streamk(int32_t on);
 
+// (round 6) One decode step of a Qwen3.5 linear-attention layer's token mixer for ONE request in one launch: exactly
+// conv1d_prefill_cuda(x_qkv, conv_weight, conv_state, tmp, C, 1, kernel_size) (ffi.rs conv1d_prefill_cuda; recurrent.rs:49-63) ->
+// gated_delta_rule_decode_cuda(tmp, b_proj, a_proj, dt_bias, A_log, state, tmp2, ...) (recurrent.rs:64-79) ->
+// rms_norm_gated_cuda(tmp2, norm_weight, gate, out, num_value_heads, val_dim, eps), bit for bit, without the two temporaries.
+// key_dim == val_dim == 128, num_value_heads a multiple of num_key_heads, kernel_size 2..5; anything else returns
+// hipErrorInvalidValue (1) and launches nothing - run the three calls.  tickets: num_key_heads int32 words, zero before the first
+// call (the value heads of a key head meet there to shift the shared q / k conv windows once; the words reset themselves), may be
+// shared by every layer and request of one stream.
+int32_t pegainfer_linear_attn_decode_fused(const Half* x_qkv, const Half* conv_weight, Half* conv_state, const Half* b_proj, const Half* a_proj, const Half* dt_bias, const float* A_log, float* state, const float* norm_weight, const Half* gate, Half* out, int32_t num_key_heads, int32_t num_value_heads, int32_t key_dim, int32_t val_dim, int32_t kernel_size, float eps, int32_t* tickets, pegainfer_stream_t stream);
+
 /* Partition-KV decode attention at head_dim 256 (Qwen3.5 full-attention layers).  No counterpart in ffi.rs (its
  * hd256 decode symbol is non-partition only, ffi.rs:1286-1306); arguments and scratch contract are exactly those of
  * paged_attention_decode_split_kv_cuda, plus the optional merge_counters of pegainfer_fused_decode_attention

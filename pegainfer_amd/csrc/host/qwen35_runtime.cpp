@@ -119,12 +119,14 @@ struct Model35 {
   Half* split_tmp_v = nullptr;
   float* split_tmp_s = nullptr;
   int32_t* merge_ctr = nullptr;  // in-launch split-KV merge tickets, zeroed at the head of every step
+  int32_t* lin_ticket = nullptr; // pegainfer_linear_attn_decode_fused: one self-resetting word per key head (zero at allocation)
   hipGraphExec_t graph = nullptr;
   std::vector<int> graph_ids;   // request ids of the captured step, then the attention path
   std::vector<std::pair<std::vector<int>, hipGraphExec_t>> graph_cache;   // parked execs of other keys (<= 8)
   // debug tap (include/pegainfer_qwen35.h, accuracy-parity-playbook.md:15-24): the residual stream leaving every layer
   Half* tap = nullptr;
   bool tap_on = false;
+  bool linattn_fused = [] { const char* e = getenv("PEGAINFER_LINATTN_FUSED"); return !(e && e[0] == '0'); }();   // read per model: tests build one of each
   int tap_rows = 0;
   // prefill workspace (grow-only)
   size_t pf_cap = 0;
@@ -235,7 +237,7 @@ struct Model35 {
         dalloc(&row_states, 1024 * 1024) || dalloc(&valid_scratch, 1) || dalloc(&sample_out_d, 1) ||
         dalloc(&wide, (size_t)std::max(C + Z + 2 * vh, 2 * q_dim + 2 * kv_dim)) ||
         dalloc(&split_tmp_v, bs * pq::kSplitMaxChunksPerRequest * q_dim) ||
-        dalloc(&split_tmp_s, bs * pq::kSplitMaxChunksPerRequest * Hq) || dalloc(&merge_ctr, bs * (size_t)Hkv * 32) || dalloc(&pf_last, H) ||
+        dalloc(&split_tmp_s, bs * pq::kSplitMaxChunksPerRequest * Hq) || dalloc(&merge_ctr, bs * (size_t)Hkv * 32) || dalloc(&lin_ticket, (size_t)kh) || dalloc(&pf_last, H) ||
         dalloc(&pf_last_normed, H) || dalloc(&pf_logits, V))
       return -1;
     auto al = [](size_t x) { return (x + 63) & ~size_t(63); };
@@ -645,10 +647,17 @@ struct Model35 {
         if (rc) { set_error("fused linear-attention projection failed"); return -1; }
         if (resid) std::swap(cur, nxt);
         if (resid && tap_layer(lin + full - 1, cur, 1)) return -1;
-        conv1d_prefill_cuda(wide, ly.conv_w, r->conv[lin], qkv_conv, C, 1, convK, S());
-        gated_delta_rule_decode_cuda(qkv_conv, wide + C + Z, wide + C + Z + vh, ly.dt_bias, ly.a_log, r->state[lin],
-                                     gdr_out, kh, vh, LK, LK, S());
-        rms_norm_gated_cuda(gdr_out, ly.norm_w, wide + C, normed_gated, vh, LK, eps, S());
+        // (round 6) conv step + gated delta rule + gated norm in ONE launch (one workgroup per key head, same bits:
+        // csrc/qwen35.hip); PEGAINFER_LINATTN_FUSED=0, or a shape that kernel does not take, runs the three calls
+        if (!linattn_fused ||
+            pegainfer_linear_attn_decode_fused(wide, ly.conv_w, r->conv[lin], wide + C + Z, wide + C + Z + vh, ly.dt_bias,
+                                               ly.a_log, r->state[lin], ly.norm_w, wide + C, normed_gated, kh, vh, LK, LK,
+                                               convK, eps, lin_ticket, S()) != 0) {
+          conv1d_prefill_cuda(wide, ly.conv_w, r->conv[lin], qkv_conv, C, 1, convK, S());
+          gated_delta_rule_decode_cuda(qkv_conv, wide + C + Z, wide + C + Z + vh, ly.dt_bias, ly.a_log, r->state[lin],
+                                       gdr_out, kh, vh, LK, LK, S());
+          rms_norm_gated_cuda(gdr_out, ly.norm_w, wide + C, normed_gated, vh, LK, eps, S());
+        }
         gemm_graphsafe_cuda(ly.out_proj, normed_gated, attn_res, H, 1, Z, S());
         ++lin;
       }

@@ -226,6 +226,180 @@ __global__ __launch_bounds__(256) void gdr_decode_kernel(const Half* __restrict_
 }
 
 // =====================================================================================================
+// (round 6) One decode step of a linear-attention layer's token mixer in ONE launch (extension, include/pegainfer_kernels_ext.h):
+// conv1d_prefill_cuda(seq_len 1) -> gated_delta_rule_decode_cuda -> rms_norm_gated_cuda, i.e. recurrent.rs:49-79 + the gated norm
+// that follows it.  In the bs-1 decode trace the three launches are 4.7 + 4.8 + 4.8 us per layer (24 layers) for ~4.3 MB of state
+// traffic: launch latency, not bytes.  One 256-thread workgroup per VALUE head: it walks the four 32-column blocks the stand-alone
+// kernel gives to four workgroups, with the same lane -> (row, column) map and the same order inside every sum, and one wave
+// normalises the head exactly as rms_norm_gated_kernel does - bit-identical to the three calls (tests/test_gpu_qwen35.py).
+// The conv windows: a head's v channels are its own; the q / k channels of its key head are read by all VPK value heads of
+// that key head, so their windows are shifted by whichever of those workgroups ARRIVES LAST at the key head's ticket (every one of
+// them holds the same old window and the same new input; the ticket resets itself).  A first form with one workgroup per KEY head
+// (no ticket, 16 workgroups x 256 KB of state) took 8.7 us - 16 CUs cannot move 4.3 MB any faster - and bought nothing.
+// =====================================================================================================
+__global__ __launch_bounds__(256) void linattn_decode_fused_kernel(
+    const Half* __restrict__ x, const Half* __restrict__ conv_w, Half* __restrict__ conv_state, const Half* __restrict__ b_proj,
+    const Half* __restrict__ a_proj, const Half* __restrict__ dt_bias, const float* __restrict__ A_log, float* __restrict__ state,
+    const float* __restrict__ norm_w, const Half* __restrict__ gate, Half* __restrict__ out, int num_key_heads, int vpk, int K,
+    float eps, int* __restrict__ ticket) {
+  constexpr int KD = 128, VD = 128, VB = VD / kGdrCols;
+  __shared__ float cv[VD];                 // conv outputs (bf16 values) of this head's v channels
+  __shared__ float sq[KD], sk[KD];
+  __shared__ float red[8];
+  __shared__ float colred[4][VD];
+  __shared__ float so[VD];                 // bf16-rounded outputs of the recurrence
+  __shared__ int last_flag;
+  const int vh = blockIdx.x, kh = vh / vpk, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int q_total = KD * num_key_heads;
+  const int sw = K - 1;
+  // the state slice first: its 64 KB are the long pole, everything below runs under these loads
+  const int cg = lane & 7, rsub = lane >> 3;
+  float* sbase = state + (size_t)vh * KD * VD + cg * 4;
+  f32x4 s[VB][4], acc[VB];
+#pragma unroll
+  for (int vb = 0; vb < VB; ++vb)
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int j = it * 32 + wave * 8 + rsub;
+      s[vb][it] = *reinterpret_cast<const f32x4*>(sbase + (size_t)j * VD + vb * kGdrCols);
+    }
+  // the gate scalars and the norm's gate / weight rows: requested now, used at the very end
+  const float a_val = bf2f(a_proj[vh]), b_val = bf2f(b_proj[vh]), bias = bf2f(dt_bias[vh]), a_log = A_log[vh];
+  float gpre[2] = {0.f, 0.f}, wpre[2] = {0.f, 0.f};
+  if (wave == 0) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { gpre[u] = bf2f(gate[(size_t)vh * VD + lane + 64 * u]); wpre[u] = norm_w[lane + 64 * u]; }
+  }
+  // ---- conv1d step (conv1d_step_kernel's arithmetic): threads 0..127 the key head's q AND k channel of their index, every
+  //      thread < 128 also one v channel of this head ----
+  auto conv = [&](int c, Half (&win)[kConvMaxK]) {
+    for (int k = 0; k < sw; ++k) win[k] = conv_state[(size_t)c * sw + k];
+    win[sw] = x[c];
+    float sum = 0.f;
+    for (int k = 0; k < K; ++k) sum += bf2f(win[k]) * bf2f(conv_w[(size_t)c * K + k]);
+    return bf2f(f2bf(silu_f(bf16_round_f(sum))));
+  };
+  float qv = 0.f, kv = 0.f;
+  Half qwin[kConvMaxK], kwin[kConvMaxK];
+  const int qc = kh * KD + tid, kc = q_total + kh * KD + tid;
+  if (tid < KD) {
+    qv = conv(qc, qwin);
+    kv = conv(kc, kwin);
+  } else {
+    const int i = tid - KD, c = 2 * q_total + vh * VD + i;
+    Half vwin[kConvMaxK];
+    cv[i] = conv(c, vwin);
+    for (int k = 0; k < sw; ++k) conv_state[(size_t)c * sw + k] = vwin[k + 1];
+  }
+  // every q / k window of this key head has been read by this workgroup (the values were consumed above): arrive
+  __syncthreads();
+  // (relaxed: the last arriver reads nothing the others wrote - it only must not WRITE before they have read, and their reads were
+  // consumed before they arrived; the returned count is looked at after the recurrence, so nobody waits for the round trip)
+  int arrived = 0;
+  if (tid == 0) arrived = __hip_atomic_fetch_add(ticket + kh, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const float q2 = wave_sum(qv * qv), k2 = wave_sum(kv * kv);
+  if (lane == 0) { red[wave] = q2; red[4 + wave] = k2; }
+  __syncthreads();
+  const float qn = rsqrtf(red[0] + red[1] + red[2] + red[3] + 1e-12f) * rsqrtf((float)KD);
+  const float kn = rsqrtf(red[4] + red[5] + red[6] + red[7] + 1e-12f);
+  if (tid < KD) { sq[tid] = qv * qn; sk[tid] = kv * kn; }
+  const float xs = a_val + bias;
+  const float softplus = xs > 20.0f ? xs : logf(1.0f + expf(xs));
+  const float exp_g = expf(-expf(a_log) * softplus);
+  const float beta = 1.0f / (1.0f + expf(-b_val));
+  __syncthreads();
+#pragma unroll
+  for (int vb = 0; vb < VB; ++vb) {
+    acc[vb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int j = it * 32 + wave * 8 + rsub;
+      s[vb][it] *= exp_g;
+      acc[vb] += s[vb][it] * sk[j];
+    }
+  }
+  // column sums: over the 8 row-lanes of a wave (xor 8, 16, 32), then over the 4 waves through LDS, in wave order
+  auto col_reduce = [&](f32x4 (&v)[VB]) {
+#pragma unroll
+    for (int vb = 0; vb < VB; ++vb)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float t = v[vb][c];
+        t += __shfl_xor(t, 8, kWave);
+        t += __shfl_xor(t, 16, kWave);
+        t += __shfl_xor(t, 32, kWave);
+        v[vb][c] = t;
+      }
+    __syncthreads();
+    if (rsub == 0) {
+#pragma unroll
+      for (int vb = 0; vb < VB; ++vb)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) colred[wave][vb * kGdrCols + cg * 4 + c] = v[vb][c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int vb = 0; vb < VB; ++vb)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int col = vb * kGdrCols + cg * 4 + c;
+        v[vb][c] = colred[0][col] + colred[1][col] + colred[2][col] + colred[3][col];
+      }
+  };
+  col_reduce(acc);
+  f32x4 delta[VB];
+#pragma unroll
+  for (int vb = 0; vb < VB; ++vb)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) delta[vb][c] = (cv[vb * kGdrCols + cg * 4 + c] - acc[vb][c]) * beta;
+#pragma unroll
+  for (int vb = 0; vb < VB; ++vb) {
+    acc[vb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int j = it * 32 + wave * 8 + rsub;
+      s[vb][it] += delta[vb] * sk[j];
+      *reinterpret_cast<f32x4*>(sbase + (size_t)j * VD + vb * kGdrCols) = s[vb][it];
+      acc[vb] += s[vb][it] * sq[j];
+    }
+  }
+  col_reduce(acc);
+  if (wave == 0 && rsub == 0) {
+#pragma unroll
+    for (int vb = 0; vb < VB; ++vb)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) so[vb * kGdrCols + cg * 4 + c] = bf2f(f2bf(acc[vb][c]));
+  }
+  if (tid == 0) {
+    last_flag = arrived == vpk - 1;
+    if (arrived == vpk - 1) __hip_atomic_store(ticket + kh, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  // ---- gated RMSNorm of the head: one wave, lane l holds dims l and l + 64 (rms_norm_gated_kernel's order) ----
+  if (wave == 0) {
+    float ss = 0.f;
+    for (int i = lane; i < VD; i += 64) ss += so[i] * so[i];
+    ss = wave_sum(ss);
+    const float inv = rsqrtf(ss / (float)VD + eps);
+    const size_t base = (size_t)vh * VD;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int i = lane + 64 * u;
+      const float normed = so[i] * inv * wpre[u];
+      const float g = gpre[u];
+      out[base + i] = f2bf(normed * (g / (1.0f + expf(-g))));
+    }
+  }
+  // the last of the key head's value heads shifts the shared q / k windows (last_flag: written in front of the norm's barrier)
+  if (last_flag && tid < KD) {
+    for (int k = 0; k < sw; ++k) {
+      conv_state[(size_t)qc * sw + k] = qwin[k + 1];
+      conv_state[(size_t)kc * sw + k] = kwin[k + 1];
+    }
+  }
+}
+
+// =====================================================================================================
 // HD256 full-attention prep (reference csrc/prefill_attention_hd256.cu): q comes interleaved with its gate
 // (q_full row = [q_h0(256) gate_h0(256) q_h1 ...]); (1+w) RMSNorm with ONE rounding, then partial NeoX RoPE
 // on the first rotary_dim dims (pairs d, d + rotary_dim/2; table row = pos*rotary_dim), rest passes through.
@@ -377,6 +551,25 @@ void gated_delta_rule_decode_cuda(const Half* qkv, const Half* b_proj, const Hal
   if (key_dim != 128 || val_dim % kGdrCols != 0 || num_value_heads <= 0) return;  // GDR_KEY_DIM = 128 in the reference
   gdr_decode_kernel<<<num_value_heads * (val_dim / kGdrCols), 256, 0, as_stream(stream)>>>(
       qkv, b_proj, a_proj, dt_bias, A_log, state, output, num_key_heads, num_value_heads, key_dim, val_dim);
+}
+
+// extension (include/pegainfer_kernels_ext.h): conv1d_prefill_cuda(seq_len 1) + gated_delta_rule_decode_cuda + rms_norm_gated_cuda
+// of ONE request's linear-attention layer in one launch, same bits.  hipErrorInvalidValue = a shape this kernel does not take
+// (the caller then runs the three calls).
+int32_t pegainfer_linear_attn_decode_fused(const Half* x_qkv, const Half* conv_weight, Half* conv_state, const Half* b_proj,
+                                           const Half* a_proj, const Half* dt_bias, const float* A_log, float* state,
+                                           const float* norm_weight, const Half* gate, Half* out, int32_t num_key_heads,
+                                           int32_t num_value_heads, int32_t key_dim, int32_t val_dim, int32_t kernel_size,
+                                           float eps, int32_t* tickets, pegainfer_stream_t stream) {
+  if (!x_qkv || !conv_weight || !conv_state || !b_proj || !a_proj || !dt_bias || !A_log || !state || !norm_weight || !gate ||
+      !out || !tickets || key_dim != 128 || val_dim != 128 || num_key_heads <= 0 || num_value_heads <= 0 ||
+      num_value_heads % num_key_heads != 0 || kernel_size < 2 || kernel_size > kConvMaxK ||
+      (reinterpret_cast<uintptr_t>(state) & 15u))
+    return static_cast<int32_t>(hipErrorInvalidValue);
+  linattn_decode_fused_kernel<<<num_value_heads, 256, 0, as_stream(stream)>>>(
+      x_qkv, conv_weight, conv_state, b_proj, a_proj, dt_bias, A_log, state, norm_weight, gate, out, num_key_heads,
+      num_value_heads / num_key_heads, kernel_size, eps, tickets);
+  return static_cast<int32_t>(hipGetLastError());
 }
 
 void prefill_attention_hd256_prep_cuda(const Half* q_full_batch, const Half* k_batch, const Half* v_batch,

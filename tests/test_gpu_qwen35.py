@@ -64,6 +64,56 @@ def test_gated_delta_rule_decode(built_libs):
         qkv = rnd(rng, 2 * kh * kd + vh * vd)
 
 
+@pytest.mark.parametrize("kh,vh", [(16, 32), (4, 4), (2, 8)])
+def test_linear_attn_decode_fused_equals_the_three_calls(built_libs, kh, vh):
+    """pegainfer_linear_attn_decode_fused (round 6: one workgroup per value head, the shared q / k conv windows shifted by the last arriver of their key head) == conv1d_prefill_cuda(seq_len 1) ->
+    gated_delta_rule_decode_cuda -> rms_norm_gated_cuda: every bit of the output, of the conv window and of the fp32 recurrent
+    state, over three steps that carry both states (recurrent.rs:49-79); and the output against the oracle's op sequence."""
+    import torch
+    from pegainfer_amd import ffi
+    rng = np.random.default_rng(kh)
+    kd = vd = 128
+    K, C, Z = 4, 2 * kh * kd + vh * vd, vh * vd
+    w, conv0 = rnd(rng, C, K, scale=0.5), rnd(rng, C, K - 1)
+    dtb = rnd(rng, vh, scale=0.5)
+    alog = (rng.standard_normal(vh) * 0.5).astype(np.float32)
+    nw = (1 + rng.standard_normal(vd) * 0.1).astype(np.float32)
+    state0 = (rng.standard_normal((vh, kd, vd)) * 0.1).astype(np.float32)
+    L = ffi.lib()
+    wd, dd, ald, nwd = to_dev(w), to_dev(dtb), torch.from_numpy(alog).cuda(), torch.from_numpy(nw).cuda()
+    cs = [to_dev(conv0), to_dev(conv0)]                                   # [three calls, fused]
+    st = [torch.from_numpy(state0.copy()).cuda(), torch.from_numpy(state0.copy()).cuda()]
+    tmp, tmp2 = to_dev(np.zeros(C, np.float32)), to_dev(np.zeros(Z, np.float32))
+    outs = [to_dev(np.zeros(Z, np.float32)), to_dev(np.zeros(Z, np.float32))]
+    tick = torch.zeros(kh, dtype=torch.int32, device="cuda")               # zero once: the words reset themselves
+    o_conv, o_state = conv0, state0
+    for step in range(3):
+        x, z, b, a = rnd(rng, C), rnd(rng, Z), rnd(rng, vh), rnd(rng, vh)
+        xd, zd, bd, ad = to_dev(x), to_dev(z), to_dev(b), to_dev(a)
+        L.conv1d_prefill_cuda(xd.data_ptr(), wd.data_ptr(), cs[0].data_ptr(), tmp.data_ptr(), C, 1, K, S())
+        L.gated_delta_rule_decode_cuda(tmp.data_ptr(), bd.data_ptr(), ad.data_ptr(), dd.data_ptr(), ald.data_ptr(),
+                                       st[0].data_ptr(), tmp2.data_ptr(), kh, vh, kd, vd, S())
+        L.rms_norm_gated_cuda(tmp2.data_ptr(), nwd.data_ptr(), zd.data_ptr(), outs[0].data_ptr(), vh, vd, 1e-6, S())
+        rc = L.pegainfer_linear_attn_decode_fused(xd.data_ptr(), wd.data_ptr(), cs[1].data_ptr(), bd.data_ptr(), ad.data_ptr(),
+                                                  dd.data_ptr(), ald.data_ptr(), st[1].data_ptr(), nwd.data_ptr(), zd.data_ptr(),
+                                                  outs[1].data_ptr(), kh, vh, kd, vd, K, 1e-6, tick.data_ptr(), S())
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(bf16_bits(from_dev(outs[0])), bf16_bits(from_dev(outs[1]))), step
+        assert np.array_equal(bf16_bits(from_dev(cs[0])), bf16_bits(from_dev(cs[1]))), step
+        assert np.array_equal(st[0].cpu().numpy().view(np.uint32), st[1].cpu().numpy().view(np.uint32)), step
+        eo, o_conv = O.conv1d_prefill(x[None], w, o_conv)
+        eg, o_state = O.gated_delta_rule_decode(eo[0], b, a, dtb, alog, o_state, kh, vh, kd, vd)
+        o_state = o_state.astype(np.float32)
+        en = O.rms_norm_gated(eg, nw, z, vd, 1e-6)
+        assert np.abs(from_dev(outs[1]) - en).max() <= 2.0 ** -6 * max(1.0, np.abs(en).max())
+    # a shape the kernel does not take launches nothing and says so
+    assert L.pegainfer_linear_attn_decode_fused(xd.data_ptr(), wd.data_ptr(), cs[1].data_ptr(), bd.data_ptr(), ad.data_ptr(),
+                                                dd.data_ptr(), ald.data_ptr(), st[1].data_ptr(), nwd.data_ptr(), zd.data_ptr(),
+                                                outs[1].data_ptr(), kh, vh, 64, vd, K, 1e-6, tick.data_ptr(), S()) == 1
+    assert int(tick.abs().sum()) == 0
+
+
 @pytest.mark.parametrize("T,prefill", [(1, False), (5, False), (40, True)])
 def test_hd256_prep_and_gate(built_libs, T, prefill):
     import torch
