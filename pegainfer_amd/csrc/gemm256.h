@@ -40,8 +40,16 @@ __global__ __launch_bounds__(512) void mfma_gemm256_kernel(const Half* __restric
                                                            int nk_slice = 0) {
   extern __shared__ __attribute__((aligned(16))) u32x4 g256_smem[];
   const int ntiles = m_tiles * t_tiles;
-  int tile = blockIdx.x;
-  {  // XCD-aware order (block b runs on XCD b % 8): every XCD walks a contiguous run of tiles, token tile fastest
+  int tile = blockIdx.x, zslice = (int)blockIdx.y;
+  if (part && so.xcd_slices) {
+    // K-split launches (round 6): one contiguous run of (slice, tile) work items per XCD in SLICE-major order, so an XCD pulls
+    // one K slice of X through its L2 instead of all of X (see mfma_gemm128x256_kernel); same work items, same bits
+    const int nitems = ntiles * (int)gridDim.y, id = (int)blockIdx.x + (int)gridDim.x * (int)blockIdx.y;
+    const int q = nitems / 8, r = nitems % 8, xcd = id % 8, idx = id / 8;
+    const int item = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    zslice = item / ntiles;
+    tile = item - zslice * ntiles;
+  } else {  // XCD-aware order (block b runs on XCD b % 8): every XCD walks a contiguous run of tiles, token tile fastest
     const int q = ntiles / 8, r = ntiles % 8, xcd = tile % 8, idx = tile / 8;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
@@ -90,7 +98,7 @@ __global__ __launch_bounds__(512) void mfma_gemm256_kernel(const Half* __restric
   // split-K form (part != null): blockIdx.y = K slice of nk_slice K tiles (even, like the last, shorter one: the
   // tiles are walked in pairs); the workgroup's fp32 tile goes to part[z][T][M] and a slice-sum launch adds the slices
   // in z order (down_proj at 1-2 k tokens: 40-80 tiles of 256 x 256 for 256 CUs)
-  const int kt_begin = part ? (int)blockIdx.y * nk_slice : 0;
+  const int kt_begin = part ? zslice * nk_slice : 0;
   const int nk_total = K / G256_BK;
   const int nk = part ? (nk_total - kt_begin < nk_slice ? nk_total - kt_begin : nk_slice) : nk_total;
 #pragma unroll
@@ -223,7 +231,7 @@ __global__ __launch_bounds__(512) void mfma_gemm256_kernel(const Half* __restric
     return;
   }
   if (part) {
-    float* pz = part + (size_t)blockIdx.y * T * M;
+    float* pz = part + (size_t)zslice * T * M;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int t = t0 + wc * 64 + j * 16 + l15;
@@ -299,6 +307,10 @@ inline void gemm256_launch(const Half* W, const Half* X, Half* Y, int M, int T, 
 }
 
 // split-K launch of the plain form: fp32 partials into `part` ([ksplit][T][M]); the caller sums the slices
+inline bool splitk_xcd_on() {   // PEGAINFER_SPLITK_XCD=0: the slices of a tile on one XCD, as until round 6 (A/B)
+  static const bool v = [] { const char* e = getenv("PEGAINFER_SPLITK_XCD"); return !(e && e[0] == '0'); }();
+  return v;
+}
 inline void gemm256_splitk_launch(const Half* W, const Half* X, int M, int T, int K, float* part, int ksplit, int nk_slice,
                                   hipStream_t s) {
   const int m_tiles = ceil_div(M, G256_BM), t_tiles = ceil_div(T, G256_BT);
@@ -310,7 +322,7 @@ inline void gemm256_splitk_launch(const Half* W, const Half* X, int M, int T, in
   (void)once;
   mfma_gemm256_kernel<false><<<dim3(m_tiles * t_tiles, ksplit), 512, kG256LdsBytes, s>>>(
       W, X, nullptr, M, T, K, m_tiles, t_tiles,
-      SplitOut{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0, t_tiles == 1 && weights_nt_on()}, part, nk_slice);
+      SplitOut{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0, t_tiles == 1 && weights_nt_on(), ksplit > 1 && splitk_xcd_on()}, part, nk_slice);
 }
 
 // ---- stream-K form of the 256 x 256 kernel (round 6) --------------------------------------------------------------------
@@ -673,8 +685,19 @@ __global__ __launch_bounds__(512 + NF * 64) void mfma_gemm128x256_kernel(const H
                                                                int nk_slice) {
   extern __shared__ __attribute__((aligned(16))) u32x4 g256_smem[];
   const int ntiles = m_tiles * t_tiles;
-  int tile = blockIdx.x;
-  {
+  int tile = blockIdx.x, zslice = (int)blockIdx.y;
+  if (part && so.xcd_slices) {
+    // (round 6) K-split launches: the hardware deals workgroups to XCDs by their linear id; give every XCD one contiguous run of
+    // (slice, tile) work items in SLICE-major order, so an XCD works on (mostly) one K slice of a few row tiles.  With the slices
+    // of a tile on one XCD (the 2-D grid's natural order: gridDim.x is a multiple of 8) every XCD pulled the WHOLE of X through
+    // its L2 - down_proj at 1024 tokens fetched 209 MB from the memory side for 70 MB of operands (FETCH_SIZE, profiles/
+    // r6b_ctx1024_pmc_fetch.csv).  Same work items, same arithmetic: same bits.
+    const int nitems = ntiles * (int)gridDim.y, id = (int)blockIdx.x + (int)gridDim.x * (int)blockIdx.y;
+    const int q = nitems / 8, r = nitems % 8, xcd = id % 8, idx = id / 8;
+    const int item = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    zslice = item / ntiles;
+    tile = item - zslice * ntiles;
+  } else {
     const int q = ntiles / 8, r = ntiles % 8, xcd = tile % 8, idx = tile / 8;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
@@ -717,7 +740,7 @@ __global__ __launch_bounds__(512 + NF * 64) void mfma_gemm128x256_kernel(const H
   }
   typedef __attribute__((address_space(3))) void* lptr_t;
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)&g256_smem[0];
-  const int kt_begin = part ? (int)blockIdx.y * nk_slice : 0;
+  const int kt_begin = part ? zslice * nk_slice : 0;
   const int nk_total = K / G256_BK;
   const int nk = part ? (nk_total - kt_begin < nk_slice ? nk_total - kt_begin : nk_slice) : nk_total;
 #pragma unroll
@@ -871,7 +894,7 @@ __global__ __launch_bounds__(512 + NF * 64) void mfma_gemm128x256_kernel(const H
     return;
   }
   if (part) {
-    float* pz = part + (size_t)blockIdx.y * T * M;
+    float* pz = part + (size_t)zslice * T * M;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int t = t0 + wc * 64 + j * 16 + l15;
@@ -955,6 +978,7 @@ inline void gemm128x256_launch(const Half* W, const Half* X, Half* Y, int M, int
                                int ksplit, int nk_slice, hipStream_t s) {
   const int t_tiles = ceil_div(T, G256_BT);
   so.w_nt = t_tiles == 1 && weights_nt_on();
+  so.xcd_slices = part && ksplit > 1 && splitk_xcd_on();
   const bool feed = gemm128x256_feed_on();
   if (so.silu_I > 0) {   // SwiGLU form (un-split only): a tile = 64 gate rows + their 64 up rows
     const int m_tiles = ceil_div(silu_cols_end(so) - so.silu_c0, 64);
