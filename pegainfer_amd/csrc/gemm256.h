@@ -53,7 +53,9 @@ __global__ __launch_bounds__(512) void mfma_gemm256_kernel(const Half* __restric
     const int q = ntiles / 8, r = ntiles % 8, xcd = tile % 8, idx = tile / 8;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int mt = tile / t_tiles, tt = tile - mt * t_tiles;
+  // (round 6) t_major: row tile fastest inside an XCD's run - for T > M (o_proj / down_proj / qkv at 10 k tokens) an XCD then pulls
+  // 1/8 of X and all of W through its L2 instead of all of X and 1/8 of W
+  const int mt = so.t_major ? tile % m_tiles : tile / t_tiles, tt = so.t_major ? tile / m_tiles : tile - mt * t_tiles;
   const int m0 = mt * G256_BM, t0 = tt * G256_BT;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int wr = wave >> 2, wc = wave & 3;
@@ -283,10 +285,15 @@ __global__ __launch_bounds__(512) void mfma_gemm256_kernel(const Half* __restric
 // K must be a multiple of 128 (K tiles are processed in pairs); same alignment rules as the other LDS-DMA kernels
 inline bool gemm256_ok(int M, int T, int K) { return (K % 128) == 0 && K >= 256 && M >= 256 && T >= 256; }
 
+inline bool gemm_t_major(int M, int T, const SplitOut& so) {   // PEGAINFER_GEMM_T_MAJOR=0: always row-tile-major runs (A/B)
+  static const bool on = [] { const char* e = getenv("PEGAINFER_GEMM_T_MAJOR"); return !(e && e[0] == '0'); }();
+  return on && so.silu_I == 0 && T > M;
+}
 inline void gemm256_launch(const Half* W, const Half* X, Half* Y, int M, int T, int K, SplitOut so, hipStream_t s) {
   const bool silu = so.silu_I > 0;
   const int m_tiles = silu ? ceil_div(silu_cols_end(so) - so.silu_c0, 128) : ceil_div(M, G256_BM), t_tiles = ceil_div(T, G256_BT);
   so.w_nt = t_tiles == 1 && weights_nt_on();
+  so.t_major = gemm_t_major(M, T, so);
   if (silu) {
     static const bool once = [] {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_gemm256_kernel<true>),
@@ -322,7 +329,7 @@ inline void gemm256_splitk_launch(const Half* W, const Half* X, int M, int T, in
   (void)once;
   mfma_gemm256_kernel<false><<<dim3(m_tiles * t_tiles, ksplit), 512, kG256LdsBytes, s>>>(
       W, X, nullptr, M, T, K, m_tiles, t_tiles,
-      SplitOut{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0, t_tiles == 1 && weights_nt_on(), ksplit > 1 && splitk_xcd_on()}, part, nk_slice);
+      SplitOut{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0, t_tiles == 1 && weights_nt_on(), ksplit > 1 && splitk_xcd_on(), 0}, part, nk_slice);
 }
 
 // ---- stream-K form of the 256 x 256 kernel (round 6) --------------------------------------------------------------------
@@ -701,7 +708,7 @@ __global__ __launch_bounds__(512 + NF * 64) void mfma_gemm128x256_kernel(const H
     const int q = ntiles / 8, r = ntiles % 8, xcd = tile % 8, idx = tile / 8;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int mt = tile / t_tiles, tt = tile - mt * t_tiles;
+  const int mt = so.t_major ? tile % m_tiles : tile / t_tiles, tt = so.t_major ? tile / m_tiles : tile - mt * t_tiles;   // see mfma_gemm256_kernel
   constexpr int BMT = 32 * MT;            // W rows per tile
   const int m0 = mt * BMT, t0 = tt * G256_BT;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -978,6 +985,7 @@ inline void gemm128x256_launch(const Half* W, const Half* X, Half* Y, int M, int
                                int ksplit, int nk_slice, hipStream_t s) {
   const int t_tiles = ceil_div(T, G256_BT);
   so.w_nt = t_tiles == 1 && weights_nt_on();
+  so.t_major = gemm_t_major(M, T, so);
   so.xcd_slices = part && ksplit > 1 && splitk_xcd_on();
   const bool feed = gemm128x256_feed_on();
   if (so.silu_I > 0) {   // SwiGLU form (un-split only): a tile = 64 gate rows + their 64 up rows
