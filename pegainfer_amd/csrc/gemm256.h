@@ -55,7 +55,23 @@ __global__ __launch_bounds__(512) void mfma_gemm256_kernel(const Half* __restric
   }
   // (round 6) t_major: row tile fastest inside an XCD's run - for T > M (o_proj / down_proj / qkv at 10 k tokens) an XCD then pulls
   // 1/8 of X and all of W through its L2 instead of all of X and 1/8 of W
-  const int mt = so.t_major ? tile % m_tiles : tile / t_tiles, tt = so.t_major ? tile / m_tiles : tile - mt * t_tiles;
+  // (round 6) chunk: the slow dimension of the order is walked in chunks of `chunk` tiles, so the ~32 workgroups an XCD runs at a time
+  // are a (32 / chunk) x chunk block of tiles sharing 32 / chunk + chunk operand panels through its L2 instead of 1 + 32: gate_up at
+  // 10 k tokens (76 x 40 tiles, token tile fastest) fetched 4.2 GB from the memory side per launch for 151 MB of operands - every X
+  // panel once per row tile (FETCH_SIZE, profiles/r6c_ctx10000_pmc_fetch.csv)
+  int mt, tt;
+  if (so.chunk > 0) {
+    const int fast_n = so.t_major ? m_tiles : t_tiles, slow_n = so.t_major ? t_tiles : m_tiles;   // fast = the inner dimension of the plain order
+    const int per_chunk = slow_n * so.chunk;                  // tiles of one full chunk of the FAST dimension
+    const int c = tile / per_chunk, rem = tile - c * per_chunk;
+    const int cw = fast_n - c * so.chunk < so.chunk ? fast_n - c * so.chunk : so.chunk;
+    const int slow = rem / cw, fast = c * so.chunk + rem - slow * cw;
+    mt = so.t_major ? fast : slow;
+    tt = so.t_major ? slow : fast;
+  } else {
+    mt = so.t_major ? tile % m_tiles : tile / t_tiles;
+    tt = so.t_major ? tile / m_tiles : tile - mt * t_tiles;
+  }
   const int m0 = mt * G256_BM, t0 = tt * G256_BT;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int wr = wave >> 2, wc = wave & 3;
@@ -294,6 +310,14 @@ inline void gemm256_launch(const Half* W, const Half* X, Half* Y, int M, int T, 
   const int m_tiles = silu ? ceil_div(silu_cols_end(so) - so.silu_c0, 128) : ceil_div(M, G256_BM), t_tiles = ceil_div(T, G256_BT);
   so.w_nt = t_tiles == 1 && weights_nt_on();
   so.t_major = gemm_t_major(M, T, so);
+  {  // PEGAINFER_GEMM_CHUNK=0: the plain order (A/B); N: chunks of N tiles
+    static const int chunk = [] { const char* e = getenv("PEGAINFER_GEMM_CHUNK"); return e && *e ? atoi(e) : 8; }();
+    // chunks of equal width (17 tiles: 6 + 6 + 5, not 8 + 8 + 1); only for launches of more than one round of tiles.  4 / 6 / 8 measure
+    // the same (TTFT(10 000) 94.9-95.4 ms against 98.4 plain, 12: 96.0, 16: 96.8 - profiles/r6_gemm_chunk_sweep.txt)
+    const int fast_n = so.t_major ? m_tiles : t_tiles;
+    const int nch = chunk > 0 ? ceil_div(fast_n, chunk) : 0;
+    so.chunk = nch > 1 && (long)m_tiles * t_tiles > 256 ? ceil_div(fast_n, nch) : 0;
+  }
   if (silu) {
     static const bool once = [] {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_gemm256_kernel<true>),

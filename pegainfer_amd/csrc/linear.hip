@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(const Half* __restrict__
 // with different tile shapes share one SwiGLU GEMM (the thin last round of the 256 x 256 tiling, glds_gemm_launch)
 // w_nt (set by the launchers, never by callers): the W tiles are requested with the non-temporal policy - each W byte is
 // read by ONE workgroup once (a single token tile), so it should not displace the x rows every workgroup re-reads from L2.
-struct SplitOut { Half* Y1; Half* Y2; Half* Y3; int M0; int M1; int M2; int silu_I; int silu_round; int silu_c0; int silu_c1; int w_nt; int xcd_slices; int t_major; };
+struct SplitOut { Half* Y1; Half* Y2; Half* Y3; int M0; int M1; int M2; int silu_I; int silu_round; int silu_c0; int silu_c1; int w_nt; int xcd_slices; int t_major; int chunk; };
 // t_major (set by the gemm256.h launchers for plain GEMMs with T > M): row tile fastest inside an XCD's run of tiles
 // xcd_slices (set by the K-split launchers of gemm256.h): deal the (slice, tile) work items to the XCDs in slice-major runs.  NOT for
 // the 128-row kernel below: at 256 tokens (6-8 slices: 0.8-1.6 KB of every W row per XCD) it measured 1.1 % slower (r6_splitk_xcd_ab2.txt)

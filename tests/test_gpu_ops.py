@@ -302,6 +302,36 @@ def test_gemm_silu_epilogue_equals_gemm_then_silu_mul_fused(P, T, I, K):
     assert np.abs(from_dev(out) - exp).max() <= 2.0 ** -6 * max(1.0, np.abs(exp).max())
 
 
+@pytest.mark.parametrize("M,T,K,silu", [(4096, 9000, 256, False),     # T > M: row tile fastest, 16 row tiles in chunks of 8
+                                        (9216 + 40, 4100, 256, False),  # M > T: token tile fastest, 17 token tiles in chunks of 8 + 8 + 1, ragged rows
+                                        (12288, 4100, 256, True)])      # the SwiGLU form: 48 (128 + 128)-row tiles x 17 token tiles
+def test_large_grid_tile_orders_cover_every_tile_once(P, M, T, K, silu):
+    """Round 6: launches of more than two rounds of 256 x 256 tiles walk them in an XCD-aware CHUNKED order (and row-tile-fastest
+    when T > M) - a pure permutation of the work items.  Every output element is written (the buffer starts as NaN) and equals a
+    float32 reference within the GEMM tolerance; the ragged last chunk / last row tile included."""
+    import torch
+    g = torch.Generator(device="cpu").manual_seed(M + T)
+    W = (torch.randn(M, K, generator=g) * 0.05).to(torch.bfloat16).cuda()
+    X = torch.randn(T, K, generator=g).to(torch.bfloat16).cuda()
+    from pegainfer_amd import ffi
+    kind = np.zeros(3, np.int32)
+    ffi.lib().pegainfer_debug_gemm_route(0 if silu else M, T, K, M // 2 if silu else 0, kind.ctypes.data)
+    assert kind[0] in (256, 257), kind      # the 256 x 256 kernel (257: with its thin tail on the feeder kernel)
+    ref = X.float() @ W.float().T
+    if silu:
+        I = M // 2
+        out = torch.full((T, I), float("nan"), dtype=torch.bfloat16, device="cuda")
+        P.gemm_silu_into(W, X, out)
+        gr, ur = ref[:, :I].to(torch.bfloat16).float(), ref[:, I:].to(torch.bfloat16).float()
+        ref = torch.nn.functional.silu(gr) * ur
+    else:
+        out = torch.full((T, M), float("nan"), dtype=torch.bfloat16, device="cuda")
+        P.gemm_into(W, X, out)
+    assert not torch.isnan(out).any()
+    err = (out.float() - ref).abs().max().item()
+    assert err <= 2.0 ** -6 * max(1.0, ref.abs().max().item()), err
+
+
 def test_gemm_split3_mid_batch_matches_oracle_and_full_gemm(P):
     """17..64 columns, stacked q|k|v of 6144 rows (the mid-batch decode path): the three outputs are the row ranges of
     ONE tiled GEMM - bit-identical to gemm_cuda over the stacked matrix, within the GEMM tolerance of the oracle."""
