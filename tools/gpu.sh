@@ -77,7 +77,7 @@ case $verb in
     cd /tmp && export TMPDIR=/tmp
     rm -rf /tmp/pmc_$name
     (cd $repo && timeout 600 rocprofv3 --pmc $ctr --kernel-trace -d /tmp/pmc_$name -o run -- python "$@" > /tmp/pmc_$name.log 2>&1)
-    python $repo/tools/rocpd_pmc.py "$(find /tmp/pmc_$name -name '*.db' | head -1)" $out/$name.csv
+    python $repo/tools/rocpd_pmc.py "$(find /tmp/pmc_$name -name '*.db' | head -1)" $out/$name.csv ${PMC_BY_GRID:+--by-grid}   # PMC_BY_GRID=1: one row per (kernel, grid size)
     head -40 $out/$name.csv | cut -c1-170
     ;;
   sweep)

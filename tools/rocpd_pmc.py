@@ -19,8 +19,18 @@ def main():
     cname = "counter_name" if "counter_name" in cols else [c for c in cols if "counter" in c and "name" in c][0]
     vname = "value" if "value" in cols else [c for c in cols if "value" in c][0]
     agg = {}
-    for k, c, v in db.execute(f"select {kname}, {cname}, {vname} from counters_collection"):
-        a = agg.setdefault((short(k), c), [0, 0.0])
+    # --by-grid: one row per (kernel, grid size) - tells the shapes of one kernel apart (qkv / o_proj / lm_head of a decode step)
+    gcols = [c for c in cols if c in ("grid_size", "grid_size_x", "grid_x")] if "--by-grid" in sys.argv else []
+    if "--by-grid" in sys.argv:
+        sys.argv.remove("--by-grid")
+        if not gcols:
+            print("no grid column among", cols, file=sys.stderr)
+    gsel = f", {gcols[0]}" if gcols else ""
+    for row in db.execute(f"select {kname}, {cname}, {vname}{gsel} from counters_collection"):
+        k, c, v = row[:3]
+        if gcols:
+            k = f"{k} grid={row[3]}"
+        a = agg.setdefault((short(k) + (f" grid={row[3]}" if gcols else ""), c), [0, 0.0])
         a[0] += 1
         a[1] += float(v)
     out = [("kernel", "counter", "dispatches", "avg_value", "total_value")]
