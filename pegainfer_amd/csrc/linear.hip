@@ -403,11 +403,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // (round 6) un-split shapes of pegainfer_gemm_add_then_rms_norm: out = bf16(a + y), normed = rms_norm(out) * w in ONE pass over
 // the rows instead of add_cuda + rms_norm_batched_cuda (10 000 tokens: 25 + 22 us and 256 MB -> one launch, 205 MB).  One wave per
 // row, the canonical order of norm_core.h over the ROUNDED sum: the same bits as the two calls.  out may alias a.
+template <int VPL>   // 0: two passes over the row (any d); 5 / 8: the row in registers (d <= 2560 / 4096), one memory pass
 __global__ __launch_bounds__(256) void add_then_rms_norm_vec_kernel(const Half* a, const Half* __restrict__ y,
                                                                     const Half* __restrict__ w, Half* out,
                                                                     Half* __restrict__ normed, int d, int rows, float eps) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
+  if constexpr (VPL > 0) {
+    wave_add_norm_row_cached<VPL, true>(a + (size_t)row * d, y + (size_t)row * d, w, out + (size_t)row * d,
+                                        normed + (size_t)row * d, d, eps, 0.0f);
+    return;
+  }
   const int lane = threadIdx.x & 63;
   const Half* ar = a + (size_t)row * d;
   const Half* yr = y + (size_t)row * d;
@@ -1206,7 +1212,13 @@ pegainfer_status_t pegainfer_gemm_add_then_rms_norm(const Half* W, const Half* X
   static const bool fuse_rows = [] { const char* e = getenv("PEGAINFER_ADD_THEN_NORM_FUSED"); return !(e && e[0] == '0'); }();
   if (vec && !split && fuse_rows && T > 16 && host_aligned16(y_scratch)) {
     gemm_dispatch(W, X, y_scratch, M, T, K, s);
-    add_then_rms_norm_vec_kernel<<<ceil_div(T, 4), 256, 0, s>>>(a, y_scratch, norm_weight, out, normed_out, M, T, eps);
+    static const bool cached = [] { const char* e = getenv("PEGAINFER_NORM_ROWS_CACHED"); return !(e && e[0] == '0'); }();
+    if (cached && M <= 8 * 64 * 5)
+      add_then_rms_norm_vec_kernel<5><<<ceil_div(T, 4), 256, 0, s>>>(a, y_scratch, norm_weight, out, normed_out, M, T, eps);
+    else if (cached && M <= 8 * 64 * 8)
+      add_then_rms_norm_vec_kernel<8><<<ceil_div(T, 4), 256, 0, s>>>(a, y_scratch, norm_weight, out, normed_out, M, T, eps);
+    else
+      add_then_rms_norm_vec_kernel<0><<<ceil_div(T, 4), 256, 0, s>>>(a, y_scratch, norm_weight, out, normed_out, M, T, eps);
     return (pegainfer_status_t)hipGetLastError();
   }
   const pegainfer_status_t rc = pegainfer_gemm_add(W, X, y_scratch, a, out, M, T, K, stream);

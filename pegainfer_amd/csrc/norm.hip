@@ -75,6 +75,17 @@ __global__ __launch_bounds__(kNormBlock) void fused_add_rms_norm_vec_kernel(Half
   }
 }
 
+// the same, one memory pass (rows of a long prompt: launch_fused below picks it from 256 rows on)
+template <int VPL>
+__global__ __launch_bounds__(kNormBlock) void fused_add_rms_norm_rows_kernel(Half* __restrict__ hidden, const Half* __restrict__ residual,
+                                                                             const Half* __restrict__ w, Half* __restrict__ out, int d,
+                                                                             int rows, float eps) {
+  const int row = blockIdx.x * kNormWaves + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  Half* hr = hidden + (size_t)row * d;
+  wave_add_norm_row_cached<VPL, false>(hr, residual + (size_t)row * d, w, hr, out + (size_t)row * d, d, eps, 0.0f);
+}
+
 template <bool OFFSET>
 __global__ __launch_bounds__(kNormBlock) void fused_add_rms_norm_scalar_kernel(Half* __restrict__ hidden,
                                                                                const Half* __restrict__ residual,
@@ -137,7 +148,13 @@ static void launch_fused(Half* hidden, const Half* residual, const Half* w, Half
   if (d <= 0 || rows <= 0) return;
   const bool vec = (d & 7) == 0 && host_aligned16(hidden) && host_aligned16(residual) &&
                    host_aligned16(w) && host_aligned16(out);
-  if (vec)
+  // PEGAINFER_NORM_ROWS_CACHED=0: the two-pass kernel at every row count (A/B)
+  static const bool cached = [] { const char* e = getenv("PEGAINFER_NORM_ROWS_CACHED"); return !(e && e[0] == '0'); }();
+  if (vec && cached && rows >= 256 && d <= 8 * 64 * 5)
+    fused_add_rms_norm_rows_kernel<5><<<ceil_div(rows, kNormWaves), kNormBlock, 0, s>>>(hidden, residual, w, out, d, rows, eps);
+  else if (vec && cached && rows >= 256 && d <= 8 * 64 * 8)
+    fused_add_rms_norm_rows_kernel<8><<<ceil_div(rows, kNormWaves), kNormBlock, 0, s>>>(hidden, residual, w, out, d, rows, eps);
+  else if (vec)
     fused_add_rms_norm_vec_kernel<false><<<ceil_div(rows, kNormWaves), kNormBlock, 0, s>>>(hidden, residual, w, out, d,
                                                                                           rows, eps);
   else fused_add_rms_norm_scalar_kernel<false><<<rows, kNormBlock, 0, s>>>(hidden, residual, w, out, d, eps);

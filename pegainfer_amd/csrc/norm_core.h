@@ -79,4 +79,42 @@ __device__ __forceinline__ u32x4 norm_scale8(const u32x4& h, const u32x4* r, con
   return o;
 }
 
+// (round 6) One row's residual add + RMSNorm with the row held in REGISTERS between the sum of squares and the scaling pass (d / 8 <=
+// 64 * VPL vectors, lane l holds vectors l, l + 64, ... - the canonical order above, so the same bits as the two-pass kernels).  For
+// the long-prompt rows kernels: with 10 000 rows in flight the second pass of the two-pass form misses the XCD's L2 and goes back to
+// memory (FETCH_SIZE 198 MB per launch for 102 MB of inputs).  ROUND = the norm over the bf16-rounded sum ("add, then norm").
+template <int VPL, bool ROUND>
+__device__ __forceinline__ void wave_add_norm_row_cached(const Half* hr, const Half* rr, const Half* __restrict__ w, Half* hout,
+                                                         Half* nout, int d, float eps, float bias) {
+  const int lane = threadIdx.x & 63, nvec = d >> 3;
+  u32x4 hv[VPL], rv[VPL];
+#pragma unroll
+  for (int u = 0; u < VPL; ++u) {
+    const int i = lane + 64 * u;
+    hv[u] = rv[u] = u32x4{0u, 0u, 0u, 0u};
+    if (i < nvec) {
+      hv[u] = reinterpret_cast<const u32x4*>(hr)[i];
+      rv[u] = reinterpret_cast<const u32x4*>(rr)[i];
+    }
+  }
+  float ss = 0.f;
+#pragma unroll
+  for (int u = 0; u < VPL; ++u) {
+    if (lane + 64 * u >= nvec) continue;
+    if (ROUND) add_round_sq8(hv[u], rv[u], ss);
+    else add_sq8(hv[u], rv[u], ss);
+  }
+  ss = wave_sum(ss);
+  const float inv = rsqrtf(__fadd_rn(ss / (float)d, eps));
+#pragma unroll
+  for (int u = 0; u < VPL; ++u) {
+    const int i = lane + 64 * u;
+    if (i >= nvec) continue;
+    u32x4 nh;
+    const u32x4 o = norm_scale8(hv[u], &rv[u], reinterpret_cast<const u32x4*>(w)[i], inv, bias, &nh, ROUND);
+    reinterpret_cast<u32x4*>(hout)[i] = nh;
+    reinterpret_cast<u32x4*>(nout)[i] = o;
+  }
+}
+
 }  // namespace pk

@@ -168,6 +168,24 @@ def test_fused_add_rms_norm(P, hidden, T):
     assert bf16_ulp_diff(from_dev(out), no) <= 1
 
 
+@pytest.mark.parametrize("hidden", [2560, 4096, 1000 * 8])
+def test_fused_add_rms_norm_long_prompt_rows_equal_the_two_pass_kernel(P, hidden):
+    """From 256 rows on the fused add + RMSNorm keeps a row in registers between its two passes (round 6: one memory pass, hidden <=
+    2560 / 4096; wider rows stay on the two-pass kernel).  Same canonical summation order: every bit of the new hidden state and of
+    the normalised output equals the two-pass kernel's, which the same call takes below 256 rows."""
+    rng = np.random.default_rng(hidden)
+    T = 300
+    h, r, w = rnd(rng, T, hidden, scale=4), rnd(rng, T, hidden, scale=0.7), bf16_round(1 + rnd(rng, hidden, scale=0.2))
+    hd, out = to_dev(h), empty_like_dev(h)
+    P.fused_add_rms_norm_batch_into(hd, to_dev(r), to_dev(w), 1e-6, out)                    # 300 rows: the one-pass rows kernel
+    wd = to_dev(w)
+    for lo in range(0, T, 100):                                                             # 100 rows: the two-pass kernel
+        h2, o2 = to_dev(h[lo:lo + 100]), empty_like_dev(h[lo:lo + 100])
+        P.fused_add_rms_norm_batch_into(h2, to_dev(r[lo:lo + 100]), wd, 1e-6, o2)
+        assert np.array_equal(bf16_bits(from_dev(hd)[lo:lo + 100]), bf16_bits(from_dev(h2)))
+        assert np.array_equal(bf16_bits(from_dev(out)[lo:lo + 100]), bf16_bits(from_dev(o2)))
+
+
 def test_rms_norm_gated(P):  # norm.cu:17-61 (Qwen3.5 linear-attention output)
     import torch
     rng = np.random.default_rng(3)
