@@ -110,16 +110,30 @@ __global__ __launch_bounds__(256) void gdr_kkt_kernel(const Half* __restrict__ k
 __global__ __launch_bounds__(64) void gdr_solve_kernel(const float* __restrict__ a_tril, Half* __restrict__ a_inv,
                                                        int T, int nvh) {
   const int c0 = blockIdx.x * GC, vh = blockIdx.y, lane = threadIdx.x;
+  // (round 6) RIGHT-looking order with the broadcasts through LDS: as soon as row j is final, every later row takes its A[i][j] x[j]
+  // term.  A row still receives its terms in ascending j - the same operations in the same order as "row i = 1 - sum_{j < i}", hence
+  // the same bits.  The row-by-row form took A[i][j] with one v_readlane per term; 2016 of them are what the kernel's 34 us were (a
+  // v_readlane costs ~28 cycles here: pinning the order and keeping eight in flight with inline asm moved it to 31.5 us, no further).
+  // Now A is stored TRANSPOSED in LDS once and a step reads its column as uniform-address (broadcast) vector loads.
+  __shared__ __attribute__((aligned(16))) float at[GC][GC + 4];   // at[j][i] = A[i][j]
   float x[GC];
 #pragma unroll
   for (int i = 0; i < GC; ++i) {
-    const int t = c0 + i;
-    const float arow = t < T ? a_tril[((size_t)t * nvh + vh) * GC + lane] : 0.f;  // A[i][lane]
-    float v = lane == i ? 1.f : 0.f;
+    const int t = c0 + i, tc = t < T ? t : T - 1;       // clamped, branch-free: rows past the end read a valid row and are zeroed
+    const float a = a_tril[((size_t)tc * nvh + vh) * GC + lane];  // A[i][lane]
+    at[lane][i] = t < T ? a : 0.f;
+    x[i] = lane == i ? 1.f : 0.f;
+  }
+  __syncthreads();
 #pragma unroll
-    for (int j = 0; j < i; ++j) v -= __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, arow), j)) * x[j];
-    x[i] = v;
-    if (t < T) a_inv[((size_t)t * nvh + vh) * GC + lane] = f2bf(v);
+  for (int j = 0; j < GC - 1; ++j) {
+#pragma unroll
+    for (int i = j + 1; i < GC; ++i) x[i] = fmaf(-at[j][i], x[j], x[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < GC; ++i) {
+    const int t = c0 + i;
+    if (t < T) a_inv[((size_t)t * nvh + vh) * GC + lane] = f2bf(x[i]);
   }
 }
 
