@@ -21,7 +21,24 @@ def S():
     return torch.cuda.current_stream().cuda_stream
 
 
-@pytest.mark.parametrize("T,C,K", [(1, 8192, 4), (37, 8192, 4), (2, 100, 4), (5, 64, 2)])
+def test_conv1d_long_prompt_kernel_equals_the_short_one(built_libs):
+    """From 256 tokens on a lane walks 8 consecutive tokens with a sliding window (round 6); per output the same taps in the same
+    order: the first 200 outputs of a 300-token call equal a 200-token call (one token per lane) bit for bit, state included."""
+    from pegainfer_amd import ffi
+    rng = np.random.default_rng(11)
+    C, K = 8192, 4
+    x, w, st = rnd(rng, 300, C), rnd(rng, C, K, scale=0.5), rnd(rng, C, K - 1)
+    wd = to_dev(w)
+    o300, o200 = to_dev(np.zeros((300, C), np.float32)), to_dev(np.zeros((200, C), np.float32))
+    s300, s200 = to_dev(st), to_dev(st)
+    ffi.lib().conv1d_prefill_cuda(to_dev(x).data_ptr(), wd.data_ptr(), s300.data_ptr(), o300.data_ptr(), C, 300, K, S())
+    ffi.lib().conv1d_prefill_cuda(to_dev(x[:200]).data_ptr(), wd.data_ptr(), s200.data_ptr(), o200.data_ptr(), C, 200, K, S())
+    assert np.array_equal(bf16_bits(from_dev(o300)[:200]), bf16_bits(from_dev(o200)))
+    eo, es = O.conv1d_prefill(x, w, st)
+    assert bf16_ulp_diff(from_dev(o300), eo) <= 1 and np.array_equal(bf16_bits(from_dev(s300)), bf16_bits(es))
+
+
+@pytest.mark.parametrize("T,C,K", [(1, 8192, 4), (37, 8192, 4), (2, 100, 4), (5, 64, 2), (300, 8192, 4)])
 def test_conv1d_prefill_and_state(built_libs, T, C, K):
     from pegainfer_amd import ffi
     rng = np.random.default_rng(T + C)
